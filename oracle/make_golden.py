@@ -1,0 +1,282 @@
+"""Generate tests/golden/* from the reference itself.  BUILD-CONTAINER ONLY.
+
+Imports the reference's own model files from /root/reference (read-only) on top
+of ``oracle/ref_stub.py`` (restatement of the un-vendored
+transformers@067923d ``pytorch_transformers`` blocks), runs them on CPU/fp32 on
+seeded inputs, cross-checks the restated blocks against the installed
+transformers==5.15 BERT modules, and writes inputs + expected outputs (data
+only) under tests/golden/.  /root/reference does not exist on the GPU box, so
+nothing at test/bench time runs this script.
+
+    python oracle/make_golden.py            # writes tests/golden/*
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import ref_stub  # noqa: E402
+
+ref_stub.install()
+sys.path.insert(0, "/root/reference/Oscar")
+from oscar.modeling.modeling_bert import BertImgModel, BertImgForPreTraining  # noqa: E402
+from oscar.modeling.modeling_rec import REC_MLM_CPT  # noqa: E402
+from oscar.utils.optim_sched import get_lr_sched  # noqa: E402
+from oscar.utils.iou import computeIoU  # noqa: E402
+
+from cpt_amd import config as cfgmod  # noqa: E402
+from cpt_amd import synth  # noqa: E402
+
+
+def to_ref_cfg(cfg, **over):
+    d = cfg.to_dict()
+    d.update(over)
+    return ref_stub.BertConfig(**d)
+
+
+def build_ref(cfg, seed, **over):
+    """reference BertImgForPreTraining + REC_MLM_CPT carrying synth weights
+    (load path of zeroshot/refcoco_cpt.py:444-447)."""
+    rc = to_ref_cfg(cfg, **over)
+    pre = BertImgForPreTraining(rc)
+    sd = synth.init_state_dict(cfg, seed, head="pretrain")
+    missing, unexpected = pre.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    pre.tie_weights()
+    m = REC_MLM_CPT(rc)
+    m.copy_from_pretraining_model(pre)
+    m.eval()
+    return m, pre
+
+
+def labels_for(batch):
+    B = batch["input_ids"].size(0)
+    lab = torch.full(batch["attention_mask"].shape, -1, dtype=torch.long)
+    lab[torch.arange(B), batch["mask_token_pos"]] = batch["colors"]     # fewshot/refcoco_cpt.py:231-233
+    return lab
+
+
+def hf_crosscheck(cfg, seed):
+    """Restated third-party blocks vs installed transformers 5.x modules, same weights."""
+    from transformers import BertConfig as HFConfig
+    from transformers.models.bert import modeling_bert as hf
+    hc = HFConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                  num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                  intermediate_size=cfg.intermediate_size, hidden_dropout_prob=0.0,
+                  attention_probs_dropout_prob=0.0, max_position_embeddings=cfg.max_position_embeddings,
+                  type_vocab_size=cfg.type_vocab_size, layer_norm_eps=cfg.layer_norm_eps, hidden_act="gelu")
+    hc._attn_implementation = "eager"
+    m, _ = build_ref(cfg, seed)
+    res = {}
+    torch.manual_seed(0)
+    B, L, H = 2, 12, cfg.hidden_size
+    x = torch.randn(B, L, H)
+    am = torch.ones(B, L)
+    am[0, -3:] = 0
+    ext = (1.0 - am[:, None, None, :]) * -10000.0
+    with torch.no_grad():
+        # encoder layer
+        ref_layer = m.bert.encoder.layer[0]
+        hl = hf.BertLayer(hc).eval()
+        hl.load_state_dict(ref_layer.state_dict())
+        hf_out = hl(x, attention_mask=ext)
+        hf_out = hf_out[0] if isinstance(hf_out, tuple) else hf_out
+        res["BertLayer"] = float((ref_layer(x, ext)[0] - hf_out).abs().max())
+        # embeddings
+        he = hf.BertEmbeddings(hc).eval()
+        he.load_state_dict(m.bert.embeddings.state_dict(), strict=False)
+        ids = torch.randint(1, cfg.vocab_size, (B, 7))
+        tt = torch.randint(0, 2, (B, 7))
+        res["BertEmbeddings"] = float((m.bert.embeddings(ids, token_type_ids=tt)
+                                       - he(input_ids=ids, token_type_ids=tt)).abs().max())
+        # LM head
+        hh = hf.BertLMPredictionHead(hc).eval()
+        sdh = dict(m.cls.state_dict())
+        sdh["decoder.bias"] = sdh["bias"]
+        hh.load_state_dict(sdh, strict=False)
+        res["BertLMPredictionHead"] = float((m.cls(x) - hh(x)).abs().max())
+        # pooler
+        hp = hf.BertPooler(hc).eval()
+        hp.load_state_dict(m.bert.pooler.state_dict())
+        res["BertPooler"] = float((m.bert.pooler(x) - hp(x)).abs().max())
+    return res
+
+
+def tiny_case():
+    cfg = cfgmod.tiny()
+    seed = 1234
+    m, pre = build_ref(cfg, seed, output_hidden_states=True)
+    batch = synth.make_batch(3, cfg, seed=7, max_seq_len=20, img_seq_len=6, n_regions=6, vary_regions=True)
+    lab = labels_for(batch)
+    out = m(batch["input_ids"], batch["segment_ids"], batch["attention_mask"],
+            img_feats=batch["img_feats"], masked_lm_labels=lab)
+    loss, scores, hiddens = out[0], out[1], out[2]
+    m.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.detach().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}
+    with torch.no_grad():
+        seq, pooled = m.bert(batch["input_ids"], batch["segment_ids"], batch["attention_mask"],
+                             img_feats=batch["img_feats"])[:2]
+        nsp = pre.cls.seq_relationship(pooled)
+    g = {"in_" + k: v.numpy() for k, v in batch.items()}
+    g["loss"] = loss.detach().numpy()
+    g["scores"] = scores.detach().numpy()
+    g["pooled"] = pooled.numpy()
+    g["nsp_scores"] = nsp.numpy()
+    for i, h in enumerate(hiddens):
+        g["hidden_%d" % i] = h.detach().numpy()
+    for k, v in grads.items():
+        g["grad_" + k] = v
+    np.savez_compressed(os.path.join(OUT, "tiny_fwd_bwd.npz"), **g)
+
+    # --- 3-step few-shot trace: AdamW groups of fewshot/refcoco_cpt.py:318-343, LR 236-243
+    m2, _ = build_ref(cfg, seed)
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    named = [(n, p) for n, p in m2.named_parameters() if "classifier" not in n]
+    lr0, wd, betas = 3e-5 * 100, 0.01, (0.9, 0.98)      # lr scaled up so 3 steps move the loss visibly
+    groups = [{"params": [], "lr": lr0, "weight_decay": wd}, {"params": [], "lr": lr0, "weight_decay": 0.0},
+              {"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": wd},
+              {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    groups = [gr for gr in groups if len(gr["params"])]
+    opt = torch.optim.AdamW(groups, lr=lr0, betas=betas)
+
+    class O(object):
+        learning_rate = lr0
+        warmup_steps = 1
+        num_train_steps = 3
+    losses, lrs = [], []
+    for step in range(3):
+        lr = get_lr_sched(step, O)
+        for gr in opt.param_groups:
+            gr["lr"] = lr
+        opt.zero_grad()
+        ls = m2(batch["input_ids"], batch["segment_ids"], batch["attention_mask"],
+                img_feats=batch["img_feats"], masked_lm_labels=lab)[0]
+        ls.backward()
+        opt.step()
+        losses.append(float(ls))
+        lrs.append(lr)
+    after = {k: v.detach().numpy().copy() for k, v in m2.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "tiny_train3.npz"), losses=np.array(losses, np.float64),
+                        lrs=np.array(lrs, np.float64), lr0=lr0, wd=wd, beta1=betas[0], beta2=betas[1],
+                        **{"after_" + k: v for k, v in after.items() if k in (
+                            "bert.encoder.layer.1.output.dense.weight", "bert.embeddings.word_embeddings.weight",
+                            "bert.encoder.layer.0.attention.self.query.bias", "cls.transform.LayerNorm.weight",
+                            "bert.img_embedding.weight", "cls.bias")})
+
+    # --- checkpoint surface: legacy gamma/beta names, loaded by the reference's own from_pretrained
+    ck = os.path.join(OUT, "tiny_ckpt")
+    os.makedirs(ck, exist_ok=True)
+    sd = synth.init_state_dict(cfg, seed, head="pretrain")
+    legacy = {}
+    for k, v in sd.items():
+        if "LayerNorm.weight" in k:
+            k = k.replace("LayerNorm.weight", "LayerNorm.gamma")
+        elif "LayerNorm.bias" in k:
+            k = k.replace("LayerNorm.bias", "LayerNorm.beta")
+        legacy[k] = v.clone()
+    torch.save(legacy, os.path.join(ck, "pytorch_model.bin"))
+    cfg.save_pretrained(ck)
+    rc = ref_stub.BertConfig.from_pretrained(ck)
+    pre2 = BertImgForPreTraining.from_pretrained(ck, config=rc)        # modeling_utils.py:689-875
+    m3 = REC_MLM_CPT(rc)
+    m3.copy_from_pretraining_model(pre2)
+    m3.eval()
+    with torch.no_grad():
+        sc3 = m3(batch["input_ids"], batch["segment_ids"], batch["attention_mask"], img_feats=batch["img_feats"])[0]
+    np.savez_compressed(os.path.join(OUT, "tiny_ckpt_expected.npz"), scores=sc3.numpy(),
+                        keys=np.array(sorted(m3.state_dict().keys())))
+    return float((sc3 - scores.detach()).abs().max())
+
+
+def base_case(name, B, n_regions, seed_w=88, seed_b=88, with_grads=False, vary=False):
+    cfg = cfgmod.oscar_base()
+    m, pre = build_ref(cfg, seed_w)
+    batch = synth.make_batch(B, cfg, seed=seed_b, n_regions=n_regions, vary_regions=vary)
+    lab = labels_for(batch)
+    ids_sub = sorted(set(list(synth.COLOR_IDS) + [synth.NONE_ID] +
+                         [int(i) for i in np.random.Generator(np.random.PCG64(5)).integers(0, cfg.vocab_size, 64)]))
+    g = dict(B=B, n_regions=n_regions, seed_w=seed_w, seed_b=seed_b, vary=int(vary), ids_sub=np.array(ids_sub))
+    if with_grads:
+        out = m(batch["input_ids"], batch["segment_ids"], batch["attention_mask"],
+                img_feats=batch["img_feats"], masked_lm_labels=lab)
+        loss, scores = out[0], out[1]
+        m.zero_grad()
+        loss.backward()
+        gn = {}
+        for k, p in m.named_parameters():
+            gn[k] = float(p.grad.double().norm()) if p.grad is not None else -1.0
+        g["grad_names"] = np.array(list(gn.keys()))
+        g["grad_norms"] = np.array(list(gn.values()), np.float64)
+        g["grad_sample_qw"] = m.bert.encoder.layer[11].attention.self.query.weight.grad[:8, :16].numpy().copy()
+        g["grad_sample_img"] = m.bert.img_embedding.weight.grad[:8, 2040:2054].numpy().copy()
+        g["grad_sample_emb_mask"] = m.bert.embeddings.word_embeddings.weight.grad[synth.MASK, :32].numpy().copy()
+        g["loss"] = float(loss)
+        scores = scores.detach()
+    else:
+        with torch.no_grad():
+            out = m(batch["input_ids"], batch["segment_ids"], batch["attention_mask"],
+                    img_feats=batch["img_feats"], masked_lm_labels=lab)
+        g["loss"] = float(out[0])
+        scores = out[1]
+    rows = scores[torch.arange(B), batch["mask_token_pos"]]                 # zeroshot/refcoco_cpt.py:219
+    g["mask_logits_sub"] = rows[:, ids_sub].numpy()
+    g["mask_logits_argmax"] = rows.argmax(-1).numpy()
+    g["mask_logits_absmax"] = float(rows.abs().max())
+    # a second row (position 0 = [CLS]) pins the all-rows head too
+    g["cls_row_logits_sub"] = scores[:, 0][:, ids_sub].numpy()
+    with torch.no_grad():
+        seq, pooled = m.bert(batch["input_ids"], batch["segment_ids"], batch["attention_mask"],
+                             img_feats=batch["img_feats"])[:2]
+        g["seq_sample"] = seq[:, ::17, ::29].numpy()
+        g["pooled_sample"] = pooled[:, ::13].numpy()
+        g["nsp_scores"] = pre.cls.seq_relationship(pooled).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **g)
+
+
+def caller_goldens():
+    """a15 + iou: outputs of the reference helper functions on seeded inputs."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    boxes = rng.integers(0, 400, size=(64, 2, 4)).astype(np.float64)
+    boxes[:, :, 2:] += 5
+    ious = np.array([computeIoU(list(b[0]), list(b[1])) for b in boxes])
+    np.savez_compressed(os.path.join(OUT, "iou.npz"), boxes=boxes, ious=ious)
+
+    class O(object):
+        learning_rate = 3e-5
+        warmup_steps = 50
+        num_train_steps = 500
+    steps = np.arange(0, 520, 7)
+    np.savez_compressed(os.path.join(OUT, "lr_sched.npz"), steps=steps,
+                        lrs=np.array([get_lr_sched(int(s), O) for s in steps], np.float64))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    meta = {"reference": "thunlp/CPT @ /root/reference (v1)",
+            "third_party_restated": "huggingface/transformers@067923d3267325f525f4e46f357360c191ba562e (pytorch_transformers)",
+            "torch": torch.__version__}
+    meta["hf_crosscheck_maxabs_tiny"] = hf_crosscheck(cfgmod.tiny(), 1234)
+    meta["hf_crosscheck_maxabs_base"] = hf_crosscheck(cfgmod.oscar_base(), 88)
+    print("hf cross-check:", meta["hf_crosscheck_maxabs_tiny"], meta["hf_crosscheck_maxabs_base"])
+    meta["tiny_ckpt_vs_direct_maxabs"] = tiny_case()
+    caller_goldens()
+    base_case("base_cfg1_b2_r36", B=2, n_regions=36)                       # BASELINE config 1 shape
+    base_case("base_cfg2_b4_r50", B=4, n_regions=50, with_grads=True)      # config 2 shape (+ grads for config 3)
+    base_case("base_ragged_b3", B=3, n_regions=50, seed_b=3, vary=True)
+    with open(os.path.join(OUT, "META.json"), "w") as f:
+        json.dump(meta, f, indent=2, sort_keys=True)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+"""CPU: the oracle (oracle/cpt_oracle.py) against every golden fixture generated
+from the reference (oracle/make_golden.py).  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cpt_amd import config as cfgmod
+from cpt_amd import synth
+from oracle import cpt_oracle as O
+
+
+def _cfg_dict(cfg):
+    return cfg.to_dict()
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_meta_crosscheck_is_tight(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "META.json")))
+    for grp in ("hf_crosscheck_maxabs_tiny", "hf_crosscheck_maxabs_base"):
+        for k, v in meta[grp].items():
+            assert v < 2e-6, (grp, k, v)
+    assert meta["tiny_ckpt_vs_direct_maxabs"] == 0.0
+
+
+def _tiny_batch(g):
+    return {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+
+
+def test_tiny_forward_all_stages(golden_dir):
+    g = _load(golden_dir, "tiny_fwd_bwd.npz")
+    cfg = cfgmod.tiny()
+    sd = synth.init_state_dict(cfg, 1234, head="pretrain")
+    sd = {k.replace("cls.predictions.", "cls."): v for k, v in sd.items()}
+    b = _tiny_batch(g)
+    seq, pooled, hid = O.bert_img_forward(sd, _cfg_dict(cfg), b["input_ids"], b["segment_ids"],
+                                          b["attention_mask"], img_feats=b["img_feats"], all_hidden=True)
+    for i, h in enumerate(hid):
+        np.testing.assert_allclose(h.numpy(), g["hidden_%d" % i], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(pooled.numpy(), g["pooled"], atol=1e-5, rtol=0)
+    scores = O.lm_head(sd, _cfg_dict(cfg), seq)
+    np.testing.assert_allclose(scores.numpy(), g["scores"], atol=2e-5, rtol=0)
+    nsp = torch.nn.functional.linear(pooled, sd["cls.seq_relationship.weight"], sd["cls.seq_relationship.bias"])
+    np.testing.assert_allclose(nsp.numpy(), g["nsp_scores"], atol=1e-5, rtol=0)
+
+
+def test_tiny_loss_and_grads(golden_dir):
+    g = _load(golden_dir, "tiny_fwd_bwd.npz")
+    cfg = cfgmod.tiny()
+    sd = synth.init_state_dict(cfg, 1234, head="cpt")
+    b = _tiny_batch(g)
+    loss, grads = O.train_step_grads(sd, _cfg_dict(cfg), b)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    n = 0
+    for k in g.files:
+        if not k.startswith("grad_"):
+            continue
+        name = k[5:]
+        if name == "cls.decoder.weight":
+            continue
+        np.testing.assert_allclose(grads[name].numpy(), g[k], atol=2e-6, rtol=1e-4, err_msg=name)
+        n += 1
+    assert n > 30
+    # pooler gets no gradient on the MLM path (find_unused_parameters in the reference DDP wrap)
+    assert grads["bert.pooler.dense.weight"] is None
+
+
+@pytest.mark.parametrize("name", ["base_cfg1_b2_r36", "base_cfg2_b4_r50", "base_ragged_b3"])
+def test_base_mask_logits(golden_dir, name):
+    g = _load(golden_dir, name + ".npz")
+    cfg = cfgmod.oscar_base()
+    sd = synth.init_state_dict(cfg, int(g["seed_w"]), head="pretrain")
+    sd = {k.replace("cls.predictions.", "cls."): v for k, v in sd.items()}
+    b = synth.make_batch(int(g["B"]), cfg, seed=int(g["seed_b"]), n_regions=int(g["n_regions"]),
+                         vary_regions=bool(int(g["vary"])))
+    B = int(g["B"])
+    lab = torch.full(b["attention_mask"].shape, -1, dtype=torch.long)
+    lab[torch.arange(B), b["mask_token_pos"]] = b["colors"]
+    with torch.no_grad():
+        loss, rows = O.rec_mlm_cpt_forward(sd, _cfg_dict(cfg), b["input_ids"], b["segment_ids"],
+                                           b["attention_mask"], masked_lm_labels=lab,
+                                           img_feats=b["img_feats"], mask_rows_only=b["mask_token_pos"])
+    ids = torch.from_numpy(g["ids_sub"])
+    np.testing.assert_allclose(rows[:, ids].numpy(), g["mask_logits_sub"], atol=2e-5, rtol=0)
+    assert (rows.argmax(-1).numpy() == g["mask_logits_argmax"]).all()
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    with torch.no_grad():
+        seq, pooled = O.bert_img_forward(sd, _cfg_dict(cfg), b["input_ids"], b["segment_ids"],
+                                         b["attention_mask"], img_feats=b["img_feats"])
+        cls_rows = O.lm_head(sd, _cfg_dict(cfg), seq[:, 0])
+    np.testing.assert_allclose(seq[:, ::17, ::29].numpy(), g["seq_sample"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(pooled[:, ::13].numpy(), g["pooled_sample"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(cls_rows[:, ids].numpy(), g["cls_row_logits_sub"], atol=2e-5, rtol=0)
+    nsp = O.nsp_cpt_scores(sd, _cfg_dict(cfg), b["input_ids"], b["segment_ids"], b["attention_mask"], b["img_feats"])
+    np.testing.assert_allclose(nsp.numpy(), g["nsp_scores"], atol=1e-5, rtol=0)
+
+
+def test_iou_and_lr_sched(golden_dir):
+    g = _load(golden_dir, "iou.npz")
+    got = np.array([O.compute_iou(list(b[0]), list(b[1])) for b in g["boxes"]])
+    assert (got == g["ious"]).all()
+    s = _load(golden_dir, "lr_sched.npz")
+    got = np.array([O.get_lr_sched(int(t), 3e-5, 50, 500) for t in s["steps"]])
+    assert (got == s["lrs"]).all()
+
+
+def test_tiny_train3_trace(golden_dir):
+    """3 AdamW steps (groups of fewshot/refcoco_cpt.py:318-343) with the oracle's
+    own adamw_step on oracle grads reproduce the reference's loss trace."""
+    t = _load(golden_dir, "tiny_train3.npz")
+    g = _load(golden_dir, "tiny_fwd_bwd.npz")
+    cfg = cfgmod.tiny()
+    sd = synth.init_state_dict(cfg, 1234, head="cpt")
+    b = _tiny_batch(g)
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    names = [k for k in sd if k != "cls.decoder.weight"]
+    m = {k: torch.zeros_like(sd[k]) for k in names}
+    v = {k: torch.zeros_like(sd[k]) for k in names}
+    lr0, wd, b1, b2 = float(t["lr0"]), float(t["wd"]), float(t["beta1"]), float(t["beta2"])
+    for step in range(3):
+        lr = O.get_lr_sched(step, lr0, 1, 3)
+        assert lr == t["lrs"][step]
+        loss, grads = O.train_step_grads(sd, _cfg_dict(cfg), b)
+        assert abs(float(loss) - t["losses"][step]) < 5e-5, (step, float(loss), t["losses"][step])
+        for k in names:
+            if grads[k] is None:
+                continue
+            w = 0.0 if any(nd in k for nd in no_decay) else wd
+            p, m[k], v[k] = O.adamw_step(sd[k], grads[k], m[k], v[k], step + 1, lr, b1, b2, 1e-8, w)
+            sd[k].copy_(p)
+    for k in t.files:
+        if k.startswith("after_"):
+            np.testing.assert_allclose(sd[k[6:]].numpy(), t[k], atol=3e-5, rtol=1e-4, err_msg=k)  # Adam m/sqrt(v) amplifies 1e-7 grad noise at lr 3e-3
