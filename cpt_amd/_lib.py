@@ -1,0 +1,107 @@
+"""ctypes binding of libcpt_hip.so (include/cpt_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcpt_hip.so")
+
+CPT_F32, CPT_BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID = 0, 1, 2, 3
+OUT_SEQ, OUT_POOLED, OUT_MASK_LOGITS, OUT_ALL_LOGITS, OUT_LOSS, OUT_REL = 1, 2, 4, 8, 16, 32
+SAVE_FOR_BWD = 1024
+K_NAMES = ["gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up", "gemm_ffn_down",
+           "embed_ln", "img_proj", "head"]
+
+vp, i32, i64p, f32p = C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("hidden", "heads", "inter", "layers", "vocab", "img_dim", "img_dim_pad", "max_pos",
+                 "type_vocab", "use_img_ln", "n_rel", "dtype")] + [("ln_eps", C.c_float), ("img_ln_eps", C.c_float)]
+
+
+class Layer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_in", "b_in", "w_out", "b_out",
+                 "ln2_g", "ln2_b")]
+
+
+class Model(C.Structure):
+    _fields_ = [("dims", Dims)] + [(n, C.c_void_p) for n in
+                ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "w_img", "b_img", "img_ln_g",
+                 "img_ln_b")] + [("layers", C.POINTER(Layer))] + [(n, C.c_void_p) for n in
+                ("w_pool", "b_pool", "w_tr", "b_tr", "tr_ln_g", "tr_ln_b", "w_dec", "b_dec", "w_rel", "b_rel")]
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Lt", C.c_int32), ("Li", C.c_int32)] + [(n, C.c_void_p) for n in
+                ("input_ids", "token_type", "position_ids", "attn_mask", "img_feats", "mask_pos", "labels")]
+
+
+class Outputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("seq", "pooled", "logits", "loss", "rel")]
+
+
+_SIGS = {
+    "cpt_version": (C.c_int, []),
+    "cpt_last_error": (C.c_char_p, []),
+    "cpt_check_device": (C.c_int, [C.c_int]),
+    "cpt_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "cpt_model_fwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), C.c_int, vp, C.c_size_t, vp]),
+    "cpt_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int,
+                           C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_embed_ln": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_layernorm_rows": (C.c_int, [vp, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, vp]),
+    "cpt_attention": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_pad_cast": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_gather_rows": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_ce_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "cpt_prof_enable": (C.c_int, [C.c_int]),
+    "cpt_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python -m cpt_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "cpt_amd: %s is missing -- the HIP extension is required (no CPU fallback). "
+                "Build it with `python -m cpt_amd.build` (hipcc --offload-arch=gfx950)." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)        # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if l.cpt_version() != 1:
+            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 1" % l.cpt_version())
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().cpt_last_error().decode("utf-8", "replace")
+        raise RuntimeError("cpt_amd %s failed (status %d): %s" % (what, rc, msg))
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,229 @@
+// Fused self-attention core for head_dim 64 (Oscar-base 12x64, Oscar-large 16x64):
+//   ctx = softmax(Q K^T / 8 + (1 - mask) * -10000) V          per (sequence, head)
+// Replaces /root/reference/Oscar/oscar/modeling/modeling_bert.py:42-67 (transpose_for_scores,
+// two batched matmuls, softmax, permute/merge) -- the (B,heads,L,L) score tensor never leaves
+// the chip.  Dropout on the probabilities (:57) is identity in eval; the training path of this
+// build runs with dropout disabled.
+//
+// gfx950 design: one 256-thread workgroup per (sequence, head, 128-query tile); the head's K
+// tile [L][64] (XOR-swizzled) and V^T tile [64][L] (+pad) are staged once in LDS; each of the 4
+// waves owns 32 query rows and keeps its whole score strip S^T = K.Q^T in MFMA accumulators
+// (sequence length <= 288, so no online softmax is needed).  Computing the TRANSPOSED scores puts
+// one query row per lane: the softmax row reduction is lane-local plus one cross-half shuffle,
+// and the probabilities already sit in the A-operand layout of the P.V MFMA if V's key order is
+// permuted the same way -- no LDS round trip for P.
+#include "common.h"
+#include "kernels.h"
+
+namespace cpt {
+
+constexpr int HD = 64;           // head dim
+constexpr int ATT_THREADS = 256;
+
+template <typename T> __device__ __forceinline__ int k_off(int row, int chunk);
+// K tile rows are 64 elements: 128 B (bf16, 8 chunks) or 256 B (f32, 16 chunks)
+template <> __device__ __forceinline__ int k_off<bf16>(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <> __device__ __forceinline__ int k_off<float>(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+
+// key index held by accumulator register r of half-wave h inside a 32-key block
+__device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <typename T, int NKB>
+__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
+    const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
+    T* __restrict__ probs, int B, int L, int heads) {
+    typedef typename FragOf<T>::type frag_t;
+    constexpr int CE = Chunk<T>::N;
+    constexpr int NC = HD / CE;                       // chunks per K row
+    constexpr int LP = NKB * 32;                      // padded key count
+    constexpr int VPAD = sizeof(T) == 2 ? 8 : 16;     // bytes: makes V^T column reads conflict-free
+    constexpr int VROW = LP * (int)sizeof(T) + VPAD;  // bytes per V^T row
+    constexpr int KS = NC / 2;                        // MFMA chunk steps over head dim
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sK = smem;                              // LP rows
+    unsigned char* sV = smem + LP * HD * sizeof(T);        // 64 rows of VROW bytes
+    float* sMask = reinterpret_cast<float*>(sV + HD * VROW);  // LP floats
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int q0 = blockIdx.y * 128 + wave * 32;
+    const int H = heads * HD;
+    const size_t ldq = (size_t)3 * H;
+    const T* base = qkv + (size_t)b * L * ldq + h * HD;
+
+    // ---- stage K (swizzled rows), V^T and the additive mask ----
+    for (int idx = tid; idx < LP * NC; idx += ATT_THREADS) {
+        const int key = idx / NC, c = idx % NC;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < L) {
+            kv = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + H + c * CE);
+            vv = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + 2 * H + c * CE);
+        }
+        *reinterpret_cast<uint4*>(sK + k_off<T>(key, c)) = kv;
+        const T* ve = reinterpret_cast<const T*>(&vv);
+#pragma unroll
+        for (int j = 0; j < CE; ++j)
+            *reinterpret_cast<T*>(sV + (c * CE + j) * VROW + key * sizeof(T)) = ve[j];
+    }
+    for (int key = tid; key < LP; key += ATT_THREADS) {
+        float mv = -INFINITY;                          // padding keys beyond L: excluded outright
+        if (key < L) mv = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
+        sMask[key] = mv;
+    }
+
+    // ---- Q fragments straight from global: lane = query row (l&31), chunks 2*ks + (l>>5) ----
+    const int fr = lane & 31, fh = lane >> 5;
+    const int q = q0 + fr;
+    frag_t fq[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (q < L) t = *reinterpret_cast<const uint4*>(base + (size_t)q * ldq + (2 * ks + fh) * CE);
+        fq[ks] = *reinterpret_cast<frag_t*>(&t);
+    }
+    __syncthreads();
+    if (q0 >= L) return;   // whole wave has no query rows (uniform per wave)
+
+    // ---- S^T = K . Q^T : accumulator rows = keys, column (lane&31) = query ----
+    f32x16 st[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const frag_t fk = *reinterpret_cast<const frag_t*>(sK + k_off<T>(kb * 32 + fr, 2 * ks + fh));
+            mfma_chunk(st[kb], fk, fq[ks]);
+        }
+    }
+
+    // ---- softmax over keys: lane-local + one exchange with the other half-wave ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float s = st[kb][r] * 0.125f + sMask[kb * 32 + key_of(r, fh)];
+            st[kb][r] = s;
+            mx = fmaxf(mx, s);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = expf(st[kb][r] - mx);
+            st[kb][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] *= inv;
+
+    if (probs && q < L) {   // [B][heads][L][L], saved for the backward pass only
+        T* pr = probs + (((size_t)b * heads + h) * L + q) * L;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + key_of(r, fh);
+                if (key < L) pr[key] = from_f32<T>(st[kb][r]);
+            }
+    }
+
+    // ---- O = P . V : A operand = P (this lane's registers), B operand = V^T rows from LDS ----
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        if constexpr (sizeof(T) == 2) {
+            // two MFMA k-steps of 16 keys; slot j of half h <-> key 16*s + (j&3) + 8*(j>>2) + 4*h
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pa;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pa[j] = (bf16)st[kb][8 * s2 + j];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const unsigned char* vr = sV + (db * 32 + fr) * VROW + (kb * 32 + 16 * s2 + 4 * fh) * 2;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 16);
+                    bf16x8 vb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vb[j] = lo[j]; vb[4 + j] = hi[j]; }
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, o[db], 0, 0, 0);
+                }
+            }
+        } else {
+            // one v_mfma_f32_32x32x2_f32 per accumulator register: keys key_of(r,0) / key_of(r,1)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const unsigned char* vr = sV + (db * 32 + fr) * VROW + (kb * 32 + 8 * g + 4 * fh) * 4;
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(vr);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(st[kb][4 * g + j], vv[j], o[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- store context rows (merge heads: column h*64 + d) ----
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = q0 + acc_row(r, lane);
+            if (qq < L) ctx[((size_t)b * L + qq) * H + h * HD + db * 32 + acc_col(lane)] = from_f32<T>(o[db][r]);
+        }
+}
+
+template <typename T, int NKB>
+static size_t att_lds_bytes() {
+    constexpr int LP = NKB * 32;
+    constexpr int VPAD = sizeof(T) == 2 ? 8 : 16;
+    return (size_t)LP * HD * sizeof(T) + (size_t)HD * (LP * sizeof(T) + VPAD) + (size_t)LP * sizeof(float);
+}
+
+template <typename T, int NKB>
+static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s) {
+    const size_t lds = att_lds_bytes<T, NKB>();
+    auto kern = attention_kernel<T, NKB>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+    }
+    dim3 grid(B * heads, (L + 127) / 128), block(ATT_THREADS);
+    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads);
+    return CPT_OK;
+}
+
+template <typename T>
+static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s) {
+    if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, s);
+    if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, s);
+    if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, s);
+    if (L <= 288) return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, s);
+    return CPT_ERR_SHAPE;
+}
+
+int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s) {
+    if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
+    if (!qkv || !ctx) return CPT_ERR_NULL;
+    if (dtype == CPT_BF16) return att_dispatch<bf16>(qkv, attn_mask, ctx, probs, B, L, heads, s);
+    if (dtype == CPT_F32) return att_dispatch<float>(qkv, attn_mask, ctx, probs, B, L, heads, s);
+    return CPT_ERR_DTYPE;
+}
+
+}  // namespace cpt

@@ -1,0 +1,70 @@
+// Shared device helpers for the CPT hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cpt {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVE = 64;
+
+// A 16-byte LDS/global chunk: 8 bf16 or 4 f32.
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16> { static constexpr int N = 8; };
+template <> struct Chunk<float> { static constexpr int N = 4; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// exact erf GELU (third-party ACT2FN["gelu"])
+__device__ __forceinline__ float gelu_erf(float x) {
+    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+}
+// d/dx gelu_erf
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// One MFMA "k-step" on 16-byte operand chunks.
+//   bf16: v_mfma_f32_32x32x16_bf16, lane l holds row (l&31), k = 8*(l>>5)+[0..7]
+//   f32 : 4 x v_mfma_f32_32x32x2_f32, lane l holds row (l&31); the chunk's 4 floats
+//         are consumed one per instruction (k pairs {j, 4+j} across the two half-waves)
+__device__ __forceinline__ void mfma_chunk(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_chunk(f32x16& acc, const f32x4& a, const f32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+}
+template <typename T> struct FragOf;
+template <> struct FragOf<bf16> { typedef bf16x8 type; };
+template <> struct FragOf<float> { typedef f32x4 type; };
+
+// 32x32 accumulator element r of lane l sits at (row, col):
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
+
+}  // namespace cpt

@@ -1,0 +1,308 @@
+// C ABI of libcpt_hip.so (see include/cpt_hip.h): argument checks, error strings, per-kernel HIP
+// event timing and the whole-model forward built from the kernels in gemm/attention/rowops.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(int rc, const char* what) {
+    if (rc != CPT_OK) return fail(rc, "%s: rejected arguments (status %d)", what, rc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CPT_ERR_HIP - (int)e, "%s: %s", what, hipGetErrorString(e));
+    return CPT_OK;
+}
+
+// ---- per-kernel event timing ---------------------------------------------------------------
+struct Prof {
+    bool on = false;
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        hipEventCreate(&e);
+        return e;
+    }
+    void recycle() {
+        for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
+        recs.clear();
+    }
+} g_prof;
+
+struct Scope {
+    int idx = -1;
+    hipStream_t s;
+    Scope(int id, hipStream_t st) : s(st) {
+        if (!g_prof.on) return;
+        Prof::Rec r{id, g_prof.get(), g_prof.get()};
+        hipEventRecord(r.a, s);
+        g_prof.recs.push_back(r);
+        idx = (int)g_prof.recs.size() - 1;
+    }
+    ~Scope() {
+        if (idx >= 0) hipEventRecord(g_prof.recs[idx].b, s);
+    }
+};
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct FwdLayout {
+    size_t x_f32, x_lp, qkv, ctx, pre, a_f32, a_lp, ffn, imgp, rows, t1, t2, pooled_f32, pooled_lp, logits_all_dummy, loss, total;
+};
+
+FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
+    const size_t es = d.dtype == CPT_BF16 ? 2 : 4;
+    const bool lp = d.dtype == CPT_BF16;
+    const size_t L = (size_t)Lt + Li, M = (size_t)B * L, H = d.hidden;
+    const size_t hr = (flags & CPT_OUT_ALL_LOGITS) ? M : (size_t)B;   // rows through the MLM head
+    FwdLayout w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t p = o; o += al(bytes); return p; };
+    w.x_f32 = take(M * H * 4);
+    w.x_lp = lp ? take(M * H * 2) : w.x_f32;
+    w.qkv = take(M * 3 * H * es);
+    w.ctx = take(M * H * es);
+    w.pre = take(M * H * 4);
+    w.a_f32 = take(M * H * 4);
+    w.a_lp = lp ? take(M * H * 2) : w.a_f32;
+    w.ffn = take(M * (size_t)d.inter * es);
+    w.imgp = take((size_t)B * Li * d.img_dim_pad * es);
+    w.rows = take(hr * H * es);
+    w.t1 = take(hr * H * 4);
+    w.t2 = lp ? take(hr * H * 2) : take(hr * H * 4);
+    w.pooled_f32 = take((size_t)B * H * 4);
+    w.pooled_lp = lp ? take((size_t)B * H * 2) : w.pooled_f32;
+    w.loss = take(256);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpt_version(void) { return CPT_ABI_VERSION; }
+const char* cpt_last_error(void) { return g_err; }
+
+int cpt_check_device(int dev) {
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return fail(CPT_ERR_HIP - (int)e, "hipGetDeviceProperties(%d): %s", dev, hipGetErrorString(e));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return fail(CPT_ERR_ARCH, "device %d is %s; libcpt_hip is built for gfx950 (MI355X) only", dev, p.gcnArchName);
+    return CPT_OK;
+}
+
+int cpt_prof_enable(int on) {
+    hipDeviceSynchronize();
+    g_prof.recycle();
+    g_prof.on = on != 0;
+    return CPT_OK;
+}
+
+int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches) {
+    if (!total_ms || !launches) return fail(CPT_ERR_NULL, "cpt_prof_read: null output");
+    hipDeviceSynchronize();
+    double t = 0;
+    int64_t n = 0;
+    for (auto& r : g_prof.recs) {
+        if (r.id != kernel_id) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { t += ms; ++n; }
+    }
+    *total_ms = t;
+    *launches = n;
+    return CPT_OK;
+}
+
+int cpt_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias,
+             const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
+             void* stream) {
+    if (!A || !W || !out) return fail(CPT_ERR_NULL, "cpt_gemm: null operand");
+    return check_launch(cpt::gemm(dtype, epi, A, lda, W, ldw, bias, resid, ldr, out, out_dtype, ldo, M, N, K, (hipStream_t)stream), "cpt_gemm");
+}
+
+int cpt_embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
+                 const float* posw, const float* typew, const float* g, const float* bta, float eps,
+                 float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
+                 int max_pos, int type_vocab, void* stream) {
+    return check_launch(cpt::embed_ln(ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, lp_dtype, B, Lt, L, H, vocab, max_pos, type_vocab, (hipStream_t)stream), "cpt_embed_ln");
+}
+
+int cpt_layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
+                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride,
+                       int grp_off, void* stream) {
+    return check_launch(cpt::layernorm_rows(x, g, bta, eps, out_f32, out_lp, lp_dtype, R, H, grp, grp_stride, grp_off, (hipStream_t)stream), "cpt_layernorm_rows");
+}
+
+int cpt_attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs,
+                  int B, int L, int heads, void* stream) {
+    return check_launch(cpt::attention(dtype, qkv, attn_mask, ctx, probs, B, L, heads, (hipStream_t)stream), "cpt_attention");
+}
+
+int cpt_pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, void* stream) {
+    if (!x || !out) return fail(CPT_ERR_NULL, "cpt_pad_cast: null operand");
+    return check_launch(cpt::pad_cast(x, out, dtype, R, K, Kp, (hipStream_t)stream), "cpt_pad_cast");
+}
+
+int cpt_gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H,
+                    void* stream) {
+    if (!src || !out) return fail(CPT_ERR_NULL, "cpt_gather_rows: null operand");
+    return check_launch(cpt::gather_rows(src, dtype, pos, out, B, L, H, (hipStream_t)stream), "cpt_gather_rows");
+}
+
+int cpt_ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V,
+                void* stream) {
+    return check_launch(cpt::ce_rows(logits, labels, loss, dlogits, R, V, (hipStream_t)stream), "cpt_ce_rows");
+}
+
+size_t cpt_fwd_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li, int flags) {
+    if (!d || B <= 0 || Lt <= 0 || Li < 0) return 0;
+    return fwd_layout(*d, B, Lt, Li, flags).total;
+}
+
+#define TRY(expr, what)                          \
+    do {                                         \
+        int rc__ = check_launch((expr), what);   \
+        if (rc__ != CPT_OK) return rc__;         \
+    } while (0)
+
+int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, int flags,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || !b || !o || !workspace) return fail(CPT_ERR_NULL, "cpt_model_fwd: null argument");
+    const cpt_dims& d = m->dims;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter;
+    if (B <= 0 || Lt <= 0 || Li < 0) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: bad batch shape B=%d Lt=%d Li=%d", B, Lt, Li);
+    if (d.heads <= 0 || H != d.heads * 64) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: hidden %d / heads %d: head_dim must be 64", H, d.heads);
+    if (L > 288) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: sequence length %d > 288 not supported", L);
+    if (d.dtype != CPT_F32 && d.dtype != CPT_BF16) return fail(CPT_ERR_DTYPE, "cpt_model_fwd: dtype %d", d.dtype);
+    if (d.img_dim_pad < d.img_dim || d.img_dim_pad % 8) return fail(CPT_ERR_ALIGN, "cpt_model_fwd: img_dim_pad %d must be >= img_dim and a multiple of 8", d.img_dim_pad);
+    if (Li > 0 && !b->img_feats) return fail(CPT_ERR_NULL, "cpt_model_fwd: img_feats is NULL with Li=%d", Li);
+    if ((flags & (CPT_OUT_MASK_LOGITS | CPT_OUT_ALL_LOGITS)) == (CPT_OUT_MASK_LOGITS | CPT_OUT_ALL_LOGITS))
+        return fail(CPT_ERR_SHAPE, "cpt_model_fwd: choose mask-row logits or all-row logits, not both");
+    if ((flags & CPT_OUT_MASK_LOGITS) && !b->mask_pos) return fail(CPT_ERR_NULL, "cpt_model_fwd: mask_pos required for CPT_OUT_MASK_LOGITS");
+    if ((flags & CPT_OUT_LOSS) && !(flags & (CPT_OUT_MASK_LOGITS | CPT_OUT_ALL_LOGITS)))
+        return fail(CPT_ERR_SHAPE, "cpt_model_fwd: CPT_OUT_LOSS needs a logits output");
+    if ((flags & CPT_OUT_LOSS) && (!b->labels || !o->loss)) return fail(CPT_ERR_NULL, "cpt_model_fwd: labels/loss required for CPT_OUT_LOSS");
+    if ((flags & CPT_OUT_REL) && (!m->w_rel || d.n_rel <= 0)) return fail(CPT_ERR_NULL, "cpt_model_fwd: model has no seq_relationship head");
+    if (flags & CPT_SAVE_FOR_BWD) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: CPT_SAVE_FOR_BWD not available in this build");
+    const FwdLayout w = fwd_layout(d, B, Lt, Li, flags);
+    if (workspace_bytes < w.total) return fail(CPT_ERR_WORKSPACE, "cpt_model_fwd: workspace %zu < required %zu bytes", workspace_bytes, w.total);
+    if ((uintptr_t)workspace & 255) return fail(CPT_ERR_ALIGN, "cpt_model_fwd: workspace must be 256-byte aligned");
+
+    unsigned char* ws = (unsigned char*)workspace;
+    const int dt = d.dtype;
+    const bool lp = dt == CPT_BF16;
+    float* x_f32 = (float*)(ws + w.x_f32);
+    void* x_lp = ws + w.x_lp;
+    void* qkv = ws + w.qkv;
+    void* ctx = ws + w.ctx;
+    float* pre = (float*)(ws + w.pre);
+    float* a_f32 = (float*)(ws + w.a_f32);
+    void* a_lp = ws + w.a_lp;
+    void* ffn = ws + w.ffn;
+
+    // (a2) text embeddings -> rows b*L + t
+    {
+        Scope p(CPT_K_EMBED, s);
+        TRY(cpt::embed_ln(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb,
+                          m->emb_ln_g, m->emb_ln_b, d.ln_eps, x_f32, lp ? x_lp : nullptr, dt, B, Lt, L, H,
+                          d.vocab, d.max_pos, d.type_vocab, s), "embed_ln");
+    }
+    // (a3,a4) region projection -> rows b*L + Lt + i
+    if (Li > 0) {
+        Scope p(CPT_K_IMG, s);
+        void* imgp = ws + w.imgp;
+        TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
+        TRY(cpt::gemm(dt, CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, pre,
+                      CPT_F32, H, B * Li, H, d.img_dim_pad, s), "gemm(img_embedding)");
+        const bool iln = d.use_img_ln && m->img_ln_g;
+        TRY(cpt::layernorm_rows(pre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, x_f32,
+                                lp ? x_lp : nullptr, dt, B * Li, H, Li, L, Lt, s), "layernorm(img)");
+    }
+    // (a5-a9) encoder
+    for (int l = 0; l < d.layers; ++l) {
+        const cpt_layer& y = m->layers[l];
+        { Scope p(CPT_K_GEMM_QKV, s);
+          TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)"); }
+        { Scope p(CPT_K_ATTN, s);
+          TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s), "attention"); }
+        { Scope p(CPT_K_GEMM_AO, s);
+          TRY(cpt::gemm(dt, CPT_EPI_RESID, ctx, H, y.w_ao, H, y.b_ao, x_f32, H, pre, CPT_F32, H, M, H, H, s), "gemm(attn out)"); }
+        { Scope p(CPT_K_LN, s);
+          TRY(cpt::layernorm_rows(pre, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, lp ? a_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(attn)"); }
+        { Scope p(CPT_K_GEMM_FFN1, s);
+          TRY(cpt::gemm(dt, CPT_EPI_GELU, a_lp, H, y.w_in, H, y.b_in, nullptr, 0, ffn, dt, I, M, I, H, s), "gemm(ffn up)"); }
+        { Scope p(CPT_K_GEMM_FFN2, s);
+          TRY(cpt::gemm(dt, CPT_EPI_RESID, ffn, I, y.w_out, I, y.b_out, a_f32, H, pre, CPT_F32, H, M, H, I, s), "gemm(ffn down)"); }
+        { Scope p(CPT_K_LN, s);
+          TRY(cpt::layernorm_rows(pre, y.ln2_g, y.ln2_b, d.ln_eps, x_f32, lp ? x_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(ffn)"); }
+    }
+
+    if (flags & CPT_OUT_SEQ) {
+        if (!o->seq) return fail(CPT_ERR_NULL, "cpt_model_fwd: seq output is NULL");
+        hipError_t e = hipMemcpyAsync(o->seq, x_f32, (size_t)M * H * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return fail(CPT_ERR_HIP - (int)e, "copy sequence_output: %s", hipGetErrorString(e));
+    }
+    // (a10) pooler, optional NSP-style relation head
+    if (flags & (CPT_OUT_POOLED | CPT_OUT_REL)) {
+        Scope p(CPT_K_HEAD, s);
+        void* rows = ws + w.rows;
+        float* pooled = (flags & CPT_OUT_POOLED) ? o->pooled : (float*)(ws + w.pooled_f32);
+        if (!pooled) return fail(CPT_ERR_NULL, "cpt_model_fwd: pooled output is NULL");
+        TRY(cpt::gather_rows(x_lp, dt, nullptr, rows, B, L, H, s), "gather([CLS])");
+        TRY(cpt::gemm(dt, CPT_EPI_TANH, rows, H, m->w_pool, H, m->b_pool, nullptr, 0, pooled, CPT_F32, H, B, H, H, s), "gemm(pooler)");
+        if (flags & CPT_OUT_REL) {
+            if (!o->rel) return fail(CPT_ERR_NULL, "cpt_model_fwd: rel output is NULL");
+            const void* pin = pooled;
+            if (lp) {
+                void* plp = ws + w.pooled_lp;
+                TRY(cpt::layernorm_rows(pooled, nullptr, nullptr, 0.f, nullptr, plp, dt, B, H, B, 0, 0, s), "cast(pooled)");
+                pin = plp;
+            }
+            TRY(cpt::gemm(dt, CPT_EPI_NONE, pin, H, m->w_rel, H, m->b_rel, nullptr, 0, o->rel, CPT_F32, d.n_rel, B, d.n_rel, H, s), "gemm(seq_relationship)");
+        }
+    }
+    // (a11,a12) MLM head on the [MASK] rows (or every row), optional CE loss
+    if (flags & (CPT_OUT_MASK_LOGITS | CPT_OUT_ALL_LOGITS)) {
+        Scope p(CPT_K_HEAD, s);
+        if (!o->logits) return fail(CPT_ERR_NULL, "cpt_model_fwd: logits output is NULL");
+        const bool all = flags & CPT_OUT_ALL_LOGITS;
+        const int R = all ? M : B;
+        const void* rows = x_lp;
+        if (!all) {
+            void* g = ws + w.rows;
+            TRY(cpt::gather_rows(x_lp, dt, b->mask_pos, g, B, L, H, s), "gather([MASK])");
+            rows = g;
+        }
+        float* t1 = (float*)(ws + w.t1);
+        void* t2 = ws + w.t2;
+        TRY(cpt::gemm(dt, CPT_EPI_GELU, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, t1, CPT_F32, H, R, H, H, s), "gemm(head transform)");
+        TRY(cpt::layernorm_rows(t1, m->tr_ln_g, m->tr_ln_b, d.ln_eps, lp ? nullptr : (float*)t2, lp ? t2 : nullptr, dt, R, H, R, 0, 0, s), "layernorm(head)");
+        TRY(cpt::gemm(dt, CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, R, d.vocab, H, s), "gemm(decoder)");
+        if (flags & CPT_OUT_LOSS) {
+            hipError_t e = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);
+            if (e != hipSuccess) return fail(CPT_ERR_HIP - (int)e, "zero loss: %s", hipGetErrorString(e));
+            TRY(cpt::ce_rows(o->logits, b->labels, o->loss, nullptr, R, d.vocab, s), "ce_rows");
+        }
+    }
+    return CPT_OK;
+}
+
+}  // extern "C"

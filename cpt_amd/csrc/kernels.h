@@ -1,0 +1,32 @@
+// Internal launcher declarations shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/cpt_hip.h"
+
+namespace cpt {
+
+int gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias,
+         const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
+         hipStream_t s);
+
+int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
+             const float* posw, const float* typew, const float* g, const float* bta, float eps,
+             float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
+             int max_pos, int type_vocab, hipStream_t s);
+
+int layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
+                   void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
+                   hipStream_t s);
+
+int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B,
+              int L, int heads, hipStream_t s);
+
+int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s);
+
+int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H,
+                hipStream_t s);
+
+int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V,
+            hipStream_t s);
+
+}  // namespace cpt

@@ -1,0 +1,233 @@
+// HBM-bound row kernels of the CPT hot path: embedding gather + LayerNorm, (residual) LayerNorm,
+// pad/cast of region features, row gather, cross-entropy over [MASK] rows.
+// One 64-lane wavefront per row, 16-byte loads, statistics by wave shuffles; fp32 math.
+#include "common.h"
+#include "kernels.h"
+
+namespace cpt {
+
+constexpr int ROW_THREADS = 256;            // 4 waves = 4 rows per workgroup
+constexpr int MAXV = 4;                     // float4 per lane: H <= 1024
+
+// two-pass mean / biased variance over a row held as up to MAXV float4 per lane
+__device__ __forceinline__ void ln_stats(const f32x4 (&v)[MAXV], int nv, int lane, int H, float& mean, float& rstd, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < H) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < H) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+}
+
+template <typename LP>
+__device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lane, int H, float mean, float rstd,
+                                         const float* g, const float* b, float* of, LP* ol) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < H) {
+            f32x4 y;
+            if (g) {
+                const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+            } else {
+                y = v[i];
+            }
+            if (of) *reinterpret_cast<f32x4*>(of + c) = y;
+            if (ol) {
+                if constexpr (sizeof(LP) == 2) {
+                    bf16x4 p;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) p[j] = (bf16)y[j];
+                    *reinterpret_cast<bf16x4*>(ol + c) = p;
+                } else {
+                    *reinterpret_cast<f32x4*>(ol + c) = y;
+                }
+            }
+        }
+    }
+}
+
+template <typename LP>
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
+    const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
+    float* __restrict__ out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int nv = (H + 255) / 256;
+    f32x4 v[MAXV];
+    const float* xr = x + (size_t)r * H;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < H) v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (g) ln_stats(v, nv, lane, H, mean, rstd, eps);
+    const size_t orow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
+    ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
+                 out_lp ? out_lp + orow * H : nullptr);
+}
+
+int layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
+                   void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
+                   hipStream_t s) {
+    if (R <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || grp <= 0) return CPT_ERR_SHAPE;
+    if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
+    if (grp_stride == 0 && grp != R) grp_stride = grp;
+    dim3 grid((R + 3) / 4), block(ROW_THREADS);
+    if (out_lp && lp_dtype == CPT_BF16)
+        layernorm_rows_kernel<bf16><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (bf16*)out_lp, R, H, grp, grp_stride, grp_off);
+    else
+        layernorm_rows_kernel<float><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (float*)out_lp, R, H, grp, grp_stride, grp_off);
+    return CPT_OK;
+}
+
+// ---- BertEmbeddings: gather 3 rows, add, LayerNorm -------------------------------------------
+template <typename LP>
+__global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(
+    const int64_t* __restrict__ ids, const int64_t* __restrict__ tt, const int64_t* __restrict__ pos,
+    const float* __restrict__ word, const float* __restrict__ posw, const float* __restrict__ typew,
+    const float* __restrict__ g, const float* __restrict__ bta, float eps, float* __restrict__ out_f32,
+    LP* __restrict__ out_lp, int B, int Lt, int L, int H, int vocab, int max_pos, int type_vocab) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+    if (r >= B * Lt) return;
+    const int b = r / Lt, t = r % Lt;
+    long wid = ids[r];
+    long pid = pos ? pos[r] : t;
+    long tid = tt ? tt[r] : 0;
+    // out-of-range ids would be a host bug; clamp so the kernel never faults
+    wid = wid < 0 ? 0 : (wid >= vocab ? vocab - 1 : wid);
+    pid = pid < 0 ? 0 : (pid >= max_pos ? max_pos - 1 : pid);
+    tid = tid < 0 ? 0 : (tid >= type_vocab ? type_vocab - 1 : tid);
+    const int nv = (H + 255) / 256;
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < H) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(word + (size_t)wid * H + c);
+            const f32x4 p = *reinterpret_cast<const f32x4*>(posw + (size_t)pid * H + c);
+            const f32x4 q = *reinterpret_cast<const f32x4*>(typew + (size_t)tid * H + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = a[j] + p[j] + q[j];
+        }
+    }
+    float mean, rstd;
+    ln_stats(v, nv, lane, H, mean, rstd, eps);
+    const size_t orow = (size_t)b * L + t;
+    ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
+                 out_lp ? out_lp + orow * H : nullptr);
+}
+
+int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
+             const float* posw, const float* typew, const float* g, const float* bta, float eps,
+             float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
+             int max_pos, int type_vocab, hipStream_t s) {
+    if (B <= 0 || Lt <= 0 || L < Lt || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
+    if (!ids || !word || !posw || !typew || !g || !bta) return CPT_ERR_NULL;
+    if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
+    dim3 grid((B * Lt + 3) / 4), block(ROW_THREADS);
+    if (out_lp && lp_dtype == CPT_BF16)
+        embed_ln_kernel<bf16><<<grid, block, 0, s>>>(ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, (bf16*)out_lp, B, Lt, L, H, vocab, max_pos, type_vocab);
+    else
+        embed_ln_kernel<float><<<grid, block, 0, s>>>(ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, (float*)out_lp, B, Lt, L, H, vocab, max_pos, type_vocab);
+    return CPT_OK;
+}
+
+// ---- pad + cast: x[R][K] f32 -> out[R][Kp] T ---------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__ x, T* __restrict__ out, int R, int K, int Kp) {
+    // one thread per pair of output elements; rows of x are only 8-byte aligned when K is even
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int hp = Kp / 2;
+    if (idx >= (size_t)R * hp) return;
+    const int r = (int)(idx / hp), c = (int)(idx % hp) * 2;
+    const float a = c < K ? x[(size_t)r * K + c] : 0.f;
+    const float b = c + 1 < K ? x[(size_t)r * K + c + 1] : 0.f;
+    out[(size_t)r * Kp + c] = from_f32<T>(a);
+    out[(size_t)r * Kp + c + 1] = from_f32<T>(b);
+}
+
+int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s) {
+    if (R <= 0 || K <= 0 || Kp < K || Kp % 2) return CPT_ERR_SHAPE;
+    const size_t n = (size_t)R * (Kp / 2);
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == CPT_BF16) pad_cast_kernel<bf16><<<grid, block, 0, s>>>(x, (bf16*)out, R, K, Kp);
+    else if (dtype == CPT_F32) pad_cast_kernel<float><<<grid, block, 0, s>>>(x, (float*)out, R, K, Kp);
+    else return CPT_ERR_DTYPE;
+    return CPT_OK;
+}
+
+// ---- gather rows: out[b] = src[b*L + pos[b]] ---------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int64_t* __restrict__ pos,
+                                                          uint4* __restrict__ out, int B, int L, int chunks) {
+    const int b = blockIdx.x;
+    long p = pos ? pos[b] : 0;
+    p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+    const uint4* s = src + ((size_t)b * L + p) * chunks;
+    for (int c = threadIdx.x; c < chunks; c += 256) out[(size_t)b * chunks + c] = s[c];
+}
+
+int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H, hipStream_t s) {
+    const int esz = dtype == CPT_BF16 ? 2 : 4;
+    if (B <= 0 || L <= 0 || (H * esz) % 16) return CPT_ERR_SHAPE;
+    gather_rows_kernel<<<dim3(B), dim3(256), 0, s>>>((const uint4*)src, pos, (uint4*)out, B, L, H * esz / 16);
+    return CPT_OK;
+}
+
+// ---- cross entropy over rows (ignore_index = -1) ----------------------------------------------
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                      float* __restrict__ loss, float* __restrict__ dlogits, int R, int V) {
+    __shared__ float red[8];
+    const int r = blockIdx.x;
+    const long lab = labels[r];
+    const float* x = logits + (size_t)r * V;
+    float* d = dlogits ? dlogits + (size_t)r * V : nullptr;
+    if (lab < 0 || lab >= V) {            // ignored row: no loss, zero gradient
+        if (d) for (int c = threadIdx.x; c < V; c += 256) d[c] = 0.f;
+        return;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < V; c += 256) sum += expf(x[c] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + w] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    const float lse = m + logf(sum);
+    if (threadIdx.x == 0) {
+        atomicAdd(&loss[0], lse - x[lab]);
+        atomicAdd(&loss[1], 1.0f);
+    }
+    if (d) {
+        const float inv = 1.0f / sum;
+        for (int c = threadIdx.x; c < V; c += 256) d[c] = expf(x[c] - m) * inv - (c == lab ? 1.f : 0.f);
+    }
+}
+
+int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V, hipStream_t s) {
+    if (R <= 0 || V <= 0) return CPT_ERR_SHAPE;
+    if (!logits || !labels || !loss) return CPT_ERR_NULL;
+    ce_rows_kernel<<<dim3(R), dim3(256), 0, s>>>(logits, labels, loss, dlogits, R, V);
+    return CPT_OK;
+}
+
+}  // namespace cpt

@@ -1,0 +1,297 @@
+"""Host-side engine: packs a model's parameters into flat device buffers, builds the
+``cpt_model`` descriptor of include/cpt_hip.h and launches the HIP forward.
+
+MI355X-first layout: every fp32 parameter lives in ONE contiguous buffer (the nn.Parameters of
+the module tree are views into it, so ``state_dict`` stays the source of truth), with
+query/key/value weights adjacent so the three projections run as one N=3H GEMM.  The same
+layout is mirrored in a bf16 shadow for the MFMA operands, in a flat gradient buffer (one RCCL
+all-reduce covers all gradients) and in flat AdamW moments (one fused optimizer kernel).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .synth import param_specs
+
+ALIGN = 64  # elements
+
+
+def pack_order(cfg, head):
+    """Parameter names in flat-buffer order: as param_specs, but q/k/v weights adjacent, then
+    q/k/v biases adjacent (fused QKV GEMM reads them as [3H][H] and [3H])."""
+    names = [n for n, _, kind in param_specs(cfg, head) if kind != "tied"]
+    final = []
+    for n in names:
+        if ".attention.self." in n:
+            continue
+        if n.endswith("attention.output.dense.weight"):
+            p = n[: -len("output.dense.weight")] + "self."
+            final += [p + "query.weight", p + "key.weight", p + "value.weight",
+                      p + "query.bias", p + "key.bias", p + "value.bias"]
+        final.append(n)
+    return final
+
+
+class PackedModel(object):
+    """Flat parameter storage + C descriptor for one nn.Module (BertImgModel or a head wrapper)."""
+
+    def __init__(self, module, cfg, head, prefix_map=None):
+        self.module = module
+        self.cfg = cfg
+        self.head = head            # 'cpt' | 'pretrain' | 'none'
+        self.flat = None
+        self.flat_lp = None
+        self.grad = None
+        self.offsets = {}
+        self._ptrs = None
+        self._sig = None
+        self._desc = {}
+        self._ws = {}
+        self.dtype = "fp32"
+
+    # ---- packing -------------------------------------------------------------------------
+    def _named(self):
+        named = dict(self.module.named_parameters())
+        pre = "" if self.head != "none" else "bert."
+        out = {}
+        for n in pack_order(self.cfg, self.head):
+            key = n[len(pre):] if pre and n.startswith(pre) else n
+            if key not in named:
+                raise RuntimeError("cpt_amd: parameter %s missing from module" % key)
+            out[n] = named[key]
+        return out
+
+    def _packed_ok(self):
+        # cheap per-call check: Module.to()/load paths replace every .data or none
+        if self.flat is None:
+            return False
+        first, last, last_off = self._probe
+        base = self.flat.data_ptr()
+        return first.data_ptr() == base and last.data_ptr() == base + last_off * 4
+
+    def ensure_packed(self):
+        if self._packed_ok():
+            return
+        named = self._named()
+        dev = next(iter(named.values())).device
+        if dev.type != "cuda":
+            raise RuntimeError("cpt_amd: model parameters are on %s; move the model to the GPU "
+                               "(the HIP path has no CPU fallback)" % dev)
+        for n, p in named.items():
+            if p.dtype != torch.float32:
+                raise RuntimeError("cpt_amd: parameter %s is %s; master weights must be fp32" % (n, p.dtype))
+        total = 0
+        self.offsets = {}
+        for n, p in named.items():
+            self.offsets[n] = (total, p.numel())
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        for n, p in named.items():
+            off, num = self.offsets[n]
+            flat[off:off + num].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + num].view(p.shape)
+        self.flat = flat
+        self._plist = list(named.values())
+        order = list(named)
+        self._probe = (named[order[0]], named[order[-1]], self.offsets[order[-1]][0])
+        self.flat_lp = None
+        self.grad = None
+        self._sig = None
+        self._desc = {}
+
+    def view(self, name, flat=None):
+        off, num = self.offsets[name]
+        return (self.flat if flat is None else flat)[off:off + num]
+
+    def _versions(self):
+        return sum(p._version for p in self._plist)
+
+    def refresh_shadow(self, force=False):
+        """bf16 copy of the flat buffer + zero-padded img weight; redone whenever a parameter
+        was written in place (load_state_dict, an optimizer step done outside this engine)."""
+        sig = self._versions()
+        if self._sig is None:
+            self._sig = {}
+        if not force and self._sig.get(self.dtype) == sig:
+            return
+        self._sig[self.dtype] = sig
+        cfg = self.cfg
+        H, D = cfg.hidden_size, cfg.img_feature_dim
+        Dp = (D + 7) // 8 * 8
+        st = L.stream_ptr()
+        w_img = self.view("bert.img_embedding.weight")
+        n = self.flat.numel()
+        if self.dtype == "bf16":
+            if self.flat_lp is None or self.flat_lp.device != self.flat.device:
+                self.flat_lp = torch.empty(n, device=self.flat.device, dtype=torch.bfloat16)
+                self.img_pad_lp = torch.empty((H, Dp), device=self.flat.device, dtype=torch.bfloat16)
+            L.check(L.lib().cpt_pad_cast(self.flat.data_ptr(), self.flat_lp.data_ptr(), L.CPT_BF16, 1, n, n, st),
+                    "cpt_pad_cast(shadow)")
+            L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_lp.data_ptr(), L.CPT_BF16, H, D, Dp, st),
+                    "cpt_pad_cast(w_img)")
+        else:
+            if getattr(self, "img_pad_f32", None) is None or self.img_pad_f32.device != self.flat.device:
+                self.img_pad_f32 = torch.empty((H, Dp), device=self.flat.device, dtype=torch.float32)
+            L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_f32.data_ptr(), L.CPT_F32, H, D, Dp, st),
+                    "cpt_pad_cast(w_img)")
+        self._desc = {}
+
+    # ---- descriptor ----------------------------------------------------------------------
+    def descriptor(self):
+        key = self.dtype
+        if key in self._desc:
+            return self._desc[key]
+        cfg = self.cfg
+        lp = self.dtype == "bf16"
+        esz = 2 if lp else 4
+        mat_base = (self.flat_lp if lp else self.flat).data_ptr()
+        vec_base = self.flat.data_ptr()
+
+        def mat(n):
+            return mat_base + self.offsets[n][0] * esz
+
+        def vec(n):
+            return vec_base + self.offsets[n][0] * 4
+
+        D = cfg.img_feature_dim
+        d = L.Dims(hidden=cfg.hidden_size, heads=cfg.num_attention_heads, inter=cfg.intermediate_size,
+                   layers=cfg.num_hidden_layers, vocab=cfg.vocab_size, img_dim=D, img_dim_pad=(D + 7) // 8 * 8,
+                   max_pos=cfg.max_position_embeddings, type_vocab=cfg.type_vocab_size,
+                   use_img_ln=1 if getattr(cfg, "use_img_layernorm", None) else 0,
+                   n_rel=getattr(cfg, "num_contrast_classes", 2) if self.head == "pretrain" else 0,
+                   dtype=L.CPT_BF16 if lp else L.CPT_F32, ln_eps=cfg.layer_norm_eps,
+                   img_ln_eps=getattr(cfg, "img_layer_norm_eps", cfg.layer_norm_eps))
+        layers = (L.Layer * cfg.num_hidden_layers)()
+        for i in range(cfg.num_hidden_layers):
+            p = "bert.encoder.layer.%d." % i
+            y = layers[i]
+            y.w_qkv = mat(p + "attention.self.query.weight")
+            y.b_qkv = vec(p + "attention.self.query.bias")
+            y.w_ao = mat(p + "attention.output.dense.weight")
+            y.b_ao = vec(p + "attention.output.dense.bias")
+            y.ln1_g = vec(p + "attention.output.LayerNorm.weight")
+            y.ln1_b = vec(p + "attention.output.LayerNorm.bias")
+            y.w_in = mat(p + "intermediate.dense.weight")
+            y.b_in = vec(p + "intermediate.dense.bias")
+            y.w_out = mat(p + "output.dense.weight")
+            y.b_out = vec(p + "output.dense.bias")
+            y.ln2_g = vec(p + "output.LayerNorm.weight")
+            y.ln2_b = vec(p + "output.LayerNorm.bias")
+        m = L.Model()
+        m.dims = d
+        m.word_emb = vec("bert.embeddings.word_embeddings.weight")
+        m.pos_emb = vec("bert.embeddings.position_embeddings.weight")
+        m.type_emb = vec("bert.embeddings.token_type_embeddings.weight")
+        m.emb_ln_g = vec("bert.embeddings.LayerNorm.weight")
+        m.emb_ln_b = vec("bert.embeddings.LayerNorm.bias")
+        m.w_img = (self.img_pad_lp if lp else self.img_pad_f32).data_ptr()
+        m.b_img = vec("bert.img_embedding.bias")
+        if d.use_img_ln:
+            m.img_ln_g = vec("bert.LayerNorm.weight")
+            m.img_ln_b = vec("bert.LayerNorm.bias")
+        m.layers = C.cast(layers, C.POINTER(L.Layer))
+        m.w_pool = mat("bert.pooler.dense.weight")
+        m.b_pool = vec("bert.pooler.dense.bias")
+        if self.head != "none":
+            hp = "cls." if self.head == "cpt" else "cls.predictions."
+            m.w_tr = mat(hp + "transform.dense.weight")
+            m.b_tr = vec(hp + "transform.dense.bias")
+            m.tr_ln_g = vec(hp + "transform.LayerNorm.weight")
+            m.tr_ln_b = vec(hp + "transform.LayerNorm.bias")
+            m.w_dec = mat("bert.embeddings.word_embeddings.weight")
+            m.b_dec = vec(hp + "bias")
+        if self.head == "pretrain":
+            m.w_rel = mat("cls.seq_relationship.weight")
+            m.b_rel = vec("cls.seq_relationship.bias")
+        self._desc[key] = (m, layers)     # keep `layers` alive
+        return self._desc[key]
+
+    # ---- forward -------------------------------------------------------------------------
+    def workspace(self, B, Lt, Li, flags):
+        m, _ = self.descriptor()
+        need = L.lib().cpt_fwd_workspace_bytes(C.byref(m.dims), B, Lt, Li, flags)
+        if need == 0:
+            raise RuntimeError("cpt_amd: cpt_fwd_workspace_bytes rejected B=%d Lt=%d Li=%d" % (B, Lt, Li))
+        ws = self._ws.get("fwd")
+        if ws is None or ws.numel() < need or ws.device != self.flat.device:
+            ws = torch.empty(need, device=self.flat.device, dtype=torch.uint8)
+            self._ws["fwd"] = ws
+        return ws
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, img_feats=None,
+                mask_pos=None, labels=None, flags=0):
+        """Returns dict with the outputs selected by `flags` (see _lib.OUT_*)."""
+        self.ensure_packed()
+        self.refresh_shadow()
+        dev = self.flat.device
+
+        def prep(t, dt, name):
+            if t is None:
+                return None
+            if not t.is_cuda:
+                raise RuntimeError("cpt_amd: %s is on %s; inputs must be on the GPU" % (name, t.device))
+            if t.dtype != dt:
+                t = t.to(dt)
+            return t.contiguous()
+
+        input_ids = prep(input_ids, torch.int64, "input_ids")
+        token_type_ids = prep(token_type_ids, torch.int64, "token_type_ids")
+        position_ids = prep(position_ids, torch.int64, "position_ids")
+        if attention_mask is not None and attention_mask.dim() != 2:
+            # reference accepts a 3-D mask too (modeling_bert.py:215-216); no CPT driver uses it
+            raise NotImplementedError("cpt_amd: only 2-D attention_mask is supported by the HIP path")
+        attention_mask = prep(attention_mask, torch.int64, "attention_mask")
+        img_feats = prep(img_feats, torch.float32, "img_feats")
+        mask_pos = prep(mask_pos, torch.int64, "mask_token_pos")
+        labels = prep(labels, torch.int64, "labels")
+        B, Lt = input_ids.shape
+        Li = img_feats.size(1) if img_feats is not None else 0
+        Lseq = Lt + Li
+        if img_feats is not None and img_feats.size(2) != self.cfg.img_feature_dim:
+            raise RuntimeError("cpt_amd: img_feats last dim %d != config.img_feature_dim %d"
+                               % (img_feats.size(2), self.cfg.img_feature_dim))
+        if attention_mask is not None and tuple(attention_mask.shape) != (B, Lseq):
+            raise RuntimeError("cpt_amd: attention_mask shape %s != (%d, %d)" % (tuple(attention_mask.shape), B, Lseq))
+        m, _ = self.descriptor()
+        H, V = self.cfg.hidden_size, self.cfg.vocab_size
+        out = {}
+        o = L.Outputs()
+        if flags & L.OUT_SEQ:
+            out["seq"] = torch.empty((B, Lseq, H), device=dev, dtype=torch.float32)
+            o.seq = out["seq"].data_ptr()
+        if flags & L.OUT_POOLED:
+            out["pooled"] = torch.empty((B, H), device=dev, dtype=torch.float32)
+            o.pooled = out["pooled"].data_ptr()
+        if flags & L.OUT_MASK_LOGITS:
+            out["logits"] = torch.empty((B, V), device=dev, dtype=torch.float32)
+            o.logits = out["logits"].data_ptr()
+        if flags & L.OUT_ALL_LOGITS:
+            out["logits"] = torch.empty((B, Lseq, V), device=dev, dtype=torch.float32)
+            o.logits = out["logits"].data_ptr()
+        if flags & L.OUT_LOSS:
+            out["loss_acc"] = torch.empty(2, device=dev, dtype=torch.float32)
+            o.loss = out["loss_acc"].data_ptr()
+        if flags & L.OUT_REL:
+            out["rel"] = torch.empty((B, m.dims.n_rel), device=dev, dtype=torch.float32)
+            o.rel = out["rel"].data_ptr()
+        bt = L.Batch(B=B, Lt=Lt, Li=Li, input_ids=input_ids.data_ptr(), token_type=L.ptr(token_type_ids),
+                     position_ids=L.ptr(position_ids), attn_mask=L.ptr(attention_mask), img_feats=L.ptr(img_feats),
+                     mask_pos=L.ptr(mask_pos), labels=L.ptr(labels))
+        ws = self.workspace(B, Lt, Li, flags)
+        L.check(L.lib().cpt_model_fwd(C.byref(m), C.byref(bt), C.byref(o), flags, ws.data_ptr(), ws.numel(),
+                                      L.stream_ptr()), "cpt_model_fwd")
+        if flags & L.OUT_LOSS:
+            acc = out["loss_acc"]
+            out["loss"] = acc[0] / acc[1]       # mean over labelled rows (CrossEntropyLoss default)
+        return out
+
+
+def profile_read():
+    """{kernel name: (total_ms, launches)} accumulated since cpt_prof_enable(1)."""
+    res = {}
+    for i, name in enumerate(L.K_NAMES):
+        t, n = C.c_double(0), C.c_int64(0)
+        L.check(L.lib().cpt_prof_read(i, C.byref(t), C.byref(n)), "cpt_prof_read")
+        res[name] = (t.value, n.value)
+    return res

@@ -1,0 +1,107 @@
+"""Operator-level wrappers over the C ABI (torch tensors in, torch tensors out).
+
+These mirror the entry points of include/cpt_hip.h one to one; the parity tests drive
+them directly.  All tensors must live on the GPU; nothing here computes on the host.
+"""
+import torch
+
+from . import _lib as L
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return L.CPT_F32
+    if t.dtype == torch.bfloat16:
+        return L.CPT_BF16
+    raise TypeError("cpt_amd: unsupported dtype %s" % t.dtype)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("cpt_amd: tensors must be on the GPU (the HIP path has no CPU fallback)")
+
+
+def gemm(a, w, bias=None, epi=L.EPI_NONE, resid=None, out_dtype=None):
+    """epi(a[M,K] @ w[N,K].T + bias (+ resid))."""
+    _need_cuda(a, w, bias, resid)
+    assert a.dim() == 2 and w.dim() == 2 and a.size(1) == w.size(1) and a.dtype == w.dtype
+    assert a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.size(0)
+    out_dtype = out_dtype or a.dtype
+    out = torch.empty((M, N), device=a.device, dtype=out_dtype)
+    if resid is not None:
+        assert resid.dtype == torch.float32 and resid.shape == (M, N) and resid.stride(1) == 1
+    L.check(L.lib().cpt_gemm(_dt(a), epi, a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), L.ptr(bias),
+                             L.ptr(resid), resid.stride(0) if resid is not None else 0, out.data_ptr(),
+                             L.CPT_BF16 if out_dtype == torch.bfloat16 else L.CPT_F32, out.stride(0), M, N, K,
+                             L.stream_ptr()), "cpt_gemm")
+    return out
+
+
+def embed_ln(ids, tt, pos, word, posw, typew, g, b, eps, L_total, lp_dtype=None):
+    _need_cuda(ids, word)
+    B, Lt = ids.shape
+    H = word.size(1)
+    out = torch.zeros((B, L_total, H), device=ids.device, dtype=torch.float32)
+    out_lp = torch.zeros((B, L_total, H), device=ids.device, dtype=lp_dtype) if lp_dtype is not None else None
+    L.check(L.lib().cpt_embed_ln(ids.data_ptr(), L.ptr(tt), L.ptr(pos), word.data_ptr(), posw.data_ptr(),
+                                 typew.data_ptr(), g.data_ptr(), b.data_ptr(), float(eps), out.data_ptr(),
+                                 L.ptr(out_lp), L.CPT_BF16 if lp_dtype == torch.bfloat16 else L.CPT_F32, B, Lt,
+                                 L_total, H, word.size(0), posw.size(0), typew.size(0), L.stream_ptr()),
+            "cpt_embed_ln")
+    return out, out_lp
+
+
+def layernorm_rows(x, g, b, eps, lp_dtype=None, out=None, out_lp=None, grp=None, grp_stride=0, grp_off=0):
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    R, H = x.shape
+    if out is None and grp is None:
+        out = torch.empty_like(x)
+    if lp_dtype is not None and out_lp is None:
+        out_lp = torch.empty((R, H), device=x.device, dtype=lp_dtype)
+    L.check(L.lib().cpt_layernorm_rows(x.data_ptr(), L.ptr(g), L.ptr(b), float(eps), L.ptr(out), L.ptr(out_lp),
+                                       L.CPT_BF16 if (out_lp is not None and out_lp.dtype == torch.bfloat16) else L.CPT_F32,
+                                       R, H, grp or R, grp_stride, grp_off, L.stream_ptr()), "cpt_layernorm_rows")
+    return out, out_lp
+
+
+def attention(qkv, attn_mask, B, Lseq, heads, want_probs=False):
+    _need_cuda(qkv, attn_mask)
+    assert qkv.is_contiguous() and qkv.shape == (B * Lseq, 3 * heads * 64)
+    ctx = torch.empty((B * Lseq, heads * 64), device=qkv.device, dtype=qkv.dtype)
+    probs = torch.zeros((B, heads, Lseq, Lseq), device=qkv.device, dtype=qkv.dtype) if want_probs else None
+    L.check(L.lib().cpt_attention(_dt(qkv), qkv.data_ptr(), L.ptr(attn_mask), ctx.data_ptr(), L.ptr(probs), B,
+                                  Lseq, heads, L.stream_ptr()), "cpt_attention")
+    return (ctx, probs) if want_probs else ctx
+
+
+def pad_cast(x, Kp, dtype):
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    R, K = x.shape
+    out = torch.empty((R, Kp), device=x.device, dtype=dtype)
+    L.check(L.lib().cpt_pad_cast(x.data_ptr(), out.data_ptr(), _dt(out), R, K, Kp, L.stream_ptr()), "cpt_pad_cast")
+    return out
+
+
+def gather_rows(src, pos, B, Lseq):
+    _need_cuda(src, pos)
+    H = src.size(-1)
+    out = torch.empty((B, H), device=src.device, dtype=src.dtype)
+    L.check(L.lib().cpt_gather_rows(src.data_ptr(), _dt(src), L.ptr(pos), out.data_ptr(), B, Lseq, H,
+                                    L.stream_ptr()), "cpt_gather_rows")
+    return out
+
+
+def ce_rows(logits, labels, want_grad=False):
+    _need_cuda(logits, labels)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and labels.dtype == torch.int64
+    R, V = logits.shape
+    loss = torch.zeros(2, device=logits.device, dtype=torch.float32)
+    d = torch.empty_like(logits) if want_grad else None
+    L.check(L.lib().cpt_ce_rows(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), L.ptr(d), R, V,
+                                L.stream_ptr()), "cpt_ce_rows")
+    return (loss, d) if want_grad else loss

@@ -1,0 +1,213 @@
+/* cpt_hip.h -- C ABI of libcpt_hip.so: the MI355X (gfx950) implementation of CPT's
+ * data-parallel hot path, the Oscar/BertImg forward/backward pass that scores colour-word
+ * [MASK] logits over text-token + VinVL region-feature sequences.
+ *
+ * The reference has no native FFI for this path: it is PyTorch eager code.  Each entry point
+ * below replaces the reference Python interface cited next to it (paths relative to
+ * /root/reference).  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch's caching allocator in practice) unless marked host.  The library never
+ *     allocates device memory and keeps no pointer after a call returns.
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (void* here so the
+ *     header needs no HIP include); no internal threads; re-entrant.
+ *   - return value: CPT_OK (0) or a negative status; cpt_last_error() gives a host string for
+ *     the calling thread.  No C++ exception crosses the boundary.
+ *   - dtype: CPT_F32 runs every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32; parity mode, matches
+ *     the reference CPU path to ~1e-5); CPT_BF16 feeds bf16 operands to v_mfma_f32_32x32x16_bf16
+ *     with fp32 accumulation and keeps the residual stream, LayerNorm, softmax, GELU and all
+ *     reductions in fp32 (throughput mode).
+ */
+#ifndef CPT_HIP_H
+#define CPT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPT_ABI_VERSION 1
+
+enum { CPT_F32 = 0, CPT_BF16 = 1 };
+enum { CPT_EPI_NONE = 0, CPT_EPI_GELU = 1, CPT_EPI_TANH = 2, CPT_EPI_RESID = 3 };
+enum {
+    CPT_OK = 0,
+    CPT_ERR_SHAPE = -1,      /* unsupported / inconsistent sizes */
+    CPT_ERR_DTYPE = -2,
+    CPT_ERR_ALIGN = -3,      /* pointer not 16-byte aligned or K/ld not a multiple of 16 bytes */
+    CPT_ERR_ARCH = -4,       /* device is not gfx950 */
+    CPT_ERR_WORKSPACE = -5,  /* workspace too small */
+    CPT_ERR_NULL = -6,
+    CPT_ERR_HIP = -1000      /* -1000 - hipError_t */
+};
+
+int cpt_version(void);
+const char* cpt_last_error(void);
+/* 0 when device `dev` is gfx950, CPT_ERR_ARCH otherwise. */
+int cpt_check_device(int dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Model description: what BertImgModel / REC_MLM_CPT hold as nn.Module state
+ * (Oscar/oscar/modeling/modeling_bert.py:153-183, modeling_rec.py:101-109).  Matrices are
+ * nn.Linear layout (out x in, row-major) in the COMPUTE dtype (fp32 master tensors in CPT_F32
+ * mode, a bf16 shadow in CPT_BF16 mode); vectors (biases, LayerNorm gain/shift) and the
+ * embedding tables used by the gather are always fp32 -- i.e. the tensors of the state dict.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t hidden;        /* config.hidden_size (multiple of 64) */
+    int32_t heads;         /* config.num_attention_heads; hidden / heads must be 64 */
+    int32_t inter;         /* config.intermediate_size */
+    int32_t layers;        /* config.num_hidden_layers */
+    int32_t vocab;         /* config.vocab_size */
+    int32_t img_dim;       /* config.img_feature_dim (2054) */
+    int32_t img_dim_pad;   /* img_dim rounded up to a multiple of 8: leading dim of w_img */
+    int32_t max_pos;       /* config.max_position_embeddings */
+    int32_t type_vocab;    /* config.type_vocab_size */
+    int32_t use_img_ln;    /* config.use_img_layernorm */
+    int32_t n_rel;         /* rows of cls.seq_relationship (num_contrast_classes), 0 if absent */
+    int32_t dtype;         /* CPT_F32 | CPT_BF16 */
+    float ln_eps;          /* config.layer_norm_eps */
+    float img_ln_eps;      /* config.img_layer_norm_eps */
+} cpt_dims;
+
+typedef struct {           /* bert.encoder.layer.{i}.* */
+    const void* w_qkv;     /* [3H][H]: attention.self.{query,key,value}.weight stacked */
+    const float* b_qkv;    /* [3H] */
+    const void* w_ao;      /* attention.output.dense.weight [H][H] */
+    const float* b_ao;
+    const float* ln1_g;    /* attention.output.LayerNorm.{weight,bias} */
+    const float* ln1_b;
+    const void* w_in;      /* intermediate.dense.weight [I][H] */
+    const float* b_in;
+    const void* w_out;     /* output.dense.weight [H][I] */
+    const float* b_out;
+    const float* ln2_g;    /* output.LayerNorm.{weight,bias} */
+    const float* ln2_b;
+} cpt_layer;
+
+typedef struct {
+    cpt_dims dims;
+    const float* word_emb;   /* bert.embeddings.word_embeddings.weight [V][H] fp32 */
+    const float* pos_emb;    /* position_embeddings.weight [P][H] */
+    const float* type_emb;   /* token_type_embeddings.weight [T][H] */
+    const float* emb_ln_g;   /* embeddings.LayerNorm */
+    const float* emb_ln_b;
+    const void* w_img;       /* bert.img_embedding.weight padded to [H][img_dim_pad], compute dtype */
+    const float* b_img;
+    const float* img_ln_g;   /* bert.LayerNorm (NULL unless use_img_ln) */
+    const float* img_ln_b;
+    const cpt_layer* layers; /* HOST array of dims.layers entries */
+    const void* w_pool;      /* bert.pooler.dense [H][H] */
+    const float* b_pool;
+    const void* w_tr;        /* cls.transform.dense [H][H] */
+    const float* b_tr;
+    const float* tr_ln_g;    /* cls.transform.LayerNorm */
+    const float* tr_ln_b;
+    const void* w_dec;       /* cls.decoder.weight [V][H] (tied word embeddings), compute dtype */
+    const float* b_dec;      /* cls.bias [V] */
+    const void* w_rel;       /* cls.seq_relationship.weight [n_rel][H] compute dtype, or NULL */
+    const float* b_rel;
+} cpt_model;
+
+/* One batch as the reference drivers hand it to the model
+ * (Oscar/oscar/zeroshot/refcoco_cpt.py:213-218): int64 ids / mask, fp32 region features. */
+typedef struct {
+    int32_t B, Lt, Li;            /* sequences, text length (70), region slots (50); L = Lt + Li */
+    const int64_t* input_ids;     /* [B][Lt] */
+    const int64_t* token_type;    /* [B][Lt] or NULL (zeros) */
+    const int64_t* position_ids;  /* [B][Lt] or NULL (arange) */
+    const int64_t* attn_mask;     /* [B][L] 1 = attend, or NULL (ones) */
+    const float* img_feats;       /* [B][Li][img_dim] fp32, or NULL when Li == 0 */
+    const int64_t* mask_pos;      /* [B] position of [MASK] per sequence (rows mode) or NULL */
+    const int64_t* labels;        /* rows mode: [B] target id (-1 ignored); all-rows: [B][L]; or NULL */
+} cpt_batch;
+
+enum {
+    CPT_OUT_SEQ = 1,        /* sequence_output [B][L][H] fp32 (BertImgModel.forward()[0]) */
+    CPT_OUT_POOLED = 2,     /* pooled_output [B][H] fp32 (modeling_bert.py:275) */
+    CPT_OUT_MASK_LOGITS = 4,/* prediction scores of the [MASK] rows only [B][V] fp32 */
+    CPT_OUT_ALL_LOGITS = 8, /* prediction scores of every position [B][L][V] (modeling_rec.py:143) */
+    CPT_OUT_LOSS = 16,      /* CrossEntropy(ignore_index=-1) (modeling_rec.py:147-150) */
+    CPT_OUT_REL = 32,       /* cls.seq_relationship(pooled) [B][n_rel] (modeling_vcr.py NSPCPT) */
+    CPT_SAVE_FOR_BWD = 1024 /* keep per-layer activations in the workspace for cpt_model_bwd */
+};
+
+typedef struct {
+    float* seq;          /* CPT_OUT_SEQ */
+    float* pooled;       /* CPT_OUT_POOLED */
+    float* logits;       /* CPT_OUT_MASK_LOGITS [B][V] or CPT_OUT_ALL_LOGITS [B][L][V] */
+    float* loss;         /* CPT_OUT_LOSS: [2] = {sum of row losses / count, count} */
+    float* rel;          /* CPT_OUT_REL */
+} cpt_outputs;
+
+/* Workspace the caller must supply for cpt_model_fwd with these flags (bytes). */
+size_t cpt_fwd_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li, int flags);
+
+/* REC_MLM_CPT.forward / BertImgModel.forward (modeling_rec.py:137-152, modeling_bert.py:199-279):
+ * embeddings + region projection written into one [B][L][H] buffer, N encoder layers, then the
+ * outputs selected by `flags`. */
+int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, int flags,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entry points (the kernels cpt_model_fwd is built from; also what the parity
+ * tests call one by one).
+ * ---------------------------------------------------------------------------------------- */
+
+/* out = epi(A[M][K] . W[N][K]^T + bias (+ resid)); A, W in `dtype`; out in `out_dtype`
+ * (CPT_F32 always allowed; CPT_BF16 only with dtype CPT_BF16).  Replaces nn.Linear (+gelu /
+ * tanh / residual add) at modeling_bert.py:38-40,85,144,145,261,275 and modeling_rec.py:143. */
+int cpt_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias,
+             const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
+             void* stream);
+
+/* BertEmbeddings.forward (call site modeling_bert.py:244-245): LN(word[ids]+pos[pid]+type[tt])
+ * for B*Lt tokens, written to rows b*L + t of out_f32 [B*L][H] (and out_lp when non-NULL). */
+int cpt_embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
+                 const float* posw, const float* typew, const float* g, const float* bta, float eps,
+                 float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
+                 int max_pos, int type_vocab, void* stream);
+
+/* BertLayerNorm over rows of x[R][H] (fp32), biased variance, eps inside the sqrt.  Input row r
+ * goes to output row (r / grp) * grp_stride + grp_off + r % grp (grp = R, stride 0, off 0 for a
+ * plain LayerNorm; grp = Li, stride = L, off = Lt places region rows behind the text rows,
+ * replacing torch.cat at modeling_bert.py:269).  g == NULL skips the affine+norm (copy/cast). */
+int cpt_layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
+                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride,
+                       int grp_off, void* stream);
+
+/* CaptionBertSelfAttention core (modeling_bert.py:42-67) for head_dim 64: qkv [B*L][3H] ->
+ * ctx [B*L][H]; softmax(QK^T/8 + (1-mask)*-10000) V, scores never leave the chip.
+ * probs (optional, [B][heads][L][L] in `dtype`) is written only for the backward pass. */
+int cpt_attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs,
+                  int B, int L, int heads, void* stream);
+
+/* x[R][K] fp32 -> out[R][Kp] in `dtype`, zero-padded (region features / img weight, K=2054). */
+int cpt_pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, void* stream);
+
+/* out[b][:] = src[b*L + pos[b]][:] (pos NULL = row 0): the [MASK] rows
+ * (zeroshot/refcoco_cpt.py:219) and the [CLS] rows of BertPooler. */
+int cpt_gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H,
+                    void* stream);
+
+/* CrossEntropyLoss(ignore_index=-1) over rows of logits[R][V] (modeling_rec.py:147-150).
+ * loss[0] += sum of row losses, loss[1] += labelled-row count (caller zeroes loss first);
+ * dlogits (optional) = softmax - onehot for labelled rows, 0 otherwise (caller scales by 1/count). */
+int cpt_ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V,
+                void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * ---------------------------------------------------------------------------------------- */
+enum { CPT_K_GEMM_QKV = 0, CPT_K_ATTN, CPT_K_GEMM_AO, CPT_K_LN, CPT_K_GEMM_FFN1, CPT_K_GEMM_FFN2,
+       CPT_K_EMBED, CPT_K_IMG, CPT_K_HEAD, CPT_K_COUNT };
+int cpt_prof_enable(int on);                          /* resets accumulators */
+int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPT_HIP_H */

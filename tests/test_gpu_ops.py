@@ -1,0 +1,174 @@
+"""GPU parity of each HIP operator (through the C ABI) against the CPU oracle / plain fp32 torch
+on the same seeded inputs.  fp32 mode must agree to ~1e-5; bf16 mode to bf16-rounding level."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cpt_amd import _lib
+    _lib.check(_lib.lib().cpt_check_device(0), "cpt_check_device")
+    return torch.device("cuda:0")
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _t(rng, *shape, scale=1.0):
+    return torch.from_numpy((rng.standard_normal(shape, dtype=np.float32) * scale).astype(np.float32))
+
+
+def _stats(name, got, ref):
+    d = (got.double() - ref.double()).abs()
+    print("%s: max_abs=%.3e mean_abs=%.3e ref_absmax=%.3e" % (name, d.max().item(), d.mean().item(), ref.abs().max().item()))
+    return d.max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 40), (7680 // 8, 2304, 768), (64, 30522, 768), (77, 3, 128),
+                                   (300, 768, 2056)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gemm_bias(dev, M, N, K, mode):
+    from cpt_amd import ops
+    rng = _rng(M * 7 + N * 3 + K)
+    a, w, b = _t(rng, M, K), _t(rng, N, K, scale=0.05), _t(rng, N)
+    # asymmetric operands: a transposed/permuted fragment layout cannot pass
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    ad, wd = a.to(dev).to(dt), w.to(dev).to(dt)
+    out = ops.gemm(ad, wd, b.to(dev), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    ref = ad.float().cpu().double() @ wd.float().cpu().double().T + b.double()
+    err = _stats("gemm %s %dx%dx%d" % (mode, M, N, K), out.cpu(), ref)
+    assert err < (2e-5 if mode == "fp32" else 2e-4) * max(1.0, math.sqrt(K / 64))   # inputs identical: only accumulation order differs
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gemm_epilogues(dev, mode):
+    from cpt_amd import ops, _lib as L
+    from oracle import cpt_oracle as O
+    rng = _rng(5)
+    M, N, K = 250, 384, 256
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    a, w, b, r = _t(rng, M, K), _t(rng, N, K, scale=0.05), _t(rng, N), _t(rng, M, N)
+    ad, wd = a.to(dev).to(dt), w.to(dev).to(dt)
+    base = ad.float().cpu() @ wd.float().cpu().T + b
+    tol = 3e-5 if mode == "fp32" else 3e-4
+    g = ops.gemm(ad, wd, b.to(dev), epi=L.EPI_GELU, out_dtype=torch.float32).cpu()
+    assert _stats("gelu", g, O.gelu_erf(base)) < tol
+    t = ops.gemm(ad, wd, b.to(dev), epi=L.EPI_TANH, out_dtype=torch.float32).cpu()
+    assert _stats("tanh", t, torch.tanh(base)) < tol
+    rs = ops.gemm(ad, wd, b.to(dev), epi=L.EPI_RESID, resid=r.to(dev), out_dtype=torch.float32).cpu()
+    assert _stats("resid", rs, base + r) < tol
+    if mode == "bf16":
+        lo = ops.gemm(ad, wd, b.to(dev), epi=L.EPI_GELU, out_dtype=torch.bfloat16).cpu()
+        assert _stats("gelu->bf16", lo.float(), O.gelu_erf(base)) < 2e-2
+
+
+def test_gemm_rejects_bad_alignment(dev):
+    from cpt_amd import ops
+    a = torch.zeros(8, 30, device=dev)
+    w = torch.zeros(8, 30, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, w)
+
+
+@pytest.mark.parametrize("H", [128, 768, 1024])
+def test_layernorm_rows(dev, H):
+    from cpt_amd import ops
+    from oracle import cpt_oracle as O
+    rng = _rng(H)
+    R = 301
+    x, g, b = _t(rng, R, H, scale=3.0) + 1.5, _t(rng, H) + 1.0, _t(rng, H)
+    out, lp = ops.layernorm_rows(x.to(dev), g.to(dev), b.to(dev), 1e-12, lp_dtype=torch.bfloat16)
+    ref = O.layer_norm(x, g, b, 1e-12)
+    assert _stats("ln H=%d" % H, out.cpu(), ref) < 1e-5
+    assert _stats("ln bf16 shadow", lp.float().cpu(), ref) < 4e-2
+    # grouped placement: rows of group i land at i*stride + off (torch.cat replacement)
+    grp, stride, off = 7, 12, 5
+    dst = torch.zeros((R // grp) * stride + stride, H, device=dev)
+    ops.layernorm_rows(x[: (R // grp) * grp].contiguous().to(dev), g.to(dev), b.to(dev), 1e-12, out=dst, grp=grp,
+                       grp_stride=stride, grp_off=off)
+    dst = dst.cpu()
+    for i in (0, 3, R // grp - 1):
+        assert torch.allclose(dst[i * stride + off: i * stride + off + grp], ref[i * grp:(i + 1) * grp], atol=1e-5)
+    assert dst[0:off].abs().max() == 0
+
+
+def test_embed_ln(dev):
+    from cpt_amd import ops
+    from oracle import cpt_oracle as O
+    rng = _rng(11)
+    V, P, H, B, Lt, L = 523, 40, 768, 5, 17, 23
+    word, posw, typew = _t(rng, V, H), _t(rng, P, H), _t(rng, 2, H)
+    g, b = _t(rng, H) + 1.0, _t(rng, H)
+    ids = torch.from_numpy(rng.integers(0, V, (B, Lt)))
+    tt = torch.from_numpy(rng.integers(0, 2, (B, Lt)))
+    sd = {"bert.embeddings.word_embeddings.weight": word, "bert.embeddings.position_embeddings.weight": posw,
+          "bert.embeddings.token_type_embeddings.weight": typew, "bert.embeddings.LayerNorm.weight": g,
+          "bert.embeddings.LayerNorm.bias": b}
+    ref = O.text_embeddings(sd, {"layer_norm_eps": 1e-12}, ids, tt)
+    out, lp = ops.embed_ln(ids.to(dev), tt.to(dev), None, word.to(dev), posw.to(dev), typew.to(dev), g.to(dev),
+                           b.to(dev), 1e-12, L, lp_dtype=torch.bfloat16)
+    assert _stats("embed", out[:, :Lt].cpu(), ref) < 1e-5
+    assert out[:, Lt:].abs().max().item() == 0
+    assert _stats("embed bf16", lp[:, :Lt].float().cpu(), ref) < 4e-2
+
+
+@pytest.mark.parametrize("L,B,heads", [(26, 3, 2), (120, 4, 12), (120, 2, 1), (210, 2, 12), (265, 2, 16)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_attention(dev, L, B, heads, mode):
+    from cpt_amd import ops
+    rng = _rng(L + heads)
+    H = heads * 64
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    qkv = _t(rng, B * L, 3 * H).to(dt)
+    mask = torch.ones(B, L, dtype=torch.int64)
+    for b in range(B):
+        mask[b, L - int(rng.integers(0, L // 2)):] = 0
+    mask[0, 3] = 0
+    ctx, probs = ops.attention(qkv.to(dev), mask.to(dev), B, L, heads, want_probs=True)
+    x = qkv.float().view(B, L, 3, heads, 64)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) / 8.0 + ((1.0 - mask.float()) * -10000.0)[:, None, None, :]
+    p = torch.softmax(s, -1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B * L, H)
+    tol = 2e-5 if mode == "fp32" else 3e-2
+    assert _stats("attn probs %s" % mode, probs.float().cpu(), p) < (1e-5 if mode == "fp32" else 1e-2)
+    assert _stats("attn ctx %s L=%d" % (mode, L), ctx.float().cpu(), ref) < tol
+
+
+def test_pad_cast_gather_ce(dev):
+    from cpt_amd import ops
+    rng = _rng(3)
+    x = _t(rng, 37, 2054)
+    p = ops.pad_cast(x.to(dev), 2056, torch.bfloat16).cpu()
+    assert torch.equal(p[:, :2054], x.to(torch.bfloat16)) and p[:, 2054:].abs().max() == 0
+    p32 = ops.pad_cast(x.to(dev), 2056, torch.float32).cpu()
+    assert torch.equal(p32[:, :2054], x) and p32[:, 2054:].abs().max() == 0
+    B, L, H = 6, 11, 768
+    src = _t(rng, B * L, H)
+    pos = torch.from_numpy(rng.integers(0, L, (B,)))
+    g = ops.gather_rows(src.to(dev), pos.to(dev), B, L).cpu()
+    assert torch.equal(g, src.view(B, L, H)[torch.arange(B), pos])
+    g0 = ops.gather_rows(src.to(dev).to(torch.bfloat16), None, B, L).cpu()
+    assert torch.equal(g0, src.to(torch.bfloat16).view(B, L, H)[:, 0])
+    R, V = 9, 30522
+    lg = _t(rng, R, V, scale=2.0)
+    lab = torch.from_numpy(rng.integers(0, V, (R,)))
+    lab[2] = -1
+    lab[7] = -1
+    loss, d = ops.ce_rows(lg.to(dev), lab.to(dev), want_grad=True)
+    loss = loss.cpu()
+    ref = torch.nn.functional.cross_entropy(lg, lab, ignore_index=-1, reduction="sum")
+    assert loss[1].item() == 7
+    assert abs(loss[0].item() - ref.item()) < 1e-3
+    lgr = lg.clone().requires_grad_(True)
+    torch.nn.functional.cross_entropy(lgr, lab, ignore_index=-1, reduction="sum").backward()
+    assert _stats("ce grad", d.cpu(), lgr.grad) < 1e-6
