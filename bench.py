@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py -- prompted (image,query) pairs/sec through the CPT [MASK]-scoring hot path.
+
+Workload (BASELINE.json configs[1]): Oscar-base CPT RefCOCO inference, batch 64 sequences per
+GPU, 50 region features + 70 text tokens (L = 120), bf16 MFMA operands, synthetic region
+features of the RefCOCO shape, random-init weights (no checkpoint on the box).  One step = one
+REC_MLM_CPT forward over one batch already resident in HBM, producing the [MASK]-row logits
+(B x 30522 fp32) every reference consumer keeps (zeroshot/refcoco_cpt.py:219).
+
+    python bench.py [--gpus N --steps K --warmup W] [--batch 64] [--dtype bf16|fp32] [--all-rows]
+N > 1 is launched by torch.distributed.run, one rank per GPU; inference shards sequences across
+ranks with no data-path collective (weak scaling: 64 sequences per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def gemm_flops(kind, M, H, I):
+    return {"gemm_qkv": 2.0 * M * 3 * H * H, "gemm_attn_out": 2.0 * M * H * H,
+            "gemm_ffn_up": 2.0 * M * I * H, "gemm_ffn_down": 2.0 * M * I * H}[kind]
+
+
+def cpu_baseline(cfg, seed, threads):
+    """The oracle (CPU fp32 restatement of the reference path) on this box's host cores."""
+    from cpt_amd import synth
+    from oracle import cpt_oracle as O
+    torch.set_num_threads(threads)
+    sd = synth.init_state_dict(cfg, seed, head="cpt", randomize_all=False)
+    Bc, iters = 16, 6
+    b = synth.make_batch(Bc, cfg, seed=seed)
+    cd = cfg.to_dict()
+
+    def run(all_rows):
+        with torch.no_grad():
+            return O.rec_mlm_cpt_forward(sd, cd, b["input_ids"], b["segment_ids"], b["attention_mask"],
+                                         img_feats=b["img_feats"],
+                                         mask_rows_only=None if all_rows else b["mask_token_pos"])[0]
+    run(False)
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        run(False)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    t0 = time.perf_counter()
+    run(True)
+    t_all = time.perf_counter() - t0
+    return {"value": round(Bc / med, 2), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "oracle (torch CPU fp32), B=%d x L=120 Oscar-base forward, [MASK]-row head, median of %d "
+                      "iterations after 1 warm-up; as-the-reference-computes-it (all-row head): %.2f pairs/s"
+                      % (Bc, iters, Bc / t_all)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--all-rows", action="store_true", help="vocabulary head on all 120 rows, as the reference computes it")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    n_gpus = world
+
+    from cpt_amd import config as cfgmod, synth, _lib, engine
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    _lib.check(_lib.lib().cpt_check_device(local), "cpt_check_device")
+    cfg = cfgmod.oscar_base()
+    seed = 88
+    model = REC_MLM_CPT(cfg)
+    model.load_state_dict(synth.init_state_dict(cfg, seed, head="cpt", randomize_all=False))
+    model.tie_weights()
+    model.to(dev).eval().set_compute_dtype(args.dtype)
+    B = args.batch
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, cfg, seed=seed + rank).items()}
+    mpos = None if args.all_rows else b["mask_token_pos"]
+
+    def step():
+        with torch.no_grad():
+            return model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                         mask_token_pos=mpos)[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * n_gpus * args.steps / dt
+
+    roof, breakdown = None, None
+    if rank == 0 and not args.no_roofline:
+        # per-kernel durations: HIP events recorded by the library on the launch stream around every
+        # launch, over a second pass of the same K steps (events off in the timed region above)
+        _lib.lib().cpt_prof_enable(1)
+        for _ in range(args.steps):
+            step()
+        prof = engine.profile_read()
+        _lib.lib().cpt_prof_enable(0)
+        M, H, I = B * 120, cfg.hidden_size, cfg.intermediate_size
+        breakdown = {k: round(t / args.steps, 4) for k, (t, n) in prof.items() if n}
+        gem = {k: prof[k] for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn_up", "gemm_ffn_down") if prof[k][1]}
+        dom = max(gem, key=lambda k: gem[k][0])
+        avg_ms = gem[dom][0] / gem[dom][1]
+        ach = gemm_flops(dom, M, H, I) / (avg_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                "flop_per_launch": gemm_flops(dom, M, H, I)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        line = {"metric": "prompted (image,query) pairs/sec at Oscar-base L=70+50", "value": round(value, 1),
+                "unit": "pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": "Oscar-base CPT RefCOCO inference, batch %d/GPU, 50 regions, seq_len 120, %s, "
+                                       "[MASK]-row logits%s" % (B, args.dtype, " (all-row head)" if args.all_rows else ""),
+                           "global_batch": B * n_gpus, "seq_len": 120, "parallelism": "dp%d" % n_gpus,
+                           "weights": "random-init N(0,0.02), seed 88"},
+                "roofline": roof, "kernel_ms_per_step": breakdown}
+        if n_gpus == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(cfg, seed, os.cpu_count() or 1)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,16 @@ _SIGS = {
 _lib = None
 
 
+def _bind_torch_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so (same soname as
+    /opt/rocm's).  Load torch's copy first so libcpt_hip.so's NEEDED entry resolves to it --
+    streams and device pointers handed over from torch must belong to the same runtime."""
+    import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def exported_symbols():
     return sorted(_SIGS)
 
@@ -81,6 +91,7 @@ def lib():
             raise RuntimeError(
                 "cpt_amd: %s is missing -- the HIP extension is required (no CPU fallback). "
                 "Build it with `python -m cpt_amd.build` (hipcc --offload-arch=gfx950)." % LIB_PATH)
+        _bind_torch_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)        # AttributeError here = header/library mismatch
