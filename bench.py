@@ -30,13 +30,31 @@ def gemm_flops(kind, M, H, I):
             "gemm_ffn_up": 2.0 * M * I * H, "gemm_ffn_down": 2.0 * M * I * H}[kind]
 
 
+def usable_cores():
+    """Host cores this process may actually use (affinity mask and cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()                      # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:                                                                         # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, seed, threads):
     """The oracle (CPU fp32 restatement of the reference path) on this box's host cores."""
     from cpt_amd import synth
     from oracle import cpt_oracle as O
     torch.set_num_threads(threads)
     sd = synth.init_state_dict(cfg, seed, head="cpt", randomize_all=False)
-    Bc, iters = 16, 6
+    Bc, iters, budget_s = 16, 6, 20.0
     b = synth.make_batch(Bc, cfg, seed=seed)
     cd = cfg.to_dict()
 
@@ -45,12 +63,16 @@ def cpu_baseline(cfg, seed, threads):
             return O.rec_mlm_cpt_forward(sd, cd, b["input_ids"], b["segment_ids"], b["attention_mask"],
                                          img_feats=b["img_feats"],
                                          mask_rows_only=None if all_rows else b["mask_token_pos"])[0]
+    t_start = time.perf_counter()
     run(False)
     ts = []
     for _ in range(iters):
         t0 = time.perf_counter()
         run(False)
         ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    iters = len(ts)
     ts.sort()
     med = ts[len(ts) // 2]
     t0 = time.perf_counter()
@@ -159,7 +181,7 @@ def main():
                            "weights": "random-init N(0,0.02), seed 88"},
                 "roofline": roof, "kernel_ms_per_step": breakdown}
         if n_gpus == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(cfg, seed, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(cfg, seed, min(usable_cores(), 64))
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -62,6 +62,7 @@ _SIGS = {
     "cpt_pad_cast": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_gather_rows": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_ce_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "cpt_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "cpt_prof_enable": (C.c_int, [C.c_int]),
     "cpt_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

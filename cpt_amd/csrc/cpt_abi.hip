@@ -108,6 +108,11 @@ int cpt_check_device(int dev) {
     return CPT_OK;
 }
 
+int cpt_set_tuning(int key, int value) {
+    if (key == 0) { cpt::set_gemm_variant(value); return CPT_OK; }
+    return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
+}
+
 int cpt_prof_enable(int on) {
     hipDeviceSynchronize();
     g_prof.recycle();

@@ -29,4 +29,6 @@ int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B
 int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V,
             hipStream_t s);
 
+void set_gemm_variant(int v);
+
 }  // namespace cpt

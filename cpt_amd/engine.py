@@ -118,7 +118,7 @@ class PackedModel(object):
         self._sig[self.dtype] = sig
         cfg = self.cfg
         H, D = cfg.hidden_size, cfg.img_feature_dim
-        Dp = (D + 7) // 8 * 8
+        Dp = (D + 63) // 64 * 64
         st = L.stream_ptr()
         w_img = self.view("bert.img_embedding.weight")
         n = self.flat.numel()
@@ -156,7 +156,7 @@ class PackedModel(object):
 
         D = cfg.img_feature_dim
         d = L.Dims(hidden=cfg.hidden_size, heads=cfg.num_attention_heads, inter=cfg.intermediate_size,
-                   layers=cfg.num_hidden_layers, vocab=cfg.vocab_size, img_dim=D, img_dim_pad=(D + 7) // 8 * 8,
+                   layers=cfg.num_hidden_layers, vocab=cfg.vocab_size, img_dim=D, img_dim_pad=(D + 63) // 64 * 64,
                    max_pos=cfg.max_position_embeddings, type_vocab=cfg.type_vocab_size,
                    use_img_ln=1 if getattr(cfg, "use_img_layernorm", None) else 0,
                    n_rel=getattr(cfg, "num_contrast_classes", 2) if self.head == "pretrain" else 0,

@@ -139,7 +139,7 @@ typedef struct {
     float* seq;          /* CPT_OUT_SEQ */
     float* pooled;       /* CPT_OUT_POOLED */
     float* logits;       /* CPT_OUT_MASK_LOGITS [B][V] or CPT_OUT_ALL_LOGITS [B][L][V] */
-    float* loss;         /* CPT_OUT_LOSS: [2] = {sum of row losses / count, count} */
+    float* loss;         /* CPT_OUT_LOSS: [2] = {sum of labelled-row losses, labelled-row count} */
     float* rel;          /* CPT_OUT_REL */
 } cpt_outputs;
 
@@ -206,6 +206,10 @@ enum { CPT_K_GEMM_QKV = 0, CPT_K_ATTN, CPT_K_GEMM_AO, CPT_K_LN, CPT_K_GEMM_FFN1,
        CPT_K_EMBED, CPT_K_IMG, CPT_K_HEAD, CPT_K_COUNT };
 int cpt_prof_enable(int on);                          /* resets accumulators */
 int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchronises */
+
+/* Kernel-variant switches for A/B measurements (key 0: GEMM variant 0 = register-staged generic
+ * kernel, 1 = LDS-DMA 128x128 tile, 2 = LDS-DMA 256x128 tile).  Results are identical. */
+int cpt_set_tuning(int key, int value);
 
 #ifdef __cplusplus
 }
