@@ -13,7 +13,7 @@ EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID = 0, 1, 2, 3
 OUT_SEQ, OUT_POOLED, OUT_MASK_LOGITS, OUT_ALL_LOGITS, OUT_LOSS, OUT_REL = 1, 2, 4, 8, 16, 32
 SAVE_FOR_BWD = 1024
 K_NAMES = ["gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up", "gemm_ffn_down",
-           "embed_ln", "img_proj", "head"]
+           "embed_ln", "img_proj", "head", "op"]
 
 vp, i32, i64p, f32p = C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p
 
@@ -63,6 +63,7 @@ _SIGS = {
     "cpt_gather_rows": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_ce_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "cpt_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "cpt_debug_gemm_trace": (C.c_int, [vp]),
     "cpt_prof_enable": (C.c_int, [C.c_int]),
     "cpt_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

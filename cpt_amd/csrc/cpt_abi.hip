@@ -110,7 +110,13 @@ int cpt_check_device(int dev) {
 
 int cpt_set_tuning(int key, int value) {
     if (key == 0) { cpt::set_gemm_variant(value); return CPT_OK; }
+    if (key == 1) { cpt::set_gemm_abl(value); return CPT_OK; }
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
+}
+
+int cpt_debug_gemm_trace(void* buf) {
+    cpt::set_gemm_trace(buf);
+    return CPT_OK;
 }
 
 int cpt_prof_enable(int on) {
@@ -139,6 +145,7 @@ int cpt_gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw,
              const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
              void* stream) {
     if (!A || !W || !out) return fail(CPT_ERR_NULL, "cpt_gemm: null operand");
+    Scope p(CPT_K_OP, (hipStream_t)stream);
     return check_launch(cpt::gemm(dtype, epi, A, lda, W, ldw, bias, resid, ldr, out, out_dtype, ldo, M, N, K, (hipStream_t)stream), "cpt_gemm");
 }
 

@@ -14,6 +14,8 @@
 // written to the other LDS buffer afterwards: one barrier per K-tile).
 //   T = bf16 : v_mfma_f32_32x32x16_bf16, fp32 accumulate
 //   T = f32  : v_mfma_f32_32x32x2_f32 (exact fp32; parity mode)
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -158,7 +160,7 @@ template <typename T, int EPI, typename OT, int TBM>
 __global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
-    OT* __restrict__ out, int ldo, int M, int N, int K) {
+    OT* __restrict__ out, int ldo, int M, int N, int K, int abl) {
     typedef typename FragOf<T>::type frag_t;
     constexpr int CE = Chunk<T>::N;
     constexpr int BK = ROWB / (int)sizeof(T);
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
         else             src[i] = W + (size_t)min(n0 + r - TBM, N - 1) * ldw + c * CE;
     }
     auto stage = [&](int buf, int k0) {
+        if (abl & 1) return;      // ablation: no operand traffic
 #pragma unroll
         for (int i = 0; i < GROUPS; ++i) {
             const int g = i * NW + wave;
@@ -219,10 +222,14 @@ __global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
                 fa[i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
                 fb[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 32 + fr, ks * 2 + fh));
             }
+            if (abl & 2) {        // ablation: LDS reads stay live, no MFMA
+                asm volatile("" ::"v"(fa[0]), "v"(fa[1]), "v"(fb[0]), "v"(fb[1]));
+            } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mfma_chunk(acc[i][j], fa[i], fb[j]);
+                    for (int j = 0; j < 2; ++j) mfma_chunk(acc[i][j], fa[i], fb[j]);
+            }
         }
         __syncthreads();     // drains this wave's LDS-DMA (vmcnt(0)) and fences the buffer swap
     }
@@ -242,23 +249,323 @@ __global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
                 if (EPI == CPT_EPI_GELU) v = gelu_erf(v);
                 if (EPI == CPT_EPI_TANH) v = tanhf(v);
                 if (EPI == CPT_EPI_RESID) v += resid[(size_t)row * ldr + col];
+                if ((abl & 4) && v != 12345.678f) continue;   // ablation: epilogue math, no stores
                 out[(size_t)row * ldo + col] = from_f32<OT>(v);
             }
         }
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined kernel: STAGES-deep LDS ring fed by LDS-DMA with COUNTED vmcnt waits (tiles stay in
+// flight across the raw s_barrier; one barrier per K-tile), generic tile/wave shape, and an
+// epilogue staged through LDS so that bias / GELU / residual / stores run on whole rows with
+// 16-byte accesses instead of 2-byte scattered stores.
+//   tile TBM x TBN, waves WM x WN, each wave (TBM/WM) x (TBN/WN) as MI x NJ MFMA 32x32 blocks
+// ---------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(
+    const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+    const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
+    OT* __restrict__ out, int ldo, int M, int N, int K, long long* __restrict__ trace) {
+#if defined(__HIP_DEVICE_COMPILE__)   // body uses gfx950-only builtins/types (buffer rsrc, "v" asm): device pass only
+    typedef typename FragOf<T>::type frag_t;
+    constexpr int CE = Chunk<T>::N;
+    constexpr int BK = ROWB / (int)sizeof(T);
+    constexpr int NW = WM * WN, NT = NW * 64;
+    long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;
+    if (trace) tr0 = clock64();
+    constexpr int MI = TBM / WM / 32, NJ = TBN / WN / 32;
+    constexpr int ROWS = TBM + TBN;
+    constexpr int G = ROWS / 8 / NW;                  // LDS-DMA pieces per wave per stage
+    constexpr int STAGE_BYTES = ROWS * ROWB;
+    constexpr int CP = TBN * 4 + 16;                  // epilogue staging pitch (bytes)
+    static_assert(ROWS % (8 * NW) == 0, "stage must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-first, then GROUP_M row tiles per group (see tile_of_block)
+    int m0, n0;
+    {
+        const int tm = (M + TBM - 1) / TBM, tn = (N + TBN - 1) / TBN;
+        const int nwg = tm * tn, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int per_group = GROUP_M * tn;
+        const int g = lid / per_group, first_m = g * GROUP_M;
+        const int gsz = min(tm - first_m, GROUP_M);
+        const int in_g = lid - g * per_group;
+        m0 = (first_m + in_g % gsz) * TBM;
+        n0 = (in_g / gsz) * TBN;
+    }
+
+    // LDS-DMA through buffer descriptors: the per-lane byte offset of every piece is computed once
+    // (row clamp + source-side swizzle), the K position travels in the scalar offset, so issuing a
+    // stage costs two SALU ops + one buffer_load...lds per 1 KiB piece and no VALU.
+    constexpr int GA = TBM / 8 / NW;                  // pieces i < GA come from A, the rest from W
+    static_assert((TBM / 8) % NW == 0, "A pieces must split evenly over the waves");
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
+    unsigned voff[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int g = i * NW + wave;
+        const int r = g * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        if (i < GA) voff[i] = (unsigned)(((size_t)min(m0 + r, M - 1) * lda + c * CE) * sizeof(T));
+        else        voff[i] = (unsigned)(((size_t)min(n0 + r - TBM, N - 1) * ldw + c * CE) * sizeof(T));
+    }
+    auto stage = [&](int slot, int k0) {
+        const int soff = k0 * (int)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int g = i * NW + wave;
+            auto lds = (__attribute__((address_space(3))) void*)(smem + slot * STAGE_BYTES + g * 1024);
+            if (i < GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lds, 16, voff[i], soff, 0, 0);
+            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lds, 16, voff[i], soff, 0, 0);
+        }
+    };
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = K / BK;
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+        if (p < nt) stage(p, p * BK);
+
+    const int fr = lane & 31, fh = lane >> 5;
+    // fragments are double-buffered in registers; k-step ks+1 (or k-step 0 of the NEXT tile) is read
+    // from LDS while the MFMAs of k-step ks run, so neither LDS latency nor the per-tile barrier
+    // leaves the matrix pipe idle
+    frag_t fa[2][MI], fb[2][NJ];
+    auto ldfrag = [&](int slot, int ks, int pb) {
+        const unsigned char* sa = smem + slot * STAGE_BYTES;
+        const unsigned char* sw = sa + TBM * ROWB;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            fa[pb][i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * (MI * 32) + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            fb[pb][j] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * (NJ * 32) + j * 32 + fr, ks * 2 + fh));
+    };
+    auto mma = [&](int pb) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) mfma_chunk(acc[i][j], fa[pb][i], fb[pb][j]);
+    };
+    // make the compiler place its lgkmcnt wait for buffer `pb` HERE (before younger ds_reads are
+    // issued) instead of in front of the MFMAs that consume it
+    auto touch = [&](int pb) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(fa[pb][i]));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[pb][j]));
+    };
+    // wait until tile `t` has landed: at most min(STAGES-2, tiles after t) younger tiles stay in flight
+    auto wait_tile = [&](int t) {
+        const int after = min(STAGES - 2, nt - 1 - t);
+        if (after >= 2) wait_vmcnt<2 * G>();
+        else if (after == 1) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+    };
+
+    if (trace) tr1 = clock64();
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ldfrag(0, 0, 0);
+    int slot = 0;
+    for (int t = 0; t < nt; ++t) {
+        // the slot tile t-1 occupied is free: every wave drained its reads before the last barrier
+        if (t + STAGES - 1 < nt) {
+            int ns = slot + STAGES - 1;
+            if (ns >= STAGES) ns -= STAGES;
+            stage(ns, (t + STAGES - 1) * BK);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            touch(ks & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(slot, ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(ks & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        int nslot = slot + 1;
+        if (nslot == STAGES) nslot = 0;
+        touch(1);                              // this wave's reads of tile t are all done
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) {
+            wait_tile(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();      // tile t+1 visible to all; nobody still reads tile t
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(nslot, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = nslot;
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> whole-row bias/act/residual/store ----
+    if (trace) tr2 = clock64();
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (MI * 32) + i * 32 + acc_row(r, lane);
+                const int col = wn * (NJ * 32) + j * 32 + acc_col(lane);
+                *reinterpret_cast<float*>(smem + row * CP + col * 4) = acc[i][j][r];
+            }
+    __syncthreads();
+    if (trace) tr3 = clock64();
+    // Each thread owns one 4-column chunk position (tid & 15) in every 64-column panel and a fixed
+    // set of rows.  ALL global loads of the epilogue (bias, residual) are issued before the first
+    // store: on gfx950 stores count in vmcnt, so a load issued after a store would make the
+    // compiler wait for that store's round trip on every iteration.
+    constexpr int PANELS = TBN / 64, RP = NT / 16, PASSES = TBM / RP;
+    static_assert(TBN % 64 == 0 && TBM % RP == 0, "epilogue mapping");
+    const int cq = tid & 15, rq = tid >> 4;
+    const bool vec_ok = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out) % 16 == 0) &&
+                        (EPI != CPT_EPI_RESID || (ldr % 4 == 0 && ((uintptr_t)resid) % 16 == 0)) &&
+                        (!bias || ((uintptr_t)bias) % 16 == 0);
+    auto vec_epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        f32x4 bv[PANELS];
+        f32x4 rv[EPI == CPT_EPI_RESID ? PANELS : 1][EPI == CPT_EPI_RESID ? PASSES : 1];
+#pragma unroll
+        for (int p = 0; p < PANELS; ++p) {
+            const int col = n0 + p * 64 + cq * 4;
+            bv[p] = (bias && (FULL || col < N)) ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == CPT_EPI_RESID) {
+#pragma unroll
+                for (int q = 0; q < PASSES; ++q) {
+                    const int row = m0 + q * RP + rq;
+                    rv[p][q] = (FULL || (row < M && col < N)) ? *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldr + col)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        // all LDS reads next (no ds_read after a store either), then math + stores
+        f32x4 vv[PANELS][PASSES];
+#pragma unroll
+        for (int p = 0; p < PANELS; ++p)
+#pragma unroll
+            for (int q = 0; q < PASSES; ++q)
+                vv[p][q] = *reinterpret_cast<const f32x4*>(smem + (q * RP + rq) * CP + (p * 64 + cq * 4) * 4);
+#pragma unroll
+        for (int p = 0; p < PANELS; ++p) {
+            const int col = n0 + p * 64 + cq * 4;
+#pragma unroll
+            for (int q = 0; q < PASSES; ++q) {
+                const int row = m0 + q * RP + rq;
+                f32x4 v = vv[p][q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e] + bv[p][e];
+                    if (EPI == CPT_EPI_GELU) x = gelu_erf(x);
+                    if (EPI == CPT_EPI_TANH) x = tanhf(x);
+                    if constexpr (EPI == CPT_EPI_RESID) x += rv[p][q][e];
+                    v[e] = x;
+                }
+                if (FULL || (row < M && col < N)) {
+                    if constexpr (sizeof(OT) == 2) {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (bf16)v[e];
+                        *reinterpret_cast<bf16x4*>(out + (size_t)row * ldo + col) = pk;
+                    } else {
+                        *reinterpret_cast<f32x4*>(out + (size_t)row * ldo + col) = v;
+                    }
+                }
+            }
+        }
+    };
+    if (vec_ok) {
+        // interior tiles take a branch-free path: one basic block lets the compiler count vmcnt
+        // exactly instead of draining it before every guarded store
+        if (m0 + TBM <= M && n0 + TBN <= N) vec_epilogue(std::true_type{});
+        else vec_epilogue(std::false_type{});
+    } else {
+        constexpr int CPR = TBN / 4;
+        for (int idx = tid; idx < TBM * CPR; idx += NT) {
+            const int rr = idx / CPR, cc = (idx - rr * CPR) * 4;
+            const int row = m0 + rr, col = n0 + cc;
+            if (row >= M || col >= N) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + rr * CP + cc * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (col + e >= N) break;
+                float x = v[e] + (bias ? bias[col + e] : 0.f);
+                if (EPI == CPT_EPI_GELU) x = gelu_erf(x);
+                if (EPI == CPT_EPI_TANH) x = tanhf(x);
+                if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col + e];
+                out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
+            }
+        }
+    }
+    if (trace && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* t = trace + (size_t)blockIdx.x * 8;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = tr3; t[4] = clock64();
+        t[5] = 0; t[6] = 0; t[7] = 0;
+    }
+#endif
+}
+
+long long* g_gemm_trace = nullptr;
+
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES>
+static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bias, const float* resid, int ldr,
+                       OT* out, int ldo, int M, int N, int K, hipStream_t s) {
+    constexpr int RING = STAGES * (TBM + TBN) * ROWB, STG = TBM * (TBN * 4 + 16);
+    constexpr int LDS = RING > STG ? RING : STG;
+    auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES>;
+    static bool attr_done = false;
+    if (LDS > 64 * 1024 && !attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+        attr_done = true;
+    }
+    const int nwg = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN);
+    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, g_gemm_trace);
+    return CPT_OK;
+}
+
+int g_gemm_abl = 0;
 int g_gemm_variant = 1;      // 0: register-staged generic kernel only; 1: LDS-DMA 128x128; 2: LDS-DMA 256x128
 
 template <typename T, int EPI, typename OT>
 static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, const float* bias,
                         const float* resid, int ldr, OT* out, int ldo, int M, int N, int K, hipStream_t s) {
+    if (variant == 3) { launch_pipe<T, EPI, OT, 128, 192, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 4) { launch_pipe<T, EPI, OT, 128, 128, 2, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 5) { launch_pipe<T, EPI, OT, 256, 128, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 6) { launch_pipe<T, EPI, OT, 128, 128, 4, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 7) { launch_pipe<T, EPI, OT, 128, 192, 2, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 2 && M >= 1024) {
         const int nwg = ((M + 255) / 256) * ((N + BN - 1) / BN);
-        gemm_glds_kernel<T, EPI, OT, 256><<<dim3(nwg), dim3(512), 0, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K);
+        gemm_glds_kernel<T, EPI, OT, 256><<<dim3(nwg), dim3(512), 0, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, g_gemm_abl);
     } else {
         const int nwg = ((M + 127) / 128) * ((N + BN - 1) / BN);
-        gemm_glds_kernel<T, EPI, OT, 128><<<dim3(nwg), dim3(256), 0, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K);
+        gemm_glds_kernel<T, EPI, OT, 128><<<dim3(nwg), dim3(256), 0, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, g_gemm_abl);
     }
 }
 
@@ -319,5 +626,7 @@ int gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, con
 }
 
 void set_gemm_variant(int v) { g_gemm_variant = v; }
+void set_gemm_abl(int v) { g_gemm_abl = v; }
+void set_gemm_trace(void* p) { g_gemm_trace = (long long*)p; }
 
 }  // namespace cpt

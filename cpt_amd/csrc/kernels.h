@@ -30,5 +30,7 @@ int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlog
             hipStream_t s);
 
 void set_gemm_variant(int v);
+void set_gemm_abl(int v);
+void set_gemm_trace(void* p);
 
 }  // namespace cpt

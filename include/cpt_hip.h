@@ -203,13 +203,16 @@ int cpt_ce_rows(const float* logits, const int64_t* labels, float* loss, float* 
  * Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * ---------------------------------------------------------------------------------------- */
 enum { CPT_K_GEMM_QKV = 0, CPT_K_ATTN, CPT_K_GEMM_AO, CPT_K_LN, CPT_K_GEMM_FFN1, CPT_K_GEMM_FFN2,
-       CPT_K_EMBED, CPT_K_IMG, CPT_K_HEAD, CPT_K_COUNT };
+       CPT_K_EMBED, CPT_K_IMG, CPT_K_HEAD, CPT_K_OP /* any operator-level call */, CPT_K_COUNT };
 int cpt_prof_enable(int on);                          /* resets accumulators */
 int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchronises */
 
 /* Kernel-variant switches for A/B measurements (key 0: GEMM variant 0 = register-staged generic
  * kernel, 1 = LDS-DMA 128x128 tile, 2 = LDS-DMA 256x128 tile).  Results are identical. */
 int cpt_set_tuning(int key, int value);
+/* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
+ * start / after prologue issue / after K loop / after staging / end, and the XCC id). */
+int cpt_debug_gemm_trace(void* buf);
 
 #ifdef __cplusplus
 }

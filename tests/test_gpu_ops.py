@@ -172,3 +172,30 @@ def test_pad_cast_gather_ce(dev):
     lgr = lg.clone().requires_grad_(True)
     torch.nn.functional.cross_entropy(lgr, lab, ignore_index=-1, reduction="sum").backward()
     assert _stats("ce grad", d.cpu(), lgr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_gemm_variants_agree(dev, variant):
+    """Every GEMM kernel variant (tile shape / pipeline depth) gives the same answer, including
+    ragged M/N edges and the unaligned-ldo decoder shape."""
+    from cpt_amd import ops, _lib as L
+    rng = _rng(77)
+    try:
+        L.check(L.lib().cpt_set_tuning(0, variant))
+        for (M, N, K, epi) in [(7680 // 4, 2304, 768, L.EPI_NONE), (333, 200, 128, L.EPI_GELU), (64, 30522, 768, L.EPI_NONE),
+                               (500, 768, 3072, L.EPI_RESID)]:
+            a, w, b = _t(rng, M, K).to(torch.bfloat16), _t(rng, N, K, scale=0.05).to(torch.bfloat16), _t(rng, N)
+            r = _t(rng, M, N) if epi == L.EPI_RESID else None
+            out = ops.gemm(a.to(dev), w.to(dev), b.to(dev), epi=epi, resid=None if r is None else r.to(dev),
+                           out_dtype=torch.float32).cpu()
+            ref = a.float() @ w.float().T + b
+            if epi == L.EPI_GELU:
+                ref = ref * 0.5 * (1.0 + torch.erf(ref / math.sqrt(2.0)))
+            if r is not None:
+                ref = ref + r
+            assert _stats("variant %d %dx%dx%d" % (variant, M, N, K), out, ref) < 3e-4 * max(1.0, math.sqrt(K / 64))
+            a32, w32 = a.float().to(dev), w.float().to(dev)
+            o32 = ops.gemm(a32, w32, b.to(dev), epi=epi, resid=None if r is None else r.to(dev)).cpu()
+            assert _stats("variant %d fp32" % variant, o32, ref) < 3e-5 * max(1.0, math.sqrt(K / 64))
+    finally:
+        L.check(L.lib().cpt_set_tuning(0, 1))

@@ -1,6 +1,7 @@
 """A/B timing of the GEMM variants on the hot path's shapes (GPU box only).
 python tools/gemm_bench.py [--batch 64] [--dtype bf16]"""
 import argparse
+import ctypes as C
 import os
 import sys
 
@@ -16,6 +17,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--variants", default="0,1,2")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--abl", default="0")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -30,25 +32,38 @@ def main():
         b = torch.randn(n, device=dev)
         r = torch.randn(m, n, device=dev) if epi == L.EPI_RESID else None
         ref = None
-        for v in [int(t) for t in a.variants.split(",")]:
+        for v, ab in [(int(t), int(u)) for t in a.variants.split(",") for u in a.abl.split(",")]:
             L.check(L.lib().cpt_set_tuning(0, v))
+            L.check(L.lib().cpt_set_tuning(1, ab))
             out = ops.gemm(x, w, b, epi=epi, resid=r, out_dtype=odt)
             torch.cuda.synchronize()
             if ref is None:
                 ref = out.float()
             err = (out.float() - ref).abs().max().item()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            lib = L.lib()
+            args = (L.CPT_BF16 if dt == torch.bfloat16 else L.CPT_F32, epi, x.data_ptr(), x.stride(0), w.data_ptr(),
+                    w.stride(0), b.data_ptr(), L.ptr(r), r.stride(0) if r is not None else 0, out.data_ptr(),
+                    L.CPT_BF16 if odt == torch.bfloat16 else L.CPT_F32, out.stride(0), m, n, k, L.stream_ptr())
             for _ in range(5):
-                ops.gemm(x, w, b, epi=epi, resid=r, out_dtype=odt)
+                lib.cpt_gemm(*args)
+            lib.cpt_prof_enable(1)
+            for _ in range(a.iters):
+                lib.cpt_gemm(*args)
+            tms, cnt = C.c_double(0), C.c_int64(0)
+            lib.cpt_prof_read(9, C.byref(tms), C.byref(cnt))
+            lib.cpt_prof_enable(0)
+            ms_ev = tms.value / cnt.value
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                ops.gemm(x, w, b, epi=epi, resid=r, out_dtype=odt)
+                lib.cpt_gemm(*args)
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / a.iters
-            print("%-9s %5dx%5dx%4d variant %d: %8.2f us  %7.1f TFLOP/s  (max diff vs first variant %.2e)"
-                  % (name, m, n, k, v, ms * 1e3, 2.0 * m * n * k / ms / 1e9, err), flush=True)
+            ms = e0.elapsed_time(e1) / a.iters       # back-to-back average (includes launch gaps)
+            print("%-9s %5dx%5dx%4d variant %d abl %d: %8.2f us  %7.1f TFLOP/s  (per-launch events %.2f us; max diff vs first variant %.2e)"
+                  % (name, m, n, k, v, ab, ms * 1e3, 2.0 * m * n * k / ms / 1e9, ms_ev * 1e3, err), flush=True)
     L.check(L.lib().cpt_set_tuning(0, 1))
+    L.check(L.lib().cpt_set_tuning(1, 0))
 
 
 if __name__ == "__main__":
