@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
     OT* __restrict__ out, int ldo, int M, int N, int K, long long* __restrict__ trace) {
@@ -346,33 +346,33 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(
         if (p < nt) stage(p, p * BK);
 
     const int fr = lane & 31, fh = lane >> 5;
-    // fragments are double-buffered in registers; k-step ks+1 (or k-step 0 of the NEXT tile) is read
-    // from LDS while the MFMAs of k-step ks run, so neither LDS latency nor the per-tile barrier
-    // leaves the matrix pipe idle
-    frag_t fa[2][MI], fb[2][NJ];
-    auto ldfrag = [&](int slot, int ks, int pb) {
+    // Register-resident fragments for all four k-steps of a tile; reads run TWO k-steps ahead of the
+    // MFMAs that consume them (across the tile boundary too), so LDS latency (~300 cycles with 8
+    // waves reading) hides behind two k-steps of matrix work of this wave and its SIMD partner.
+    frag_t fa[4][MI], fb[4][NJ];
+    auto ldfrag = [&](int slot, int ks) {
         const unsigned char* sa = smem + slot * STAGE_BYTES;
         const unsigned char* sw = sa + TBM * ROWB;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-            fa[pb][i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * (MI * 32) + i * 32 + fr, ks * 2 + fh));
+            fa[ks][i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * (MI * 32) + i * 32 + fr, ks * 2 + fh));
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            fb[pb][j] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * (NJ * 32) + j * 32 + fr, ks * 2 + fh));
+            fb[ks][j] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * (NJ * 32) + j * 32 + fr, ks * 2 + fh));
     };
-    auto mma = [&](int pb) {
+    auto mma = [&](int ks) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) mfma_chunk(acc[i][j], fa[pb][i], fb[pb][j]);
+            for (int j = 0; j < NJ; ++j) mfma_chunk(acc[i][j], fa[ks][i], fb[ks][j]);
     };
-    // make the compiler place its lgkmcnt wait for buffer `pb` HERE (before younger ds_reads are
+    // make the compiler place its lgkmcnt wait for k-step `ks` HERE (before younger ds_reads are
     // issued) instead of in front of the MFMAs that consume it
-    auto touch = [&](int pb) {
+    auto touch = [&](int ks) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(fa[pb][i]));
+        for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(fa[ks][i]));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[pb][j]));
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[ks][j]));
     };
     // wait until tile `t` has landed: at most min(STAGES-2, tiles after t) younger tiles stay in flight
     auto wait_tile = [&](int t) {
@@ -381,45 +381,45 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(
         else if (after == 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
     };
+#define CPT_SB() __builtin_amdgcn_sched_barrier(0)
 
     if (trace) tr1 = clock64();
     wait_tile(0);
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    ldfrag(0, 0, 0);
+    CPT_SB();
+    ldfrag(0, 0);
+    ldfrag(0, 1);
+    CPT_SB();
     int slot = 0;
-    for (int t = 0; t < nt; ++t) {
-        // the slot tile t-1 occupied is free: every wave drained its reads before the last barrier
-        if (t + STAGES - 1 < nt) {
+    // MAIN iterations (every condition true) are one basic block, so the compiler's waitcnt pass
+    // counts outstanding LDS reads exactly; the last STAGES-1 tiles run the guarded version.
+    auto body = [&](int t, auto main_tag) {
+        constexpr bool MAIN = decltype(main_tag)::value;
+        const bool more = MAIN || (t + 1 < nt);
+        int nslot = slot + 1;
+        if (nslot == STAGES) nslot = 0;
+        // refill the slot tile t-1 occupied (GEMM pipeline hazards)
+        if (MAIN || t + STAGES - 1 < nt) {
             int ns = slot + STAGES - 1;
             if (ns >= STAGES) ns -= STAGES;
             stage(ns, (t + STAGES - 1) * BK);
         }
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            touch(ks & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            ldfrag(slot, ks + 1, (ks + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(ks & 1);
-            __builtin_amdgcn_sched_barrier(0);
+        touch(0); CPT_SB(); ldfrag(slot, 2); CPT_SB(); mma(0); CPT_SB();
+        touch(1); CPT_SB(); ldfrag(slot, 3); CPT_SB(); mma(1); CPT_SB();
+        if (more) {
+            if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1);
+            CPT_SB();
+            __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves
+            CPT_SB();
         }
-        int nslot = slot + 1;
-        if (nslot == STAGES) nslot = 0;
-        touch(1);                              // this wave's reads of tile t are all done
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nt) {
-            wait_tile(t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();      // tile t+1 visible to all; nobody still reads tile t
-            __builtin_amdgcn_sched_barrier(0);
-            ldfrag(nslot, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        mma(1);
-        __builtin_amdgcn_sched_barrier(0);
+        touch(2); CPT_SB(); if (more) ldfrag(nslot, 0); CPT_SB(); mma(2); CPT_SB();
+        touch(3); CPT_SB(); if (more) ldfrag(nslot, 1); CPT_SB(); mma(3); CPT_SB();
         slot = nslot;
-    }
+    };
+    const int t_main = max(nt - (STAGES - 1), 0);
+    for (int t = 0; t < t_main; ++t) body(t, std::true_type{});
+    for (int t = t_main; t < nt; ++t) body(t, std::false_type{});
+#undef CPT_SB
 
     // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> whole-row bias/act/residual/store ----
     if (trace) tr2 = clock64();
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = v[e] + bv[p][e];
-                    if (EPI == CPT_EPI_GELU) x = gelu_erf(x);
+                    if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
                     if (EPI == CPT_EPI_TANH) x = tanhf(x);
                     if constexpr (EPI == CPT_EPI_RESID) x += rv[p][q][e];
                     v[e] = x;
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(
             for (int e = 0; e < 4; ++e) {
                 if (col + e >= N) break;
                 float x = v[e] + (bias ? bias[col + e] : 0.f);
-                if (EPI == CPT_EPI_GELU) x = gelu_erf(x);
+                if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
                 if (EPI == CPT_EPI_TANH) x = tanhf(x);
                 if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col + e];
                 out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
@@ -550,7 +550,7 @@ static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bi
 }
 
 int g_gemm_abl = 0;
-int g_gemm_variant = 1;      // 0: register-staged generic kernel only; 1: LDS-DMA 128x128; 2: LDS-DMA 256x128
+int g_gemm_variant = 3;      // 0: register-staged generic kernel only; 1: LDS-DMA 128x128; 2: LDS-DMA 256x128
 
 template <typename T, int EPI, typename OT>
 static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, const float* bias,

@@ -198,4 +198,4 @@ def test_gemm_variants_agree(dev, variant):
             o32 = ops.gemm(a32, w32, b.to(dev), epi=epi, resid=None if r is None else r.to(dev)).cpu()
             assert _stats("variant %d fp32" % variant, o32, ref) < 3e-5 * max(1.0, math.sqrt(K / 64))
     finally:
-        L.check(L.lib().cpt_set_tuning(0, 1))
+        L.check(L.lib().cpt_set_tuning(0, 3))

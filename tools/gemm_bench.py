@@ -62,7 +62,7 @@ def main():
             ms = e0.elapsed_time(e1) / a.iters       # back-to-back average (includes launch gaps)
             print("%-9s %5dx%5dx%4d variant %d abl %d: %8.2f us  %7.1f TFLOP/s  (per-launch events %.2f us; max diff vs first variant %.2e)"
                   % (name, m, n, k, v, ab, ms * 1e3, 2.0 * m * n * k / ms / 1e9, ms_ev * 1e3, err), flush=True)
-    L.check(L.lib().cpt_set_tuning(0, 1))
+    L.check(L.lib().cpt_set_tuning(0, 3))
     L.check(L.lib().cpt_set_tuning(1, 0))
 
 

@@ -41,4 +41,4 @@ for variant in [int(v) for v in sys.argv[1].split(",")]:
               " k-loop p10/p90: %d/%d" % (np.percentile(loop, 10), np.percentile(loop, 90)))
         print("   inside k-loop (wave 0, sums over tiles): vmcnt-wait %6.0f  barrier %6.0f  glds-issue %6.0f  rest(ds_read+mfma) %6.0f"
               % (t[:, 5].mean(), t[:, 6].mean(), t[:, 7].mean(), (loop - t[:, 5] - t[:, 6] - t[:, 7]).mean()))
-L.check(L.lib().cpt_set_tuning(0, 1))
+L.check(L.lib().cpt_set_tuning(0, 3))
