@@ -42,6 +42,18 @@ class Batch(C.Structure):
                 ("input_ids", "token_type", "position_ids", "attn_mask", "img_feats", "mask_pos", "labels")]
 
 
+class LayerGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_in", "b_in", "w_out", "b_out",
+                 "ln2_g", "ln2_b")]
+
+
+class ModelGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "w_img", "b_img",
+                                          "img_ln_g", "img_ln_b")] + [("layers", C.POINTER(LayerGrads))] + \
+               [(n, C.c_void_p) for n in ("w_tr", "b_tr", "tr_ln_g", "tr_ln_b", "b_dec")]
+
+
 class Outputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("seq", "pooled", "logits", "loss", "rel")]
 
@@ -52,6 +64,11 @@ _SIGS = {
     "cpt_check_device": (C.c_int, [C.c_int]),
     "cpt_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.c_int]),
     "cpt_model_fwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), C.c_int, vp, C.c_size_t, vp]),
+    "cpt_train_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int]),
+    "cpt_train_fwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), vp, C.c_size_t, vp]),
+    "cpt_train_bwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(ModelGrads), C.c_float, vp, C.c_size_t, vp]),
+    "cpt_adamw": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                            C.c_int, C.c_float, vp]),
     "cpt_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int,
                            C.c_int, C.c_int, C.c_int, vp]),
     "cpt_embed_ln": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int,

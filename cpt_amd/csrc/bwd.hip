@@ -1,0 +1,549 @@
+// Backward-pass and optimizer kernels of the CPT few-shot step:
+// what autograd runs for `loss.backward()` at /root/reference/Oscar/oscar/fewshot/refcoco_cpt.py:248
+// and `optimizer.step()` (torch.optim.AdamW, :249,:343), restated as explicit kernels.
+// The dense parts (dgrad / wgrad) reuse the MFMA GEMM of gemm.hip on transposed, zero-padded
+// operands produced here; everything in this file is HBM-bound row / element work in fp32.
+#include "common.h"
+#include "kernels.h"
+
+namespace cpt {
+
+// ---- transpose + cast: in[R][C] (ld ldi) -> out[C][ldo], columns R..ldo-1 zero -----------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, int ldi, TO* __restrict__ out,
+                                                        int ldo, int R, int C) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < R && c < C) ? to_f32(in[(size_t)r * ldi + c]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;      // out row = c, out col = r
+        if (c < C && r < ldo) out[(size_t)c * ldo + r] = from_f32<TO>(tile[tx][ty + 4 * i]);
+    }
+}
+
+int transpose_cast(const void* in, int in_dtype, int ldi, void* out, int out_dtype, int ldo, int R, int C, hipStream_t s) {
+    if (R <= 0 || C <= 0 || ldo < R || ldi < C) return CPT_ERR_SHAPE;
+    dim3 grid((C + 63) / 64, (ldo + 63) / 64), block(256);
+    if (in_dtype == CPT_F32 && out_dtype == CPT_F32) transpose_kernel<float, float><<<grid, block, 0, s>>>((const float*)in, ldi, (float*)out, ldo, R, C);
+    else if (in_dtype == CPT_F32 && out_dtype == CPT_BF16) transpose_kernel<float, bf16><<<grid, block, 0, s>>>((const float*)in, ldi, (bf16*)out, ldo, R, C);
+    else if (in_dtype == CPT_BF16 && out_dtype == CPT_BF16) transpose_kernel<bf16, bf16><<<grid, block, 0, s>>>((const bf16*)in, ldi, (bf16*)out, ldo, R, C);
+    else return CPT_ERR_DTYPE;
+    return CPT_OK;
+}
+
+// ---- column sums (bias gradients): out[c] += sum_r x[r][c] ----------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ x, int ld, float* __restrict__ out, int R, int C, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += to_f32(x[(size_t)r * ld + c]);
+    atomicAdd(&out[c], acc);
+}
+
+int colsum(const void* x, int dtype, int ld, float* out, int R, int C, hipStream_t s) {
+    if (R <= 0 || C <= 0) return CPT_ERR_SHAPE;
+    const int rpb = 64;
+    dim3 grid((C + 255) / 256, (R + rpb - 1) / rpb), block(256);
+    if (dtype == CPT_BF16) colsum_kernel<bf16><<<grid, block, 0, s>>>((const bf16*)x, ld, out, R, C, rpb);
+    else if (dtype == CPT_F32) colsum_kernel<float><<<grid, block, 0, s>>>((const float*)x, ld, out, R, C, rpb);
+    else return CPT_ERR_DTYPE;
+    return CPT_OK;
+}
+
+// ---- GELU forward / backward on [n] elements ---------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ u, T* __restrict__ h, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (i + e < n) h[i + e] = from_f32<T>(gelu_for<T>(to_f32(u[i + e])));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ u, T* __restrict__ du, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (i + e < n) du[i + e] = from_f32<T>(to_f32(dh[i + e]) * gelu_erf_grad(to_f32(u[i + e])));
+}
+int gelu_fwd(const void* u, void* h, int dtype, size_t n, hipStream_t s) {
+    dim3 grid((unsigned)((n / 4 + 255) / 256 + 1)), block(256);
+    if (dtype == CPT_BF16) gelu_fwd_kernel<bf16><<<grid, block, 0, s>>>((const bf16*)u, (bf16*)h, n);
+    else gelu_fwd_kernel<float><<<grid, block, 0, s>>>((const float*)u, (float*)h, n);
+    return CPT_OK;
+}
+int gelu_bwd(const void* dh, const void* u, void* du, int dtype, size_t n, hipStream_t s) {
+    dim3 grid((unsigned)((n / 4 + 255) / 256 + 1)), block(256);
+    if (dtype == CPT_BF16) gelu_bwd_kernel<bf16><<<grid, block, 0, s>>>((const bf16*)dh, (const bf16*)u, (bf16*)du, n);
+    else gelu_bwd_kernel<float><<<grid, block, 0, s>>>((const float*)dh, (const float*)u, (float*)du, n);
+    return CPT_OK;
+}
+
+// ---- LayerNorm backward --------------------------------------------------------------------------
+// y = (x - mean) * rstd * g + b over rows of x[R][H] (x = gelu(u) when GELU_IN).
+// dy row r is read at (r / grp) * grp_stride + grp_off + r % grp (the residual-stream placement used
+// in the forward).  dx (fp32) and dx_lp (optional) are written compact at row r; dg/db accumulated
+// with one atomicAdd per column per workgroup.
+constexpr int LNB_MAXV = 4;
+template <typename LP, bool GELU_IN>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ g, float eps, float* __restrict__ dx,
+                                                     LP* __restrict__ dx_lp, float* __restrict__ dg, float* __restrict__ db,
+                                                     int R, int H, int grp, int grp_stride, int grp_off, int rows_per_block) {
+    __shared__ float red[2][4][256 * LNB_MAXV];     // [dg|db][wave][column]  (32 KB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = (H + 255) / 256;
+    f32x4 gsum[LNB_MAXV], bsum[LNB_MAXV], gg[LNB_MAXV];
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+        gsum[i] = f32x4{0, 0, 0, 0};
+        bsum[i] = f32x4{0, 0, 0, 0};
+        const int c = (lane + 64 * i) * 4;
+        gg[i] = (i < nv && c < H) ? *reinterpret_cast<const f32x4*>(g + c) : f32x4{0, 0, 0, 0};
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const size_t yrow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
+        f32x4 xv[LNB_MAXV], dv[LNB_MAXV], uv[LNB_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (i < nv && c < H) {
+                xv[i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
+                if (GELU_IN) {
+                    uv[i] = xv[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[i][j] = gelu_erf(uv[i][j]);
+                }
+                dv[i] = *reinterpret_cast<const f32x4*>(dy + yrow * H + c);
+                s += xv[i][0] + xv[i][1] + xv[i][2] + xv[i][3];
+            }
+        }
+        const float mean = wave_sum(s) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i)
+            if (i < nv && (lane + 64 * i) * 4 < H) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = xv[i][j] - mean; q += d * d; }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+        float s1 = 0.f, s2 = 0.f;     // sum(dy*g), sum(dy*g*xhat)
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i)
+            if (i < nv && (lane + 64 * i) * 4 < H) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xv[i][j] - mean) * rstd;
+                    const float gy = dv[i][j] * gg[i][j];
+                    s1 += gy;
+                    s2 += gy * xh;
+                    gsum[i][j] += dv[i][j] * xh;
+                    bsum[i][j] += dv[i][j];
+                }
+            }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (i < nv && c < H) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xv[i][j] - mean) * rstd;
+                    float d = rstd * (dv[i][j] * gg[i][j] - s1 - xh * s2);
+                    if (GELU_IN) d *= gelu_erf_grad(uv[i][j]);
+                    o[j] = d;
+                }
+                if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)r * H + c) = o;
+                if (dx_lp) {
+                    if constexpr (sizeof(LP) == 2) {
+                        bf16x4 p;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) p[j] = (bf16)o[j];
+                        *reinterpret_cast<bf16x4*>(dx_lp + (size_t)r * H + c) = p;
+                    } else {
+                        *reinterpret_cast<f32x4*>(dx_lp + (size_t)r * H + c) = o;
+                    }
+                }
+            }
+        }
+    }
+    // reduce dg/db over the 4 waves, one atomic per column per workgroup
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[0][wave][(lane + 64 * i) * 4 + j] = gsum[i][j];
+            red[1][wave][(lane + 64 * i) * 4 + j] = bsum[i][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        atomicAdd(&dg[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(&db[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
+           float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s) {
+    if (R <= 0 || H % 4 || H > 256 * LNB_MAXV || grp <= 0) return CPT_ERR_SHAPE;
+    if (!dy || !x || !g || !dg || !db) return CPT_ERR_NULL;
+    const int rpb = 32;
+    dim3 grid((R + rpb - 1) / rpb), block(256);
+    const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
+#define LNB(LPT, GI) ln_bwd_kernel<LPT, GI><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb)
+    if (lp16) { if (gelu_in) LNB(bf16, true); else LNB(bf16, false); }
+    else      { if (gelu_in) LNB(float, true); else LNB(float, false); }
+#undef LNB
+    return CPT_OK;
+}
+
+// ---- embedding LayerNorm backward + scatter-add into the three tables -----------------------------
+__global__ __launch_bounds__(256) void embed_bwd_kernel(
+    const float* __restrict__ dy, const int64_t* __restrict__ ids, const int64_t* __restrict__ tt, const int64_t* __restrict__ pos,
+    const float* __restrict__ word, const float* __restrict__ posw, const float* __restrict__ typew, const float* __restrict__ g,
+    float eps, float* __restrict__ dword, float* __restrict__ dposw, float* __restrict__ dtypew, float* __restrict__ dg,
+    float* __restrict__ db, int B, int Lt, int L, int H, int vocab, int max_pos, int type_vocab, int rows_per_block) {
+    __shared__ float red[2][4][256 * LNB_MAXV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = (H + 255) / 256;
+    const int R = B * Lt;
+    f32x4 gsum[LNB_MAXV], bsum[LNB_MAXV], gg[LNB_MAXV];
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+        gsum[i] = f32x4{0, 0, 0, 0};
+        bsum[i] = f32x4{0, 0, 0, 0};
+        const int c = (lane + 64 * i) * 4;
+        gg[i] = (i < nv && c < H) ? *reinterpret_cast<const f32x4*>(g + c) : f32x4{0, 0, 0, 0};
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const int b = r / Lt, t = r % Lt;
+        long wid = ids[r], pid = pos ? pos[r] : t, tid = tt ? tt[r] : 0;
+        wid = wid < 0 ? 0 : (wid >= vocab ? vocab - 1 : wid);
+        pid = pid < 0 ? 0 : (pid >= max_pos ? max_pos - 1 : pid);
+        tid = tid < 0 ? 0 : (tid >= type_vocab ? type_vocab - 1 : tid);
+        f32x4 xv[LNB_MAXV], dv[LNB_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (i < nv && c < H) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(word + (size_t)wid * H + c);
+                const f32x4 p = *reinterpret_cast<const f32x4*>(posw + (size_t)pid * H + c);
+                const f32x4 q = *reinterpret_cast<const f32x4*>(typew + (size_t)tid * H + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[i][j] = a[j] + p[j] + q[j];
+                dv[i] = *reinterpret_cast<const f32x4*>(dy + ((size_t)b * L + t) * H + c);
+                s += xv[i][0] + xv[i][1] + xv[i][2] + xv[i][3];
+            }
+        }
+        const float mean = wave_sum(s) / (float)H;
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i)
+            if (i < nv && (lane + 64 * i) * 4 < H) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = xv[i][j] - mean; q2 += d * d; }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)H + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i)
+            if (i < nv && (lane + 64 * i) * 4 < H) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xv[i][j] - mean) * rstd;
+                    const float gy = dv[i][j] * gg[i][j];
+                    s1 += gy;
+                    s2 += gy * xh;
+                    gsum[i][j] += dv[i][j] * xh;
+                    bsum[i][j] += dv[i][j];
+                }
+            }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (i < nv && c < H) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xv[i][j] - mean) * rstd;
+                    const float d = rstd * (dv[i][j] * gg[i][j] - s1 - xh * s2);
+                    // nn.Embedding(padding_idx=0): the lookup contributes no gradient to row 0
+                    if (wid != 0) atomicAdd(&dword[(size_t)wid * H + c + j], d);
+                    atomicAdd(&dposw[(size_t)pid * H + c + j], d);
+                    atomicAdd(&dtypew[(size_t)tid * H + c + j], d);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[0][wave][(lane + 64 * i) * 4 + j] = gsum[i][j];
+            red[1][wave][(lane + 64 * i) * 4 + j] = bsum[i][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        atomicAdd(&dg[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(&db[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
+              const float* posw, const float* typew, const float* g, float eps, float* dword, float* dposw,
+              float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,
+              int type_vocab, hipStream_t s) {
+    if (B <= 0 || Lt <= 0 || H % 4 || H > 256 * LNB_MAXV) return CPT_ERR_SHAPE;
+    const int rpb = 16;
+    dim3 grid((B * Lt + rpb - 1) / rpb), block(256);
+    embed_bwd_kernel<<<grid, block, 0, s>>>(dy, ids, tt, pos, word, posw, typew, g, eps, dword, dposw, dtypew, dg, db,
+                                           B, Lt, L, H, vocab, max_pos, type_vocab, rpb);
+    return CPT_OK;
+}
+
+// ---- small helpers ------------------------------------------------------------------------------------
+// dst[b*L + pos[b]][:] += src[b][:]   (gradient of the [MASK]-row gather)
+__global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __restrict__ src, const int64_t* __restrict__ pos,
+                                                               float* __restrict__ dst, int L, int H) {
+    const int b = blockIdx.x;
+    long p = pos ? pos[b] : 0;
+    p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+    for (int c = threadIdx.x; c < H; c += 256) dst[((size_t)b * L + p) * H + c] += src[(size_t)b * H + c];
+}
+int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s) {
+    scatter_rows_add_kernel<<<dim3(B), dim3(256), 0, s>>>(src, pos, dst, L, H);
+    return CPT_OK;
+}
+
+// dst[R][K] += src[R][Kp]  (drop the zero padding of the img weight gradient)
+__global__ __launch_bounds__(256) void unpad_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int K, int Kp) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)R * K) return;
+    const int r = (int)(idx / K), c = (int)(idx % K);
+    dst[idx] += src[(size_t)r * Kp + c];
+}
+int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s) {
+    const size_t n = (size_t)R * K;
+    unpad_add_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(src, dst, R, K, Kp);
+    return CPT_OK;
+}
+
+// out[r][c] = x[r][c] * scale / max(count,1) for c < C, 0 for C <= c < ldo; count read from device
+template <typename TO>
+__global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ x, const float* __restrict__ loss_acc,
+                                                         float scale, TO* __restrict__ out, int R, int C, int ldo) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)R * ldo) return;
+    const int r = (int)(idx / ldo), c = (int)(idx % ldo);
+    const float k = scale / fmaxf(loss_acc ? loss_acc[1] : 1.f, 1.f);
+    out[idx] = from_f32<TO>(c < C ? x[(size_t)r * C + c] * k : 0.f);
+}
+int scale_cast(const float* x, const float* loss_acc, float scale, void* out, int out_dtype, int R, int C, int ldo, hipStream_t s) {
+    const size_t n = (size_t)R * ldo;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (out_dtype == CPT_BF16) scale_cast_kernel<bf16><<<grid, block, 0, s>>>(x, loss_acc, scale, (bf16*)out, R, C, ldo);
+    else scale_cast_kernel<float><<<grid, block, 0, s>>>(x, loss_acc, scale, (float*)out, R, C, ldo);
+    return CPT_OK;
+}
+
+// ---- attention backward (generic, fp32 math on LDS tiles; one workgroup per (sequence, head)) ----
+// Recomputes P = softmax(QK^T/8 + mask) per 32-query block, then
+//   dV += P^T dO,  dP = dO V^T,  dS = P (dP - rowsum(dP P)),  dQ = dS K / 8,  dK += dS^T Q / 8.
+constexpr int AB_QB = 32, AB_D = 64;
+template <typename T, int MAXE>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
+                                                       const T* __restrict__ dctx, T* __restrict__ dqkv, int B, int L, int heads) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int LP1 = L + 1;
+    float* sK = reinterpret_cast<float*>(smem);          // [L][65]
+    float* sV = sK + L * 65;                              // [L][65]
+    float* sQ = sV + L * 65;                              // [32][65]
+    float* sO = sQ + AB_QB * 65;                          // [32][65]  (dO block)
+    float* sP = sO + AB_QB * 65;                          // [32][L+1]
+    float* sS = sP + AB_QB * LP1;                         // [32][L+1]  (dP then dS)
+    float* sM = sS + AB_QB * LP1;                         // [L] additive mask
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int H = heads * AB_D;
+    const size_t ldq = (size_t)3 * H;
+    const T* base = qkv + (size_t)b * L * ldq + h * AB_D;
+    T* dbase = dqkv + (size_t)b * L * ldq + h * AB_D;
+    for (int idx = tid; idx < L * AB_D; idx += 256) {
+        const int r = idx / AB_D, c = idx % AB_D;
+        sK[r * 65 + c] = to_f32(base[(size_t)r * ldq + H + c]);
+        sV[r * 65 + c] = to_f32(base[(size_t)r * ldq + 2 * H + c]);
+    }
+    for (int j = tid; j < L; j += 256) sM[j] = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + j]) * -10000.0f : 0.f;
+
+    // this thread's share of the dK / dV accumulators: elements e = tid + 256*k of the [L][64] tiles
+    float accK[MAXE], accV[MAXE];                          // MAXE >= L*64/256
+    const int ne = (L * AB_D + 255) / 256;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) { accK[k] = 0.f; accV[k] = 0.f; }
+
+    for (int q0 = 0; q0 < L; q0 += AB_QB) {
+        const int nq = min(AB_QB, L - q0);
+        __syncthreads();
+        for (int idx = tid; idx < AB_QB * AB_D; idx += 256) {
+            const int r = idx / AB_D, c = idx % AB_D;
+            const bool ok = r < nq;
+            sQ[r * 65 + c] = ok ? to_f32(base[(size_t)(q0 + r) * ldq + c]) : 0.f;
+            sO[r * 65 + c] = ok ? to_f32(dctx[((size_t)b * L + q0 + r) * H + h * AB_D + c]) : 0.f;
+        }
+        __syncthreads();
+        // scores and dP for the block
+        for (int idx = tid; idx < AB_QB * L; idx += 256) {
+            const int i = idx / L, j = idx % L;
+            float s = 0.f, dp = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < AB_D; ++d) {
+                s += sQ[i * 65 + d] * sK[j * 65 + d];
+                dp += sO[i * 65 + d] * sV[j * 65 + d];
+            }
+            sP[i * LP1 + j] = s * 0.125f + sM[j];
+            sS[i * LP1 + j] = dp;
+        }
+        __syncthreads();
+        // softmax rows + dS: wave w owns rows w, w+4, ...
+        for (int i = wave; i < AB_QB; i += 4) {
+            float m = -INFINITY;
+            for (int j = lane; j < L; j += 64) m = fmaxf(m, sP[i * LP1 + j]);
+            m = wave_max(m);
+            float sum = 0.f;
+            for (int j = lane; j < L; j += 64) { const float p = expf(sP[i * LP1 + j] - m); sP[i * LP1 + j] = p; sum += p; }
+            sum = wave_sum(sum);
+            const float inv = 1.0f / sum;
+            float dd = 0.f;
+            for (int j = lane; j < L; j += 64) { const float p = sP[i * LP1 + j] * inv; sP[i * LP1 + j] = p; dd += p * sS[i * LP1 + j]; }
+            dd = wave_sum(dd);
+            for (int j = lane; j < L; j += 64) sS[i * LP1 + j] = sP[i * LP1 + j] * (sS[i * LP1 + j] - dd);
+        }
+        __syncthreads();
+        // dQ block
+        for (int idx = tid; idx < AB_QB * AB_D; idx += 256) {
+            const int i = idx / AB_D, d = idx % AB_D;
+            if (i < nq) {
+                float a = 0.f;
+                for (int j = 0; j < L; ++j) a += sS[i * LP1 + j] * sK[j * 65 + d];
+                dbase[(size_t)(q0 + i) * ldq + d] = from_f32<T>(a * 0.125f);
+            }
+        }
+        // dK, dV accumulation
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+            if (k < ne) {
+                const int e = tid + 256 * k;
+                if (e < L * AB_D) {
+                    const int j = e / AB_D, d = e % AB_D;
+                    float ak = 0.f, av = 0.f;
+                    for (int i = 0; i < nq; ++i) {
+                        ak += sS[i * LP1 + j] * sQ[i * 65 + d];
+                        av += sP[i * LP1 + j] * sO[i * 65 + d];
+                    }
+                    accK[k] += ak;
+                    accV[k] += av;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+        if (k < ne) {
+            const int e = tid + 256 * k;
+            if (e < L * AB_D) {
+                const int j = e / AB_D, d = e % AB_D;
+                dbase[(size_t)j * ldq + H + d] = from_f32<T>(accK[k] * 0.125f);
+                dbase[(size_t)j * ldq + 2 * H + d] = from_f32<T>(accV[k]);
+            }
+        }
+    }
+}
+
+int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s) {
+    if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
+    const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + 2 * AB_QB * (L + 1) + L) * sizeof(float);
+    if (lds > 160 * 1024) return CPT_ERR_SHAPE;            // L <= ~176 in this round (RefCOCO L = 120)
+    dim3 grid(B * heads), block(256);
+    hipError_t e;
+#define ABK(TT, ME)                                                                                                   \
+    do {                                                                                                              \
+        auto k = attn_bwd_kernel<TT, ME>;                                                                             \
+        if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)             \
+            return CPT_ERR_HIP - (int)e;                                                                              \
+        k<<<grid, block, lds, s>>>((const TT*)qkv, attn_mask, (const TT*)dctx, (TT*)dqkv, B, L, heads);               \
+    } while (0)
+    if (dtype == CPT_BF16) { if (L <= 128) ABK(bf16, 32); else ABK(bf16, 44); }
+    else if (dtype == CPT_F32) { if (L <= 128) ABK(float, 32); else ABK(float, 44); }
+    else return CPT_ERR_DTYPE;
+#undef ABK
+    return CPT_OK;
+}
+
+// ---- fused AdamW over the flat parameter buffer (torch.optim.AdamW single-tensor update) ---------
+// code[i]: 0 = parameter has no gradient (skipped, as torch skips grad=None), 1 = weight decay, 2 = no decay
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, const unsigned char* __restrict__ code,
+                                                    bf16* __restrict__ shadow, size_t n, float lr, float beta1, float beta2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float grad_scale) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    const f32x4 pv = *reinterpret_cast<const f32x4*>(p + i0);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i0);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + i0);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + i0);
+    const uchar4 cv = *reinterpret_cast<const uchar4*>(code + i0);
+    const unsigned char cc[4] = {cv.x, cv.y, cv.z, cv.w};
+    f32x4 po = pv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (cc[e] == 0) continue;
+        const float gr = gv[e] * grad_scale;
+        float pe = pv[e] * (1.0f - lr * (cc[e] == 1 ? wd : 0.f));
+        mv[e] = mv[e] + (gr - mv[e]) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1-beta1)
+        vv[e] = vv[e] * beta2 + gr * gr * (1.0f - beta2);
+        const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+        pe = pe - (lr / bc1) * (mv[e] / denom);
+        po[e] = pe;
+    }
+    *reinterpret_cast<f32x4*>(p + i0) = po;
+    *reinterpret_cast<f32x4*>(m + i0) = mv;
+    *reinterpret_cast<f32x4*>(v + i0) = vv;
+    if (SHADOW) {
+        bf16x4 s4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s4[e] = (bf16)po[e];
+        *reinterpret_cast<bf16x4*>(shadow + i0) = s4;
+    }
+}
+
+int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16, size_t n,
+               float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s) {
+    if (!p || !g || !m || !v || !code) return CPT_ERR_NULL;
+    if (n % 4 || step < 1) return CPT_ERR_SHAPE;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    dim3 grid((unsigned)((n / 4 + 255) / 256)), block(256);
+    if (shadow_bf16) adamw_kernel<true><<<grid, block, 0, s>>>(p, g, m, v, code, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
+    else adamw_kernel<false><<<grid, block, 0, s>>>(p, g, m, v, code, nullptr, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
+    return CPT_OK;
+}
+
+}  // namespace cpt

@@ -26,6 +26,21 @@ int check_launch(int rc, const char* what) {
     return CPT_OK;
 }
 
+}  // namespace
+
+namespace cpt {
+int abi_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int abi_check(int rc, const char* what) { return check_launch(rc, what); }
+}  // namespace cpt
+
+namespace {
+
 // ---- per-kernel event timing ---------------------------------------------------------------
 struct Prof {
     bool on = false;

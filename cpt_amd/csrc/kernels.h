@@ -29,6 +29,25 @@ int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B
 int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V,
             hipStream_t s);
 
+int transpose_cast(const void* in, int in_dtype, int ldi, void* out, int out_dtype, int ldo, int R, int C, hipStream_t s);
+int colsum(const void* x, int dtype, int ld, float* out, int R, int C, hipStream_t s);
+int gelu_fwd(const void* u, void* h, int dtype, size_t n, hipStream_t s);
+int gelu_bwd(const void* dh, const void* u, void* du, int dtype, size_t n, hipStream_t s);
+int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
+           float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s);
+int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
+              const float* posw, const float* typew, const float* g, float eps, float* dword, float* dposw,
+              float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,
+              int type_vocab, hipStream_t s);
+int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s);
+int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s);
+int scale_cast(const float* x, const float* loss_acc, float scale, void* out, int out_dtype, int R, int C, int ldo, hipStream_t s);
+int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s);
+int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16, size_t n,
+               float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s);
+int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
+                      int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s);
+
 void set_gemm_variant(int v);
 void set_gemm_abl(int v);
 void set_gemm_trace(void* p);

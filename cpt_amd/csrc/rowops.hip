@@ -57,7 +57,7 @@ __device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lan
     }
 }
 
-template <typename LP>
+template <typename LP, bool GELU_IN>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* __restrict__ out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off) {
@@ -70,7 +70,13 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = (lane + 64 * i) * 4;
-        if (i < nv && c < H) v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+        if (i < nv && c < H) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+            if (GELU_IN) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = gelu_erf(v[i][j]);
+            }
+        }
     }
     float mean = 0.f, rstd = 1.f;
     if (g) ln_stats(v, nv, lane, H, mean, rstd, eps);
@@ -79,18 +85,25 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
                  out_lp ? out_lp + orow * H : nullptr);
 }
 
-int layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
-                   void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
-                   hipStream_t s) {
+int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
+                      void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
+                      int gelu_in, hipStream_t s) {
     if (R <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
     if (grp_stride == 0 && grp != R) grp_stride = grp;
     dim3 grid((R + 3) / 4), block(ROW_THREADS);
-    if (out_lp && lp_dtype == CPT_BF16)
-        layernorm_rows_kernel<bf16><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (bf16*)out_lp, R, H, grp, grp_stride, grp_off);
-    else
-        layernorm_rows_kernel<float><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (float*)out_lp, R, H, grp, grp_stride, grp_off);
+    const bool lp16 = out_lp && lp_dtype == CPT_BF16;
+#define LNK(LPT, GI) layernorm_rows_kernel<LPT, GI><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off)
+    if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
+    else      { if (gelu_in) LNK(float, true); else LNK(float, false); }
+#undef LNK
     return CPT_OK;
+}
+
+int layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
+                   void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
+                   hipStream_t s) {
+    return layernorm_rows_ex(x, g, bta, eps, out_f32, out_lp, lp_dtype, R, H, grp, grp_stride, grp_off, 0, s);
 }
 
 // ---- BertEmbeddings: gather 3 rows, add, LayerNorm -------------------------------------------

@@ -1,0 +1,288 @@
+// Few-shot training step of the CPT hot path: forward with saved activations, explicit backward,
+// fused AdamW.  Replaces autograd over /root/reference/Oscar/oscar/modeling/modeling_rec.py:137-152 +
+// modeling_bert.py:199-279 as driven by Oscar/oscar/fewshot/refcoco_cpt.py:231-249.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace cpt { int abi_fail(int code, const char* fmt, ...); int abi_check(int rc, const char* what); }
+using cpt::abi_check;
+using cpt::abi_fail;
+
+namespace {
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int up64(int x) { return (x + 63) / 64 * 64; }
+
+struct TrainLayout {
+    size_t x_f32, a_f32, layer0, layer_stride;
+    size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2;     // offsets inside a layer block
+    size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
+    size_t dx, dpre, da, dpre_lp, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp;
+    size_t total;
+    int Mp, Bp, Vp, Rp;
+};
+
+TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li) {
+    const size_t es = d.dtype == CPT_BF16 ? 2 : 4;
+    const size_t L = (size_t)Lt + Li, M = (size_t)B * L, H = d.hidden, I = d.inter, V = d.vocab, Dp = d.img_dim_pad;
+    const size_t R = (size_t)B * Li;
+    TrainLayout w;
+    w.Mp = up64((int)M); w.Bp = up64(B); w.Vp = up64((int)V); w.Rp = up64((int)std::max<size_t>(R, 1));
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t p = o; o += al(bytes); return p; };
+    w.x_f32 = take(M * H * 4);
+    w.a_f32 = take(M * H * 4);
+    {   // one block per layer
+        size_t q = 0;
+        auto sub = [&](size_t bytes) { size_t p = q; q += al(bytes); return p; };
+        w.o_xin = sub(M * H * es); w.o_qkv = sub(M * 3 * H * es); w.o_ctx = sub(M * H * es); w.o_pre1 = sub(M * H * 4);
+        w.o_a = sub(M * H * es); w.o_u = sub(M * I * es); w.o_h = sub(M * I * es); w.o_pre2 = sub(M * H * 4);
+        w.layer_stride = q;
+        w.layer0 = take(q * d.layers);
+    }
+    w.xout = take(M * H * es);
+    w.imgp = take(R * Dp * es);
+    w.imgpre = take(R * H * 4);
+    w.rows = take((size_t)B * H * es);
+    w.uh = take((size_t)B * H * 4);
+    w.t2 = take((size_t)B * H * es);
+    w.dlogits = take((size_t)B * V * 4);
+    w.loss = take(256);
+    // backward temporaries
+    w.dx = take(M * H * 4);
+    w.dpre = take(M * H * 4);
+    w.da = take(M * H * 4);
+    w.dpre_lp = take(M * H * es);
+    w.dctx = take(M * H * es);
+    w.dbig = take(M * std::max(3 * H, I) * es);
+    const size_t cols = std::max<size_t>({(size_t)w.Mp, (size_t)w.Bp, (size_t)w.Rp});
+    w.tA = take(std::max<size_t>({3 * H, I, V}) * cols * es);
+    w.tB = take(std::max<size_t>({I, Dp, H}) * cols * es);
+    w.wT = take(std::max<size_t>({3 * H * H, I * H, H * (size_t)w.Vp}) * es);
+    w.gimg = take(H * Dp * 4);
+    w.dl_lp = take((size_t)B * w.Vp * es);
+    w.dt2 = take((size_t)B * H * 4);
+    w.duh = take((size_t)B * H * 4);
+    w.duh_lp = take((size_t)B * H * es);
+    w.drows = take((size_t)B * H * 4);
+    w.dimg = take(R * H * 4);
+    w.dimg_lp = take(R * H * es);
+    w.total = o;
+    return w;
+}
+
+int check_common(const cpt_model* m, const cpt_batch* b, void* ws, size_t ws_bytes, const TrainLayout& w, const char* who) {
+    const cpt_dims& d = m->dims;
+    if (b->B <= 0 || b->Lt <= 0 || b->Li < 0) return abi_fail(CPT_ERR_SHAPE, "%s: bad batch shape", who);
+    if (d.heads <= 0 || d.hidden != d.heads * 64) return abi_fail(CPT_ERR_SHAPE, "%s: head_dim must be 64", who);
+    if (d.dtype != CPT_F32 && d.dtype != CPT_BF16) return abi_fail(CPT_ERR_DTYPE, "%s: dtype %d", who, d.dtype);
+    if (d.img_dim_pad < d.img_dim || d.img_dim_pad % 64) return abi_fail(CPT_ERR_ALIGN, "%s: img_dim_pad must be a multiple of 64 for training", who);
+    if (d.hidden % 64 || d.inter % 64) return abi_fail(CPT_ERR_ALIGN, "%s: hidden/intermediate sizes must be multiples of 64", who);
+    if (!b->mask_pos || !b->labels) return abi_fail(CPT_ERR_NULL, "%s: mask_pos and labels are required", who);
+    if (b->Li > 0 && !b->img_feats) return abi_fail(CPT_ERR_NULL, "%s: img_feats is NULL", who);
+    if (b->Li > 0 && !(d.use_img_ln && m->img_ln_g)) return abi_fail(CPT_ERR_SHAPE, "%s: training without use_img_layernorm is not implemented", who);
+    if (!m->w_tr || !m->w_dec) return abi_fail(CPT_ERR_NULL, "%s: model has no MLM head", who);
+    if (ws_bytes < w.total) return abi_fail(CPT_ERR_WORKSPACE, "%s: workspace %zu < required %zu bytes", who, ws_bytes, w.total);
+    if ((uintptr_t)ws & 255) return abi_fail(CPT_ERR_ALIGN, "%s: workspace must be 256-byte aligned", who);
+    return CPT_OK;
+}
+
+}  // namespace
+
+#define TRY(expr, what)                        \
+    do {                                       \
+        int rc__ = abi_check((expr), what);    \
+        if (rc__ != CPT_OK) return rc__;       \
+    } while (0)
+
+extern "C" {
+
+size_t cpt_train_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li) {
+    if (!d || B <= 0 || Lt <= 0 || Li < 0) return 0;
+    return train_layout(*d, B, Lt, Li).total;
+}
+
+int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+    if (!m || !b || !o || !workspace) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: null argument");
+    const cpt_dims& d = m->dims;
+    const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li);
+    int rc = check_common(m, b, workspace, workspace_bytes, w, "cpt_train_fwd");
+    if (rc) return rc;
+    if (!o->logits || !o->loss) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: logits and loss outputs are required");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, dt = d.dtype;
+    if (L > 288) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: sequence length %d > 288", L);
+    unsigned char* ws = (unsigned char*)workspace;
+    float* x_f32 = (float*)(ws + w.x_f32);
+    float* a_f32 = (float*)(ws + w.a_f32);
+    auto LB = [&](int l, size_t off) { return (void*)(ws + w.layer0 + (size_t)l * w.layer_stride + off); };
+
+    TRY(cpt::embed_ln(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g,
+                      m->emb_ln_b, d.ln_eps, x_f32, LB(0, w.o_xin), dt, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, s), "embed_ln");
+    if (Li > 0) {
+        void* imgp = ws + w.imgp;
+        float* imgpre = (float*)(ws + w.imgpre);
+        TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
+        TRY(cpt::gemm(dt, CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, imgpre, CPT_F32, H,
+                      B * Li, H, d.img_dim_pad, s), "gemm(img_embedding)");
+        TRY(cpt::layernorm_rows(imgpre, m->img_ln_g, m->img_ln_b, d.img_ln_eps, x_f32, LB(0, w.o_xin), dt, B * Li, H, Li, L, Lt, s), "layernorm(img)");
+    }
+    for (int l = 0; l < d.layers; ++l) {
+        const cpt_layer& y = m->layers[l];
+        void* xin = LB(l, w.o_xin);
+        void* xnext = l + 1 < d.layers ? LB(l + 1, w.o_xin) : (void*)(ws + w.xout);
+        TRY(cpt::gemm(dt, CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
+        TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s), "attention");
+        TRY(cpt::gemm(dt, CPT_EPI_RESID, LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, x_f32, H, LB(l, w.o_pre1), CPT_F32, H, M, H, H, s), "gemm(attn out)");
+        TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, s), "layernorm(attn)");
+        TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_a), H, y.w_in, H, y.b_in, nullptr, 0, LB(l, w.o_u), dt, I, M, I, H, s), "gemm(ffn up)");
+        TRY(cpt::gelu_fwd(LB(l, w.o_u), LB(l, w.o_h), dt, (size_t)M * I, s), "gelu");
+        TRY(cpt::gemm(dt, CPT_EPI_RESID, LB(l, w.o_h), I, y.w_out, I, y.b_out, a_f32, H, LB(l, w.o_pre2), CPT_F32, H, M, H, I, s), "gemm(ffn down)");
+        TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, s), "layernorm(ffn)");
+    }
+    // head on the [MASK] rows
+    void* rows = ws + w.rows;
+    float* uh = (float*)(ws + w.uh);
+    void* t2 = ws + w.t2;
+    TRY(cpt::gather_rows(ws + w.xout, dt, b->mask_pos, rows, B, L, H, s), "gather([MASK])");
+    TRY(cpt::gemm(dt, CPT_EPI_NONE, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, uh, CPT_F32, H, B, H, H, s), "gemm(head transform)");
+    TRY(cpt::layernorm_rows_ex(uh, m->tr_ln_g, m->tr_ln_b, d.ln_eps, dt == CPT_F32 ? (float*)t2 : nullptr,
+                               dt == CPT_F32 ? nullptr : t2, dt, B, H, B, 0, 0, 1, s), "gelu+layernorm(head)");
+    TRY(cpt::gemm(dt, CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, B, d.vocab, H, s), "gemm(decoder)");
+    hipError_t e = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero loss: %s", hipGetErrorString(e));
+    TRY(cpt::ce_rows(o->logits, b->labels, o->loss, (float*)(ws + w.dlogits), B, d.vocab, s), "ce_rows");
+    e = hipMemcpyAsync(ws + w.loss, o->loss, 2 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "save loss: %s", hipGetErrorString(e));
+    return CPT_OK;
+}
+
+int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || !b || !g || !workspace) return abi_fail(CPT_ERR_NULL, "cpt_train_bwd: null argument");
+    const cpt_dims& d = m->dims;
+    const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li);
+    int rc = check_common(m, b, workspace, workspace_bytes, w, "cpt_train_bwd");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, V = d.vocab, dt = d.dtype;
+    const int Mp = w.Mp, Bp = w.Bp, Vp = w.Vp, Rp = w.Rp, Dp = d.img_dim_pad;
+    unsigned char* ws = (unsigned char*)workspace;
+    auto LB = [&](int l, size_t off) { return (void*)(ws + w.layer0 + (size_t)l * w.layer_stride + off); };
+    float* dx = (float*)(ws + w.dx);
+    float* dpre = (float*)(ws + w.dpre);
+    float* da = (float*)(ws + w.da);
+    void* dpre_lp = ws + w.dpre_lp;
+    void* dctx = ws + w.dctx;
+    void* dbig = ws + w.dbig;
+    void* tA = ws + w.tA;
+    void* tB = ws + w.tB;
+    void* wT = ws + w.wT;
+    // out[Nout][Kout] (fp32 gradient of a Linear weight) = dY^T . X over the M rows
+    auto wgrad = [&](const void* dY, int dY_dt, int ldy, int Nout, const void* X, int ldx, int Kout, int rows, int rows_p,
+                     float* out, int ldo, const char* what) -> int {
+        TRY(cpt::transpose_cast(dY, dY_dt, ldy, tA, dt, rows_p, rows, Nout, s), what);
+        TRY(cpt::transpose_cast(X, dt, ldx, tB, dt, rows_p, rows, Kout, s), what);
+        TRY(cpt::gemm(dt, CPT_EPI_NONE, tA, rows_p, tB, rows_p, nullptr, nullptr, 0, out, CPT_F32, ldo, Nout, Kout, rows_p, s), what);
+        return CPT_OK;
+    };
+    // out[rows][Kout] = dY[rows][Nout] . Wt[Nout][Kout]  (+ resid), Wt given as the Linear weight [Nout][Kout]
+    auto dgrad = [&](const void* dY, int ldy, int Nout_p, const void* Wt, int ldw, int Nout, int Kout, int rows,
+                     const float* resid, void* out, int out_dt, const char* what) -> int {
+        TRY(cpt::transpose_cast(Wt, dt, ldw, wT, dt, Nout_p, Nout, Kout, s), what);
+        TRY(cpt::gemm(dt, resid ? CPT_EPI_RESID : CPT_EPI_NONE, dY, ldy, wT, Nout_p, nullptr, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s), what);
+        return CPT_OK;
+    };
+
+    // ---- head ------------------------------------------------------------------------------------
+    void* dl_lp = ws + w.dl_lp;
+    float* dt2 = (float*)(ws + w.dt2);
+    float* duh = (float*)(ws + w.duh);
+    void* duh_lp = ws + w.duh_lp;
+    float* drows = (float*)(ws + w.drows);
+    TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, dl_lp, dt, B, V, Vp, s), "scale(dlogits)");
+    TRY(cpt::colsum(dl_lp, dt, Vp, g->b_dec, B, V, s), "colsum(cls.bias)");
+    rc = dgrad(dl_lp, Vp, Vp, m->w_dec, H, V, H, B, nullptr, dt2, CPT_F32, "dgrad(decoder)");
+    if (rc) return rc;
+    rc = wgrad(dl_lp, dt, Vp, V, ws + w.t2, H, H, B, Bp, g->word_emb, H, "wgrad(decoder)");
+    if (rc) return rc;
+    TRY(cpt::ln_bwd(dt2, (const float*)(ws + w.uh), m->tr_ln_g, d.ln_eps, duh, dt == CPT_BF16 ? duh_lp : nullptr, dt, g->tr_ln_g,
+                    g->tr_ln_b, B, H, B, 0, 0, 1, s), "ln_bwd(head)");
+    const void* duh_in = dt == CPT_BF16 ? duh_lp : (const void*)duh;
+    TRY(cpt::colsum(duh, CPT_F32, H, g->b_tr, B, H, s), "colsum(transform bias)");
+    rc = wgrad(duh_in, dt, H, H, ws + w.rows, H, H, B, Bp, g->w_tr, H, "wgrad(head transform)");
+    if (rc) return rc;
+    rc = dgrad(duh_in, H, H, m->w_tr, H, H, H, B, nullptr, drows, CPT_F32, "dgrad(head transform)");
+    if (rc) return rc;
+    hipError_t e = hipMemsetAsync(dx, 0, (size_t)M * H * 4, s);
+    if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero dx: %s", hipGetErrorString(e));
+    TRY(cpt::scatter_rows_add(drows, b->mask_pos, dx, B, L, H, s), "scatter([MASK] rows)");
+
+    // ---- encoder layers, last to first -----------------------------------------------------------
+    const void* dpre_in = dt == CPT_BF16 ? dpre_lp : (const void*)dpre;
+    for (int l = d.layers - 1; l >= 0; --l) {
+        const cpt_layer& y = m->layers[l];
+        const cpt_layer_grads& gy = g->layers[l];
+        // x_out = LN2(pre2); pre2 = h W_out^T + b_out + a
+        TRY(cpt::ln_bwd(dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln2_g, gy.ln2_b,
+                        M, H, M, 0, 0, 0, s), "ln_bwd(ffn)");
+        TRY(cpt::colsum(dpre, CPT_F32, H, gy.b_out, M, H, s), "colsum(b_out)");
+        rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_h), I, I, M, Mp, gy.w_out, I, "wgrad(ffn down)");
+        if (rc) return rc;
+        rc = dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)");
+        if (rc) return rc;
+        // h = gelu(u); u = a W_in^T + b_in
+        TRY(cpt::gelu_bwd(dbig, LB(l, w.o_u), dbig, dt, (size_t)M * I, s), "gelu_bwd");
+        TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
+        rc = wgrad(dbig, dt, I, I, LB(l, w.o_a), H, H, M, Mp, gy.w_in, H, "wgrad(ffn up)");
+        if (rc) return rc;
+        rc = dgrad(dbig, I, I, y.w_in, H, I, H, M, dpre, da, CPT_F32, "dgrad(ffn up)+residual");
+        if (rc) return rc;
+        // a = LN1(pre1); pre1 = ctx W_ao^T + b_ao + x_in
+        TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln1_g, gy.ln1_b,
+                        M, H, M, 0, 0, 0, s), "ln_bwd(attn)");
+        TRY(cpt::colsum(dpre, CPT_F32, H, gy.b_ao, M, H, s), "colsum(b_ao)");
+        rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_ctx), H, H, M, Mp, gy.w_ao, H, "wgrad(attn out)");
+        if (rc) return rc;
+        rc = dgrad(dpre_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
+        if (rc) return rc;
+        TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s), "attention_bwd");
+        TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
+        rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)");
+        if (rc) return rc;
+        rc = dgrad(dbig, 3 * H, 3 * H, y.w_qkv, H, 3 * H, H, M, dpre, dx, CPT_F32, "dgrad(qkv)+residual");
+        if (rc) return rc;
+    }
+
+    // ---- region projection and text embeddings ----------------------------------------------------
+    if (Li > 0) {
+        const int R = B * Li;
+        float* dimg = (float*)(ws + w.dimg);
+        void* dimg_lp = ws + w.dimg_lp;
+        TRY(cpt::ln_bwd(dx, (const float*)(ws + w.imgpre), m->img_ln_g, d.img_ln_eps, dimg, dt == CPT_BF16 ? dimg_lp : nullptr, dt,
+                        g->img_ln_g, g->img_ln_b, R, H, Li, L, Lt, 0, s), "ln_bwd(img)");
+        TRY(cpt::colsum(dimg, CPT_F32, H, g->b_img, R, H, s), "colsum(b_img)");
+        float* gimg = (float*)(ws + w.gimg);
+        rc = wgrad(dt == CPT_BF16 ? dimg_lp : (const void*)dimg, dt, H, H, ws + w.imgp, Dp, Dp, R, Rp, gimg, Dp, "wgrad(img_embedding)");
+        if (rc) return rc;
+        TRY(cpt::unpad_add(gimg, g->w_img, H, d.img_dim, Dp, s), "unpad(img weight grad)");
+    }
+    TRY(cpt::embed_bwd(dx, b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g,
+                       d.ln_eps, g->word_emb, g->pos_emb, g->type_emb, g->emb_ln_g, g->emb_ln_b, B, Lt, L, H, d.vocab, d.max_pos,
+                       d.type_vocab, s), "embed_bwd");
+    return CPT_OK;
+}
+
+int cpt_adamw(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16,
+              size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+              float grad_scale, void* stream) {
+    return abi_check(cpt::adamw_flat(p, g, m, v, code, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                                     (hipStream_t)stream), "cpt_adamw");
+}
+
+}  // extern "C"

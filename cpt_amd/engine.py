@@ -126,6 +126,7 @@ class PackedModel(object):
             if self.flat_lp is None or self.flat_lp.device != self.flat.device:
                 self.flat_lp = torch.empty(n, device=self.flat.device, dtype=torch.bfloat16)
                 self.img_pad_lp = torch.empty((H, Dp), device=self.flat.device, dtype=torch.bfloat16)
+                self._desc = {}
             L.check(L.lib().cpt_pad_cast(self.flat.data_ptr(), self.flat_lp.data_ptr(), L.CPT_BF16, 1, n, n, st),
                     "cpt_pad_cast(shadow)")
             L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_lp.data_ptr(), L.CPT_BF16, H, D, Dp, st),
@@ -133,9 +134,30 @@ class PackedModel(object):
         else:
             if getattr(self, "img_pad_f32", None) is None or self.img_pad_f32.device != self.flat.device:
                 self.img_pad_f32 = torch.empty((H, Dp), device=self.flat.device, dtype=torch.float32)
+                self._desc = {}
             L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_f32.data_ptr(), L.CPT_F32, H, D, Dp, st),
                     "cpt_pad_cast(w_img)")
-        self._desc = {}
+
+    def weights_updated(self, shadow_fresh=False):
+        """Called after the fused optimizer wrote the flat buffer through raw pointers (which does
+        not bump tensor versions): the padded img weight must be rebuilt; the bf16 shadow too unless
+        the optimizer kernel already refreshed it."""
+        cfg = self.cfg
+        H, D = cfg.hidden_size, cfg.img_feature_dim
+        Dp = (D + 63) // 64 * 64
+        st = L.stream_ptr()
+        w_img = self.view("bert.img_embedding.weight")
+        self._sig = {}
+        if self.dtype == "bf16":
+            if self.flat_lp is None or not shadow_fresh:
+                self.refresh_shadow(force=True)
+                return
+            L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_lp.data_ptr(), L.CPT_BF16, H, D, Dp, st),
+                    "cpt_pad_cast(w_img)")
+        else:
+            self.refresh_shadow(force=True)
+            return
+        self._sig[self.dtype] = self._versions()
 
     # ---- descriptor ----------------------------------------------------------------------
     def descriptor(self):

@@ -52,8 +52,16 @@ class REC_MLM_CPT(_EngineMixin, BertPreTrainedModel):
             labels = masked_lm_labels
             if rows and labels.dim() == 2:       # (B, L) label grid of fewshot/refcoco_cpt.py:231-233
                 labels = labels[torch.arange(labels.size(0), device=labels.device), mask_token_pos]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and masked_lm_labels is not None:
+        if torch.is_grad_enabled() and masked_lm_labels is not None and self.bert.img_embedding.weight.requires_grad:
             from .train import mlm_loss_with_grad
+            if mask_token_pos is None:
+                # reference call form: a (B, L) grid with -1 everywhere except the [MASK] slot
+                # (fewshot/refcoco_cpt.py:231-233, 245-247) -> recover the slot per row
+                grid = masked_lm_labels != -1
+                if not bool((grid.sum(1) == 1).all()):
+                    raise NotImplementedError("cpt_amd: training expects exactly one labelled position per sequence")
+                mask_token_pos = grid.long().argmax(1)
+                labels = masked_lm_labels[torch.arange(grid.size(0), device=grid.device), mask_token_pos]
             return mlm_loss_with_grad(self, input_ids, token_type_ids, attention_mask, labels, position_ids,
                                       img_feats, mask_token_pos)
         out = self._engine().forward(input_ids, token_type_ids, attention_mask, position_ids, img_feats,

@@ -153,6 +153,43 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Few-shot training step (Oscar/oscar/fewshot/refcoco_cpt.py:231-249): forward that keeps the
+ * activations, backward into caller-owned fp32 gradient tensors laid out like the parameters,
+ * fused AdamW.  [MASK]-rows mode only (the loss of modeling_rec.py:147-150 sees only those rows).
+ * Dropout is not applied (identity), see DESIGN.md.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {           /* gradients of cpt_layer, all fp32, same shapes */
+    float* w_qkv; float* b_qkv; float* w_ao; float* b_ao; float* ln1_g; float* ln1_b;
+    float* w_in; float* b_in; float* w_out; float* b_out; float* ln2_g; float* ln2_b;
+} cpt_layer_grads;
+
+typedef struct {           /* gradients of cpt_model (pooler / seq_relationship get none on this path) */
+    float* word_emb;       /* [V][H]: tied table, decoder + embedding-lookup contributions */
+    float* pos_emb; float* type_emb; float* emb_ln_g; float* emb_ln_b;
+    float* w_img;          /* [H][img_dim] (unpadded) */
+    float* b_img; float* img_ln_g; float* img_ln_b;
+    const cpt_layer_grads* layers;   /* HOST array */
+    float* w_tr; float* b_tr; float* tr_ln_g; float* tr_ln_b; float* b_dec;
+} cpt_model_grads;
+
+size_t cpt_train_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li);
+/* forward: o->logits [B][V] and o->loss[2] = {sum of row losses, labelled-row count} are written;
+ * b->mask_pos and b->labels ([B], -1 = ignored) are required. */
+int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* backward of loss = loss_scale * mean over labelled rows; g's tensors must be zero on entry
+ * (vector gradients are accumulated with atomics); uses the workspace cpt_train_fwd filled. */
+int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
+                  void* workspace, size_t workspace_bytes, void* stream);
+/* torch.optim.AdamW update (fewshot/refcoco_cpt.py:343,249) over flat buffers of n fp32 elements
+ * (n % 4 == 0).  code[i]: 0 = no gradient on this path (skipped), 1 = weight decay, 2 = no decay
+ * (fewshot/refcoco_cpt.py:320-338).  grad is multiplied by grad_scale first (1/world after a
+ * sum all-reduce).  shadow_bf16 (optional) receives the bf16 copy of the updated parameters. */
+int cpt_adamw(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16,
+              size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+              float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Operator-level entry points (the kernels cpt_model_fwd is built from; also what the parity
  * tests call one by one).
  * ---------------------------------------------------------------------------------------- */

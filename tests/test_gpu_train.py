@@ -1,0 +1,154 @@
+"""GPU parity of the few-shot training step (cpt_train_fwd / cpt_train_bwd / cpt_adamw through the
+C ABI) against the golden gradients generated from the reference (tiny config: every gradient;
+Oscar-base: loss, gradient norms and samples) and against the reference's 3-step AdamW trace."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cpt_amd import config as cfgmod
+from cpt_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _model(cfg, seed, dev, dtype):
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, seed, head="cpt"))
+    m.tie_weights()
+    m.to(dev).train()
+    m.set_compute_dtype(dtype)
+    return m
+
+
+def _rel(got, ref):
+    got, ref = got.double().cpu().flatten(), torch.as_tensor(ref).double().flatten()
+    return float((got - ref).norm() / (ref.norm() + 1e-30)), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_tiny_all_gradients(dev, golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, "tiny_fwd_bwd.npz"))
+    cfg = cfgmod.tiny()
+    m = _model(cfg, 1234, dev, mode)
+    b = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    lab = torch.full(b["attention_mask"].shape, -1, dtype=torch.long, device=dev)
+    lab[torch.arange(3, device=dev), b["mask_token_pos"]] = b["colors"]
+    # reference call form: (B, L) label grid, no mask_token_pos
+    loss, scores = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=lab)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < (1e-4 if mode == "fp32" else 3e-2)
+    worst = 0.0
+    n = 0
+    for name, p in m.named_parameters():
+        key = "grad_" + name
+        if key not in g.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name     # pooler: no gradient
+            continue
+        rel, mx = _rel(p.grad, g[key])
+        print("%-60s rel=%.2e maxabs=%.2e" % (name, rel, mx))
+        worst = max(worst, rel)
+        n += 1
+        assert rel < (2e-4 if mode == "fp32" else 6e-2), (name, rel, mx)
+    assert n > 30
+    assert m.bert.pooler.dense.weight.grad is None
+    print("worst relative gradient error (%s): %.3e" % (mode, worst))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_base_gradients_cfg3_shape(dev, golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, "base_cfg2_b4_r50.npz"))
+    cfg = cfgmod.oscar_base()
+    m = _model(cfg, int(g["seed_w"]), dev, mode)
+    b = {k: v.to(dev) for k, v in synth.make_batch(int(g["B"]), cfg, seed=int(g["seed_b"]), n_regions=int(g["n_regions"])).items()}
+    loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
+                mask_token_pos=b["mask_token_pos"])
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < (1e-3 if mode == "fp32" else 5e-2)
+    names, norms = list(g["grad_names"]), g["grad_norms"]
+    params = dict(m.named_parameters())
+    tol = 1e-3 if mode == "fp32" else 8e-2
+    for name, ref in zip(names, norms):
+        name = str(name)
+        if ref < 0:
+            continue
+        got = float(params[name].grad.double().norm())
+        assert abs(got - ref) <= tol * max(ref, 1e-6), (name, got, ref)
+    q = params["bert.encoder.layer.11.attention.self.query.weight"].grad[:8, :16]
+    rel, mx = _rel(q, g["grad_sample_qw"])
+    assert rel < (1e-3 if mode == "fp32" else 0.15), (rel, mx)
+    gi = params["bert.img_embedding.weight"].grad[:8, 2040:2054]
+    rel, mx = _rel(gi, g["grad_sample_img"])
+    assert rel < (1e-3 if mode == "fp32" else 0.15), (rel, mx)
+    ge = params["bert.embeddings.word_embeddings.weight"].grad[synth.MASK, :32]
+    rel, mx = _rel(ge, g["grad_sample_emb_mask"])
+    assert rel < (1e-3 if mode == "fp32" else 0.15), (rel, mx)
+
+
+def test_tiny_train3_trace_fp32(dev, golden_dir):
+    """3 few-shot steps (label grid, LR schedule, AdamW groups) reproduce the reference's loss trace
+    and updated parameters."""
+    from cpt_amd.train import build_optimizer, get_lr_sched
+    t = np.load(os.path.join(golden_dir, "tiny_train3.npz"))
+    g = np.load(os.path.join(golden_dir, "tiny_fwd_bwd.npz"))
+    cfg = cfgmod.tiny()
+    m = _model(cfg, 1234, dev, "fp32")
+    b = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+
+    class O(object):
+        learning_rate = float(t["lr0"])
+        weight_decay = float(t["wd"])
+        betas = (float(t["beta1"]), float(t["beta2"]))
+        warmup_steps = 1
+        num_train_steps = 3
+    opt = build_optimizer(m, O)
+    for step in range(3):
+        lr = get_lr_sched(step, O)
+        assert lr == t["lrs"][step]
+        for gr in opt.param_groups:
+            gr["lr"] = lr
+        opt.zero_grad()
+        loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                    masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - t["losses"][step]) < 2e-4, (step, loss.item(), t["losses"][step])
+    sd = m.state_dict()
+    for k in t.files:
+        if k.startswith("after_"):
+            rel, mx = _rel(sd[k[6:]], t[k])
+            assert mx < 5e-5, (k, rel, mx)
+    assert torch.equal(sd["cls.decoder.weight"], sd["bert.embeddings.word_embeddings.weight"])
+
+
+def test_bf16_training_reduces_loss(dev):
+    """bf16 mode: 5 steps on one batch drive the loss down and keep the bf16 shadow in sync
+    (inference after training sees the updated weights)."""
+    from cpt_amd.train import FusedAdamW
+    cfg = cfgmod.tiny()
+    m = _model(cfg, 7, dev, "bf16")
+    b = {k: v.to(dev) for k, v in synth.make_batch(6, cfg, seed=5, max_seq_len=20, img_seq_len=6).items()}
+    opt = FusedAdamW(m, lr=2e-3, betas=(0.9, 0.98), weight_decay=0.01)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                    masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] - 0.5, losses
+    m.eval()
+    with torch.no_grad():
+        l2 = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+               masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])[0].item()
+    assert l2 < losses[-1] + 0.05
