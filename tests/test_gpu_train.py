@@ -58,7 +58,9 @@ def test_tiny_all_gradients(dev, golden_dir, mode):
         print("%-60s rel=%.2e maxabs=%.2e" % (name, rel, mx))
         worst = max(worst, rel)
         n += 1
-        assert rel < (2e-4 if mode == "fp32" else 6e-2), (name, rel, mx)
+        # key.bias gradients are exactly zero in exact arithmetic (softmax is shift-invariant per row):
+        # both sides hold rounding noise there, so fall back to an absolute bound
+        assert rel < (2e-4 if mode == "fp32" else 6e-2) or mx < (1e-9 if mode == "fp32" else 2e-6), (name, rel, mx)
     assert n > 30
     assert m.bert.pooler.dense.weight.grad is None
     print("worst relative gradient error (%s): %.3e" % (mode, worst))
@@ -82,6 +84,9 @@ def test_base_gradients_cfg3_shape(dev, golden_dir, mode):
         if ref < 0:
             continue
         got = float(params[name].grad.double().norm())
+        if ".key.bias" in name:            # exactly zero in exact arithmetic: noise on both sides
+            assert got < 1e-4 and ref < 1e-6, (name, got, ref)
+            continue
         assert abs(got - ref) <= tol * max(ref, 1e-6), (name, got, ref)
     q = params["bert.encoder.layer.11.attention.self.query.weight"].grad[:8, :16]
     rel, mx = _rel(q, g["grad_sample_qw"])
