@@ -1,0 +1,173 @@
+"""CPU: host-side logic of the drop-in surface -- scoring/IoU vs golden vectors and the oracle,
+LR schedule, optimizer grouping codes, config/checkpoint round trip, data-parallel helpers with
+world_size 2 on gloo."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from cpt_amd import config as cfgmod
+from cpt_amd import scoring, synth, dist as cdist
+from oracle import cpt_oracle as O
+
+
+def test_iou_matches_reference_vectors(golden_dir):
+    g = np.load(os.path.join(golden_dir, "iou.npz"))
+    got = np.array([scoring.compute_iou(list(b[0]), list(b[1])) for b in g["boxes"]])
+    assert (got == g["ious"]).all()
+
+
+def test_lr_schedule_matches_reference_vectors(golden_dir):
+    from cpt_amd.train import get_lr_sched
+    s = np.load(os.path.join(golden_dir, "lr_sched.npz"))
+
+    class Opt(object):
+        learning_rate, warmup_steps, num_train_steps = 3e-5, 50, 500
+    got = np.array([get_lr_sched(int(t), Opt) for t in s["steps"]])
+    assert (got == s["lrs"]).all()
+
+
+def test_select_region_matches_oracle_and_ties():
+    rng = np.random.Generator(np.random.PCG64(4))
+    V = 7000
+    for trial in range(20):
+        P = int(rng.integers(1, 6))
+        scores = torch.from_numpy(rng.standard_normal((P, V)).astype(np.float32))
+        sets = [list(rng.choice(synth.COLOR_IDS, size=int(rng.integers(1, 4)), replace=False)) for _ in range(P)]
+        rects = [[[i, j, i + 5, j + 7] for j in range(len(s))] for i, s in enumerate(sets)]
+        i1, r1, sc1 = scoring.select_region(scores, sets, rects, synth.NONE_ID)
+        i0, sc0 = O.select_region_zeroshot(scores, sets, synth.NONE_ID)
+        assert i1 == i0 and torch.equal(sc1, sc0)
+        i1, r1, sc1 = scoring.select_region(scores, sets, rects, synth.NONE_ID, few_shot=True)
+        i0, sc0 = O.select_region_fewshot(scores, sets, synth.NONE_ID)
+        assert i1 == i0 and torch.equal(sc1, sc0)
+    # first-max tie-break, as torch.argmax in the reference
+    s = torch.zeros(2, V)
+    s[0, synth.COLOR_IDS[1]] = 3.0
+    s[1, synth.COLOR_IDS[0]] = 3.0
+    idx, rect, _ = scoring.select_region(s, [[synth.COLOR_IDS[0], synth.COLOR_IDS[1]], [synth.COLOR_IDS[0]]],
+                                         [[[0, 0, 1, 1], [1, 1, 2, 2]], [[2, 2, 3, 3]]], synth.NONE_ID)
+    assert idx == 1 and rect == [1, 1, 2, 2]
+
+
+def test_accuracy_counts_iou_over_half():
+    preds = {"a": [10, 10, 50, 50], "b": [0, 0, 10, 10]}
+    gts = {"a": [10, 10, 41, 41], "b": [100, 100, 20, 20]}
+    assert scoring.accuracy(preds, gts) == 50.0
+
+
+def test_state_dict_keys_and_checkpoint_roundtrip(golden_dir):
+    from cpt_amd.modeling_bert import BertImgForPreTraining
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    ck = os.path.join(golden_dir, "tiny_ckpt")
+    cfg = cfgmod.BertConfig.from_pretrained(ck)
+    pre, info = BertImgForPreTraining.from_pretrained(ck, config=cfg, output_loading_info=True)
+    assert not info["missing_keys"] and not info["unexpected_keys"] and not info["error_msgs"]
+    assert not pre.training                                           # eval() as the reference loader
+    e = np.load(os.path.join(golden_dir, "tiny_ckpt_expected.npz"))
+    m = REC_MLM_CPT(cfg)
+    m.copy_from_pretraining_model(pre)
+    assert sorted(m.state_dict().keys()) == list(e["keys"])
+    assert m.cls.decoder.weight is m.bert.embeddings.word_embeddings.weight      # tied
+    with tempfile.TemporaryDirectory() as d:
+        m.save_pretrained(d)
+        assert sorted(os.listdir(d)) == ["config.json", "pytorch_model.bin"]
+        m2 = REC_MLM_CPT.from_pretrained(d)                            # fewshot/refcoco_cpt.py:503-505
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, m2.state_dict()[k]), k
+        assert m2.config.img_feature_dim == cfg.img_feature_dim
+    # size mismatch on cls.seq_relationship is tolerated (modeling_utils.py:858-860), anything else raises
+    cfg2 = cfgmod.BertConfig.from_pretrained(ck)
+    cfg2.num_contrast_classes = 2
+    BertImgForPreTraining.from_pretrained(ck, config=cfg2)
+    cfg3 = cfgmod.BertConfig.from_pretrained(ck)
+    cfg3.intermediate_size = 256
+    with pytest.raises(RuntimeError):
+        BertImgForPreTraining.from_pretrained(ck, config=cfg3)
+
+
+def test_unsupported_surface_raises():
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    m = REC_MLM_CPT(cfgmod.tiny())
+    ids = torch.zeros(1, 4, dtype=torch.long)
+    with pytest.raises(NotImplementedError):
+        m(ids, head_mask=torch.ones(2))
+    with pytest.raises(NotImplementedError):
+        m.bert(ids, encoder_history_states=[ids])
+
+
+def test_optimizer_codes_follow_reference_groups():
+    """decay / no-decay split of fewshot/refcoco_cpt.py:320-338 and skip of gradient-less params."""
+    from cpt_amd.train import NO_DECAY, NO_GRAD_PREFIXES
+    from cpt_amd.engine import pack_order
+    cfg = cfgmod.tiny()
+    names = pack_order(cfg, "cpt")
+    decay = [n for n in names if not n.startswith(NO_GRAD_PREFIXES) and not any(nd in n for nd in NO_DECAY)]
+    nodecay = [n for n in names if not n.startswith(NO_GRAD_PREFIXES) and any(nd in n for nd in NO_DECAY)]
+    assert "bert.encoder.layer.0.attention.self.query.weight" in decay
+    assert "bert.img_embedding.weight" in decay and "bert.embeddings.word_embeddings.weight" in decay
+    assert "cls.bias" in nodecay and "bert.LayerNorm.weight" in nodecay and "bert.encoder.layer.1.output.dense.bias" in nodecay
+    assert all(n.startswith("bert.pooler.") for n in names if n.startswith(NO_GRAD_PREFIXES))
+    # q/k/v weights adjacent, then q/k/v biases adjacent (fused N=3H GEMM)
+    i = names.index("bert.encoder.layer.0.attention.self.query.weight")
+    assert names[i:i + 6] == ["bert.encoder.layer.0.attention.self.%s.%s" % (a, b) for b in ("weight", "bias")
+                              for a in ("query", "key", "value")]
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 64, 1001):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = cdist.shard_range(n, r, world)
+                cover += list(range(lo, hi))
+            assert cover == list(range(n))
+            sizes = [cdist.shard_range(n, r, world)[1] - cdist.shard_range(n, r, world)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _dp_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 11
+        lo, hi = cdist.shard_range(n, rank, world)
+        # inference: each rank scores its own queries; fixed-shape gather rebuilds global order
+        local = torch.arange(lo, hi, dtype=torch.float32).unsqueeze(1) * torch.tensor([[1.0, 10.0]])
+        allv = cdist.gather_fixed(local, n)
+        assert torch.equal(allv, torch.arange(n, dtype=torch.float32).unsqueeze(1) * torch.tensor([[1.0, 10.0]]))
+        # training: one all-reduce over the flat gradient = mean of per-rank gradients
+        g = torch.full((1000,), float(rank + 1))
+        cdist.allreduce_mean_(g)
+        assert torch.allclose(g, torch.full((1000,), (1 + world) / 2.0))
+        p = torch.full((10,), float(rank))
+        cdist.broadcast_(p, 0)
+        assert float(p.sum()) == 0.0
+        # DP-averaged AdamW step == single-process step on the concatenated batch gradient mean
+        torch.manual_seed(0)
+        w0 = torch.randn(64)
+        grads = [torch.randn(64) for _ in range(world)]
+        gl = grads[rank].clone()
+        cdist.allreduce_mean_(gl)
+        p1, m1, v1 = O.adamw_step(w0, gl, torch.zeros(64), torch.zeros(64), 1, 1e-3, 0.9, 0.98, 1e-8, 0.01)
+        p_ref, _, _ = O.adamw_step(w0, sum(grads) / world, torch.zeros(64), torch.zeros(64), 1, 1e-3, 0.9, 0.98, 1e-8, 0.01)
+        assert torch.allclose(p1, p_ref, atol=1e-7)
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_helpers_world2_gloo():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_dp_worker, args=(2, port, tmp), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(tmp, "ok0")) and os.path.exists(os.path.join(tmp, "ok1"))
