@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--all-rows", action="store_true", help="vocabulary head on all 120 rows, as the reference computes it")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer: BASELINE configs[1] (default, the headline metric); train: few-shot step "
+                         "(configs[2]: forward+backward+grad all-reduce+AdamW, 32 sequences per GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -118,11 +121,25 @@ def main():
     model.load_state_dict(synth.init_state_dict(cfg, seed, head="cpt", randomize_all=False))
     model.tie_weights()
     model.to(dev).eval().set_compute_dtype(args.dtype)
+    train = args.mode == "train"
+    if train and args.batch == 64:
+        args.batch = 32
     B = args.batch
     b = {k: v.to(dev) for k, v in synth.make_batch(B, cfg, seed=seed + rank).items()}
+    if train:
+        from cpt_amd.train import FusedAdamW
+        model.train()
+        opt = FusedAdamW(model, lr=3e-5, betas=(0.9, 0.98), weight_decay=0.01)     # fewshot/refcoco_cpt.py:509-513
     mpos = None if args.all_rows else b["mask_token_pos"]
 
     def step():
+        if train:
+            opt.zero_grad()
+            loss, logits = model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                                 masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+            loss.backward()
+            opt.step()                      # includes the ONE flat gradient all-reduce when world > 1
+            return logits
         with torch.no_grad():
             return model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
                          mask_token_pos=mpos)[0]
@@ -149,7 +166,7 @@ def main():
     value = B * n_gpus * args.steps / dt
 
     roof, breakdown = None, None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not train:
         # per-kernel durations: HIP events recorded by the library on the launch stream around every
         # launch, over a second pass of the same K steps (events off in the timed region above)
         _lib.lib().cpt_prof_enable(1)
@@ -175,12 +192,14 @@ def main():
                 "unit": "pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                "config": {"workload": "Oscar-base CPT RefCOCO inference, batch %d/GPU, 50 regions, seq_len 120, %s, "
+                "config": {"workload": ("Oscar-base CPT few-shot training step (fwd+bwd+grad all-reduce+AdamW), batch %d/GPU, "
+                                        "50 regions, seq_len 120, %s, dropout off" % (B, args.dtype)) if train else
+                                       "Oscar-base CPT RefCOCO inference, batch %d/GPU, 50 regions, seq_len 120, %s, "
                                        "[MASK]-row logits%s" % (B, args.dtype, " (all-row head)" if args.all_rows else ""),
                            "global_batch": B * n_gpus, "seq_len": 120, "parallelism": "dp%d" % n_gpus,
                            "weights": "random-init N(0,0.02), seed 88"},
                 "roofline": roof, "kernel_ms_per_step": breakdown}
-        if n_gpus == 1 and not args.no_cpu:
+        if n_gpus == 1 and not args.no_cpu and not train:
             line["cpu_baseline"] = cpu_baseline(cfg, seed, min(usable_cores(), 64))
         else:
             line["cpu_baseline"] = None

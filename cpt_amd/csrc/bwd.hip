@@ -475,8 +475,230 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
 }
 
+// ---- attention backward on MFMA (bf16, L <= 128): same math, scores recomputed on the matrix cores ----
+// One workgroup per (sequence, head).  LDS holds Q, K, V, dO as swizzled row tiles (A/B operands
+// of the score-shaped products) and Q^T, K^T, dO^T as padded transposed tiles (B operands of the
+// products that contract over rows).  Phase A (wave <-> 32-query block, transposed scores: one query
+// per lane) yields the softmax statistics, D = rowsum(dP.P) and dQ; phase B (wave <-> 32-key block,
+// one key per lane) recomputes P/dS blockwise and accumulates dK, dV over the query blocks.
+// As in the forward kernel, probabilities sit in the A-operand layout of the next MFMA once the
+// contraction index of the B operand is permuted identically, so nothing round-trips through LDS.
+__device__ __forceinline__ int kq_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
+                                                            const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int B, int L, int heads) {
+    constexpr int LP = NKB * 32;
+    constexpr int TROW = LP * 2 + 8;                  // bytes per transposed-tile row (pad: conflict-free b64 reads)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sQ = smem;                          // [LP][64] bf16 swizzled rows
+    unsigned char* sK = sQ + LP * 128;
+    unsigned char* sV = sK + LP * 128;
+    unsigned char* sO = sV + LP * 128;                 // dO rows
+    unsigned char* tQ = sO + LP * 128;                 // [64][LP] transposed (+pad)
+    unsigned char* tK = tQ + 64 * TROW;
+    unsigned char* tO = tK + 64 * TROW;
+    float* sMask = reinterpret_cast<float*>(tO + 64 * TROW);   // [LP]
+    float* sM = sMask + LP;                            // row max
+    float* sLi = sM + LP;                              // 1 / row sum
+    float* sD = sLi + LP;                              // rowsum(dP * P)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int H = heads * 64;
+    const size_t ldq = (size_t)3 * H;
+    const bf16* base = qkv + (size_t)b * L * ldq + h * 64;
+    bf16* dbase = dqkv + (size_t)b * L * ldq + h * 64;
+
+    for (int idx = tid; idx < LP * 8; idx += 256) {
+        const int r = idx >> 3, c = idx & 7;
+        uint4 q4 = make_uint4(0, 0, 0, 0), k4 = q4, v4 = q4, o4 = q4;
+        if (r < L) {
+            q4 = *reinterpret_cast<const uint4*>(base + (size_t)r * ldq + c * 8);
+            k4 = *reinterpret_cast<const uint4*>(base + (size_t)r * ldq + H + c * 8);
+            v4 = *reinterpret_cast<const uint4*>(base + (size_t)r * ldq + 2 * H + c * 8);
+            o4 = *reinterpret_cast<const uint4*>(dctx + ((size_t)b * L + r) * H + h * 64 + c * 8);
+        }
+        *reinterpret_cast<uint4*>(sQ + kq_off(r, c)) = q4;
+        *reinterpret_cast<uint4*>(sK + kq_off(r, c)) = k4;
+        *reinterpret_cast<uint4*>(sV + kq_off(r, c)) = v4;
+        *reinterpret_cast<uint4*>(sO + kq_off(r, c)) = o4;
+        const bf16* qe = reinterpret_cast<const bf16*>(&q4);
+        const bf16* ke = reinterpret_cast<const bf16*>(&k4);
+        const bf16* oe = reinterpret_cast<const bf16*>(&o4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            *reinterpret_cast<bf16*>(tQ + (c * 8 + j) * TROW + r * 2) = qe[j];
+            *reinterpret_cast<bf16*>(tK + (c * 8 + j) * TROW + r * 2) = ke[j];
+            *reinterpret_cast<bf16*>(tO + (c * 8 + j) * TROW + r * 2) = oe[j];
+        }
+    }
+    for (int key = tid; key < LP; key += 256) {
+        float mv = -INFINITY;
+        if (key < L) mv = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
+        sMask[key] = mv;
+    }
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    auto rowfrag = [&](const unsigned char* tile, int row, int ks) {
+        return *reinterpret_cast<const bf16x8*>(tile + kq_off(row, 2 * ks + fh));
+    };
+    auto pack8 = [&](const f32x16& x, int s2) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)x[8 * s2 + j];
+        return o;
+    };
+    auto ldT = [&](const unsigned char* tile, int row, int e0) {       // 4 elements at e0, 4 at e0 + 8
+        const unsigned char* p = tile + row * TROW + e0 * 2;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 16);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = lo[j]; o[4 + j] = hi[j]; }
+        return o;
+    };
+
+    // ================= phase A: query blocks (lane = query) =================
+    for (int qb = wave; qb < NKB; qb += 4) {
+        f32x16 st[NKB], dp[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sK, kb * 32 + fr, ks), rowfrag(sQ, qb * 32 + fr, ks), st[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sV, kb * 32 + fr, ks), rowfrag(sO, qb * 32 + fr, ks), dp[kb], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = st[kb][r] * 0.125f + sMask[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+                st[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = expf(st[kb][r] - mx); st[kb][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        float dd = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] *= inv; dd += st[kb][r] * dp[kb][r]; }
+        dd += __shfl_xor(dd, 32, 64);
+        if (fh == 0) { sM[qb * 32 + fr] = mx; sLi[qb * 32 + fr] = inv; sD[qb * 32 + fr] = dd; }
+        // dS^T in place of dp, then dQ = dS K / 8
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[kb][r] = st[kb][r] * (dp[kb][r] - dd);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pa = pack8(dp[kb], s2);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, ldT(tK, db * 32 + fr, kb * 32 + 16 * s2 + 4 * fh), o[db], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + acc_row(r, lane);
+                if (q < L) dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = (bf16)(o[db][r] * 0.125f);
+            }
+    }
+    __syncthreads();
+
+    // ================= phase B: key blocks (lane = key) =================
+    for (int kb = wave; kb < NKB; kb += 4) {
+        f32x16 aK[2], aV[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aK[db][r] = 0.f; aV[db][r] = 0.f; }
+        const float mk = sMask[kb * 32 + fr];
+#pragma unroll 1
+        for (int qb = 0; qb < NKB; ++qb) {
+            f32x16 sb, db_;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sb[r] = 0.f; db_[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sQ, qb * 32 + fr, ks), rowfrag(sK, kb * 32 + fr, ks), sb, 0, 0, 0);
+                db_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sO, qb * 32 + fr, ks), rowfrag(sV, kb * 32 + fr, ks), db_, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float p = expf(sb[r] * 0.125f + mk - sM[q]) * sLi[q];
+                sb[r] = p;
+                db_[r] = p * (db_[r] - sD[q]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pp = pack8(sb, s2), pd = pack8(db_, s2);
+                const int e0 = qb * 32 + 16 * s2 + 4 * fh;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    aV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pp, ldT(tO, db * 32 + fr, e0), aV[db], 0, 0, 0);
+                    aK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pd, ldT(tQ, db * 32 + fr, e0), aK[db], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + acc_row(r, lane);
+                if (key < L) {
+                    dbase[(size_t)key * ldq + H + db * 32 + acc_col(lane)] = (bf16)(aK[db][r] * 0.125f);
+                    dbase[(size_t)key * ldq + 2 * H + db * 32 + acc_col(lane)] = (bf16)aV[db][r];
+                }
+            }
+    }
+}
+
+template <int NKB>
+static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s) {
+    constexpr int LP = NKB * 32;
+    const size_t lds = (size_t)4 * LP * 128 + (size_t)3 * 64 * (LP * 2 + 8) + (size_t)4 * LP * sizeof(float);
+    auto k = attn_bwd_mfma_kernel<NKB>;
+    static bool done = false;
+    if (lds > 64 * 1024 && !done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+        done = true;
+    }
+    k<<<dim3(B * heads), dim3(256), lds, s>>>((const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, heads);
+    return CPT_OK;
+}
+
+int g_attn_bwd_variant = 1;      // 1: MFMA kernel for bf16 when L <= 128; 0: generic kernel always
+void set_attn_bwd_variant(int v) { g_attn_bwd_variant = v; }
+
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
+    if (dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L <= 128) {
+        if (L <= 32) return attn_bwd_mfma_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, s);
+        if (L <= 64) return attn_bwd_mfma_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, s);
+        return attn_bwd_mfma_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, s);
+    }
     const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + 2 * AB_QB * (L + 1) + L) * sizeof(float);
     if (lds > 160 * 1024) return CPT_ERR_SHAPE;            // L <= ~176 in this round (RefCOCO L = 120)
     dim3 grid(B * heads), block(256);

@@ -48,6 +48,7 @@ int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s);
 
+void set_attn_bwd_variant(int v);
 void set_gemm_variant(int v);
 void set_gemm_abl(int v);
 void set_gemm_trace(void* p);

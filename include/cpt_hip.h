@@ -245,7 +245,8 @@ int cpt_prof_enable(int on);                          /* resets accumulators */
 int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchronises */
 
 /* Kernel-variant switches for A/B measurements (key 0: GEMM variant 0 = register-staged generic
- * kernel, 1 = LDS-DMA 128x128 tile, 2 = LDS-DMA 256x128 tile).  Results are identical. */
+ * kernel, 1 = LDS-DMA 128x128 tile, 2 = LDS-DMA 256x128 tile, 3..7 = pipelined tile shapes; key 2:
+ * attention backward 0 = generic fp32-math kernel, 1 = MFMA kernel for bf16, L <= 128). */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
  * start / after prologue issue / after K loop / after staging / end, and the XCC id). */

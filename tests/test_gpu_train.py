@@ -157,3 +157,26 @@ def test_bf16_training_reduces_loss(dev):
         l2 = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
                masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])[0].item()
     assert l2 < losses[-1] + 0.05
+
+
+def test_attention_backward_variants_agree(dev):
+    """MFMA attention backward (bf16) against the generic fp32-math kernel on the same inputs."""
+    from cpt_amd import _lib as L
+    cfg = cfgmod.oscar_base(num_hidden_layers=2)
+    b = {k: v.to(dev) for k, v in synth.make_batch(3, cfg, seed=9, vary_regions=True).items()}
+    grads = {}
+    for variant in (0, 1):
+        L.check(L.lib().cpt_set_tuning(2, variant))
+        try:
+            m = _model(cfg, 3, dev, "bf16")
+            loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                        masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+            loss.backward()
+            grads[variant] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            L.check(L.lib().cpt_set_tuning(2, 1))
+    for n in grads[0]:
+        if ".key.bias" in n:
+            continue
+        rel, mx = _rel(grads[1][n], grads[0][n].cpu())
+        assert rel < 3e-2, (n, rel, mx)
