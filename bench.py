@@ -97,6 +97,7 @@ def main():
                          "(configs[2]: forward+backward+grad all-reduce+AdamW, 32 sequences per GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tune", default="", help="debug: comma list of key=value passed to cpt_set_tuning")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,6 +116,9 @@ def main():
     from cpt_amd import config as cfgmod, synth, _lib, engine
     from cpt_amd.modeling_rec import REC_MLM_CPT
     _lib.check(_lib.lib().cpt_check_device(local), "cpt_check_device")
+    for kv in [t for t in args.tune.split(",") if t]:
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().cpt_set_tuning(int(k), int(v)), "cpt_set_tuning")
     cfg = cfgmod.oscar_base()
     seed = 88
     model = REC_MLM_CPT(cfg)

@@ -127,6 +127,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 0) { cpt::set_gemm_variant(value); return CPT_OK; }
     if (key == 1) { cpt::set_gemm_abl(value); return CPT_OK; }
     if (key == 2) { cpt::set_attn_bwd_variant(value); return CPT_OK; }
+    if (key == 3) { cpt::set_splitk_target(value); return CPT_OK; }
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
 }
 

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(
 // tiles so that the ~64 workgroups resident on one XCD share A/W panels through that XCD's L2.
 // ---------------------------------------------------------------------------------------------
 constexpr int GROUP_M = 8;
+constexpr int CPT_EPI_ATOMIC = 4;      // internal: split-K partial tiles added with fp32 atomics
 
 template <int TBM>
 __device__ __forceinline__ void tile_of_block(int M, int N, int& m0, int& n0) {
@@ -270,7 +271,7 @@ template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, in
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
-    OT* __restrict__ out, int ldo, int M, int N, int K, long long* __restrict__ trace) {
+    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses gfx950-only builtins/types (buffer rsrc, "v" asm): device pass only
     typedef typename FragOf<T>::type frag_t;
     constexpr int CE = Chunk<T>::N;
@@ -291,12 +292,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-first, then GROUP_M row tiles per group (see tile_of_block)
-    int m0, n0;
+    int m0, n0, split;
     {
         const int tm = (M + TBM - 1) / TBM, tn = (N + TBN - 1) / TBN;
-        const int nwg = tm * tn, bid = blockIdx.x;
+        const int nwg = tm * tn * splitk, bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int lid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int lid = lid0 / splitk;
+        split = lid0 - lid * splitk;
         const int per_group = GROUP_M * tn;
         const int g = lid / per_group, first_m = g * GROUP_M;
         const int gsz = min(tm - first_m, GROUP_M);
@@ -340,10 +343,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nt = K / BK;
+    // split-K: this workgroup owns K-tiles [kt0, kt0 + nt) and adds its partial tile atomically
+    const int nt_all = K / BK, nt_per = (nt_all + splitk - 1) / splitk;
+    const int kt0 = split * nt_per;
+    const int nt = max(0, min(nt_per, nt_all - kt0));
+    const int kbase = kt0 * BK;
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p)
-        if (p < nt) stage(p, p * BK);
+        if (p < nt) stage(p, kbase + p * BK);
 
     const int fr = lane & 31, fh = lane >> 5;
     // Register-resident fragments for all four k-steps of a tile; reads run TWO k-steps ahead of the
@@ -384,12 +391,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
 #define CPT_SB() __builtin_amdgcn_sched_barrier(0)
 
     if (trace) tr1 = clock64();
-    wait_tile(0);
-    __builtin_amdgcn_s_barrier();
-    CPT_SB();
-    ldfrag(0, 0);
-    ldfrag(0, 1);
-    CPT_SB();
+    if (nt > 0) {
+        wait_tile(0);
+        __builtin_amdgcn_s_barrier();
+        CPT_SB();
+        ldfrag(0, 0);
+        ldfrag(0, 1);
+        CPT_SB();
+    }
     int slot = 0;
     // MAIN iterations (every condition true) are one basic block, so the compiler's waitcnt pass
     // counts outstanding LDS reads exactly; the last STAGES-1 tiles run the guarded version.
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
         if (MAIN || t + STAGES - 1 < nt) {
             int ns = slot + STAGES - 1;
             if (ns >= STAGES) ns -= STAGES;
-            stage(ns, (t + STAGES - 1) * BK);
+            stage(ns, kbase + (t + STAGES - 1) * BK);
         }
         touch(0); CPT_SB(); ldfrag(slot, 2); CPT_SB(); mma(0); CPT_SB();
         touch(1); CPT_SB(); ldfrag(slot, 3); CPT_SB(); mma(1); CPT_SB();
@@ -443,6 +452,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
     constexpr int PANELS = TBN / 64, RP = NT / 16, PASSES = TBM / RP;
     static_assert(TBN % 64 == 0 && TBM % RP == 0, "epilogue mapping");
     const int cq = tid & 15, rq = tid >> 4;
+    if (split != 0) bias = nullptr;                   // split-K: the bias is added once
     const bool vec_ok = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out) % 16 == 0) &&
                         (EPI != CPT_EPI_RESID || (ldr % 4 == 0 && ((uintptr_t)resid) % 16 == 0)) &&
                         (!bias || ((uintptr_t)bias) % 16 == 0);
@@ -491,6 +501,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; ++e) pk[e] = (bf16)v[e];
                         *reinterpret_cast<bf16x4*>(out + (size_t)row * ldo + col) = pk;
+                    } else if constexpr (EPI == CPT_EPI_ATOMIC) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, v[e]);
                     } else {
                         *reinterpret_cast<f32x4*>(out + (size_t)row * ldo + col) = v;
                     }
@@ -517,7 +530,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
                 if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
                 if (EPI == CPT_EPI_TANH) x = tanhf(x);
                 if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col + e];
-                out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
+                if constexpr (EPI == CPT_EPI_ATOMIC && sizeof(OT) == 4) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, x);
+                else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
             }
         }
     }
@@ -534,7 +548,7 @@ long long* g_gemm_trace = nullptr;
 
 template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES>
 static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bias, const float* resid, int ldr,
-                       OT* out, int ldo, int M, int N, int K, hipStream_t s) {
+                       OT* out, int ldo, int M, int N, int K, hipStream_t s, int splitk = 1) {
     constexpr int RING = STAGES * (TBM + TBN) * ROWB, STG = TBM * (TBN * 4 + 16);
     constexpr int LDS = RING > STG ? RING : STG;
     auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES>;
@@ -544,8 +558,8 @@ static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bi
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         attr_done = true;
     }
-    const int nwg = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN);
-    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, g_gemm_trace);
+    const int nwg = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN) * splitk;
+    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, g_gemm_trace);
     return CPT_OK;
 }
 
@@ -622,6 +636,27 @@ int gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, con
         if (out_dtype != CPT_F32) return CPT_ERR_DTYPE;
         return launch_epi<float, float>(epi, (const float*)A, lda, (const float*)W, ldw, bias, resid, ldr, (float*)out, ldo, M, N, K, s);
     }
+    return CPT_ERR_DTYPE;
+}
+
+int g_splitk_target = 384;
+void set_splitk_target(int v) { g_splitk_target = v; }
+
+// out[M][N] (fp32, caller-zeroed or holding a partial sum) += A[M][K] . W[N][K]^T, K split over
+// enough workgroups to fill the chip; used for weight gradients (M, N small; K = rows of the batch)
+int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0) return CPT_ERR_SHAPE;
+    const int bke = dtype == CPT_BF16 ? 64 : 32;
+    if (K % bke || lda % 8 || ldw % 8 || (((uintptr_t)A | (uintptr_t)W) & 15)) return CPT_ERR_ALIGN;
+    const int tiles = ((M + 127) / 128) * ((N + 191) / 192);
+    const int nt = K / bke;
+    int splitk = (g_splitk_target + tiles - 1) / tiles;
+    if (splitk > nt) splitk = nt;
+    if (splitk < 1) splitk = 1;
+    if (dtype == CPT_BF16)
+        return launch_pipe<bf16, CPT_EPI_ATOMIC, float, 128, 192, 4, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, nullptr, nullptr, 0, out, ldo, M, N, K, s, splitk);
+    if (dtype == CPT_F32)
+        return launch_pipe<float, CPT_EPI_ATOMIC, float, 128, 192, 4, 2, 3>((const float*)A, lda, (const float*)W, ldw, nullptr, nullptr, 0, out, ldo, M, N, K, s, splitk);
     return CPT_ERR_DTYPE;
 }
 

@@ -188,6 +188,7 @@ int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads*
                      float* out, int ldo, const char* what) -> int {
         TRY(cpt::transpose_cast(dY, dY_dt, ldy, tA, dt, rows_p, rows, Nout, s), what);
         TRY(cpt::transpose_cast(X, dt, ldx, tB, dt, rows_p, rows, Kout, s), what);
+        // (split-K with fp32 atomics was measured slower at B=32: 11.7-16.6 ms/step vs 10.4 -- see DESIGN.md)
         TRY(cpt::gemm(dt, CPT_EPI_NONE, tA, rows_p, tB, rows_p, nullptr, nullptr, 0, out, CPT_F32, ldo, Nout, Kout, rows_p, s), what);
         return CPT_OK;
     };
@@ -268,6 +269,8 @@ int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads*
                         g->img_ln_g, g->img_ln_b, R, H, Li, L, Lt, 0, s), "ln_bwd(img)");
         TRY(cpt::colsum(dimg, CPT_F32, H, g->b_img, R, H, s), "colsum(b_img)");
         float* gimg = (float*)(ws + w.gimg);
+        e = hipMemsetAsync(gimg, 0, (size_t)H * Dp * 4, s);
+        if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero img grad temp: %s", hipGetErrorString(e));
         rc = wgrad(dt == CPT_BF16 ? dimg_lp : (const void*)dimg, dt, H, H, ws + w.imgp, Dp, Dp, R, Rp, gimg, Dp, "wgrad(img_embedding)");
         if (rc) return rc;
         TRY(cpt::unpad_add(gimg, g->w_img, H, d.img_dim, Dp, s), "unpad(img weight grad)");
