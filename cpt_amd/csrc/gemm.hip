@@ -267,11 +267,11 @@ __global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
 // ---------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
-template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
-    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace) {
+    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace, int abl) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses gfx950-only builtins/types (buffer rsrc, "v" asm): device pass only
     typedef typename FragOf<T>::type frag_t;
     constexpr int CE = Chunk<T>::N;
@@ -325,6 +325,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
         else        voff[i] = (unsigned)(((size_t)min(n0 + r - TBM, N - 1) * ldw + c * CE) * sizeof(T));
     }
     auto stage = [&](int slot, int k0) {
+        if (abl & 1) return;                          // ablation: no operand traffic
         const int soff = k0 * (int)sizeof(T);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
     // waves reading) hides behind two k-steps of matrix work of this wave and its SIMD partner.
     frag_t fa[4][MI], fb[4][NJ];
     auto ldfrag = [&](int slot, int ks) {
+        if (abl & 2) return;                          // ablation: no LDS fragment reads
         const unsigned char* sa = smem + slot * STAGE_BYTES;
         const unsigned char* sw = sa + TBM * ROWB;
 #pragma unroll
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
             fb[ks][j] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * (NJ * 32) + j * 32 + fr, ks * 2 + fh));
     };
     auto mma = [&](int ks) {
+        if (abl & 4) return;                          // ablation: no MFMA
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -432,27 +435,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
 
     // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> whole-row bias/act/residual/store ----
     if (trace) tr2 = clock64();
+    constexpr int RPP = TBM / EP;                     // tile rows staged per epilogue pass
+    static_assert(RPP % (MI * 32) == 0, "a wave's rows must fall into one epilogue pass");
+    if (split != 0) bias = nullptr;                   // split-K: the bias is added once
+#pragma unroll 1
+    for (int ep = 0; ep < EP; ++ep) {
+    const int mrow0 = m0 + ep * RPP;                  // global row of staged row 0
     __syncthreads();
+    if ((wm * (MI * 32)) / RPP == ep) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (MI * 32) + i * 32 + acc_row(r, lane);
-                const int col = wn * (NJ * 32) + j * 32 + acc_col(lane);
-                *reinterpret_cast<float*>(smem + row * CP + col * 4) = acc[i][j][r];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (MI * 32) + i * 32 + acc_row(r, lane) - ep * RPP;
+                    const int col = wn * (NJ * 32) + j * 32 + acc_col(lane);
+                    *reinterpret_cast<float*>(smem + row * CP + col * 4) = acc[i][j][r];
+                }
+    }
     __syncthreads();
     if (trace) tr3 = clock64();
     // Each thread owns one 4-column chunk position (tid & 15) in every 64-column panel and a fixed
     // set of rows.  ALL global loads of the epilogue (bias, residual) are issued before the first
     // store: on gfx950 stores count in vmcnt, so a load issued after a store would make the
     // compiler wait for that store's round trip on every iteration.
-    constexpr int PANELS = TBN / 64, RP = NT / 16, PASSES = TBM / RP;
-    static_assert(TBN % 64 == 0 && TBM % RP == 0, "epilogue mapping");
+    constexpr int PANELS = TBN / 64, RP = NT / 16, PASSES = RPP / RP;
+    static_assert(TBN % 64 == 0 && RPP % RP == 0, "epilogue mapping");
     const int cq = tid & 15, rq = tid >> 4;
-    if (split != 0) bias = nullptr;                   // split-K: the bias is added once
     const bool vec_ok = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out) % 16 == 0) &&
                         (EPI != CPT_EPI_RESID || (ldr % 4 == 0 && ((uintptr_t)resid) % 16 == 0)) &&
                         (!bias || ((uintptr_t)bias) % 16 == 0);
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
             if constexpr (EPI == CPT_EPI_RESID) {
 #pragma unroll
                 for (int q = 0; q < PASSES; ++q) {
-                    const int row = m0 + q * RP + rq;
+                    const int row = mrow0 + q * RP + rq;
                     rv[p][q] = (FULL || (row < M && col < N)) ? *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldr + col)
                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
             const int col = n0 + p * 64 + cq * 4;
 #pragma unroll
             for (int q = 0; q < PASSES; ++q) {
-                const int row = m0 + q * RP + rq;
+                const int row = mrow0 + q * RP + rq;
                 f32x4 v = vv[p][q];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -514,13 +524,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
     if (vec_ok) {
         // interior tiles take a branch-free path: one basic block lets the compiler count vmcnt
         // exactly instead of draining it before every guarded store
-        if (m0 + TBM <= M && n0 + TBN <= N) vec_epilogue(std::true_type{});
+        if (mrow0 + RPP <= M && n0 + TBN <= N) vec_epilogue(std::true_type{});
         else vec_epilogue(std::false_type{});
     } else {
         constexpr int CPR = TBN / 4;
-        for (int idx = tid; idx < TBM * CPR; idx += NT) {
+        for (int idx = tid; idx < RPP * CPR; idx += NT) {
             const int rr = idx / CPR, cc = (idx - rr * CPR) * 4;
-            const int row = m0 + rr, col = n0 + cc;
+            const int row = mrow0 + rr, col = n0 + cc;
             if (row >= M || col >= N) continue;
             const f32x4 v = *reinterpret_cast<const f32x4*>(smem + rr * CP + cc * 4);
 #pragma unroll
@@ -535,6 +545,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
             }
         }
     }
+    }   // epilogue passes
     if (trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long* t = trace + (size_t)blockIdx.x * 8;
@@ -545,13 +556,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_pipe_kernel(
 }
 
 long long* g_gemm_trace = nullptr;
+extern int g_gemm_abl;
 
-template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES>
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1>
 static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bias, const float* resid, int ldr,
                        OT* out, int ldo, int M, int N, int K, hipStream_t s, int splitk = 1) {
-    constexpr int RING = STAGES * (TBM + TBN) * ROWB, STG = TBM * (TBN * 4 + 16);
+    constexpr int RING = STAGES * (TBM + TBN) * ROWB, STG = (TBM / EP) * (TBN * 4 + 16);
     constexpr int LDS = RING > STG ? RING : STG;
-    auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES>;
+    auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP>;
     static bool attr_done = false;
     if (LDS > 64 * 1024 && !attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -559,7 +571,7 @@ static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bi
         attr_done = true;
     }
     const int nwg = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN) * splitk;
-    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, g_gemm_trace);
+    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, g_gemm_trace, g_gemm_abl);
     return CPT_OK;
 }
 
@@ -569,10 +581,33 @@ int g_gemm_variant = 3;      // 0: register-staged generic kernel only; 1: LDS-D
 template <typename T, int EPI, typename OT>
 static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, const float* bias,
                         const float* resid, int ldr, OT* out, int ldo, int M, int N, int K, hipStream_t s) {
-    if (variant == 3) { launch_pipe<T, EPI, OT, 128, 192, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 3) {
+        // Tile shape by a two-term model measured on MI355X (tools/ubench.hip): the K loop is
+        // bound by operand bytes through the CU's LDS-DMA path (~35 B/clk/CU), i.e. cost per tile-step is
+        // proportional to TBM + TBN, and a launch takes ceil(workgroups / 256 CUs) rounds.
+        struct Cand { int bm, bn; };
+        const Cand cand[3] = {{128, 192}, {192, 192}, {128, 384}};
+        int best = 0;
+        long best_cost = -1;
+        for (int i = 0; i < 3; ++i) {
+            const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
+            const long cost = ((wgs + 255) / 256) * (cand[i].bm + cand[i].bn);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
+        }
+        if (best == 1) launch_pipe<T, EPI, OT, 192, 192, 6, 2, 3, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
+        else if (best == 2) launch_pipe<T, EPI, OT, 128, 384, 2, 4, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
+        else launch_pipe<T, EPI, OT, 128, 192, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
+        return;
+    }
+    if (variant == 13) { launch_pipe<T, EPI, OT, 128, 192, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 4) { launch_pipe<T, EPI, OT, 128, 128, 2, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 5) { launch_pipe<T, EPI, OT, 256, 128, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 6) { launch_pipe<T, EPI, OT, 128, 128, 4, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 11) { launch_pipe<T, EPI, OT, 192, 192, 6, 2, 3, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 12) { launch_pipe<T, EPI, OT, 256, 192, 4, 2, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 9) { launch_pipe<T, EPI, OT, 256, 192, 4, 2, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 10) { launch_pipe<T, EPI, OT, 128, 384, 2, 4, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 8) { launch_pipe<T, EPI, OT, 128, 192, 4, 2, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 7) { launch_pipe<T, EPI, OT, 128, 192, 2, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 2 && M >= 1024) {
         const int nwg = ((M + 255) / 256) * ((N + BN - 1) / BN);
