@@ -1,0 +1,82 @@
+"""Driver-side hot loops on the HIP path: counterparts of the reference's ``val`` and ``train_batch``.
+
+  * ``val_queries``  <- /root/reference/Oscar/oscar/zeroshot/refcoco_cpt.py:208-288 (and the few-shot
+    variant fewshot/refcoco_cpt.py:258-315): per query, score every proposal sequence at its [MASK]
+    slot, gather the colour logits, argmax -> chosen rectangle; queries are sharded across ranks and
+    the chosen indices are gathered with one fixed-shape all_gather.
+  * ``train_batch``  <- fewshot/refcoco_cpt.py:225-255: label grid, LR schedule, zero_grad / loss /
+    backward / step, RuntimeError per step logged and skipped.
+Datasets, tokeniser and TSV decoding stay outside: a *query* here is already
+tensors, in the layout ``test_collate`` (zeroshot/refcoco_cpt.py:159-172) produces.
+"""
+import logging
+
+import torch
+
+from . import dist as cdist
+from . import scoring
+from .train import get_lr_sched
+
+logger = logging.getLogger(__name__)
+
+
+def val_queries(model, queries, none_id, device, few_shot=False, batch_queries=4):
+    """queries: list of dicts with tensors ``img_feats (P,Li,D)``, ``input_ids (P,Lt)``,
+    ``segment_ids``, ``attention_mask (P,Lt+Li)``, ``mask_token_pos (P,)`` and python lists
+    ``colors`` (per proposal sequence: colour-token ids) and ``rects`` (per sequence: rectangles).
+    Returns {global query index: (max_idx, rect)} on every rank."""
+    model.eval()
+    rank, world = cdist.rank_world()
+    lo, hi = cdist.shard_range(len(queries), rank, world)
+    chosen = torch.full((hi - lo,), -1, dtype=torch.int64, device=device)
+    for start in range(lo, hi, batch_queries):
+        chunk = queries[start:min(start + batch_queries, hi)]
+        cat = {k: torch.cat([q[k] for q in chunk], 0).to(device, non_blocking=True)
+               for k in ("img_feats", "input_ids", "segment_ids", "attention_mask", "mask_token_pos")}
+        with torch.no_grad():
+            scores = model(cat["input_ids"], cat["segment_ids"], cat["attention_mask"], img_feats=cat["img_feats"],
+                           mask_token_pos=cat["mask_token_pos"])[0]
+        # only the colour columns are needed on the host: gather them on the device first
+        ids = sorted({i for q in chunk for s in q["colors"] for i in s} | {none_id})
+        col = {v: j for j, v in enumerate(ids)}
+        small = scores[:, torch.tensor(ids, device=device)].float().cpu()
+        ptr = 0
+        for qi, q in enumerate(chunk):
+            P = q["input_ids"].size(0)
+            rows = small[ptr:ptr + P]
+            ptr += P
+            sets = [[col[i] for i in s] for s in q["colors"]]
+            idx, _, _ = scoring.select_region(rows, sets, q["rects"], col[none_id], few_shot=few_shot)
+            chosen[start - lo + qi] = idx
+    allc = cdist.gather_fixed(chosen, len(queries), fill=-1).cpu().tolist()
+    out = {}
+    for gi, idx in enumerate(allc):
+        rects = [r for rs in queries[gi]["rects"] for r in rs]
+        out[gi] = (idx, rects[idx])
+    return out
+
+
+def train_batch(model, optimizer, batches, opts, device, global_step=0):
+    """One pass over ``batches`` (dicts with img_feats, input_ids, attention_mask, segment_ids,
+    mask_token_pos, colors), as fewshot/refcoco_cpt.py:225-255."""
+    model.train()
+    losses = []
+    for step, b in enumerate(batches):
+        b = {k: v.to(device) for k, v in b.items()}
+        mlm_labels = torch.full(b["attention_mask"].size(), -1, dtype=torch.long, device=device)
+        mlm_labels[torch.arange(b["attention_mask"].size(0), device=device), b["mask_token_pos"]] = b["colors"]
+        lr_this_step = get_lr_sched(global_step, opts)
+        for i, group in enumerate(optimizer.param_groups):
+            group["lr"] = lr_this_step * getattr(opts, "lr_mul", 1.0) if i < 2 else lr_this_step
+        try:
+            optimizer.zero_grad()
+            loss, _ = model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                            masked_lm_labels=mlm_labels)
+            loss.backward()
+            optimizer.step()
+            global_step += 1
+            losses.append(loss.detach())
+        except RuntimeError as e:
+            logger.info("run time error at step %d, which is %s", step, str(e))
+            continue
+    return global_step, losses
