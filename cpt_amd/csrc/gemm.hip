@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
 // ---------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
-template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1>
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
@@ -357,32 +357,35 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
     // Register-resident fragments for all four k-steps of a tile; reads run TWO k-steps ahead of the
     // MFMAs that consume them (across the tile boundary too), so LDS latency (~300 cycles with 8
     // waves reading) hides behind two k-steps of matrix work of this wave and its SIMD partner.
-    frag_t fa[4][MI], fb[4][NJ];
-    auto ldfrag = [&](int slot, int ks) {
+    // FD = 4: all four k-steps of a tile live in registers, reads run TWO k-steps ahead.
+    // FD = 2: ping-pong buffers, reads run one k-step ahead (for big wave tiles, where six MFMAs
+    //         per k-step per wave already cover the LDS latency and registers are the scarce resource).
+    frag_t fa[FD][MI], fb[FD][NJ];
+    auto ldfrag = [&](int slot, int ks, int pb) {
         if (abl & 2) return;                          // ablation: no LDS fragment reads
         const unsigned char* sa = smem + slot * STAGE_BYTES;
         const unsigned char* sw = sa + TBM * ROWB;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-            fa[ks][i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * (MI * 32) + i * 32 + fr, ks * 2 + fh));
+            fa[pb][i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * (MI * 32) + i * 32 + fr, ks * 2 + fh));
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            fb[ks][j] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * (NJ * 32) + j * 32 + fr, ks * 2 + fh));
+            fb[pb][j] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * (NJ * 32) + j * 32 + fr, ks * 2 + fh));
     };
-    auto mma = [&](int ks) {
+    auto mma = [&](int pb) {
         if (abl & 4) return;                          // ablation: no MFMA
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) mfma_chunk(acc[i][j], fa[ks][i], fb[ks][j]);
+            for (int j = 0; j < NJ; ++j) mfma_chunk(acc[i][j], fa[pb][i], fb[pb][j]);
     };
-    // make the compiler place its lgkmcnt wait for k-step `ks` HERE (before younger ds_reads are
+    // make the compiler place its lgkmcnt wait for buffer `pb` HERE (before younger ds_reads are
     // issued) instead of in front of the MFMAs that consume it
-    auto touch = [&](int ks) {
+    auto touch = [&](int pb) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(fa[ks][i]));
+        for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(fa[pb][i]));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[ks][j]));
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[pb][j]));
     };
     // wait until tile `t` has landed: at most min(STAGES-2, tiles after t) younger tiles stay in flight
     auto wait_tile = [&](int t) {
@@ -398,8 +401,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
         wait_tile(0);
         __builtin_amdgcn_s_barrier();
         CPT_SB();
-        ldfrag(0, 0);
-        ldfrag(0, 1);
+        ldfrag(0, 0, 0);
+        if (FD == 4) ldfrag(0, 1, 1);
         CPT_SB();
     }
     int slot = 0;
@@ -416,16 +419,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
             if (ns >= STAGES) ns -= STAGES;
             stage(ns, kbase + (t + STAGES - 1) * BK);
         }
-        touch(0); CPT_SB(); ldfrag(slot, 2); CPT_SB(); mma(0); CPT_SB();
-        touch(1); CPT_SB(); ldfrag(slot, 3); CPT_SB(); mma(1); CPT_SB();
-        if (more) {
-            if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1);
-            CPT_SB();
-            __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves
-            CPT_SB();
+        if constexpr (FD == 4) {
+            touch(0); CPT_SB(); ldfrag(slot, 2, 2); CPT_SB(); mma(0); CPT_SB();
+            touch(1); CPT_SB(); ldfrag(slot, 3, 3); CPT_SB(); mma(1); CPT_SB();
+            if (more) {
+                if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1);
+                CPT_SB();
+                __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves
+                CPT_SB();
+            }
+            touch(2); CPT_SB(); if (more) ldfrag(nslot, 0, 0); CPT_SB(); mma(2); CPT_SB();
+            touch(3); CPT_SB(); if (more) ldfrag(nslot, 1, 1); CPT_SB(); mma(3); CPT_SB();
+        } else {
+            touch(0); CPT_SB(); ldfrag(slot, 1, 1); CPT_SB(); mma(0); CPT_SB();
+            touch(1); CPT_SB(); ldfrag(slot, 2, 0); CPT_SB(); mma(1); CPT_SB();
+            touch(0); CPT_SB(); ldfrag(slot, 3, 1); CPT_SB(); mma(0); CPT_SB();
+            touch(1); CPT_SB();                    // this wave's reads of tile t are all done
+            if (more) {
+                if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1);
+                CPT_SB();
+                __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves; nobody still reads tile t
+                CPT_SB();
+                ldfrag(nslot, 0, 0);
+                CPT_SB();
+            }
+            mma(1); CPT_SB();
         }
-        touch(2); CPT_SB(); if (more) ldfrag(nslot, 0); CPT_SB(); mma(2); CPT_SB();
-        touch(3); CPT_SB(); if (more) ldfrag(nslot, 1); CPT_SB(); mma(3); CPT_SB();
         slot = nslot;
     };
     const int t_main = max(nt - (STAGES - 1), 0);
@@ -433,79 +452,75 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
     for (int t = t_main; t < nt; ++t) body(t, std::false_type{});
 #undef CPT_SB
 
-    // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> whole-row bias/act/residual/store ----
+    // ---- epilogue: per-WAVE staging through LDS, no workgroup barriers --------------------------------
+    // Each wave owns a private 16-row x (NJ*32)-column fp32 slab in LDS.  For every 16-row slice of its
+    // accumulators it writes the slab (ds_write_b32, MFMA layout), waits for its own writes, and reads it
+    // back as whole rows (ds_read_b128) to apply bias / GELU / residual and store 8-16 bytes per lane on
+    // contiguous row segments.  Waves run this independently; residual loads are software-pipelined one
+    // slice ahead so no load is ever issued behind a store (stores count in vmcnt on gfx950).
     if (trace) tr2 = clock64();
-    constexpr int RPP = TBM / EP;                     // tile rows staged per epilogue pass
-    static_assert(RPP % (MI * 32) == 0, "a wave's rows must fall into one epilogue pass");
+    constexpr int WCOLS = NJ * 32;                    // columns of this wave's sub-tile
+    constexpr int CPW = WCOLS * 4 + 16;               // slab pitch (bytes)
+    constexpr int CH = WCOLS / 4;                     // float4 chunks per slab row
+    constexpr int NIT = (16 * CH + 63) / 64;          // read-back iterations per slice
+    constexpr int NSL = MI * 2;                       // 16-row slices per wave
+    static_assert(16 * CPW * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
     if (split != 0) bias = nullptr;                   // split-K: the bias is added once
-#pragma unroll 1
-    for (int ep = 0; ep < EP; ++ep) {
-    const int mrow0 = m0 + ep * RPP;                  // global row of staged row 0
-    __syncthreads();
-    if ((wm * (MI * 32)) / RPP == ep) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * (MI * 32) + i * 32 + acc_row(r, lane) - ep * RPP;
-                    const int col = wn * (NJ * 32) + j * 32 + acc_col(lane);
-                    *reinterpret_cast<float*>(smem + row * CP + col * 4) = acc[i][j][r];
-                }
-    }
-    __syncthreads();
+    __syncthreads();                                  // every wave is done reading the operand ring
     if (trace) tr3 = clock64();
-    // Each thread owns one 4-column chunk position (tid & 15) in every 64-column panel and a fixed
-    // set of rows.  ALL global loads of the epilogue (bias, residual) are issued before the first
-    // store: on gfx950 stores count in vmcnt, so a load issued after a store would make the
-    // compiler wait for that store's round trip on every iteration.
-    constexpr int PANELS = TBN / 64, RP = NT / 16, PASSES = RPP / RP;
-    static_assert(TBN % 64 == 0 && RPP % RP == 0, "epilogue mapping");
-    const int cq = tid & 15, rq = tid >> 4;
+    unsigned char* slab = smem + wave * (16 * CPW);
+    const int wrow0 = m0 + wm * (MI * 32), wcol0 = n0 + wn * WCOLS;
     const bool vec_ok = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out) % 16 == 0) &&
                         (EPI != CPT_EPI_RESID || (ldr % 4 == 0 && ((uintptr_t)resid) % 16 == 0)) &&
                         (!bias || ((uintptr_t)bias) % 16 == 0);
-    auto vec_epilogue = [&](auto full_tag) {
+    static_assert((16 * CH) % 64 == 0, "slab read-back must fill whole waves");
+    // FULL (interior sub-tile, aligned pointers): one basic block, no guards, so the compiler's vmcnt
+    // bookkeeping is exact and stores issue back to back.  Otherwise the guarded element-wise path.
+    auto epilogue = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        f32x4 bv[PANELS];
-        f32x4 rv[EPI == CPT_EPI_RESID ? PANELS : 1][EPI == CPT_EPI_RESID ? PASSES : 1];
+        f32x4 bv[NIT];
 #pragma unroll
-        for (int p = 0; p < PANELS; ++p) {
-            const int col = n0 + p * 64 + cq * 4;
-            bv[p] = (bias && (FULL || col < N)) ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == CPT_EPI_RESID) {
-#pragma unroll
-                for (int q = 0; q < PASSES; ++q) {
-                    const int row = mrow0 + q * RP + rq;
-                    rv[p][q] = (FULL || (row < M && col < N)) ? *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldr + col)
-                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
+        for (int it = 0; it < NIT; ++it) {
+            const int col = wcol0 + ((it * 64 + lane) % CH) * 4;
+            bv[it] = (FULL && bias) ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // all LDS reads next (no ds_read after a store either), then math + stores
-        f32x4 vv[PANELS][PASSES];
+        auto load_resid = [&](int sl, f32x4 (&rv)[NIT]) {
 #pragma unroll
-        for (int p = 0; p < PANELS; ++p)
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 64 + lane, rr = idx / CH, ch = idx % CH;
+                rv[it] = *reinterpret_cast<const f32x4*>(resid + (size_t)(wrow0 + sl * 16 + rr) * ldr + wcol0 + ch * 4);
+            }
+        };
+        f32x4 rv_a[NIT], rv_b[NIT];
+        if constexpr (FULL && EPI == CPT_EPI_RESID) load_resid(0, rv_a);
 #pragma unroll
-            for (int q = 0; q < PASSES; ++q)
-                vv[p][q] = *reinterpret_cast<const f32x4*>(smem + (q * RP + rq) * CP + (p * 64 + cq * 4) * 4);
+        for (int sl = 0; sl < NSL; ++sl) {
+            const int i = sl >> 1, half = sl & 1;
 #pragma unroll
-        for (int p = 0; p < PANELS; ++p) {
-            const int col = n0 + p * 64 + cq * 4;
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int q = 0; q < PASSES; ++q) {
-                const int row = mrow0 + q * RP + rq;
-                f32x4 v = vv[p][q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[e] + bv[p][e];
-                    if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
-                    if (EPI == CPT_EPI_TANH) x = tanhf(x);
-                    if constexpr (EPI == CPT_EPI_RESID) x += rv[p][q][e];
-                    v[e] = x;
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int rr = (r8 & 3) + 8 * (r8 >> 2) + 4 * (lane >> 5);
+                    *reinterpret_cast<float*>(slab + rr * CPW + (j * 32 + (lane & 31)) * 4) = acc[i][j][half * 8 + r8];
                 }
-                if (FULL || (row < M && col < N)) {
+            if constexpr (FULL && EPI == CPT_EPI_RESID) {
+                if (sl + 1 < NSL) { if (sl & 1) load_resid(sl + 1, rv_a); else load_resid(sl + 1, rv_b); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's slab writes have landed
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 64 + lane, rr = idx / CH, ch = idx % CH;
+                const int row = wrow0 + sl * 16 + rr, col = wcol0 + ch * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(slab + rr * CPW + ch * 16);
+                if constexpr (FULL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[e] + bv[it][e];
+                        if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
+                        if (EPI == CPT_EPI_TANH) x = tanhf(x);
+                        if constexpr (EPI == CPT_EPI_RESID) x += (sl & 1) ? rv_b[it][e] : rv_a[it][e];
+                        v[e] = x;
+                    }
                     if constexpr (sizeof(OT) == 2) {
                         bf16x4 pk;
 #pragma unroll
@@ -517,35 +532,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
                     } else {
                         *reinterpret_cast<f32x4*>(out + (size_t)row * ldo + col) = v;
                     }
+                } else {
+                    if (row < M) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (col + e < N) {
+                                float x = v[e] + (bias ? bias[col + e] : 0.f);
+                                if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
+                                if (EPI == CPT_EPI_TANH) x = tanhf(x);
+                                if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col + e];
+                                if constexpr (EPI == CPT_EPI_ATOMIC && sizeof(OT) == 4) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, x);
+                                else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
+                            }
+                        }
+                    }
                 }
             }
+            // (LDS operations of one wave execute in issue order: the next slice's writes cannot pass these reads)
         }
     };
-    if (vec_ok) {
-        // interior tiles take a branch-free path: one basic block lets the compiler count vmcnt
-        // exactly instead of draining it before every guarded store
-        if (mrow0 + RPP <= M && n0 + TBN <= N) vec_epilogue(std::true_type{});
-        else vec_epilogue(std::false_type{});
-    } else {
-        constexpr int CPR = TBN / 4;
-        for (int idx = tid; idx < RPP * CPR; idx += NT) {
-            const int rr = idx / CPR, cc = (idx - rr * CPR) * 4;
-            const int row = mrow0 + rr, col = n0 + cc;
-            if (row >= M || col >= N) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + rr * CP + cc * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (col + e >= N) break;
-                float x = v[e] + (bias ? bias[col + e] : 0.f);
-                if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
-                if (EPI == CPT_EPI_TANH) x = tanhf(x);
-                if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col + e];
-                if constexpr (EPI == CPT_EPI_ATOMIC && sizeof(OT) == 4) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, x);
-                else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
-            }
-        }
-    }
-    }   // epilogue passes
+    if (vec_ok && wrow0 + MI * 32 <= M && wcol0 + WCOLS <= N) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if (trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long* t = trace + (size_t)blockIdx.x * 8;
@@ -558,12 +565,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
 long long* g_gemm_trace = nullptr;
 extern int g_gemm_abl;
 
-template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1>
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4>
 static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bias, const float* resid, int ldr,
                        OT* out, int ldo, int M, int N, int K, hipStream_t s, int splitk = 1) {
-    constexpr int RING = STAGES * (TBM + TBN) * ROWB, STG = (TBM / EP) * (TBN * 4 + 16);
-    constexpr int LDS = RING > STG ? RING : STG;
-    auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP>;
+    constexpr int LDS = STAGES * (TBM + TBN) * ROWB;     // the epilogue's per-wave slabs reuse the ring
+    auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP, FD>;
     static bool attr_done = false;
     if (LDS > 64 * 1024 && !attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -585,16 +591,17 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         // Tile shape by a two-term model measured on MI355X (tools/ubench.hip): the K loop is
         // bound by operand bytes through the CU's LDS-DMA path (~35 B/clk/CU), i.e. cost per tile-step is
         // proportional to TBM + TBN, and a launch takes ceil(workgroups / 256 CUs) rounds.
-        struct Cand { int bm, bn; };
-        const Cand cand[3] = {{128, 192}, {192, 192}, {128, 384}};
+        struct Cand { int bm, bn, step_cost; };       // step_cost ~ cycles per K-tile step / 3.6
+        const Cand cand[4] = {{128, 192, 320}, {192, 192, 384}, {128, 384, 512}, {384, 192, 645 /* MFMA-bound */}};
         int best = 0;
         long best_cost = -1;
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
-            const long cost = ((wgs + 255) / 256) * (cand[i].bm + cand[i].bn);
+            const long cost = ((wgs + 255) / 256) * cand[i].step_cost;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
         }
-        if (best == 1) launch_pipe<T, EPI, OT, 192, 192, 6, 2, 3, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
+        if (best == 3) launch_pipe<T, EPI, OT, 384, 192, 6, 2, 2, 6, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
+        else if (best == 1) launch_pipe<T, EPI, OT, 192, 192, 6, 2, 3, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
         else if (best == 2) launch_pipe<T, EPI, OT, 128, 384, 2, 4, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
         else launch_pipe<T, EPI, OT, 128, 192, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
         return;
@@ -603,6 +610,7 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
     if (variant == 4) { launch_pipe<T, EPI, OT, 128, 128, 2, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 5) { launch_pipe<T, EPI, OT, 256, 128, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 6) { launch_pipe<T, EPI, OT, 128, 128, 4, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 14) { launch_pipe<T, EPI, OT, 384, 192, 6, 2, 2, 6, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 11) { launch_pipe<T, EPI, OT, 192, 192, 6, 2, 3, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 12) { launch_pipe<T, EPI, OT, 256, 192, 4, 2, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 9) { launch_pipe<T, EPI, OT, 256, 192, 4, 2, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }

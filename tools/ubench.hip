@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512) void k_gemm_loop(long long* out, float* sink, 
 }
 
 // same loop + the operand stream: 5 x 1 KiB LDS-DMA pieces per wave per tile into a 3-slot ring, counted vmcnt
-template <int MODE, int PANELS = 60>   // 0: LDS-DMA (buffer_load..lds)  1: global_load to VGPRs + ds_write_b128  2: issue DMA but never wait (overwrites allowed)
+template <int MODE, int PANELS = 60, bool LINEAR = false>   // 0: LDS-DMA (buffer_load..lds)  1: global_load to VGPRs + ds_write_b128  2: issue DMA but never wait (overwrites allowed)
 __global__ __launch_bounds__(512) void k_gemm_loop_dma(long long* out, float* sink, const unsigned char* __restrict__ src, int iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
@@ -125,16 +125,17 @@ __global__ __launch_bounds__(512) void k_gemm_loop_dma(long long* out, float* si
     unsigned voff[5];
     for (int i = 0; i < 5; ++i) {
         const int g = i * 8 + wave, r = g * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-        voff[i] = (unsigned)(((blockIdx.x % PANELS) * 320 + r) * 1536 + c * 16);
+        voff[i] = LINEAR ? (unsigned)((blockIdx.x % PANELS) * 491520 + g * 1024 + lane * 16)     // 1 KiB contiguous per piece
+                         : (unsigned)(((blockIdx.x % PANELS) * 320 + r) * 1536 + c * 16);
     }
     uint4 regs[5];
     auto piece = [&](int slot, int t, int i) {
-        const int soff = (t % 12) * 128;
+        const int soff = LINEAR ? (t % 12) * 40960 : (t % 12) * 128;
         const int g = i * 8 + wave;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + slot * 40960 + g * 1024), 16, voff[i], soff, 0, 0);
     };
     auto stage = [&](int slot, int t) {
-        const int soff = (t % 12) * 128;
+        const int soff = LINEAR ? (t % 12) * 40960 : (t % 12) * 128;
         for (int i = 0; i < 5; ++i) {
             const int g = i * 8 + wave;
             if (MODE == 1) regs[i] = *reinterpret_cast<const uint4*>(src + voff[i] + soff);
@@ -223,6 +224,10 @@ int main() {
     run("gemm loop + LDS-DMA, 2 hot panels", [&] { k_gemm_loop_dma<0, 2><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_loop_dma<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 122880);
     run("gemm loop + LDS-DMA, 8 hot panels", [&] { k_gemm_loop_dma<0, 8><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_loop_dma<0, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 122880);
+    run("LDS-DMA, 8 hot panels, LINEAR src", [&] { k_gemm_loop_dma<0, 8, true><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_loop_dma<0, 60, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 122880);
+    run("LDS-DMA, 60 panels, LINEAR src", [&] { k_gemm_loop_dma<0, 60, true><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
     run("gemm loop + LDS-DMA spread, 8w", [&] { k_gemm_loop_dma<3><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
     run("gemm loop + reg-staged stream, 8w", [&] { k_gemm_loop_dma<1><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
     run("gemm loop + LDS-DMA no wait, 8w", [&] { k_gemm_loop_dma<2><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
