@@ -25,6 +25,22 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X_MICROARCH.md: dense MFMA peaks
 
 
+def pmc_traffic_bytes(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_pmc_bench_summary.json, produced by tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in
+    separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams on gfx950).
+    None when the summary is absent or the batch differs from the profiled one."""
+    fn = os.path.join(ROOT, "profiles", "r01_pmc_bench_summary.json")
+    try:
+        d = json.load(open(fn))
+        fam = {"gemm_ffn_up": "gemm_ffn_up(+gelu)", "gemm_qkv": "gemm_qkv"}.get(kernel)
+        if fam is None or fam not in d:
+            return None
+        return int((2.0 * d[fam]["FETCH_SIZE"]["mean_per_launch"] + d[fam]["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+    except Exception:
+        return None
+
+
 def gemm_flops(kind, M, H, I):
     return {"gemm_qkv": 2.0 * M * 3 * H * H, "gemm_attn_out": 2.0 * M * H * H,
             "gemm_ffn_up": 2.0 * M * I * H, "gemm_ffn_down": 2.0 * M * I * H}[kind]
@@ -186,7 +202,9 @@ def main():
         ach = gemm_flops(dom, M, H, I) / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                "frac": round(ach / peak, 4),
+                "traffic": pmc_traffic_bytes(dom) if (B == 64 and args.dtype == "bf16") else None,
+                "avg_launch_ms": round(avg_ms, 5),
                 "flop_per_launch": gemm_flops(dom, M, H, I)}
     if world > 1:
         dist.barrier()
