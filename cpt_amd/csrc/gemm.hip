@@ -349,8 +349,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
     const int kt0 = split * nt_per;
     const int nt = max(0, min(nt_per, nt_all - kt0));
     const int kbase = kt0 * BK;
+    // all STAGES slots are filled up front; afterwards tile t+STAGES is issued into tile t's slot right
+    // after the mid-iteration barrier of iteration t (every wave has issued its last reads of tile t by then)
 #pragma unroll
-    for (int p = 0; p < STAGES - 1; ++p)
+    for (int p = 0; p < STAGES; ++p)
         if (p < nt) stage(p, kbase + p * BK);
 
     const int fr = lane & 31, fh = lane >> 5;
@@ -387,10 +389,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
 #pragma unroll
         for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[pb][j]));
     };
-    // wait until tile `t` has landed: at most min(STAGES-2, tiles after t) younger tiles stay in flight
-    auto wait_tile = [&](int t) {
-        const int after = min(STAGES - 2, nt - 1 - t);
-        if (after >= 2) wait_vmcnt<2 * G>();
+    // wait until tile `t` has landed, called when tiles up to index `last` have been issued:
+    // (last - t) younger tiles may stay in flight
+    auto wait_tile = [&](int t, int last) {
+        const int after = last - t;
+        if (after >= 3) wait_vmcnt<3 * G>();
+        else if (after == 2) wait_vmcnt<2 * G>();
         else if (after == 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
     };
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
 
     if (trace) tr1 = clock64();
     if (nt > 0) {
-        wait_tile(0);
+        wait_tile(0, min(nt, STAGES) - 1);
         __builtin_amdgcn_s_barrier();
         CPT_SB();
         ldfrag(0, 0, 0);
@@ -413,19 +417,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
         const bool more = MAIN || (t + 1 < nt);
         int nslot = slot + 1;
         if (nslot == STAGES) nslot = 0;
-        // refill the slot tile t-1 occupied (GEMM pipeline hazards)
-        if (MAIN || t + STAGES - 1 < nt) {
-            int ns = slot + STAGES - 1;
-            if (ns >= STAGES) ns -= STAGES;
-            stage(ns, kbase + (t + STAGES - 1) * BK);
-        }
+        auto refill = [&]() {      // tile t+STAGES into the slot tile t occupies (pipeline hazards)
+            if (MAIN || t + STAGES < nt) stage(slot, kbase + (t + STAGES) * BK);
+        };
         if constexpr (FD == 4) {
             touch(0); CPT_SB(); ldfrag(slot, 2, 2); CPT_SB(); mma(0); CPT_SB();
             touch(1); CPT_SB(); ldfrag(slot, 3, 3); CPT_SB(); mma(1); CPT_SB();
             if (more) {
-                if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1);
+                if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1, min(nt, t + STAGES) - 1);
                 CPT_SB();
-                __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves
+                __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves; tile t's reads all issued
+                CPT_SB();
+                refill();
                 CPT_SB();
             }
             touch(2); CPT_SB(); if (more) ldfrag(nslot, 0, 0); CPT_SB(); mma(2); CPT_SB();
@@ -436,9 +439,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
             touch(0); CPT_SB(); ldfrag(slot, 3, 1); CPT_SB(); mma(0); CPT_SB();
             touch(1); CPT_SB();                    // this wave's reads of tile t are all done
             if (more) {
-                if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1);
+                if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1, min(nt, t + STAGES) - 1);
                 CPT_SB();
                 __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves; nobody still reads tile t
+                CPT_SB();
+                refill();
                 CPT_SB();
                 ldfrag(nslot, 0, 0);
                 CPT_SB();
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
         }
         slot = nslot;
     };
-    const int t_main = max(nt - (STAGES - 1), 0);
+    const int t_main = max(nt - STAGES, 0);      // iterations that still have a tile to issue
     for (int t = 0; t < t_main; ++t) body(t, std::true_type{});
     for (int t = t_main; t < nt; ++t) body(t, std::false_type{});
 #undef CPT_SB
