@@ -267,8 +267,8 @@ __global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
 // ---------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
-template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_kernel(
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1>
+__global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_pipe_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
     OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace, int abl) {
@@ -570,11 +570,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN + 3) / 4) void gemm_pipe_ker
 long long* g_gemm_trace = nullptr;
 extern int g_gemm_abl;
 
-template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4>
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1>
 static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bias, const float* resid, int ldr,
                        OT* out, int ldo, int M, int N, int K, hipStream_t s, int splitk = 1) {
     constexpr int LDS = STAGES * (TBM + TBN) * ROWB;     // the epilogue's per-wave slabs reuse the ring
-    auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP, FD>;
+    auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP, FD, OCC>;
     static bool attr_done = false;
     if (LDS > 64 * 1024 && !attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -596,16 +596,19 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         // Tile shape by a two-term model measured on MI355X (tools/ubench.hip): the K loop is
         // bound by operand bytes through the CU's LDS-DMA path (~35 B/clk/CU), i.e. cost per tile-step is
         // proportional to TBM + TBN, and a launch takes ceil(workgroups / 256 CUs) rounds.
-        struct Cand { int bm, bn, step_cost; };       // step_cost ~ cycles per K-tile step / 3.6
-        const Cand cand[4] = {{128, 192, 320}, {192, 192, 384}, {128, 384, 512}, {384, 192, 645 /* MFMA-bound */}};
+        struct Cand { int bm, bn, slots, round_cost; };   // round_cost ~ cycles for one round of `slots` workgroups
+        const Cand cand[5] = {{128, 192, 256, 320}, {192, 192, 256, 384}, {128, 384, 256, 512},
+                              {384, 192, 256, 645 /* MFMA-bound */},
+                              {128, 192, 512, 460 /* two co-resident workgroups per CU: epilogue under the other's K loop */}};
         int best = 0;
         long best_cost = -1;
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 5; ++i) {
             const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
-            const long cost = ((wgs + 255) / 256) * cand[i].step_cost;
+            const long cost = ((wgs + cand[i].slots - 1) / cand[i].slots) * cand[i].round_cost;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
         }
-        if (best == 3) launch_pipe<T, EPI, OT, 384, 192, 6, 2, 2, 6, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
+        if (best == 4) launch_pipe<T, EPI, OT, 128, 192, 4, 2, 2, 1, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
+        else if (best == 3) launch_pipe<T, EPI, OT, 384, 192, 6, 2, 2, 6, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
         else if (best == 1) launch_pipe<T, EPI, OT, 192, 192, 6, 2, 3, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
         else if (best == 2) launch_pipe<T, EPI, OT, 128, 384, 2, 4, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
         else launch_pipe<T, EPI, OT, 128, 192, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
@@ -615,6 +618,8 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
     if (variant == 4) { launch_pipe<T, EPI, OT, 128, 128, 2, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 5) { launch_pipe<T, EPI, OT, 256, 128, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 6) { launch_pipe<T, EPI, OT, 128, 128, 4, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 15) { launch_pipe<T, EPI, OT, 128, 192, 4, 2, 2, 1, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
+    if (variant == 16) { launch_pipe<T, EPI, OT, 128, 128, 2, 2, 2, 1, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 14) { launch_pipe<T, EPI, OT, 384, 192, 6, 2, 2, 6, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 11) { launch_pipe<T, EPI, OT, 192, 192, 6, 2, 3, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
     if (variant == 12) { launch_pipe<T, EPI, OT, 256, 192, 4, 2, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
