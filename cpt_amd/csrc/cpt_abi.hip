@@ -123,7 +123,10 @@ int cpt_check_device(int dev) {
     return CPT_OK;
 }
 
+static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
+
 int cpt_set_tuning(int key, int value) {
+    if (key == 4) { g_lp_resid = value; return CPT_OK; }
     if (key == 0) { cpt::set_gemm_variant(value); return CPT_OK; }
     if (key == 1) { cpt::set_gemm_abl(value); return CPT_OK; }
     if (key == 2) { cpt::set_attn_bwd_variant(value); return CPT_OK; }
@@ -272,16 +275,18 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
           TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)"); }
         { Scope p(CPT_K_ATTN, s);
           TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s), "attention"); }
+        const bool lpr = lp && g_lp_resid;                       // residual operand read as bf16, fp32 copy not written
+        const bool last = l + 1 == d.layers;
         { Scope p(CPT_K_GEMM_AO, s);
-          TRY(cpt::gemm(dt, CPT_EPI_RESID, ctx, H, y.w_ao, H, y.b_ao, x_f32, H, pre, CPT_F32, H, M, H, H, s), "gemm(attn out)"); }
+          TRY(cpt::gemm(dt, lpr ? 5 : CPT_EPI_RESID, ctx, H, y.w_ao, H, y.b_ao, lpr ? (const float*)x_lp : x_f32, H, pre, CPT_F32, H, M, H, H, s), "gemm(attn out)"); }
         { Scope p(CPT_K_LN, s);
-          TRY(cpt::layernorm_rows(pre, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, lp ? a_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(attn)"); }
+          TRY(cpt::layernorm_rows(pre, y.ln1_g, y.ln1_b, d.ln_eps, lpr ? nullptr : a_f32, lp ? a_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(attn)"); }
         { Scope p(CPT_K_GEMM_FFN1, s);
           TRY(cpt::gemm(dt, CPT_EPI_GELU, a_lp, H, y.w_in, H, y.b_in, nullptr, 0, ffn, dt, I, M, I, H, s), "gemm(ffn up)"); }
         { Scope p(CPT_K_GEMM_FFN2, s);
-          TRY(cpt::gemm(dt, CPT_EPI_RESID, ffn, I, y.w_out, I, y.b_out, a_f32, H, pre, CPT_F32, H, M, H, I, s), "gemm(ffn down)"); }
+          TRY(cpt::gemm(dt, lpr ? 5 : CPT_EPI_RESID, ffn, I, y.w_out, I, y.b_out, lpr ? (const float*)a_lp : a_f32, H, pre, CPT_F32, H, M, H, I, s), "gemm(ffn down)"); }
         { Scope p(CPT_K_LN, s);
-          TRY(cpt::layernorm_rows(pre, y.ln2_g, y.ln2_b, d.ln_eps, x_f32, lp ? x_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(ffn)"); }
+          TRY(cpt::layernorm_rows(pre, y.ln2_g, y.ln2_b, d.ln_eps, (lpr && !(last && (flags & CPT_OUT_SEQ))) ? nullptr : x_f32, lp ? x_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(ffn)"); }
     }
 
     if (flags & CPT_OUT_SEQ) {

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int GROUP_M = 8;
 constexpr int CPT_EPI_ATOMIC = 4;      // internal: split-K partial tiles added with fp32 atomics
+constexpr int CPT_EPI_RESID_LP = 5;    // internal: residual operand is in the compute dtype T (bf16 residual stream)
 
 template <int TBM>
 __device__ __forceinline__ void tile_of_block(int M, int N, int& m0, int& n0) {
@@ -475,8 +476,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     if (trace) tr3 = clock64();
     unsigned char* slab = smem + wave * (16 * CPW);
     const int wrow0 = m0 + wm * (MI * 32), wcol0 = n0 + wn * WCOLS;
+    constexpr bool HAS_RESID = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP;
+    const T* resid_lp = reinterpret_cast<const T*>(resid);      // EPI_RESID_LP: same rows, compute dtype
     const bool vec_ok = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out) % 16 == 0) &&
-                        (EPI != CPT_EPI_RESID || (ldr % 4 == 0 && ((uintptr_t)resid) % 16 == 0)) &&
+                        (!HAS_RESID || (ldr % 4 == 0 && ((uintptr_t)resid) % 16 == 0)) &&
                         (!bias || ((uintptr_t)bias) % 16 == 0);
     static_assert((16 * CH) % 64 == 0, "slab read-back must fill whole waves");
     // FULL (interior sub-tile, aligned pointers): one basic block, no guards, so the compiler's vmcnt
@@ -493,11 +496,19 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 64 + lane, rr = idx / CH, ch = idx % CH;
-                rv[it] = *reinterpret_cast<const f32x4*>(resid + (size_t)(wrow0 + sl * 16 + rr) * ldr + wcol0 + ch * 4);
+                const size_t off = (size_t)(wrow0 + sl * 16 + rr) * ldr + wcol0 + ch * 4;
+                if constexpr (EPI == CPT_EPI_RESID_LP && sizeof(T) == 2) {
+                    const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(resid_lp + off);
+                    rv[it] = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
+                } else if constexpr (EPI == CPT_EPI_RESID_LP) {
+                    rv[it] = *reinterpret_cast<const f32x4*>(resid_lp + off);
+                } else {
+                    rv[it] = *reinterpret_cast<const f32x4*>(resid + off);
+                }
             }
         };
         f32x4 rv_a[NIT], rv_b[NIT];
-        if constexpr (FULL && EPI == CPT_EPI_RESID) load_resid(0, rv_a);
+        if constexpr (FULL && HAS_RESID) load_resid(0, rv_a);
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl) {
             const int i = sl >> 1, half = sl & 1;
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     const int rr = (r8 & 3) + 8 * (r8 >> 2) + 4 * (lane >> 5);
                     *reinterpret_cast<float*>(slab + rr * CPW + (j * 32 + (lane & 31)) * 4) = acc[i][j][half * 8 + r8];
                 }
-            if constexpr (FULL && EPI == CPT_EPI_RESID) {
+            if constexpr (FULL && HAS_RESID) {
                 if (sl + 1 < NSL) { if (sl & 1) load_resid(sl + 1, rv_a); else load_resid(sl + 1, rv_b); }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's slab writes have landed
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         float x = v[e] + bv[it][e];
                         if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
                         if (EPI == CPT_EPI_TANH) x = tanhf(x);
-                        if constexpr (EPI == CPT_EPI_RESID) x += (sl & 1) ? rv_b[it][e] : rv_a[it][e];
+                        if constexpr (HAS_RESID) x += (sl & 1) ? rv_b[it][e] : rv_a[it][e];
                         v[e] = x;
                     }
                     if constexpr (sizeof(OT) == 2) {
@@ -546,6 +557,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                                 if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
                                 if (EPI == CPT_EPI_TANH) x = tanhf(x);
                                 if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col + e];
+                                if (EPI == CPT_EPI_RESID_LP) x += to_f32(resid_lp[(size_t)row * ldr + col + e]);
                                 if constexpr (EPI == CPT_EPI_ATOMIC && sizeof(OT) == 4) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, x);
                                 else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
                             }
@@ -650,6 +662,9 @@ static int launch_epi(int epi, const T* A, int lda, const T* W, int ldw, const f
             case CPT_EPI_RESID:
                 if (!resid) return CPT_ERR_SHAPE;
                 launch_fast<T, CPT_EPI_RESID, OT>(g_gemm_variant, A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return CPT_OK;
+            case CPT_EPI_RESID_LP:
+                if (!resid || g_gemm_variant < 3) return CPT_ERR_SHAPE;
+                launch_fast<T, CPT_EPI_RESID_LP, OT>(g_gemm_variant, A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return CPT_OK;
             default: return CPT_ERR_SHAPE;
         }
     }
