@@ -30,11 +30,16 @@ class Layer(C.Structure):
                  "ln2_g", "ln2_b")]
 
 
+class LayerFold(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_qkv_f", "c_qkv", "d_qkv", "w_in_f", "c_in", "d_in")]
+
+
 class Model(C.Structure):
     _fields_ = [("dims", Dims)] + [(n, C.c_void_p) for n in
                 ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "w_img", "b_img", "img_ln_g",
                  "img_ln_b")] + [("layers", C.POINTER(Layer))] + [(n, C.c_void_p) for n in
-                ("w_pool", "b_pool", "w_tr", "b_tr", "tr_ln_g", "tr_ln_b", "w_dec", "b_dec", "w_rel", "b_rel")]
+                ("w_pool", "b_pool", "w_tr", "b_tr", "tr_ln_g", "tr_ln_b", "w_dec", "b_dec", "w_rel", "b_rel")] + \
+               [("fold", C.POINTER(LayerFold))]
 
 
 class Batch(C.Structure):
@@ -77,6 +82,7 @@ _SIGS = {
                                      C.c_int, vp]),
     "cpt_attention": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_pad_cast": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_fold_ln_weights": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "cpt_gather_rows": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_ce_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "cpt_set_tuning": (C.c_int, [C.c_int, C.c_int]),

@@ -77,7 +77,7 @@ struct Scope {
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FwdLayout {
-    size_t x_f32, x_lp, qkv, ctx, pre, a_f32, a_lp, ffn, imgp, rows, t1, t2, pooled_f32, pooled_lp, logits_all_dummy, loss, total;
+    size_t x_f32, x_lp, qkv, ctx, pre, a_f32, a_lp, ffn, imgp, rows, rows_f32, t1, t2, pooled_f32, pooled_lp, stats, loss, total;
 };
 
 FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
@@ -98,6 +98,8 @@ FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
     w.ffn = take(M * (size_t)d.inter * es);
     w.imgp = take((size_t)B * Li * d.img_dim_pad * es);
     w.rows = take(hr * H * es);
+    w.rows_f32 = take((size_t)B * H * 4);
+    w.stats = take((size_t)d.layers * 2 * M * 2 * 4);
     w.t1 = take(hr * H * 4);
     w.t2 = lp ? take(hr * H * 2) : take(hr * H * 4);
     w.pooled_f32 = take((size_t)B * H * 4);
@@ -123,10 +125,12 @@ int cpt_check_device(int dev) {
     return CPT_OK;
 }
 
+static int g_fold_ln = 1;      // bf16 mode with cpt_model.fold: fold the encoder LayerNorms into the GEMMs (0 = run them as kernels)
 static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
 
 int cpt_set_tuning(int key, int value) {
     if (key == 4) { g_lp_resid = value; return CPT_OK; }
+    if (key == 5) { g_fold_ln = value; return CPT_OK; }
     if (key == 0) { cpt::set_gemm_variant(value); return CPT_OK; }
     if (key == 1) { cpt::set_gemm_abl(value); return CPT_OK; }
     if (key == 2) { cpt::set_attn_bwd_variant(value); return CPT_OK; }
@@ -190,6 +194,11 @@ int cpt_attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ct
 int cpt_pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, void* stream) {
     if (!x || !out) return fail(CPT_ERR_NULL, "cpt_pad_cast: null operand");
     return check_launch(cpt::pad_cast(x, out, dtype, R, K, Kp, (hipStream_t)stream), "cpt_pad_cast");
+}
+
+int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,
+                        float* colc, float* cold, int N, int K, void* stream) {
+    return check_launch(cpt::fold_ln_weights(W, gamma, beta, bias, Wf_bf16, colc, cold, N, K, (hipStream_t)stream), "cpt_fold_ln_weights");
 }
 
 int cpt_gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H,
@@ -269,6 +278,42 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                                 lp ? x_lp : nullptr, dt, B * Li, H, Li, L, Lt, s), "layernorm(img)");
     }
     // (a5-a9) encoder
+    const bool fold = lp && m->fold && g_fold_ln && !g_lp_resid;
+    const bool pre_ln = fold && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS));   // x_f32 left un-normalised after the encoder
+    if (fold) {
+        // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
+        // producer GEMMs accumulate their row sums, the consumer GEMMs normalise in their epilogue.
+        float* stats = (float*)(ws + w.stats);
+        hipError_t e = hipMemsetAsync(stats, 0, (size_t)d.layers * 2 * M * 2 * sizeof(float), s);
+        if (e != hipSuccess) return fail(CPT_ERR_HIP - (int)e, "zero LayerNorm statistics: %s", hipGetErrorString(e));
+        for (int l = 0; l < d.layers; ++l) {
+            const cpt_layer& y = m->layers[l];
+            const cpt_layer_fold& f = m->fold[l];
+            float* st1 = stats + ((size_t)l * 2 + 0) * M * 2;
+            float* st2 = stats + ((size_t)l * 2 + 1) * M * 2;
+            const float* st2p = l > 0 ? stats + ((size_t)(l - 1) * 2 + 1) * M * 2 : nullptr;
+            const cpt_layer* yp = l > 0 ? &m->layers[l - 1] : nullptr;
+            { Scope p(CPT_K_GEMM_QKV, s);
+              if (l == 0) TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
+              else TRY(cpt::gemm_ln_cons(x_lp, H, f.w_qkv_f, H, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, 0, qkv, 3 * H, M, 3 * H, H, s), "gemm(qkv, folded LN)"); }
+            { Scope p(CPT_K_ATTN, s);
+              TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s), "attention"); }
+            { Scope p(CPT_K_GEMM_AO, s);
+              TRY(cpt::gemm_ln_prod(ctx, H, y.w_ao, H, y.b_ao, x_f32, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
+                                    a_f32, a_lp, st1, H, M, H, H, s), "gemm(attn out, LN producer)"); }
+            { Scope p(CPT_K_GEMM_FFN1, s);
+              TRY(cpt::gemm_ln_cons(a_lp, H, f.w_in_f, H, st1, f.c_in, f.d_in, d.ln_eps, H, 1, ffn, I, M, I, H, s), "gemm(ffn up, folded LN)"); }
+            { Scope p(CPT_K_GEMM_FFN2, s);
+              TRY(cpt::gemm_ln_prod(ffn, I, y.w_out, I, y.b_out, a_f32, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_f32, x_lp, st2, H, M, H, I, s),
+                  "gemm(ffn down, LN producer)"); }
+        }
+        // x_f32 now holds the last pre-LayerNorm sum: materialise LayerNorm only where an output needs it
+        const cpt_layer& yl = m->layers[d.layers - 1];
+        if (flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) {
+            Scope p(CPT_K_LN, s);
+            TRY(cpt::layernorm_rows(x_f32, yl.ln2_g, yl.ln2_b, d.ln_eps, x_f32, x_lp, dt, M, H, M, 0, 0, s), "layernorm(final)");
+        }
+    } else
     for (int l = 0; l < d.layers; ++l) {
         const cpt_layer& y = m->layers[l];
         { Scope p(CPT_K_GEMM_QKV, s);
@@ -300,6 +345,12 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         void* rows = ws + w.rows;
         float* pooled = (flags & CPT_OUT_POOLED) ? o->pooled : (float*)(ws + w.pooled_f32);
         if (!pooled) return fail(CPT_ERR_NULL, "cpt_model_fwd: pooled output is NULL");
+        if (pre_ln) {
+            const cpt_layer& yl = m->layers[d.layers - 1];
+            float* rf = (float*)(ws + w.rows_f32);
+            TRY(cpt::gather_rows(x_f32, CPT_F32, nullptr, rf, B, L, H, s), "gather([CLS] pre-LN)");
+            TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, rows, dt, B, H, B, 0, 0, s), "layernorm([CLS] rows)");
+        } else
         TRY(cpt::gather_rows(x_lp, dt, nullptr, rows, B, L, H, s), "gather([CLS])");
         TRY(cpt::gemm(dt, CPT_EPI_TANH, rows, H, m->w_pool, H, m->b_pool, nullptr, 0, pooled, CPT_F32, H, B, H, H, s), "gemm(pooler)");
         if (flags & CPT_OUT_REL) {
@@ -322,7 +373,14 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         const void* rows = x_lp;
         if (!all) {
             void* g = ws + w.rows;
-            TRY(cpt::gather_rows(x_lp, dt, b->mask_pos, g, B, L, H, s), "gather([MASK])");
+            if (pre_ln) {
+                const cpt_layer& yl = m->layers[d.layers - 1];
+                float* rf = (float*)(ws + w.rows_f32);
+                TRY(cpt::gather_rows(x_f32, CPT_F32, b->mask_pos, rf, B, L, H, s), "gather([MASK] pre-LN)");
+                TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, g, dt, B, H, B, 0, 0, s), "layernorm([MASK] rows)");
+            } else {
+                TRY(cpt::gather_rows(x_lp, dt, b->mask_pos, g, B, L, H, s), "gather([MASK])");
+            }
             rows = g;
         }
         float* t1 = (float*)(ws + w.t1);

@@ -132,132 +132,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Fast path (K a multiple of the K-tile): operands go HBM/L2 -> LDS directly with
-// global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass); the XOR swizzle is applied to
-// the per-lane SOURCE address because the LDS destination of an LDS-DMA is lane-linear.
-// Out-of-range rows are clamped to a valid row (their results are never stored), so the loop has
-// no exec-mask branches.  Workgroups are numbered XCD-first and then in groups of GROUP_M row
-// tiles so that the ~64 workgroups resident on one XCD share A/W panels through that XCD's L2.
-// ---------------------------------------------------------------------------------------------
-constexpr int GROUP_M = 8;
+constexpr int GROUP_M = 8;             // row tiles per group in the XCD-first workgroup order
 constexpr int CPT_EPI_ATOMIC = 4;      // internal: split-K partial tiles added with fp32 atomics
 constexpr int CPT_EPI_RESID_LP = 5;    // internal: residual operand is in the compute dtype T (bf16 residual stream)
-
-template <int TBM>
-__device__ __forceinline__ void tile_of_block(int M, int N, int& m0, int& n0) {
-    const int tm = (M + TBM - 1) / TBM, tn = (N + BN - 1) / BN;
-    const int nwg = tm * tn, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);   // bijective
-    const int per_group = GROUP_M * tn;
-    const int g = lid / per_group, first_m = g * GROUP_M;
-    const int gsz = min(tm - first_m, GROUP_M);
-    const int in_g = lid - g * per_group;
-    m0 = (first_m + in_g % gsz) * TBM;
-    n0 = (in_g / gsz) * BN;
-}
-
-template <typename T, int EPI, typename OT, int TBM>
-__global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
-    const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
-    const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
-    OT* __restrict__ out, int ldo, int M, int N, int K, int abl) {
-    typedef typename FragOf<T>::type frag_t;
-    constexpr int CE = Chunk<T>::N;
-    constexpr int BK = ROWB / (int)sizeof(T);
-    constexpr int NW = TBM / 32;                 // waves: (TBM/64) x 2, 64x64 outputs each
-    constexpr int ROWS = TBM + BN;               // A rows then W rows in one LDS image
-    constexpr int GROUPS = ROWS / 8 / NW;        // 1 KiB LDS-DMA pieces per wave per K-tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][ROWS * ROWB];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int m0, n0;
-    tile_of_block<TBM>(M, N, m0, n0);
-
-    // per-lane source pointers for this wave's pieces (advance by BK elements per K-tile)
-    const T* src[GROUPS];
-#pragma unroll
-    for (int i = 0; i < GROUPS; ++i) {
-        const int g = i * NW + wave;
-        const int r = g * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);         // logical chunk stored at this lane's slot
-        if (g * 8 < TBM) src[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * CE;
-        else             src[i] = W + (size_t)min(n0 + r - TBM, N - 1) * ldw + c * CE;
-    }
-    auto stage = [&](int buf, int k0) {
-        if (abl & 1) return;      // ablation: no operand traffic
-#pragma unroll
-        for (int i = 0; i < GROUPS; ++i) {
-            const int g = i * NW + wave;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(src[i] + k0),
-                (__attribute__((address_space(3))) void*)(&smem[buf][g * 1024]), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nt = K / BK;
-    stage(0, 0);
-    __syncthreads();
-
-    const int fr = lane & 31, fh = lane >> 5;
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) stage(buf ^ 1, (t + 1) * BK);
-        const unsigned char* sa = smem[buf];
-        const unsigned char* sw = smem[buf] + TBM * ROWB;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            frag_t fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
-                fb[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 32 + fr, ks * 2 + fh));
-            }
-            if (abl & 2) {        // ablation: LDS reads stay live, no MFMA
-                asm volatile("" ::"v"(fa[0]), "v"(fa[1]), "v"(fb[0]), "v"(fb[1]));
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) mfma_chunk(acc[i][j], fa[i], fb[j]);
-            }
-        }
-        __syncthreads();     // drains this wave's LDS-DMA (vmcnt(0)) and fences the buffer swap
-    }
-
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + acc_col(lane);
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bv;
-                if (EPI == CPT_EPI_GELU) v = gelu_erf(v);
-                if (EPI == CPT_EPI_TANH) v = tanhf(v);
-                if (EPI == CPT_EPI_RESID) v += resid[(size_t)row * ldr + col];
-                if ((abl & 4) && v != 12345.678f) continue;   // ablation: epilogue math, no stores
-                out[(size_t)row * ldo + col] = from_f32<OT>(v);
-            }
-        }
-    }
-}
-
+constexpr int CPT_EPI_LNPROD = 6;      // internal: + residual (optionally LayerNorm'ed on the fly), writes fp32 + T copies and row sums
+constexpr int CPT_EPI_LNCONS = 7;      // internal: A operand is a pre-LayerNorm tensor; LayerNorm folded into the epilogue
+constexpr int CPT_EPI_LNCONS_GELU = 8; // internal: same + GELU
 
 // ---------------------------------------------------------------------------------------------
 // Pipelined kernel: STAGES-deep LDS ring fed by LDS-DMA with COUNTED vmcnt waits (tiles stay in
@@ -266,13 +146,26 @@ __global__ __launch_bounds__(TBM * 2) void gemm_glds_kernel(
 // 16-byte accesses instead of 2-byte scattered stores.
 //   tile TBM x TBN, waves WM x WN, each wave (TBM/WM) x (TBN/WN) as MI x NJ MFMA 32x32 blocks
 // ---------------------------------------------------------------------------------------------
+// extra epilogue operands of the LayerNorm-folding modes (see cpt_abi.hip, "folded LayerNorm")
+struct EpiX {
+    const float* st_in;    // [M][2] row sums (sum, sum of squares) of the LayerNorm INPUT this GEMM reads / of the residual source
+    const float* g_in;     // LNPROD: gain of the LayerNorm applied to the residual source on the fly (NULL: residual used as is)
+    const float* b_in;
+    float* st_out;         // LNPROD: [M][2] row sums of this GEMM's output (atomically accumulated; caller zeroes)
+    void* out_lp;          // LNPROD: copy of the output in the compute dtype
+    const float* colc;     // LNCONS: c[n] = sum_k W'[n][k]  (W' = gain-folded weight as the MFMA sees it)
+    const float* cold;     // LNCONS: d[n] = sum_k beta[k] W[n][k] + bias[n]
+    float eps, inv_h;      // LayerNorm eps, 1 / hidden
+};
+
+constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1>
 __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_pipe_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
-    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace, int abl) {
+    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace, int abl, EpiX ex) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses gfx950-only builtins/types (buffer rsrc, "v" asm): device pass only
     typedef typename FragOf<T>::type frag_t;
     constexpr int CE = Chunk<T>::N;
@@ -470,45 +363,118 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     constexpr int CH = WCOLS / 4;                     // float4 chunks per slab row
     constexpr int NIT = (16 * CH + 63) / 64;          // read-back iterations per slice
     constexpr int NSL = MI * 2;                       // 16-row slices per wave
-    static_assert(16 * CPW * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
+    constexpr int SIDE = MI * 32 * 8 + 2 * WCOLS * 4; // per-wave side area: (mean, rstd) per row + two column vectors
+    static_assert((16 * CPW + SIDE) * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
+    static_assert(MI * 32 <= 64 && CH <= 64, "side area is filled by one wave pass");
     if (split != 0) bias = nullptr;                   // split-K: the bias is added once
     __syncthreads();                                  // every wave is done reading the operand ring
     if (trace) tr3 = clock64();
     unsigned char* slab = smem + wave * (16 * CPW);
+    unsigned char* side = smem + NW * (16 * CPW) + wave * SIDE;
     const int wrow0 = m0 + wm * (MI * 32), wcol0 = n0 + wn * WCOLS;
-    constexpr bool HAS_RESID = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP;
+    constexpr bool LNPROD = EPI == CPT_EPI_LNPROD;
+    constexpr bool LNCONS = EPI == CPT_EPI_LNCONS || EPI == CPT_EPI_LNCONS_GELU;
+    constexpr bool HAS_RESID = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || LNPROD;
+    constexpr bool DO_GELU = EPI == CPT_EPI_GELU || EPI == CPT_EPI_LNCONS_GELU;
     const T* resid_lp = reinterpret_cast<const T*>(resid);      // EPI_RESID_LP: same rows, compute dtype
+    const bool fold_resid = LNPROD && ex.g_in != nullptr;       // residual = LayerNorm(resid; st_in, g_in, b_in)
     const bool vec_ok = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out) % 16 == 0) &&
                         (!HAS_RESID || (ldr % 4 == 0 && ((uintptr_t)resid) % 16 == 0)) &&
                         (!bias || ((uintptr_t)bias) % 16 == 0);
-    static_assert((16 * CH) % 64 == 0, "slab read-back must fill whole waves");
+    static_assert((16 * CH) % 64 == 0 && CH % 4 == 0, "slab read-back must fill whole waves");
+    // row statistics -> (mean, rstd)
+    auto stats_of = [&](float sum, float sq, float& mu, float& rs) {
+        mu = sum * ex.inv_h;
+        rs = rsqrtf(fmaxf(sq * ex.inv_h - mu * mu, 0.f) + ex.eps);
+    };
+    // element-wise finish shared by the guarded path: a = accumulator, returns the output value
+    auto finish1 = [&](float a, int row, int col) {
+        float x;
+        if constexpr (LNCONS) {
+            float mu, rs;
+            stats_of(ex.st_in[2 * row], ex.st_in[2 * row + 1], mu, rs);
+            x = rs * (a - mu * ex.colc[col]) + ex.cold[col];
+        } else {
+            x = a + (bias ? bias[col] : 0.f);
+        }
+        if (DO_GELU) x = gelu_for<T>(x);
+        if (EPI == CPT_EPI_TANH) x = tanhf(x);
+        if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col];
+        if (EPI == CPT_EPI_RESID_LP) x += to_f32(resid_lp[(size_t)row * ldr + col]);
+        if constexpr (LNPROD) {
+            float r = resid[(size_t)row * ldr + col];
+            if (fold_resid) {
+                float mu, rs;
+                stats_of(ex.st_in[2 * row], ex.st_in[2 * row + 1], mu, rs);
+                r = (r - mu) * rs * ex.g_in[col] + ex.b_in[col];
+            }
+            x += r;
+        }
+        return x;
+    };
     // FULL (interior sub-tile, aligned pointers): one basic block, no guards, so the compiler's vmcnt
     // bookkeeping is exact and stores issue back to back.  Otherwise the guarded element-wise path.
     auto epilogue = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        f32x4 bv[NIT];
+        // per-column operands: the column chunk of read-back iteration `it` is ((it*64 + lane) % CH), which
+        // repeats with period P = CH / gcd(64, CH) in `it` -- P register sets serve all NIT iterations
+        constexpr int P = CH / gcd_c(64, CH);
+        f32x4 bv[P], cv[LNCONS ? P : 1];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int col = wcol0 + ((it * 64 + lane) % CH) * 4;
-            bv[it] = (FULL && bias) ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < P; ++q) {
+            const int col = wcol0 + ((q * 64 + lane) % CH) * 4;
+            if constexpr (LNCONS) {
+                bv[q] = FULL ? *reinterpret_cast<const f32x4*>(ex.cold + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                cv[q] = FULL ? *reinterpret_cast<const f32x4*>(ex.colc + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                bv[q] = (FULL && bias) ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
-        auto load_resid = [&](int sl, f32x4 (&rv)[NIT]) {
+        // LayerNorm-folding modes: (mean, rstd) of this wave's rows and the residual LayerNorm's gain/bias go to a
+        // small per-wave LDS side area once, ahead of every store; the slice loop reads them with ds_read
+        float2* side_row = reinterpret_cast<float2*>(side);
+        float* side_g = reinterpret_cast<float*>(side + MI * 32 * 8);
+        float* side_t = side_g + WCOLS;
+        if constexpr (FULL && (LNCONS || LNPROD)) {
+            if (lane < MI * 32) {
+                float2 ms = {0.f, 1.f};
+                if (LNCONS || fold_resid) {
+                    const float2 s2 = *reinterpret_cast<const float2*>(ex.st_in + 2 * (size_t)(wrow0 + lane));
+                    stats_of(s2.x, s2.y, ms.x, ms.y);
+                }
+                side_row[lane] = ms;
+            }
+            if constexpr (LNPROD) {
+                if (lane < CH) {
+                    const f32x4 g4 = fold_resid ? *reinterpret_cast<const f32x4*>(ex.g_in + wcol0 + lane * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    const f32x4 t4 = fold_resid ? *reinterpret_cast<const f32x4*>(ex.b_in + wcol0 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(side_g + lane * 4) = g4;
+                    *reinterpret_cast<f32x4*>(side_t + lane * 4) = t4;
+                }
+            }
+        }
+        // residual rows, loaded one slice ahead of their use
+        struct Aux { f32x4 r[HAS_RESID ? NIT : 1]; };
+        auto load_aux = [&](int sl, Aux& a) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 64 + lane, rr = idx / CH, ch = idx % CH;
-                const size_t off = (size_t)(wrow0 + sl * 16 + rr) * ldr + wcol0 + ch * 4;
-                if constexpr (EPI == CPT_EPI_RESID_LP && sizeof(T) == 2) {
-                    const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(resid_lp + off);
-                    rv[it] = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
-                } else if constexpr (EPI == CPT_EPI_RESID_LP) {
-                    rv[it] = *reinterpret_cast<const f32x4*>(resid_lp + off);
-                } else {
-                    rv[it] = *reinterpret_cast<const f32x4*>(resid + off);
+                const int row = wrow0 + sl * 16 + rr;
+                if constexpr (HAS_RESID) {
+                    const size_t off = (size_t)row * ldr + wcol0 + ch * 4;
+                    if constexpr (EPI == CPT_EPI_RESID_LP && sizeof(T) == 2) {
+                        const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(resid_lp + off);
+                        a.r[it] = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
+                    } else if constexpr (EPI == CPT_EPI_RESID_LP) {
+                        a.r[it] = *reinterpret_cast<const f32x4*>(resid_lp + off);
+                    } else {
+                        a.r[it] = *reinterpret_cast<const f32x4*>(resid + off);
+                    }
                 }
             }
         };
-        f32x4 rv_a[NIT], rv_b[NIT];
-        if constexpr (FULL && HAS_RESID) load_resid(0, rv_a);
+        Aux aux_a, aux_b;
+        if constexpr (FULL && HAS_RESID) load_aux(0, aux_a);
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl) {
             const int i = sl >> 1, half = sl & 1;
@@ -520,21 +486,33 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     *reinterpret_cast<float*>(slab + rr * CPW + (j * 32 + (lane & 31)) * 4) = acc[i][j][half * 8 + r8];
                 }
             if constexpr (FULL && HAS_RESID) {
-                if (sl + 1 < NSL) { if (sl & 1) load_resid(sl + 1, rv_a); else load_resid(sl + 1, rv_b); }
+                if (sl + 1 < NSL) { if (sl & 1) load_aux(sl + 1, aux_a); else load_aux(sl + 1, aux_b); }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's slab writes have landed
+            Aux& ax = (sl & 1) ? aux_b : aux_a;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 64 + lane, rr = idx / CH, ch = idx % CH;
                 const int row = wrow0 + sl * 16 + rr, col = wcol0 + ch * 4;
                 f32x4 v = *reinterpret_cast<const f32x4*>(slab + rr * CPW + ch * 16);
                 if constexpr (FULL) {
+                    float2 ms = {0.f, 1.f};
+                    f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (LNCONS || LNPROD) ms = side_row[sl * 16 + rr];
+                    if constexpr (LNPROD) {
+                        g4 = *reinterpret_cast<const f32x4*>(side_g + ch * 4);
+                        t4 = *reinterpret_cast<const f32x4*>(side_t + ch * 4);
+                    }
+                    const float mu = ms.x, rs = ms.y;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = v[e] + bv[it][e];
-                        if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
+                        float x;
+                        if constexpr (LNCONS) x = rs * (v[e] - mu * cv[it % P][e]) + bv[it % P][e];
+                        else x = v[e] + bv[it % P][e];
+                        if (DO_GELU) x = gelu_for<T>(x);
                         if (EPI == CPT_EPI_TANH) x = tanhf(x);
-                        if constexpr (HAS_RESID) x += (sl & 1) ? rv_b[it][e] : rv_a[it][e];
+                        if constexpr (LNPROD) x += (ax.r[it][e] - mu) * rs * g4[e] + t4[e];     // mu=0, rs=1, g=1, b=0 when not folded
+                        else if constexpr (HAS_RESID) x += ax.r[it][e];
                         v[e] = x;
                     }
                     if constexpr (sizeof(OT) == 2) {
@@ -548,21 +526,52 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     } else {
                         *reinterpret_cast<f32x4*>(out + (size_t)row * ldo + col) = v;
                     }
+                    if constexpr (LNPROD) {
+                        T* olp = reinterpret_cast<T*>(ex.out_lp) + (size_t)row * ldo + col;
+                        if constexpr (sizeof(T) == 2) {
+                            bf16x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pk[e] = (bf16)v[e];
+                            *reinterpret_cast<bf16x4*>(olp) = pk;
+                        } else {
+                            *reinterpret_cast<f32x4*>(olp) = v;
+                        }
+                        *reinterpret_cast<f32x4*>(slab + rr * CPW + ch * 16) = v;      // finished values back for the row sums
+                    }
                 } else {
                     if (row < M) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (col + e < N) {
-                                float x = v[e] + (bias ? bias[col + e] : 0.f);
-                                if (EPI == CPT_EPI_GELU) x = gelu_for<T>(x);
-                                if (EPI == CPT_EPI_TANH) x = tanhf(x);
-                                if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col + e];
-                                if (EPI == CPT_EPI_RESID_LP) x += to_f32(resid_lp[(size_t)row * ldr + col + e]);
+                                const float x = finish1(v[e], row, col + e);
                                 if constexpr (EPI == CPT_EPI_ATOMIC && sizeof(OT) == 4) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, x);
                                 else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
+                                if constexpr (LNPROD) {
+                                    reinterpret_cast<T*>(ex.out_lp)[(size_t)row * ldo + col + e] = from_f32<T>(x);
+                                    atomicAdd(ex.st_out + 2 * (size_t)row, x);
+                                    atomicAdd(ex.st_out + 2 * (size_t)row + 1, x * x);
+                                }
                             }
                         }
                     }
+                }
+            }
+            if constexpr (LNPROD && FULL) {
+                // row sums of the finished slice: 4 lanes per row, CH/4 chunks each, two shuffles, 2 atomics per row
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int r16 = lane >> 2, part = lane & 3;
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int k = 0; k < CH / 4; ++k) {
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (part * (CH / 4) + k) * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sm += f[e]; sq += f[e] * f[e]; }
+                }
+                sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
+                sm += __shfl_xor(sm, 2, 64); sq += __shfl_xor(sq, 2, 64);
+                if (part == 0) {
+                    atomicAdd(ex.st_out + 2 * (size_t)(wrow0 + sl * 16 + r16), sm);
+                    atomicAdd(ex.st_out + 2 * (size_t)(wrow0 + sl * 16 + r16) + 1, sq);
                 }
             }
             // (LDS operations of one wave execute in issue order: the next slice's writes cannot pass these reads)
@@ -584,7 +593,7 @@ extern int g_gemm_abl;
 
 template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1>
 static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bias, const float* resid, int ldr,
-                       OT* out, int ldo, int M, int N, int K, hipStream_t s, int splitk = 1) {
+                       OT* out, int ldo, int M, int N, int K, hipStream_t s, int splitk = 1, const EpiX* ex = nullptr) {
     constexpr int LDS = STAGES * (TBM + TBN) * ROWB;     // the epilogue's per-wave slabs reuse the ring
     auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP, FD, OCC>;
     static bool attr_done = false;
@@ -593,58 +602,52 @@ static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bi
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         attr_done = true;
     }
+    const EpiX none = {};
     const int nwg = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN) * splitk;
-    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, g_gemm_trace, g_gemm_abl);
+    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, g_gemm_trace, g_gemm_abl,
+                                                    ex ? *ex : none);
     return CPT_OK;
 }
 
 int g_gemm_abl = 0;
-int g_gemm_variant = 3;      // 0: register-staged generic kernel only; 1: LDS-DMA 128x128; 2: LDS-DMA 256x128
+int g_gemm_variant = 3;      // 0: generic register-staged kernel only; 3: pipelined kernel, tile shape chosen per GEMM; 10/11/13/14/15: one fixed shape
+
+// the five tile configurations of the pipelined kernel
+#define CPT_CFG_128x192 128, 192, 4, 2, 3
+#define CPT_CFG_192x192 192, 192, 6, 2, 3, 2
+#define CPT_CFG_128x384 128, 384, 2, 4, 2, 2
+#define CPT_CFG_384x192 384, 192, 6, 2, 2, 6, 2
+#define CPT_CFG_128x192_OCC2 128, 192, 4, 2, 2, 1, 2, 2
 
 template <typename T, int EPI, typename OT>
 static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, const float* bias,
-                        const float* resid, int ldr, OT* out, int ldo, int M, int N, int K, hipStream_t s) {
+                        const float* resid, int ldr, OT* out, int ldo, int M, int N, int K, hipStream_t s,
+                        const EpiX* ex = nullptr) {
+    int pick = 0;
     if (variant == 3) {
         // Tile shape by a two-term model measured on MI355X (tools/ubench.hip): the K loop is
-        // bound by operand bytes through the CU's LDS-DMA path (~35 B/clk/CU), i.e. cost per tile-step is
-        // proportional to TBM + TBN, and a launch takes ceil(workgroups / 256 CUs) rounds.
+        // bound by LDS port time (LDS-DMA writes + fragment reads) unless the tile does >= 3.6 MFMA per KiB of
+        // operands, and a launch takes ceil(workgroups / slots) rounds.
         struct Cand { int bm, bn, slots, round_cost; };   // round_cost ~ cycles for one round of `slots` workgroups
         const Cand cand[5] = {{128, 192, 256, 320}, {192, 192, 256, 384}, {128, 384, 256, 512},
                               {384, 192, 256, 645 /* MFMA-bound */},
                               {128, 192, 512, 460 /* two co-resident workgroups per CU: epilogue under the other's K loop */}};
-        int best = 0;
         long best_cost = -1;
         for (int i = 0; i < 5; ++i) {
             const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
             const long cost = ((wgs + cand[i].slots - 1) / cand[i].slots) * cand[i].round_cost;
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = i; }
         }
-        if (best == 4) launch_pipe<T, EPI, OT, 128, 192, 4, 2, 2, 1, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
-        else if (best == 3) launch_pipe<T, EPI, OT, 384, 192, 6, 2, 2, 6, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
-        else if (best == 1) launch_pipe<T, EPI, OT, 192, 192, 6, 2, 3, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
-        else if (best == 2) launch_pipe<T, EPI, OT, 128, 384, 2, 4, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
-        else launch_pipe<T, EPI, OT, 128, 192, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s);
-        return;
-    }
-    if (variant == 13) { launch_pipe<T, EPI, OT, 128, 192, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 4) { launch_pipe<T, EPI, OT, 128, 128, 2, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 5) { launch_pipe<T, EPI, OT, 256, 128, 4, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 6) { launch_pipe<T, EPI, OT, 128, 128, 4, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 15) { launch_pipe<T, EPI, OT, 128, 192, 4, 2, 2, 1, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 16) { launch_pipe<T, EPI, OT, 128, 128, 2, 2, 2, 1, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 14) { launch_pipe<T, EPI, OT, 384, 192, 6, 2, 2, 6, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 11) { launch_pipe<T, EPI, OT, 192, 192, 6, 2, 3, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 12) { launch_pipe<T, EPI, OT, 256, 192, 4, 2, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 9) { launch_pipe<T, EPI, OT, 256, 192, 4, 2, 2, 4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 10) { launch_pipe<T, EPI, OT, 128, 384, 2, 4, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 8) { launch_pipe<T, EPI, OT, 128, 192, 4, 2, 2, 2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 7) { launch_pipe<T, EPI, OT, 128, 192, 2, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s); return; }
-    if (variant == 2 && M >= 1024) {
-        const int nwg = ((M + 255) / 256) * ((N + BN - 1) / BN);
-        gemm_glds_kernel<T, EPI, OT, 256><<<dim3(nwg), dim3(512), 0, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, g_gemm_abl);
-    } else {
-        const int nwg = ((M + 127) / 128) * ((N + BN - 1) / BN);
-        gemm_glds_kernel<T, EPI, OT, 128><<<dim3(nwg), dim3(256), 0, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, g_gemm_abl);
+    } else if (variant == 11) pick = 1;
+    else if (variant == 10) pick = 2;
+    else if (variant == 14) pick = 3;
+    else if (variant == 15) pick = 4;
+    switch (pick) {
+        case 1: launch_pipe<T, EPI, OT, CPT_CFG_192x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
+        case 2: launch_pipe<T, EPI, OT, CPT_CFG_128x384>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
+        case 3: launch_pipe<T, EPI, OT, CPT_CFG_384x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
+        case 4: launch_pipe<T, EPI, OT, CPT_CFG_128x192_OCC2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
+        default: launch_pipe<T, EPI, OT, CPT_CFG_128x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
     }
 }
 
@@ -726,6 +729,36 @@ int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw,
     if (dtype == CPT_F32)
         return launch_pipe<float, CPT_EPI_ATOMIC, float, 128, 192, 4, 2, 3>((const float*)A, lda, (const float*)W, ldw, nullptr, nullptr, 0, out, ldo, M, N, K, s, splitk);
     return CPT_ERR_DTYPE;
+}
+
+// ---- LayerNorm folded into the GEMMs around it (bf16 throughput path) -------------------------------
+// Producer: out_f32 = A.W^T + bias + R, where R = resid or LayerNorm(resid; st_in, g_in, b_in) computed on
+// the fly; also writes the bf16 copy and accumulates the row sums (sum, sum of squares) of out into st_out.
+int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
+                 const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
+                 float* out_f32, void* out_lp, float* st_out, int ldo, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
+    if (!A || !W || !resid || !out_f32 || !out_lp || !st_out) return CPT_ERR_NULL;
+    EpiX ex = {};
+    ex.st_in = st_in; ex.g_in = g_in; ex.b_in = b_in; ex.st_out = st_out; ex.out_lp = out_lp;
+    ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
+    launch_fast<bf16, CPT_EPI_LNPROD, float>(g_gemm_variant >= 3 ? g_gemm_variant : 3, (const bf16*)A, lda, (const bf16*)W, ldw, bias,
+                                            resid, ldr, out_f32, ldo, M, N, K, s, &ex);
+    return CPT_OK;
+}
+
+// Consumer: A is the bf16 copy of a pre-LayerNorm tensor, Wf the gain-folded weight;
+// out = [gelu]( rstd[m] * (A.Wf^T - mean[m] * colc[n]) + cold[n] )  ==  [gelu]( LayerNorm(A) . W^T + bias )
+int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
+                 float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
+    if (!A || !Wf || !st_in || !colc || !cold || !out_lp) return CPT_ERR_NULL;
+    EpiX ex = {};
+    ex.st_in = st_in; ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
+    const int v = g_gemm_variant >= 3 ? g_gemm_variant : 3;
+    if (gelu) launch_fast<bf16, CPT_EPI_LNCONS_GELU, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
+    else launch_fast<bf16, CPT_EPI_LNCONS, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
+    return CPT_OK;
 }
 
 void set_gemm_variant(int v) { g_gemm_variant = v; }

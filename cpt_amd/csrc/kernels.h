@@ -49,6 +49,13 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s);
 
 int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s);
+int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
+                 const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
+                 float* out_f32, void* out_lp, float* st_out, int ldo, int M, int N, int K, hipStream_t s);
+int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
+                 float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s);
+int fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* colc,
+                    float* cold, int N, int K, hipStream_t s);
 void set_splitk_target(int v);
 void set_attn_bwd_variant(int v);
 void set_gemm_variant(int v);

@@ -183,6 +183,43 @@ int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStre
     return CPT_OK;
 }
 
+// ---- fold a LayerNorm (gamma, beta) into the Linear that consumes its output ------------------------
+// Wf[n][k] = bf16(gamma[k] * W[n][k]);  colc[n] = sum_k float(Wf[n][k]) (what the MFMA will see);
+// cold[n] = sum_k beta[k] * W[n][k] + bias[n].  One wave per output row n.
+__global__ __launch_bounds__(256) void fold_ln_weights_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ bias,
+                                                              bf16* __restrict__ Wf, float* __restrict__ colc, float* __restrict__ cold,
+                                                              int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float c = 0.f, d = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + k);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (bf16)(g[e] * w[e]);
+            c += (float)o[e];
+            d += b[e] * w[e];
+        }
+        *reinterpret_cast<bf16x4*>(Wf + (size_t)n * K + k) = o;
+    }
+    c = wave_sum(c);
+    d = wave_sum(d);
+    if (lane == 0) { colc[n] = c; cold[n] = d + (bias ? bias[n] : 0.f); }
+}
+
+int fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* colc,
+                    float* cold, int N, int K, hipStream_t s) {
+    if (N <= 0 || K <= 0 || K % 4) return CPT_ERR_SHAPE;
+    if (!W || !gamma || !beta || !Wf_bf16 || !colc || !cold) return CPT_ERR_NULL;
+    fold_ln_weights_kernel<<<dim3((N + 3) / 4), dim3(256), 0, s>>>(W, gamma, beta, bias, (bf16*)Wf_bf16, colc, cold, N, K);
+    return CPT_OK;
+}
+
 // ---- gather rows: out[b] = src[b*L + pos[b]] ---------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int64_t* __restrict__ pos,
                                                           uint4* __restrict__ out, int B, int L, int chunks) {

@@ -49,6 +49,9 @@ class PackedModel(object):
         self._desc = {}
         self._ws = {}
         self.dtype = "fp32"
+        self.fold_ln = True         # bf16 inference: fold the encoder LayerNorms into the GEMMs around them
+        self._fold = None
+        self._fold_stale = True
 
     # ---- packing -------------------------------------------------------------------------
     def _named(self):
@@ -116,6 +119,7 @@ class PackedModel(object):
         if not force and self._sig.get(self.dtype) == sig:
             return
         self._sig[self.dtype] = sig
+        self._fold_stale = True
         cfg = self.cfg
         H, D = cfg.hidden_size, cfg.img_feature_dim
         Dp = (D + 63) // 64 * 64
@@ -148,6 +152,7 @@ class PackedModel(object):
         st = L.stream_ptr()
         w_img = self.view("bert.img_embedding.weight")
         self._sig = {}
+        self._fold_stale = True
         if self.dtype == "bf16":
             if self.flat_lp is None or not shadow_fresh:
                 self.refresh_shadow(force=True)
@@ -159,9 +164,52 @@ class PackedModel(object):
             return
         self._sig[self.dtype] = self._versions()
 
+    def ensure_fold(self):
+        """LayerNorm-folded copies of the two GEMM weights that consume a LayerNorm output
+        (include/cpt_hip.h cpt_layer_fold), rebuilt lazily after any weight change.  bf16 inference only."""
+        if not self._fold_stale and self._fold is not None:
+            return
+        cfg = self.cfg
+        H, I, nl = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        dev = self.flat.device
+        if self._fold is None or self._fold["w"].device != dev:
+            self._fold = {"w": torch.empty(nl * (3 * H * H + I * H), device=dev, dtype=torch.bfloat16),
+                          "v": torch.empty(nl * 2 * (3 * H + I), device=dev, dtype=torch.float32),
+                          "arr": (L.LayerFold * nl)()}
+            self._desc = {}
+        wbuf, vbuf, arr = self._fold["w"], self._fold["v"], self._fold["arr"]
+        st = L.stream_ptr()
+        base = self.flat.data_ptr()
+
+        def fp(n):
+            return base + self.offsets[n][0] * 4
+        wo, vo = 0, 0
+        for i in range(nl):
+            p = "bert.encoder.layer.%d." % i
+            f = arr[i]
+            f.w_in_f = wbuf.data_ptr() + wo * 2
+            wo += I * H
+            f.c_in = vbuf.data_ptr() + vo * 4
+            f.d_in = vbuf.data_ptr() + (vo + I) * 4
+            vo += 2 * I
+            L.check(L.lib().cpt_fold_ln_weights(fp(p + "intermediate.dense.weight"), fp(p + "attention.output.LayerNorm.weight"),
+                                                fp(p + "attention.output.LayerNorm.bias"), fp(p + "intermediate.dense.bias"),
+                                                f.w_in_f, f.c_in, f.d_in, I, H, st), "cpt_fold_ln_weights(ffn up)")
+            if i > 0:
+                q = "bert.encoder.layer.%d." % (i - 1)
+                f.w_qkv_f = wbuf.data_ptr() + wo * 2
+                f.c_qkv = vbuf.data_ptr() + vo * 4
+                f.d_qkv = vbuf.data_ptr() + (vo + 3 * H) * 4
+                L.check(L.lib().cpt_fold_ln_weights(fp(p + "attention.self.query.weight"), fp(q + "output.LayerNorm.weight"),
+                                                    fp(q + "output.LayerNorm.bias"), fp(p + "attention.self.query.bias"),
+                                                    f.w_qkv_f, f.c_qkv, f.d_qkv, 3 * H, H, st), "cpt_fold_ln_weights(qkv)")
+            wo += 3 * H * H
+            vo += 2 * 3 * H
+        self._fold_stale = False
+
     # ---- descriptor ----------------------------------------------------------------------
     def descriptor(self):
-        key = self.dtype
+        key = (self.dtype, bool(self.fold_ln))
         if key in self._desc:
             return self._desc[key]
         cfg = self.cfg
@@ -226,6 +274,8 @@ class PackedModel(object):
         if self.head == "pretrain":
             m.w_rel = mat("cls.seq_relationship.weight")
             m.b_rel = vec("cls.seq_relationship.bias")
+        if lp and self.fold_ln and self._fold is not None:
+            m.fold = C.cast(self._fold["arr"], C.POINTER(L.LayerFold))
         self._desc[key] = (m, layers)     # keep `layers` alive
         return self._desc[key]
 
@@ -246,6 +296,8 @@ class PackedModel(object):
         """Returns dict with the outputs selected by `flags` (see _lib.OUT_*)."""
         self.ensure_packed()
         self.refresh_shadow()
+        if self.dtype == "bf16" and self.fold_ln:
+            self.ensure_fold()
         dev = self.flat.device
 
         def prep(t, dt, name):

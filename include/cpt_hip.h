@@ -88,6 +88,15 @@ typedef struct {           /* bert.encoder.layer.{i}.* */
     const float* ln2_b;
 } cpt_layer;
 
+typedef struct {           /* optional LayerNorm-folded operands of layer i (CPT_BF16 only) */
+    const void* w_qkv_f;   /* [3H][H] bf16 = output.LayerNorm.weight of layer i-1 (columns) * w_qkv; NULL for layer 0 */
+    const float* c_qkv;    /* [3H] sum_k w_qkv_f[n][k] */
+    const float* d_qkv;    /* [3H] sum_k output.LayerNorm.bias(i-1)[k] * w_qkv[n][k] + b_qkv[n] */
+    const void* w_in_f;    /* [I][H] bf16 = attention.output.LayerNorm.weight of layer i * w_in */
+    const float* c_in;     /* [I] */
+    const float* d_in;     /* [I] */
+} cpt_layer_fold;
+
 typedef struct {
     cpt_dims dims;
     const float* word_emb;   /* bert.embeddings.word_embeddings.weight [V][H] fp32 */
@@ -110,6 +119,8 @@ typedef struct {
     const float* b_dec;      /* cls.bias [V] */
     const void* w_rel;       /* cls.seq_relationship.weight [n_rel][H] compute dtype, or NULL */
     const float* b_rel;
+    const cpt_layer_fold* fold; /* HOST array of dims.layers entries, or NULL: with it (and CPT_BF16) the encoder's
+                                 * LayerNorms are folded into the GEMMs around them instead of running as kernels */
 } cpt_model;
 
 /* One batch as the reference drivers hand it to the model
@@ -224,6 +235,11 @@ int cpt_attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ct
 
 /* x[R][K] fp32 -> out[R][Kp] in `dtype`, zero-padded (region features / img weight, K=2054). */
 int cpt_pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, void* stream);
+
+/* Fold LayerNorm(gamma, beta) into the Linear (W [N][K] fp32, bias [N] or NULL) that consumes its output:
+ * Wf = bf16(gamma[k] * W[n][k]), colc[n] = sum_k Wf[n][k], cold[n] = sum_k beta[k] W[n][k] + bias[n]. */
+int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,
+                        float* colc, float* cold, int N, int K, void* stream);
 
 /* out[b][:] = src[b*L + pos[b]][:] (pos NULL = row 0): the [MASK] rows
  * (zeroshot/refcoco_cpt.py:219) and the [CLS] rows of BertPooler. */

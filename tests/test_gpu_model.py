@@ -158,3 +158,36 @@ def test_config2_vs_oracle(dev, mode):
                   mask_token_pos=D["mask_token_pos"])[0]
     assert torch.isfinite(got64).all()
     assert _stats("B=64 rows 0..7 vs B=8", got64[:8], got.cpu()) < (1e-4 if mode == "fp32" else 2e-2)
+
+
+def test_bf16_folded_layernorm(dev):
+    """bf16 mode folds the encoder LayerNorms into the GEMMs around them.  The folded and the
+    explicit-LayerNorm encoders compute the same function: both must sit inside the bf16 band of the oracle,
+    and every output surface (sequence, pooled, all-row logits, [MASK]-row logits) must agree between them."""
+    from oracle import cpt_oracle as O
+    cfg = cfgmod.oscar_base()
+    m, _ = _model(cfg, 88, dev, "bf16")
+    sd = synth.init_state_dict(cfg, 88, head="cpt")
+    b = synth.make_batch(6, cfg, seed=33, vary_regions=True)
+    with torch.no_grad():
+        ref = O.rec_mlm_cpt_forward(sd, cfg.to_dict(), b["input_ids"], b["segment_ids"], b["attention_mask"],
+                                    img_feats=b["img_feats"], mask_rows_only=b["mask_token_pos"])[0]
+    d = _dev_batch(b, dev)
+    m.bert.set_compute_dtype("bf16")
+    res = {}
+    for fold in (True, False):
+        for eng in (m._engine(), m.bert._engine()):
+            eng.fold_ln = fold
+        with torch.no_grad():
+            rows = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"],
+                     mask_token_pos=d["mask_token_pos"])[0]
+            allr = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])[0]
+            seq, pooled = m.bert(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])
+        res[fold] = (rows.cpu(), allr.cpu(), seq.cpu(), pooled.cpu())
+        err = _stats("fold=%s [MASK] logits vs oracle" % fold, rows, ref)
+        assert err < 0.15
+    pos = b["mask_token_pos"]
+    for i, nm in enumerate(("mask rows", "all rows", "seq", "pooled")):
+        assert _stats("folded vs explicit LN: " + nm, res[True][i], res[False][i]) < (0.15 if i < 2 else 0.1)
+    # the all-row head's [MASK] rows are the [MASK]-row head's output
+    assert _stats("all-row head at [MASK]", res[True][1][torch.arange(6), pos], res[True][0]) < 2e-2
