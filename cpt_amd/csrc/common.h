@@ -38,8 +38,29 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float r = fmaf(-p, __expf(-ax * ax), 1.0f);
     return copysignf(r, x);
 }
+// erf-GELU of the bf16 throughput path, by Abramowitz-Stegun 7.1.28: erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16,
+// |error| <= 3e-7.  With z = |x|/sqrt(2) and the 0.5 of the GELU folded into the polynomial (2^(1/16) scale):
+//   gelu(x) = max(x, 0) - |x| * r^16,   r = 1 / P(|x|)
+// One v_rcp_f32 and no exp; everything else is fma/mul, written on float pairs so that it compiles to the packed
+// fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32).  |gelu error| < 1e-6 absolute over all x (checked against
+// scipy erf on 2M points, tests/test_gpu_ops.py checks the kernel): four orders below bf16 resolution.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    f32x2 p = ax * 5.6212996640e-06f + 5.1055209009e-05f;
+    p = p * ax + 3.9686137011e-05f;
+    p = p * ax + 3.4227392389e-03f;
+    p = p * ax + 2.2076998457e-02f;
+    p = p * ax + 5.2075163037e-02f;
+    p = p * ax + 1.0442737824e+00f;
+    f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+    r = r * r; r = r * r; r = r * r; r = r * r;
+    const f32x2 m = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return m - ax * r;
+}
 __device__ __forceinline__ float gelu_fast(float x) {
-    return x * 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+    const f32x2 g = gelu_fast2(f32x2{x, x});
+    return g[0];
 }
 // exact-erf GELU for the fp32 parity path, fast-erf GELU for the bf16 path
 template <typename T> __device__ __forceinline__ float gelu_for(float x);

@@ -180,6 +180,69 @@ __global__ __launch_bounds__(512) void k_gemm_loop_dma(long long* out, float* si
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
 }
 
+// register-staged operand stream, software-pipelined: the global loads of tile t+2 are issued at the top of
+// iteration t into one of two register sets and written to LDS (ds_write_b128) at the end of iteration t+1,
+// so a full iteration of MFMA work covers their latency.  Tests whether ds_write_b128 is cheaper for the LDS
+// port than the LDS-DMA path.
+template <int PANELS>
+__global__ __launch_bounds__(512, 2) void k_gemm_loop_reg(long long* out, float* sink, const unsigned char* __restrict__ src, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+    for (int i = threadIdx.x; i < 122880 / 4; i += blockDim.x) reinterpret_cast<float*>(smem)[i] = 1.0f;
+    __syncthreads();
+    f32x16 acc[3];
+    for (int a = 0; a < 3; ++a)
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    bf16x8 fa[4], fb[4][3];
+    auto ld = [&](int slot, int ks) {
+        const unsigned char* b = smem + slot * 40960;
+        fa[ks] = *reinterpret_cast<const bf16x8*>(b + lds_off(wm * 32 + fr, ks * 2 + fh));
+        for (int j = 0; j < 3; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(b + 128 * 128 + lds_off(wn * 96 + j * 32 + fr, ks * 2 + fh));
+    };
+    auto touch = [&](int ks) {
+        asm volatile("" : "+v"(fa[ks]));
+        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(fb[ks][j]));
+    };
+    auto mma = [&](int ks) {
+        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks][j], acc[j], 0, 0, 0);
+    };
+    unsigned voff[5];
+    for (int i = 0; i < 5; ++i) {
+        const int g = i * 8 + wave, r = g * 8 + (lane >> 3), c = (lane & 7);
+        voff[i] = (unsigned)(((blockIdx.x % PANELS) * 320 + r) * 1536 + c * 16);
+    }
+    uint4 a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;      // two register sets (named scalars: arrays behind lambdas end up in scratch)
+#define UB_LOAD(i, t) (*reinterpret_cast<const uint4*>(src + voff[i] + ((t) % 12) * 128))
+#define UB_STORE(i, slot, v) (*reinterpret_cast<uint4*>(smem + (slot) * 40960 + lds_off(((i) * 8 + wave) * 8 + (lane >> 3), lane & 7)) = (v))
+#define UB_SB() __builtin_amdgcn_sched_barrier(0)
+#define UB_ITER(t, n0, n1, n2, n3, n4, o0, o1, o2, o3, o4)                                                  \
+    {                                                                                                       \
+        const int nslot = slot + 1 == 3 ? 0 : slot + 1, wslot = slot + 2 >= 3 ? slot - 1 : slot + 2;        \
+        n0 = UB_LOAD(0, (t) + 2); n1 = UB_LOAD(1, (t) + 2); n2 = UB_LOAD(2, (t) + 2); n3 = UB_LOAD(3, (t) + 2); n4 = UB_LOAD(4, (t) + 2); \
+        UB_SB(); touch(0); UB_SB(); ld(slot, 2); UB_SB(); mma(0); UB_SB();                                  \
+        touch(1); UB_SB(); ld(slot, 3); UB_SB(); mma(1); UB_SB();                                           \
+        __builtin_amdgcn_s_barrier(); UB_SB();                                                              \
+        touch(2); UB_SB(); ld(nslot, 0); UB_SB(); mma(2); UB_SB();                                          \
+        UB_STORE(0, wslot, o0); UB_STORE(1, wslot, o1); UB_STORE(2, wslot, o2); UB_STORE(3, wslot, o3); UB_STORE(4, wslot, o4); \
+        UB_SB(); touch(3); UB_SB(); ld(nslot, 1); UB_SB(); mma(3); UB_SB();                                 \
+        slot = nslot;                                                                                       \
+    }
+    b0 = UB_LOAD(0, 1); b1 = UB_LOAD(1, 1); b2 = UB_LOAD(2, 1); b3 = UB_LOAD(3, 1); b4 = UB_LOAD(4, 1);
+    __builtin_amdgcn_s_barrier();
+    ld(0, 0); ld(0, 1);
+    int slot = 0;
+    long long t0 = clock64();
+    for (int t = 0; t < iters; t += 2) {
+        UB_ITER(t, a0, a1, a2, a3, a4, b0, b1, b2, b3, b4)
+        UB_ITER(t + 1, b0, b1, b2, b3, b4, a0, a1, a2, a3, a4)
+    }
+    long long t1 = clock64();
+    float s = acc[0][0] + acc[1][0] + acc[2][0];
+    if (s == 12345.f) sink[0] = s;
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+}
+
 template <typename F>
 static void run(const char* name, F launch, long long* d, int nblk, double work_per_blk_iter, int iters) {
     hipEvent_t e0, e1;
@@ -230,6 +293,10 @@ int main() {
     run("LDS-DMA, 60 panels, LINEAR src", [&] { k_gemm_loop_dma<0, 60, true><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
     run("gemm loop + LDS-DMA spread, 8w", [&] { k_gemm_loop_dma<3><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
     run("gemm loop + reg-staged stream, 8w", [&] { k_gemm_loop_dma<1><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_loop_reg<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 122880);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_loop_reg<60>), hipFuncAttributeMaxDynamicSharedMemorySize, 122880);
+    run("reg-staged PIPELINED, 2 hot panels", [&] { k_gemm_loop_reg<2><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
+    run("reg-staged PIPELINED, 60 panels", [&] { k_gemm_loop_reg<60><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
     run("gemm loop + LDS-DMA no wait, 8w", [&] { k_gemm_loop_dma<2><<<256, 512, 122880>>>(d, sink, src, iters); }, d, 256, fl * 12 * 8, iters);
     run("gemm loop (LDS reads 2 ahead), 8w", [&] { k_gemm_loop<2><<<256, 512, 122880>>>(d, sink, iters); }, d, 256, fl * 12 * 8, iters);
     run("gemm loop (reads after use), 8w", [&] { k_gemm_loop<0><<<256, 512, 122880>>>(d, sink, iters); }, d, 256, fl * 12 * 8, iters);
