@@ -19,6 +19,20 @@ namespace cpt {
 
 constexpr int HD = 64;           // head dim
 constexpr int ATT_THREADS = 256;
+// bf16 path: V row pitch in LDS.  64 d x 2 B + 64 B pad: the four key rows one ds_read_b64_tr_b16 lane group
+// touches (32 B each, two groups per half-wave) land in four distinct 64-B bank quarters.
+constexpr int VP16 = 192;
+constexpr float LOG2E = 1.44269504088896340736f;
+
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read; lane mapping measured with tools/tr_probe.hip): within a 16-lane
+// group lane i, slot j receives element (i & 3) of the 8 bytes addressed by lane 4*j + (i >> 2).  With lane s
+// pointing at V[key0 + (s >> 2)][d0 + 4*(s & 3) ...] the group reads a row-major [4 keys][16 d] block and lane i
+// gets V[key0 + 0..3][d0 + i]: four consecutive keys of ONE head-dim column, i.e. half an MFMA operand of V^T.
+__device__ __forceinline__ bf16x4 lds_read_tr16(const unsigned char* p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    return *reinterpret_cast<const bf16x4*>(&v);
+}
 
 template <typename T> __device__ __forceinline__ int k_off(int row, int chunk);
 // K tile rows are 64 elements: 128 B (bf16, 8 chunks) or 256 B (f32, 16 chunks)
@@ -36,14 +50,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     constexpr int CE = Chunk<T>::N;
     constexpr int NC = HD / CE;                       // chunks per K row
     constexpr int LP = NKB * 32;                      // padded key count
-    constexpr int VPAD = sizeof(T) == 2 ? 8 : 16;     // bytes: makes V^T column reads conflict-free
-    constexpr int VROW = LP * (int)sizeof(T) + VPAD;  // bytes per V^T row
+    constexpr bool LPT = sizeof(T) == 2;              // bf16 path: V stays row-major, read with the hardware transpose
+    constexpr int VPAD = 16;                          // f32: bytes, makes V^T column reads conflict-free
+    constexpr int VROW = LP * (int)sizeof(T) + VPAD;  // f32: bytes per V^T row
     constexpr int KS = NC / 2;                        // MFMA chunk steps over head dim
+    constexpr int V_BYTES = LPT ? LP * VP16 : HD * VROW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sK = smem;                              // LP rows
-    unsigned char* sV = smem + LP * HD * sizeof(T);        // 64 rows of VROW bytes
-    float* sMask = reinterpret_cast<float*>(sV + HD * VROW);  // LP floats
+    unsigned char* sV = smem + LP * HD * sizeof(T);        // bf16: LP rows of VP16 bytes; f32: 64 rows of VROW bytes (V^T)
+    float* sMask = reinterpret_cast<float*>(sV + V_BYTES); // LP floats
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
@@ -52,27 +68,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     const size_t ldq = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ldq + h * HD;
 
-    // ---- stage K (swizzled rows), V^T and the additive mask ----
-    for (int idx = tid; idx < LP * NC; idx += ATT_THREADS) {
-        const int key = idx / NC, c = idx % NC;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < L) {
-            kv = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + H + c * CE);
-            vv = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + 2 * H + c * CE);
-        }
-        *reinterpret_cast<uint4*>(sK + k_off<T>(key, c)) = kv;
-        const T* ve = reinterpret_cast<const T*>(&vv);
-#pragma unroll
-        for (int j = 0; j < CE; ++j)
-            *reinterpret_cast<T*>(sV + (c * CE + j) * VROW + key * sizeof(T)) = ve[j];
-    }
-    for (int key = tid; key < LP; key += ATT_THREADS) {
-        float mv = -INFINITY;                          // padding keys beyond L: excluded outright
-        if (key < L) mv = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
-        sMask[key] = mv;
-    }
-
-    // ---- Q fragments straight from global: lane = query row (l&31), chunks 2*ks + (l>>5) ----
+    // ---- all global loads first (Q fragments, K/V chunks, mask), then the LDS writes: one memory round trip ----
+    // Q fragments straight from global: lane = query row (l&31), chunks 2*ks + (l>>5)
     const int fr = lane & 31, fh = lane >> 5;
     const int q = q0 + fr;
     frag_t fq[KS];
@@ -81,6 +78,39 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
         uint4 t = make_uint4(0, 0, 0, 0);
         if (q < L) t = *reinterpret_cast<const uint4*>(base + (size_t)q * ldq + (2 * ks + fh) * CE);
         fq[ks] = *reinterpret_cast<frag_t*>(&t);
+    }
+    constexpr int NLD = (LP * NC + ATT_THREADS - 1) / ATT_THREADS;
+    uint4 kreg[NLD], vreg[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * ATT_THREADS, key = idx / NC, c = idx % NC;
+        kreg[i] = make_uint4(0, 0, 0, 0);
+        vreg[i] = make_uint4(0, 0, 0, 0);
+        if (idx < LP * NC && key < L) {
+            kreg[i] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + H + c * CE);
+            vreg[i] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + 2 * H + c * CE);
+        }
+    }
+    for (int key = tid; key < LP; key += ATT_THREADS) {
+        float mv = -INFINITY;                          // padding keys beyond L: excluded outright
+        if (key < L) mv = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
+        sMask[key] = LPT ? mv * LOG2E : mv;            // bf16 path: softmax in base 2 (one v_exp_f32 per score)
+    }
+    // K rows XOR-swizzled; V row-major (bf16, transpose-read later) or transposed element-wise (f32)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * ATT_THREADS, key = idx / NC, c = idx % NC;
+        if (idx < LP * NC) {
+            *reinterpret_cast<uint4*>(sK + k_off<T>(key, c)) = kreg[i];
+            if constexpr (LPT) {
+                *reinterpret_cast<uint4*>(sV + key * VP16 + c * 16) = vreg[i];
+            } else {
+                const T* ve = reinterpret_cast<const T*>(&vreg[i]);
+#pragma unroll
+                for (int j = 0; j < CE; ++j)
+                    *reinterpret_cast<T*>(sV + (c * CE + j) * VROW + key * sizeof(T)) = ve[j];
+            }
+        }
     }
     __syncthreads();
     if (q0 >= L) return;   // whole wave has no query rows (uniform per wave)
@@ -104,7 +134,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float s = st[kb][r] * 0.125f + sMask[kb * 32 + key_of(r, fh)];
+            const float s = st[kb][r] * (LPT ? 0.125f * LOG2E : 0.125f) + sMask[kb * 32 + key_of(r, fh)];
             st[kb][r] = s;
             mx = fmaxf(mx, s);
         }
@@ -114,7 +144,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = expf(st[kb][r] - mx);
+            const float p = LPT ? __builtin_amdgcn_exp2f(st[kb][r] - mx) : expf(st[kb][r] - mx);
             st[kb][r] = p;
             sum += p;
         }
@@ -146,7 +176,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         if constexpr (sizeof(T) == 2) {
-            // two MFMA k-steps of 16 keys; slot j of half h <-> key 16*s + (j&3) + 8*(j>>2) + 4*h
+            // O^T = V^T . P^T: two MFMA k-steps of 16 keys; operand slot j of half h <-> key 16*s + 4*h + (j&3) + 8*(j>>2).
+            // A operand = V^T (row = head-dim column db*32 + fr) by two transpose reads of 4 consecutive keys each,
+            // B operand = P^T (column = this lane's query): the probabilities already sit in that layout.
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 pa;
@@ -154,13 +186,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
                 for (int j = 0; j < 8; ++j) pa[j] = (bf16)st[kb][8 * s2 + j];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const unsigned char* vr = sV + (db * 32 + fr) * VROW + (kb * 32 + 16 * s2 + 4 * fh) * 2;
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 16);
+                    const unsigned char* vr = sV + (kb * 32 + 16 * s2 + 4 * fh + ((lane & 15) >> 2)) * VP16 +
+                                              (db * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+                    const bf16x4 lo = lds_read_tr16(vr);
+                    const bf16x4 hi = lds_read_tr16(vr + 8 * VP16);
                     bf16x8 vb;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { vb[j] = lo[j]; vb[4 + j] = hi[j]; }
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pa, o[db], 0, 0, 0);
                 }
             }
         } else {
@@ -180,6 +213,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     }
 
     // ---- store context rows (merge heads: column h*64 + d) ----
+    if constexpr (LPT) {
+        // O^T accumulators: register r <-> head-dim column db*32 + 8*(r>>2) + 4*fh + (r&3), lane&31 <-> query:
+        // four consecutive columns per register quad -> one 8-byte store
+        if (q < L) {
+            T* crow = ctx + ((size_t)b * L + q) * H + h * HD + 4 * fh;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (bf16)o[db][4 * g + e];
+                    *reinterpret_cast<bf16x4*>(crow + db * 32 + 8 * g) = pk;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -192,8 +242,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
 template <typename T, int NKB>
 static size_t att_lds_bytes() {
     constexpr int LP = NKB * 32;
-    constexpr int VPAD = sizeof(T) == 2 ? 8 : 16;
-    return (size_t)LP * HD * sizeof(T) + (size_t)HD * (LP * sizeof(T) + VPAD) + (size_t)LP * sizeof(float);
+    const size_t v_bytes = sizeof(T) == 2 ? (size_t)LP * VP16 : (size_t)HD * (LP * sizeof(T) + 16);
+    return (size_t)LP * HD * sizeof(T) + v_bytes + (size_t)LP * sizeof(float);
 }
 
 template <typename T, int NKB>
