@@ -13,26 +13,15 @@
 // and the probabilities already sit in the A-operand layout of the P.V MFMA if V's key order is
 // permuted the same way -- no LDS round trip for P.
 #include "common.h"
+#include "attn_core.h"
 #include "kernels.h"
 
 namespace cpt {
 
 constexpr int HD = 64;           // head dim
 constexpr int ATT_THREADS = 256;
-// bf16 path: V row pitch in LDS.  64 d x 2 B + 64 B pad: the four key rows one ds_read_b64_tr_b16 lane group
-// touches (32 B each, two groups per half-wave) land in four distinct 64-B bank quarters.
-constexpr int VP16 = 192;
-constexpr float LOG2E = 1.44269504088896340736f;
-
-// ds_read_b64_tr_b16 (gfx950 LDS transpose read; lane mapping measured with tools/tr_probe.hip): within a 16-lane
-// group lane i, slot j receives element (i & 3) of the 8 bytes addressed by lane 4*j + (i >> 2).  With lane s
-// pointing at V[key0 + (s >> 2)][d0 + 4*(s & 3) ...] the group reads a row-major [4 keys][16 d] block and lane i
-// gets V[key0 + 0..3][d0 + i]: four consecutive keys of ONE head-dim column, i.e. half an MFMA operand of V^T.
-__device__ __forceinline__ bf16x4 lds_read_tr16(const unsigned char* p) {
-    typedef short s16x4 __attribute__((ext_vector_type(4)));
-    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-    return *reinterpret_cast<const bf16x4*>(&v);
-}
+constexpr int VP16 = ATT_VP16;
+constexpr float LOG2E = ATT_LOG2E;
 
 template <typename T> __device__ __forceinline__ int k_off(int row, int chunk);
 // K tile rows are 64 elements: 128 B (bf16, 8 chunks) or 256 B (f32, 16 chunks)
@@ -114,6 +103,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     }
     __syncthreads();
     if (q0 >= L) return;   // whole wave has no query rows (uniform per wave)
+    if constexpr (LPT) {
+        T* crow = ctx + ((size_t)b * L + min(q, L - 1)) * H + h * HD;
+        T* prow = probs ? probs + (((size_t)b * heads + h) * L + min(q, L - 1)) * L : nullptr;
+        attn_core_bf16<NKB>(fq, sK, sV, sMask, lane, q < L, crow, prow, L);
+        return;
+    }
 
     // ---- S^T = K . Q^T : accumulator rows = keys, column (lane&31) = query ----
     f32x16 st[NKB];

@@ -1,0 +1,133 @@
+// bf16 self-attention core shared by the stand-alone attention kernel (attention.hip) and the fused
+// QKV-projection + attention kernel (gemm.hip, CPT_EPI_ATTN*): one wave, 32 queries, K / V / mask tiles in LDS.
+//   ctx[q][:] = softmax(Q K^T / 8 + mask) V        (modeling_bert.py:42-67 of the reference, per sequence and head)
+#pragma once
+#include "common.h"
+
+namespace cpt {
+
+constexpr int ATT_HD = 64;        // head dim
+// V row pitch in LDS: 64 d x 2 B + 64 B pad: the four key rows one ds_read_b64_tr_b16 lane group touches
+// (32 B each, two groups per half-wave) land in four distinct 64-B bank quarters.
+constexpr int ATT_VP16 = 192;
+constexpr float ATT_LOG2E = 1.44269504088896340736f;
+
+// K / Q tile rows are 64 bf16 = 128 B = 8 chunks of 16 B, XOR-swizzled so that fragment reads are conflict-free
+__device__ __forceinline__ int att_koff16(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read; lane mapping measured with tools/tr_probe.hip): within a 16-lane
+// group lane i, slot j receives element (i & 3) of the 8 bytes addressed by lane 4*j + (i >> 2).  With lane s
+// pointing at V[key0 + (s >> 2)][d0 + 4*(s & 3) ...] the group reads a row-major [4 keys][16 d] block and lane i
+// gets V[key0 + 0..3][d0 + i]: four consecutive keys of ONE head-dim column, i.e. half an MFMA operand of V^T.
+__device__ __forceinline__ bf16x4 lds_read_tr16(const unsigned char* p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    return *reinterpret_cast<const bf16x4*>(&v);
+}
+
+// key index held by accumulator register r of half-wave h inside a 32-key block
+__device__ __forceinline__ int att_key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// One wave: queries fq (lane = query lane&31, chunks 2*ks + (lane>>5) of its Q row), keys/values/mask in LDS:
+//   sK   [NKB*32][64] bf16, rows swizzled with att_koff16
+//   sV   [NKB*32] rows of ATT_VP16 bytes, row-major
+//   sMask[NKB*32] additive mask already multiplied by log2(e); -inf for padding keys
+// Writes ctx_row[0..63] (this lane's query, head slice) if `valid`; optionally the probabilities (training).
+template <int NKB>
+__device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsigned char* sK, const unsigned char* sV,
+                                               const float* sMask, int lane, bool valid, bf16* ctx_row,
+                                               bf16* probs_row, int L) {
+    const int fr = lane & 31, fh = lane >> 5;
+    // S^T = K . Q^T : accumulator rows = keys, column (lane&31) = query
+    f32x16 st[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 fk = *reinterpret_cast<const bf16x8*>(sK + att_koff16(kb * 32 + fr, 2 * ks + fh));
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], st[kb], 0, 0, 0);
+        }
+    }
+    // softmax over keys in base 2: lane-local + one exchange with the other half-wave
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float s = st[kb][r] * (0.125f * ATT_LOG2E) + sMask[kb * 32 + att_key_of(r, fh)];
+            st[kb][r] = s;
+            mx = fmaxf(mx, s);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(st[kb][r] - mx);
+            st[kb][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] *= inv;
+
+    if (probs_row && valid) {   // [B][heads][L][L], saved for the backward pass only
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + att_key_of(r, fh);
+                if (key < L) probs_row[key] = (bf16)st[kb][r];
+            }
+    }
+
+    // O^T = V^T . P^T: two MFMA k-steps of 16 keys per 32-key block; operand slot j of half h <-> key
+    // 16*s + 4*h + (j&3) + 8*(j>>2).  A operand = V^T (row = head-dim column db*32 + fr) by two transpose reads of
+    // 4 consecutive keys each, B operand = P^T (column = this lane's query): the probabilities already sit there.
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pa;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[j] = (bf16)st[kb][8 * s2 + j];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const unsigned char* vr = sV + (kb * 32 + 16 * s2 + 4 * fh + ((lane & 15) >> 2)) * ATT_VP16 +
+                                          (db * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+                const bf16x4 lo = lds_read_tr16(vr);
+                const bf16x4 hi = lds_read_tr16(vr + 8 * ATT_VP16);
+                bf16x8 vb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vb[j] = lo[j]; vb[4 + j] = hi[j]; }
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pa, o[db], 0, 0, 0);
+            }
+        }
+    }
+    // O^T accumulators: register r <-> head-dim column db*32 + 8*(r>>2) + 4*fh + (r&3), lane&31 <-> query:
+    // four consecutive columns per register quad -> one 8-byte store
+    if (valid) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16)o[db][4 * g + e];
+                *reinterpret_cast<bf16x4*>(ctx_row + 4 * fh + db * 32 + 8 * g) = pk;
+            }
+    }
+}
+
+}  // namespace cpt

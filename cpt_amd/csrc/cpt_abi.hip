@@ -126,11 +126,13 @@ int cpt_check_device(int dev) {
 }
 
 static int g_fold_ln = 1;      // bf16 mode with cpt_model.fold: fold the encoder LayerNorms into the GEMMs (0 = run them as kernels)
+static int g_fuse_attn = 1;    // bf16, L <= 128: QKV projection + attention in one kernel (0 = two kernels; 2 = one workgroup per CU)
 static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
 
 int cpt_set_tuning(int key, int value) {
     if (key == 4) { g_lp_resid = value; return CPT_OK; }
     if (key == 5) { g_fold_ln = value; return CPT_OK; }
+    if (key == 6) { g_fuse_attn = value; return CPT_OK; }
     if (key == 0) { cpt::set_gemm_variant(value); return CPT_OK; }
     if (key == 1) { cpt::set_gemm_abl(value); return CPT_OK; }
     if (key == 2) { cpt::set_attn_bwd_variant(value); return CPT_OK; }
@@ -279,6 +281,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     }
     // (a5-a9) encoder
     const bool fold = lp && m->fold && g_fold_ln && !g_lp_resid;
+    const bool fuse_attn = lp && g_fuse_attn && L <= 128 && H % 64 == 0;
     const bool pre_ln = fold && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS));   // x_f32 left un-normalised after the encoder
     if (fold) {
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
@@ -293,11 +296,19 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
             float* st2 = stats + ((size_t)l * 2 + 1) * M * 2;
             const float* st2p = l > 0 ? stats + ((size_t)(l - 1) * 2 + 1) * M * 2 : nullptr;
             const cpt_layer* yp = l > 0 ? &m->layers[l - 1] : nullptr;
+            if (fuse_attn) {
+              Scope p(CPT_K_GEMM_QKV, s);      // QKV projection + attention, one kernel; q/k/v never reach HBM
+              if (l == 0) TRY(cpt::gemm_qkv_attn(x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, nullptr, nullptr, d.ln_eps, H, b->attn_mask, ctx, H,
+                                                 B, L, d.heads, H, g_fuse_attn, s), "gemm(qkv)+attention");
+              else TRY(cpt::gemm_qkv_attn(x_lp, H, f.w_qkv_f, H, nullptr, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, b->attn_mask, ctx, H,
+                                          B, L, d.heads, H, g_fuse_attn, s), "gemm(qkv, folded LN)+attention");
+            } else {
             { Scope p(CPT_K_GEMM_QKV, s);
               if (l == 0) TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
               else TRY(cpt::gemm_ln_cons(x_lp, H, f.w_qkv_f, H, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, 0, qkv, 3 * H, M, 3 * H, H, s), "gemm(qkv, folded LN)"); }
             { Scope p(CPT_K_ATTN, s);
               TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s), "attention"); }
+            }
             { Scope p(CPT_K_GEMM_AO, s);
               TRY(cpt::gemm_ln_prod(ctx, H, y.w_ao, H, y.b_ao, x_f32, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
                                     a_f32, a_lp, st1, H, M, H, H, s), "gemm(attn out, LN producer)"); }
@@ -316,10 +327,16 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     } else
     for (int l = 0; l < d.layers; ++l) {
         const cpt_layer& y = m->layers[l];
+        if (fuse_attn) {
+          Scope p(CPT_K_GEMM_QKV, s);
+          TRY(cpt::gemm_qkv_attn(x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, nullptr, nullptr, d.ln_eps, H, b->attn_mask, ctx, H,
+                                 B, L, d.heads, H, g_fuse_attn, s), "gemm(qkv)+attention");
+        } else {
         { Scope p(CPT_K_GEMM_QKV, s);
           TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)"); }
         { Scope p(CPT_K_ATTN, s);
           TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s), "attention"); }
+        }
         const bool lpr = lp && g_lp_resid;                       // residual operand read as bf16, fp32 copy not written
         const bool last = l + 1 == d.layers;
         { Scope p(CPT_K_GEMM_AO, s);

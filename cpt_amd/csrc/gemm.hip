@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "attn_core.h"
 #include "kernels.h"
 
 namespace cpt {
@@ -138,6 +139,8 @@ constexpr int CPT_EPI_RESID_LP = 5;    // internal: residual operand is in the c
 constexpr int CPT_EPI_LNPROD = 6;      // internal: + residual (optionally LayerNorm'ed on the fly), writes fp32 + T copies and row sums
 constexpr int CPT_EPI_LNCONS = 7;      // internal: A operand is a pre-LayerNorm tensor; LayerNorm folded into the epilogue
 constexpr int CPT_EPI_LNCONS_GELU = 8; // internal: same + GELU
+constexpr int CPT_EPI_ATTN = 9;        // internal: fused QKV projection + self-attention of one (sequence, head) per workgroup
+constexpr int CPT_EPI_ATTN_LN = 10;    // internal: same, A operand is a pre-LayerNorm tensor (LayerNorm folded like LNCONS)
 
 // ---------------------------------------------------------------------------------------------
 // Pipelined kernel: STAGES-deep LDS ring fed by LDS-DMA with COUNTED vmcnt waits (tiles stay in
@@ -156,6 +159,8 @@ struct EpiX {
     const float* colc;     // LNCONS: c[n] = sum_k W'[n][k]  (W' = gain-folded weight as the MFMA sees it)
     const float* cold;     // LNCONS: d[n] = sum_k beta[k] W[n][k] + bias[n]
     float eps, inv_h;      // LayerNorm eps, 1 / hidden
+    const int64_t* mask;   // ATTN: [B][L] attention mask (1 keep / 0 drop) or NULL
+    int seq_len, heads;    // ATTN: tokens per sequence (<= 128), attention heads
 };
 
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
@@ -186,7 +191,22 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-first, then GROUP_M row tiles per group (see tile_of_block)
+    constexpr bool ATTN = EPI == CPT_EPI_ATTN || EPI == CPT_EPI_ATTN_LN;
     int m0, n0, split;
+    int att_b = 0, att_h = 0;
+    if constexpr (ATTN) {
+        // one workgroup per (sequence, head): rows = the sequence's tokens, columns = that head's Q | K | V slices.
+        // XCD x owns a contiguous range of (sequence, head) pairs, so a sequence's 12 heads share one L2.
+        static_assert(TBM == 128 && TBN == 192 && MI == 1 && NJ == 3, "fused attention: 128 tokens x (64 Q | 64 K | 64 V)");
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int lid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        att_b = lid0 / ex.heads;
+        att_h = lid0 - att_b * ex.heads;
+        m0 = att_b * ex.seq_len;
+        n0 = 0;
+        split = 0;
+    } else
     {
         const int tm = (M + TBM - 1) / TBM, tn = (N + TBN - 1) / TBN;
         const int nwg = tm * tn * splitk, bid = blockIdx.x;
@@ -216,6 +236,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         const int r = g * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         if (i < GA) voff[i] = (unsigned)(((size_t)min(m0 + r, M - 1) * lda + c * CE) * sizeof(T));
+        else if constexpr (ATTN) {
+            const int rw = r - TBM;                   // 0..191 -> row of the fused [3H][K] weight: (q|k|v) block, this head, row in head
+            voff[i] = (unsigned)(((size_t)((rw >> 6) * (ex.heads * 64) + att_h * 64 + (rw & 63)) * ldw + c * CE) * sizeof(T));
+        }
         else        voff[i] = (unsigned)(((size_t)min(n0 + r - TBM, N - 1) * ldw + c * CE) * sizeof(T));
     }
     auto stage = [&](int slot, int k0) {
@@ -273,7 +297,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) mfma_chunk(acc[i][j], fa[pb][i], fb[pb][j]);
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (ATTN) mfma_chunk(acc[i][j], fb[pb][j], fa[pb][i]);   // transposed tile: lane = token, registers = output columns
+                else mfma_chunk(acc[i][j], fa[pb][i], fb[pb][j]);
+            }
     };
     // make the compiler place its lgkmcnt wait for buffer `pb` HERE (before younger ds_reads are
     // issued) instead of in front of the MFMAs that consume it
@@ -369,6 +396,63 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     if (split != 0) bias = nullptr;                   // split-K: the bias is added once
     __syncthreads();                                  // every wave is done reading the operand ring
     if (trace) tr3 = clock64();
+    if constexpr (ATTN) {
+        // ---- fused attention: the finished Q | K | V tiles go to LDS as bf16 (never to HBM), then four waves run
+        // the attention core on 32 queries each.  The accumulators are TRANSPOSED (lane = token, register quads =
+        // four consecutive output columns), so every LDS write is one 8-byte bf16x4.
+        unsigned char* sQ = smem;
+        unsigned char* sK = smem + 128 * 128;
+        unsigned char* sV = smem + 2 * 128 * 128;
+        float* sMask = reinterpret_cast<float*>(smem + 2 * 128 * 128 + 128 * ATT_VP16);
+        static_assert(2 * 128 * 128 + 128 * ATT_VP16 + 128 * 4 <= STAGES * STAGE_BYTES, "attention tiles must fit in the ring");
+        const int Ls = ex.seq_len, hd = ex.heads;
+        const int trow = wm * 32 + fr;                // token row inside the tile
+        float mu = 0.f, rs = 1.f;
+        if constexpr (EPI == CPT_EPI_ATTN_LN) {
+            const float2 s2 = *reinterpret_cast<const float2*>(ex.st_in + 2 * (size_t)min(m0 + trow, M - 1));
+            mu = s2.x * ex.inv_h;
+            rs = rsqrtf(fmaxf(s2.y * ex.inv_h - mu * mu, 0.f) + ex.eps);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wn * 96 + j * 32 + 8 * g + 4 * fh;               // tile column of this register quad
+                const int which = col >> 6, cc = col & 63;                       // 0 Q, 1 K, 2 V; column inside the head
+                const int gcol = which * (hd * 64) + att_h * 64 + cc;            // row of the fused weight / bias vectors
+                f32x4 x;
+                if constexpr (EPI == CPT_EPI_ATTN_LN) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(ex.colc + gcol);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(ex.cold + gcol);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = rs * (acc[0][j][4 * g + e] - mu * c4[e]) + d4[e];
+                } else {
+                    const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + gcol) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = acc[0][j][4 * g + e] + b4[e];
+                }
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16)x[e];
+                unsigned char* dst = which == 2 ? sV + trow * ATT_VP16 + cc * 2
+                                                : (which == 1 ? sK : sQ) + att_koff16(trow, cc >> 3) + (cc & 7) * 2;
+                *reinterpret_cast<bf16x4*>(dst) = pk;
+            }
+        if (tid < 128) {
+            float mv = -INFINITY;                     // rows past the sequence (next sequence's tokens): not keys
+            if (tid < Ls) mv = ex.mask ? (1.0f - (float)ex.mask[(size_t)att_b * Ls + tid]) * (-10000.0f * ATT_LOG2E) : 0.f;
+            sMask[tid] = mv;
+        }
+        __syncthreads();
+        if (wave < 4 && wave * 32 < Ls) {             // one attention wave per SIMD
+            const int q = wave * 32 + fr;
+            bf16x8 fq[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const bf16x8*>(sQ + att_koff16(q, 2 * ks + fh));
+            bf16* crow = reinterpret_cast<bf16*>(out) + ((size_t)m0 + min(q, Ls - 1)) * ldo + att_h * 64;
+            attn_core_bf16<4>(fq, sK, sV, sMask, lane, q < Ls, crow, nullptr, Ls);
+        }
+    } else {
     unsigned char* slab = smem + wave * (16 * CPW);
     unsigned char* side = smem + NW * (16 * CPW) + wave * SIDE;
     const int wrow0 = m0 + wm * (MI * 32), wcol0 = n0 + wn * WCOLS;
@@ -589,6 +673,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     if (abl & 8) { if (acc[0][0][0] == 12345.678f) out[0] = from_f32<OT>(1.f); }     // ablation: no epilogue
     else if (vec_ok && wrow0 + MI * 32 <= M && wcol0 + WCOLS <= N) epilogue(std::true_type{});
     else epilogue(std::false_type{});
+    }   // !ATTN
     if (trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long* t = trace + (size_t)blockIdx.x * 8;
@@ -775,6 +860,44 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
     if (gelu) launch_fast<bf16, CPT_EPI_LNCONS_GELU, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
     else launch_fast<bf16, CPT_EPI_LNCONS, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
     return CPT_OK;
+}
+
+// Fused QKV projection + self-attention (bf16, seq_len <= 128, head_dim 64): one workgroup per (sequence, head)
+// computes that head's Q | K | V for the sequence's tokens (A rows b*L .., the three 64-row slices of the fused
+// [3H][K] weight) and runs softmax(QK^T/8 + mask)V on them from LDS; only the context rows reach HBM.
+//   st_in == NULL: plain projection (x W^T + bias);  else LayerNorm folded as in gemm_ln_cons (W = gain-folded).
+template <int EPI, int STAGES, int FD, int OCC>
+static int launch_qkv_attn(const bf16* A, int lda, const bf16* W, int ldw, const float* bias, bf16* ctx, int ldo,
+                           int M, int N, int K, const EpiX& ex, int B, hipStream_t s) {
+    constexpr int LDS = STAGES * (128 + 192) * ROWB;
+    auto kern = gemm_pipe_kernel<bf16, EPI, bf16, 128, 192, 4, 2, STAGES, 1, FD, OCC>;
+    static bool attr_done = false;
+    if (LDS > 64 * 1024 && !attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+        attr_done = true;
+    }
+    kern<<<dim3(B * ex.heads), dim3(512), LDS, s>>>(A, lda, W, ldw, bias, nullptr, 0, ctx, ldo, M, N, K, 1, g_gemm_trace, g_gemm_abl, ex);
+    return CPT_OK;
+}
+
+int gemm_qkv_attn(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
+                  const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads,
+                  int K, int config, hipStream_t s) {
+    if (B <= 0 || L <= 0 || L > 128 || heads <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8 || ldo % 4) return CPT_ERR_SHAPE;
+    if (!A || !W || !ctx || (st_in && (!colc || !cold))) return CPT_ERR_NULL;
+    EpiX ex = {};
+    ex.st_in = st_in; ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
+    ex.mask = mask; ex.seq_len = L; ex.heads = heads;
+    const int M = B * L, N = 3 * heads * 64;
+    const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W; bf16* c = (bf16*)ctx;
+    if (config == 2) {      // one workgroup per CU, 3-stage ring
+        return st_in ? launch_qkv_attn<CPT_EPI_ATTN_LN, 3, 4, 1>(a, lda, w, ldw, bias, c, ldo, M, N, K, ex, B, s)
+                     : launch_qkv_attn<CPT_EPI_ATTN, 3, 4, 1>(a, lda, w, ldw, bias, c, ldo, M, N, K, ex, B, s);
+    }
+    // two co-resident workgroups per CU: one's softmax (VALU) runs under the other's K loop (MFMA)
+    return st_in ? launch_qkv_attn<CPT_EPI_ATTN_LN, 2, 2, 2>(a, lda, w, ldw, bias, c, ldo, M, N, K, ex, B, s)
+                 : launch_qkv_attn<CPT_EPI_ATTN, 2, 2, 2>(a, lda, w, ldw, bias, c, ldo, M, N, K, ex, B, s);
 }
 
 void set_gemm_variant(int v) { g_gemm_variant = v; }

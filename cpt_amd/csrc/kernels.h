@@ -54,6 +54,11 @@ int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bi
                  float* out_f32, void* out_lp, float* st_out, int ldo, int M, int N, int K, hipStream_t s);
 int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
                  float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s);
+// fused QKV projection + self-attention (bf16, L <= 128); st_in NULL: plain bias, else LayerNorm folded (colc/cold);
+// config 1: two workgroups per CU (2-stage ring), 2: one workgroup per CU (3-stage ring)
+int gemm_qkv_attn(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
+                  const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads,
+                  int K, int config, hipStream_t s);
 int fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* colc,
                     float* cold, int N, int K, hipStream_t s);
 void set_splitk_target(int v);

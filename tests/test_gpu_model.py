@@ -160,10 +160,12 @@ def test_config2_vs_oracle(dev, mode):
     assert _stats("B=64 rows 0..7 vs B=8", got64[:8], got.cpu()) < (1e-4 if mode == "fp32" else 2e-2)
 
 
-def test_bf16_folded_layernorm(dev):
-    """bf16 mode folds the encoder LayerNorms into the GEMMs around them.  The folded and the
-    explicit-LayerNorm encoders compute the same function: both must sit inside the bf16 band of the oracle,
-    and every output surface (sequence, pooled, all-row logits, [MASK]-row logits) must agree between them."""
+def test_bf16_folded_layernorm_and_fused_attention(dev):
+    """bf16 mode folds the encoder LayerNorms into the GEMMs around them and fuses the QKV projection with the
+    attention core.  Every combination of the two switches computes the same function: each must
+    sit inside the bf16 band of the oracle, and every output surface (sequence, pooled, all-row logits,
+    [MASK]-row logits) must agree with the plain kernel-per-op encoder."""
+    from cpt_amd import _lib as L
     from oracle import cpt_oracle as O
     cfg = cfgmod.oscar_base()
     m, _ = _model(cfg, 88, dev, "bf16")
@@ -175,19 +177,28 @@ def test_bf16_folded_layernorm(dev):
     d = _dev_batch(b, dev)
     m.bert.set_compute_dtype("bf16")
     res = {}
-    for fold in (True, False):
-        for eng in (m._engine(), m.bert._engine()):
-            eng.fold_ln = fold
-        with torch.no_grad():
-            rows = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"],
-                     mask_token_pos=d["mask_token_pos"])[0]
-            allr = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])[0]
-            seq, pooled = m.bert(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])
-        res[fold] = (rows.cpu(), allr.cpu(), seq.cpu(), pooled.cpu())
-        err = _stats("fold=%s [MASK] logits vs oracle" % fold, rows, ref)
-        assert err < 0.15
+    try:
+        for fold, fuse in ((False, 0), (True, 0), (True, 1), (True, 2), (False, 1)):
+            for eng in (m._engine(), m.bert._engine()):
+                eng.fold_ln = fold
+            L.check(L.lib().cpt_set_tuning(6, fuse), "cpt_set_tuning")
+            with torch.no_grad():
+                rows = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"],
+                         mask_token_pos=d["mask_token_pos"])[0]
+                allr = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])[0]
+                seq, pooled = m.bert(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])
+            res[(fold, fuse)] = (rows.cpu(), allr.cpu(), seq.cpu(), pooled.cpu())
+            err = _stats("fold=%s fuse=%d [MASK] logits vs oracle" % (fold, fuse), rows, ref)
+            assert err < 0.15
+    finally:
+        L.lib().cpt_set_tuning(6, 1)
     pos = b["mask_token_pos"]
-    for i, nm in enumerate(("mask rows", "all rows", "seq", "pooled")):
-        assert _stats("folded vs explicit LN: " + nm, res[True][i], res[False][i]) < (0.15 if i < 2 else 0.1)
+    base = res[(False, 0)]
+    for key, r in res.items():
+        if key == (False, 0):
+            continue
+        for i, nm in enumerate(("mask rows", "all rows", "seq", "pooled")):
+            assert _stats("%s vs kernel-per-op: %s" % (key, nm), r[i], base[i]) < (0.15 if i < 2 else 0.1)
     # the all-row head's [MASK] rows are the [MASK]-row head's output
-    assert _stats("all-row head at [MASK]", res[True][1][torch.arange(6), pos], res[True][0]) < 2e-2
+    r = res[(True, 1)]
+    assert _stats("all-row head at [MASK]", r[1][torch.arange(6), pos], r[0]) < 2e-2
