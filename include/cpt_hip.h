@@ -260,9 +260,17 @@ enum { CPT_K_GEMM_QKV = 0, CPT_K_ATTN, CPT_K_GEMM_AO, CPT_K_LN, CPT_K_GEMM_FFN1,
 int cpt_prof_enable(int on);                          /* resets accumulators */
 int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchronises */
 
-/* Kernel-variant switches for A/B measurements (key 0: GEMM variant 0 = register-staged generic
- * kernel, 1 = LDS-DMA 128x128 tile, 2 = LDS-DMA 256x128 tile, 3..7 = pipelined tile shapes; key 2:
- * attention backward 0 = generic fp32-math kernel, 1 = MFMA kernel for bf16, L <= 128). */
+/* Kernel-variant switches for A/B measurements; defaults are the shipped configuration.
+ *   key 0  GEMM: 0 = generic register-staged kernel only; 3 (default) = pipelined LDS-DMA kernel, tile shape chosen
+ *          per GEMM; fixed shapes 13 = 128x192 (3-stage), 11 = 192x192, 10 = 128x384, 14 = 384x192,
+ *          15 = 128x192 two workgroups per CU, 16 = 128x192 with 4 waves of 64x96, 17 = 256x192
+ *   key 1  GEMM ablation bits: 1 no operand LDS-DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue, 16 no global stores
+ *   key 2  attention backward: 0 = generic fp32-math kernel, 1 (default) = MFMA kernel for bf16, L <= 128
+ *   key 3  split-K target for the generic path
+ *   key 4  1 = bf16 residual stream in the kernel-per-op bf16 encoder (default 0: fp32 residual)
+ *   key 5  0 = run the encoder LayerNorms as kernels even when cpt_model.fold is given (default 1: folded)
+ *   key 6  QKV projection + attention: 0 = two kernels, 1 (default) = fused, two workgroups per CU,
+ *          2 = fused, one workgroup per CU (bf16, L <= 128 only; otherwise always two kernels) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
  * start / after prologue issue / after K loop / after staging / end, and the XCC id). */
