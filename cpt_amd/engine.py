@@ -229,7 +229,7 @@ class PackedModel(object):
                    layers=cfg.num_hidden_layers, vocab=cfg.vocab_size, img_dim=D, img_dim_pad=(D + 63) // 64 * 64,
                    max_pos=cfg.max_position_embeddings, type_vocab=cfg.type_vocab_size,
                    use_img_ln=1 if getattr(cfg, "use_img_layernorm", None) else 0,
-                   n_rel=getattr(cfg, "num_contrast_classes", 2) if self.head == "pretrain" else 0,
+                   n_rel=getattr(cfg, "num_contrast_classes", 2) if self.head in ("pretrain", "nsp") else 0,
                    dtype=L.CPT_BF16 if lp else L.CPT_F32, ln_eps=cfg.layer_norm_eps,
                    img_ln_eps=getattr(cfg, "img_layer_norm_eps", cfg.layer_norm_eps))
         layers = (L.Layer * cfg.num_hidden_layers)()
@@ -263,7 +263,10 @@ class PackedModel(object):
         m.layers = C.cast(layers, C.POINTER(L.Layer))
         m.w_pool = mat("bert.pooler.dense.weight")
         m.b_pool = vec("bert.pooler.dense.bias")
-        if self.head != "none":
+        if self.head == "nsp":
+            m.w_rel = mat("cls.weight")
+            m.b_rel = vec("cls.bias")
+        elif self.head != "none":
             hp = "cls." if self.head == "cpt" else "cls.predictions."
             m.w_tr = mat(hp + "transform.dense.weight")
             m.b_tr = vec(hp + "transform.dense.bias")

@@ -45,3 +45,19 @@ def accuracy(predictions, gts, thresh=0.5):
         q = [p[0], p[1], p[2] - p[0] + 1, p[3] - p[1] + 1]
         hit += compute_iou(q, gts[k]) > thresh
     return hit / max(len(predictions), 1) * 100
+
+
+def nsp_choice_labels(labels, interval, n_seq, device=None):
+    """fewshot/vcr_nsp_cpt.py:433-436: class 0 for the correct answer choice of each question, 1 elsewhere."""
+    cls_labels = torch.ones([n_seq], dtype=torch.long, device=device)
+    for i, lb in enumerate(labels):
+        cls_labels[i * interval + int(lb)] = 0
+    return cls_labels
+
+
+def nsp_choose(rel_scores, interval):
+    """fewshot/vcr_nsp_cpt.py:597-604: choice score = 1 - softmax(rel)[:, 1]; first-max argmax inside each
+    question's `interval` answer choices.  Returns (scores (N,), [pred per question])."""
+    logits = 1 - (rel_scores[:, :].softmax(-1)[:, 1].view(-1))
+    n = rel_scores.size(0) // interval
+    return logits, [int(logits[q * interval:(q + 1) * interval].argmax()) for q in range(n)]

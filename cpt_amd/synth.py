@@ -25,7 +25,7 @@ def param_specs(cfg, head="cpt"):
     Keys are the ones listed in SURVEY.md section 8(b) (verified there by
     instantiating the reference).  kind: 'w' Linear/Embedding weight, 'b' bias,
     'g' LayerNorm weight.  head: 'cpt' (REC_MLM_CPT, modeling_rec.py:100-109),
-    'pretrain' (BertImgForPreTraining, modeling_bert.py:981-991), 'none'.
+    'pretrain' (BertImgForPreTraining, modeling_bert.py:981-991), 'nsp' (NSPCPT, modeling_vcr.py:79-92), 'none'.
     """
     H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
     s = [("bert.embeddings.word_embeddings.weight", (V, H), "w"),
@@ -55,6 +55,9 @@ def param_specs(cfg, head="cpt"):
         s += [("bert.LayerNorm.weight", (H,), "g"), ("bert.LayerNorm.bias", (H,), "b")]
     if head == "none":
         return s
+    if head == "nsp":          # NSPCPT after copy_from_pretraining_model: cls IS the seq_relationship Linear (modeling_vcr.py:90-92)
+        n = getattr(cfg, "num_contrast_classes", 2)
+        return s + [("cls.weight", (n, H), "w"), ("cls.bias", (n,), "b")]
     hp = "cls." if head == "cpt" else "cls.predictions."
     s += [(hp + "bias", (V,), "b"),
           (hp + "transform.dense.weight", (H, H), "w"), (hp + "transform.dense.bias", (H,), "b"),

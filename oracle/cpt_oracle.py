@@ -173,6 +173,34 @@ def nsp_cpt_scores(sd, cfg, input_ids, token_type_ids, attention_mask, img_feats
     return F.linear(pooled, sd["cls.seq_relationship.weight"], sd["cls.seq_relationship.bias"])
 
 
+def nsp_cpt_forward(sd, cfg, input_ids, token_type_ids, attention_mask, img_feats, next_sentence_label=None,
+                    w_key="cls.seq_relationship.weight", b_key="cls.seq_relationship.bias"):
+    """NSPCPT.forward (Oscar/oscar/modeling/modeling_vcr.py:115-129): relation scores on the pooled [CLS]
+    and, with labels, CrossEntropyLoss(ignore_index=-1) over the num_contrast_classes scores."""
+    _, pooled = bert_img_forward(sd, cfg, input_ids, token_type_ids, attention_mask, None, img_feats)
+    rel = F.linear(pooled, sd[w_key], sd[b_key])
+    if next_sentence_label is None:
+        return (rel,)
+    loss = F.cross_entropy(rel.view(-1, rel.size(-1)), next_sentence_label.view(-1), ignore_index=-1)
+    return (loss, rel)
+
+
+def nsp_choice_labels(labels, interval, n_seq):
+    """fewshot/vcr_nsp_cpt.py:433-436: class 0 ("is next") for the correct answer of each question, 1 elsewhere."""
+    cls_labels = torch.ones([n_seq], dtype=torch.long)
+    for i, lb in enumerate(labels):
+        cls_labels[i * interval + int(lb)] = 0
+    return cls_labels
+
+
+def nsp_choose(rel, interval):
+    """fewshot/vcr_nsp_cpt.py:597-604: score = 1 - softmax(rel)[:, 1]; first-max argmax inside each question's
+    `interval` answer choices.  Returns (choice scores, [pred per question])."""
+    logits = 1 - (rel.softmax(-1)[:, 1].view(-1))
+    n = rel.size(0) // interval
+    return logits, [int(logits[q * interval:(q + 1) * interval].argmax()) for q in range(n)]
+
+
 # ---- a15: score extraction (callers) ---------------------------------------
 
 def select_region_zeroshot(mask_scores, color_id_sets, none_id):

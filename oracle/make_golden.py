@@ -242,6 +242,41 @@ def base_case(name, B, n_regions, seed_w=88, seed_b=88, with_grads=False, vary=F
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **g)
 
 
+def vcr_nsp_case():
+    """Section 8(f).1: the reference's NSPCPT (modeling_vcr.py:79-129) on the tiny config, 2 questions x 4 answer
+    choices: relation scores, CE loss against the driver's label construction (fewshot/vcr_nsp_cpt.py:433-436) and
+    the driver's choice rule 1 - softmax[:,1] -> argmax per question (:597-604)."""
+    from oscar.modeling.modeling_vcr import NSPCPT
+    cfg = cfgmod.tiny()
+    rc = to_ref_cfg(cfg)
+    pre = BertImgForPreTraining(rc)
+    sd = synth.init_state_dict(cfg, 4321, head="pretrain")
+    pre.load_state_dict(sd, strict=True)
+    pre.tie_weights()
+    m = NSPCPT(rc)
+    m.copy_from_pretraining_model(pre)
+    m.eval()
+    interval, labels = 4, [2, 0]
+    batch = synth.make_batch(8, cfg, seed=17, max_seq_len=20, img_seq_len=6, n_regions=6, vary_regions=True)
+    cls_labels = torch.ones([8], dtype=torch.long)
+    for i, lb in enumerate(labels):
+        cls_labels[i * interval + lb] = 0
+    loss, rel = m(batch["input_ids"], batch["segment_ids"], batch["attention_mask"], next_sentence_label=cls_labels,
+                  img_feats=batch["img_feats"])[:2]
+    m.zero_grad()
+    loss.backward()
+    logits = 1 - (rel[:, :].softmax(-1)[:, 1].view(-1))
+    preds = [int(logits[n * interval:(n + 1) * interval].argmax()) for n in range(2)]
+    g = {"in_" + k: v.numpy() for k, v in batch.items()}
+    g.update(rel=rel.detach().numpy(), loss=loss.detach().numpy(), cls_labels=cls_labels.numpy(),
+             choice_logits=logits.detach().numpy(), preds=np.array(preds), interval=np.array(interval),
+             grad_cls_weight=m.cls.weight.grad.numpy(), grad_cls_bias=m.cls.bias.grad.numpy(),
+             grad_pooler_weight=m.bert.pooler.dense.weight.grad.numpy(),
+             grad_q0_weight=m.bert.encoder.layer[0].attention.self.query.weight.grad.numpy(),
+             keys=np.array(sorted(m.state_dict().keys())))
+    np.savez_compressed(os.path.join(OUT, "tiny_vcr_nsp.npz"), **g)
+
+
 def caller_goldens():
     """a15 + iou: outputs of the reference helper functions on seeded inputs."""
     rng = np.random.Generator(np.random.PCG64(99))
@@ -262,6 +297,9 @@ def caller_goldens():
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-vcr" in sys.argv:          # add the section 8(f).1 fixture without rewriting the others
+        vcr_nsp_case()
+        return
     meta = {"reference": "thunlp/CPT @ /root/reference (v1)",
             "third_party_restated": "huggingface/transformers@067923d3267325f525f4e46f357360c191ba562e (pytorch_transformers)",
             "torch": torch.__version__}
@@ -270,6 +308,7 @@ def main():
     print("hf cross-check:", meta["hf_crosscheck_maxabs_tiny"], meta["hf_crosscheck_maxabs_base"])
     meta["tiny_ckpt_vs_direct_maxabs"] = tiny_case()
     caller_goldens()
+    vcr_nsp_case()
     base_case("base_cfg1_b2_r36", B=2, n_regions=36)                       # BASELINE config 1 shape
     base_case("base_cfg2_b4_r50", B=4, n_regions=50, with_grads=True)      # config 2 shape (+ grads for config 3)
     base_case("base_ragged_b3", B=3, n_regions=50, seed_b=3, vary=True)

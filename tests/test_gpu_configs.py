@@ -1,6 +1,8 @@
 """GPU parity at the other BASELINE.json config shapes (the bench line is configs[1]; these are the
 parity-test cases): GQA-CPT shape (L = 165 + 45, answer-id gather), Oscar-large blocks with the NSP-style
 relation head (H = 1024, 16 heads, L = 165 + 100), and the driver loops (val / train_batch)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -129,3 +131,40 @@ def test_train_batch_driver_runs_and_learns(dev):
     step, losses = drivers.train_batch(m, opt, [batch] * 12, Opts, dev)
     assert step == 12 and len(losses) == 12
     assert float(losses[-1]) < float(losses[0]) - 0.3
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_vcr_nspcpt_golden(dev, golden_dir, mode):
+    """Section 8(f).1: NSPCPT (modeling_vcr.py:79-129) through the HIP path against the fixture produced by the
+    reference's own class: relation scores, CE loss (fewshot/vcr_nsp_cpt.py:433-436 labels) and the driver's
+    choice rule (:597-604)."""
+    from cpt_amd.modeling_bert import BertImgForPreTraining
+    from cpt_amd.modeling_vcr import NSPCPT
+    from cpt_amd import scoring
+    g = np.load(os.path.join(golden_dir, "tiny_vcr_nsp.npz"))
+    cfg = cfgmod.tiny()
+    pre = BertImgForPreTraining(cfg)
+    pre.load_state_dict(synth.init_state_dict(cfg, 4321, head="pretrain"))
+    pre.tie_weights()
+    m = NSPCPT(cfg)
+    m.copy_from_pretraining_model(pre)
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    m.to(dev).eval().set_compute_dtype(mode)
+    b = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    interval = int(g["interval"])
+    lab = scoring.nsp_choice_labels([2, 0], interval, 8, device=dev)
+    assert (lab.cpu().numpy() == g["cls_labels"]).all()
+    with torch.no_grad():
+        loss, rel = m(b["input_ids"], b["segment_ids"], b["attention_mask"], next_sentence_label=lab, img_feats=b["img_feats"])
+        rel_only = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"])[0]
+    tol = 2e-5 if mode == "fp32" else 5e-3
+    assert (rel.cpu() - torch.from_numpy(g["rel"])).abs().max().item() < tol
+    assert torch.equal(rel, rel_only)
+    assert abs(loss.item() - float(g["loss"])) < (1e-5 if mode == "fp32" else 5e-3)
+    logits, preds = scoring.nsp_choose(rel.cpu(), interval)
+    assert (logits - torch.from_numpy(g["choice_logits"])).abs().max().item() < tol
+    if mode == "fp32":
+        assert preds == list(g["preds"])
+    with pytest.raises(NotImplementedError):
+        m.train()
+        m(b["input_ids"], b["segment_ids"], b["attention_mask"], next_sentence_label=lab, img_feats=b["img_feats"])

@@ -171,3 +171,31 @@ def test_data_parallel_helpers_world2_gloo():
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_dp_worker, args=(2, port, tmp), nprocs=2, join=True)
         assert os.path.exists(os.path.join(tmp, "ok0")) and os.path.exists(os.path.join(tmp, "ok1"))
+
+
+def test_nspcpt_surface_and_choice_rule(golden_dir):
+    """Section 8(f).1 host side: NSPCPT's state-dict surface after copy_from_pretraining_model equals the
+    reference's (fixture keys), the label construction and the 1 - softmax[:,1] choice rule reproduce the
+    reference's outputs from the reference's own relation scores, and there is no CPU fallback."""
+    import numpy as np
+    import pytest
+    from cpt_amd import config as cfgmod, scoring
+    from cpt_amd.modeling_bert import BertImgForPreTraining
+    from cpt_amd.modeling_vcr import NSPCPT
+    g = np.load(os.path.join(golden_dir, "tiny_vcr_nsp.npz"))
+    cfg = cfgmod.tiny()
+    m = NSPCPT(cfg)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, dtype=torch.long))                  # before copy_from_pretraining_model
+    m.copy_from_pretraining_model(BertImgForPreTraining(cfg))
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    interval = int(g["interval"])
+    lab = scoring.nsp_choice_labels([2, 0], interval, 8)
+    assert (lab.numpy() == g["cls_labels"]).all()
+    logits, preds = scoring.nsp_choose(torch.from_numpy(g["rel"]), interval)
+    np.testing.assert_allclose(logits.numpy(), g["choice_logits"], atol=1e-6, rtol=0)
+    assert preds == list(g["preds"])
+    with pytest.raises(RuntimeError):                             # parameters on the CPU: the HIP path refuses
+        with torch.no_grad():
+            m(torch.from_numpy(g["in_input_ids"]), torch.from_numpy(g["in_segment_ids"]),
+              torch.from_numpy(g["in_attention_mask"]), img_feats=torch.from_numpy(g["in_img_feats"]))

@@ -136,3 +136,22 @@ def test_tiny_train3_trace(golden_dir):
     for k in t.files:
         if k.startswith("after_"):
             np.testing.assert_allclose(sd[k[6:]].numpy(), t[k], atol=3e-5, rtol=1e-4, err_msg=k)  # Adam m/sqrt(v) amplifies 1e-7 grad noise at lr 3e-3
+
+
+def test_vcr_nsp_cpt_golden(golden_dir):
+    """Section 8(f).1: NSPCPT scores / loss / choice rule of the reference (modeling_vcr.py:79-129,
+    fewshot/vcr_nsp_cpt.py:433-436,597-604) reproduced by the oracle."""
+    g = np.load(os.path.join(golden_dir, "tiny_vcr_nsp.npz"))
+    cfg = cfgmod.tiny()
+    sd = synth.init_state_dict(cfg, 4321, head="pretrain")
+    b = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    interval = int(g["interval"])
+    lab = O.nsp_choice_labels([2, 0], interval, 8)
+    assert (lab.numpy() == g["cls_labels"]).all()
+    loss, rel = O.nsp_cpt_forward(sd, _cfg_dict(cfg), b["input_ids"], b["segment_ids"], b["attention_mask"],
+                                  b["img_feats"], next_sentence_label=lab)
+    np.testing.assert_allclose(rel.numpy(), g["rel"], atol=1e-5, rtol=0)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    logits, preds = O.nsp_choose(rel, interval)
+    np.testing.assert_allclose(logits.numpy(), g["choice_logits"], atol=1e-5, rtol=0)
+    assert preds == list(g["preds"])
