@@ -89,6 +89,14 @@ _SIGS = {
     "cpt_debug_gemm_trace": (C.c_int, [vp]),
     "cpt_prof_enable": (C.c_int, [C.c_int]),
     "cpt_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    # include/cpt_io.h (host-side wire-format decoder)
+    "cpt_b64_decode_f32": (C.c_int, [C.c_char_p, C.c_size_t, vp, C.c_int]),
+    "cpt_decode_regions": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, vp, vp]),
+    "cpt_decode_regions_batch": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]),
+    "cpt_decode_tsv_rows": (C.c_int, [C.POINTER(C.c_char_p), vp, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp,
+                                      vp, vp, vp, vp, vp, C.c_int]),
+    "cpt_json_find_strings": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, vp, vp, C.c_int, vp, C.c_size_t,
+                                        C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
 }
 
 _lib = None

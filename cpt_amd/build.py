@@ -27,6 +27,7 @@ def _stale(out, deps):
 def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cpt_hip.h"))
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cpt_io.h"))
     objs, jobs = [], []
     for f in _sources():
         src = os.path.join(CSRC, f)
@@ -46,7 +47,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
     return LIB
 
 

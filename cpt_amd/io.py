@@ -1,0 +1,241 @@
+"""Region-feature input pipeline: TSV + lineidx reader, wire-format decode into pinned
+host memory through the C ABI (include/cpt_io.h), and staging to the GPU on a side stream.
+
+Counterparts in the reference:
+  * ``TSVFile``            Oscar/oscar/utils/tsv_file.py:8-85 (seek by byte offset from the .lineidx companion)
+  * ``decode_features``    Oscar/oscar/datasets/refcoco_zsl_cpt_dataset.py:161-180 (json -> per-box base64 -> float32)
+  * zero padding + image part of the attention mask   refcoco_zsl_cpt_dataset.py:119-120 and tokenize()
+The reference decodes box by box in Python; here one C call per TSV row decodes every ``feature`` string of the row
+straight into a pinned ``(P, img_seq_len, 2054)`` buffer and hands json.loads a copy of the row without them.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def generate_lineidx_file(filein, idxout):
+    """tsv_file.py:8-18: byte offset of every line."""
+    tmp = idxout + ".tmp"
+    with open(filein, "rb") as tsvin, open(tmp, "w") as out:
+        fsize = os.fstat(tsvin.fileno()).st_size
+        fpos = 0
+        while fpos != fsize:
+            out.write(str(fpos) + "\n")
+            tsvin.readline()
+            fpos = tsvin.tell()
+    os.rename(tmp, idxout)
+
+
+class TSVFile(object):
+    """tsv_file.py:21-85.  Rows are returned as ``bytes`` columns by ``seek_raw`` (what the decoder wants) and as
+    stripped ``str`` columns by ``seek`` / ``[]`` exactly like the reference."""
+
+    def __init__(self, tsv_file, generate_lineidx=False):
+        self.tsv_file = tsv_file
+        self.lineidx = os.path.splitext(tsv_file)[0] + ".lineidx"
+        self._fp = None
+        self._lineidx = None
+        self.pid = None
+        if not os.path.isfile(self.lineidx) and generate_lineidx:
+            generate_lineidx_file(self.tsv_file, self.lineidx)
+
+    def __del__(self):
+        if self._fp:
+            self._fp.close()
+
+    def __str__(self):
+        return "TSVFile(tsv_file='{}')".format(self.tsv_file)
+
+    __repr__ = __str__
+
+    def num_rows(self):
+        self._ensure_lineidx_loaded()
+        return len(self._lineidx)
+
+    __len__ = num_rows
+
+    def seek_raw(self, idx):
+        self._ensure_tsv_opened()
+        self._ensure_lineidx_loaded()
+        self._fp.seek(self._lineidx[idx])
+        return self._fp.readline().split(b"\t")
+
+    def seek(self, idx):
+        return [c.decode("utf-8").strip() for c in self.seek_raw(idx)]
+
+    __getitem__ = seek
+
+    def seek_first_column(self, idx):
+        return self.seek_raw(idx)[0].decode("utf-8")
+
+    def _ensure_lineidx_loaded(self):
+        if self._lineidx is None:
+            with open(self.lineidx, "r") as fp:
+                self._lineidx = [int(i.strip()) for i in fp.readlines()]
+
+    def _ensure_tsv_opened(self):
+        if self._fp is None or self.pid != os.getpid():     # re-open after fork (DataLoader workers), as the reference
+            self._fp = open(self.tsv_file, "rb")
+            self.pid = os.getpid()
+
+
+def b64_to_f32(s, dim=2054):
+    """One region: np.frombuffer(base64.b64decode(s), np.float32) of refcoco_zsl_cpt_dataset.py:173."""
+    if isinstance(s, str):
+        s = s.encode("ascii")
+    out = torch.empty(dim, dtype=torch.float32)
+    L.check(L.lib().cpt_b64_decode_f32(s, len(s), out.data_ptr(), dim), "cpt_b64_decode_f32")
+    return out
+
+
+def _batch_decode(base_ptr, offsets, lens, counts, img_seq_len, dim, out, mask, threads):
+    P = len(counts)
+    if P == 0:
+        return
+    cnt = np.asarray(counts, dtype=np.int32)
+    first = np.zeros(max(P, 1), dtype=np.int32)
+    if P > 1:
+        np.cumsum(cnt[:-1], out=first[1:P])
+    L.check(L.lib().cpt_decode_regions_batch(base_ptr, offsets.ctypes.data, lens.ctypes.data, first.ctypes.data,
+                                             cnt.ctypes.data if P else first.ctypes.data, P, dim, img_seq_len,
+                                             out.data_ptr(), mask.data_ptr() if mask is not None else None, threads),
+            "cpt_decode_regions_batch")
+
+
+def decode_regions(feature_lists, img_seq_len=50, dim=2054, out=None, mask=None, threads=1):
+    """feature_lists: per proposal sequence, the list of base64 strings of its boxes.  Returns
+    (feats (P, img_seq_len, dim) f32 zero padded, mask (P, img_seq_len) int64).  ``out`` / ``mask`` may be
+    preallocated (pinned) tensors."""
+    P = len(feature_lists)
+    if out is None:
+        out = torch.empty((P, img_seq_len, dim), dtype=torch.float32)
+    if mask is None:
+        mask = torch.empty((P, img_seq_len), dtype=torch.int64)
+    assert out.is_contiguous() and mask.is_contiguous() and tuple(out.shape) == (P, img_seq_len, dim)
+    flat = [s.encode("ascii") if isinstance(s, str) else s for fl in feature_lists for s in fl]
+    blob = b"".join(flat)
+    lens = np.fromiter((len(s) for s in flat), dtype=np.uint64, count=len(flat))
+    offsets = np.zeros(max(len(flat), 1), dtype=np.uint64)
+    if len(flat) > 1:
+        np.cumsum(lens[:-1], out=offsets[1:len(flat)])
+    if len(flat) == 0:
+        lens = np.zeros(1, dtype=np.uint64)
+    buf = C.c_char_p(blob)
+    _batch_decode(C.cast(buf, C.c_void_p), offsets, lens, [len(fl) for fl in feature_lists], img_seq_len, dim, out, mask, threads)
+    return out, mask
+
+
+def decode_row(payload, img_seq_len=50, dim=2054, out=None, mask=None, key=b"feature", threads=1):
+    """One TSV payload (the JSON text of a row, bytes): returns (info, feats, mask, counts) where ``info`` is the
+    parsed JSON with every feature string replaced by "", ``feats`` (P, img_seq_len, dim) the zero-padded features of
+    the P box lists in ``info["objects"][0]``, ``mask`` (P, img_seq_len) and ``counts`` the box-list lengths.
+    The base64 text is decoded in place from the row: it never becomes a Python string."""
+    if isinstance(payload, str):
+        payload = payload.encode("utf-8")
+    # every value we are after is the base64 of dim float32 -> at least 16*dim/3 characters: bounds their number
+    max_values = len(payload) // ((16 * dim) // 3) + 1
+    offsets = np.empty(max_values, dtype=np.uint64)
+    lens = np.empty(max_values, dtype=np.uint64)
+    stripped = np.empty(len(payload) + 1, dtype=np.uint8)
+    n_val, slen = C.c_int(0), C.c_size_t(0)
+    L.check(L.lib().cpt_json_find_strings(payload, len(payload), key, offsets.ctypes.data, lens.ctypes.data, max_values,
+                                          stripped.ctypes.data, len(payload) + 1, C.byref(n_val), C.byref(slen)),
+            "cpt_json_find_strings")
+    info = json.loads(stripped[:slen.value].tobytes())
+    objs = info["objects"][0]
+    counts = [len(bl) for bl in objs]
+    if sum(counts) != n_val.value:
+        raise RuntimeError("cpt_amd.io: %d feature strings for %d boxes" % (n_val.value, sum(counts)))
+    P = len(objs)
+    if out is None:
+        out = torch.empty((P, img_seq_len, dim), dtype=torch.float32)
+    if mask is None:
+        mask = torch.empty((P, img_seq_len), dtype=torch.int64)
+    buf = C.c_char_p(payload)
+    _batch_decode(C.cast(buf, C.c_void_p), offsets, lens, counts, img_seq_len, dim, out[:P], mask[:P], threads)
+    return info, out[:P], mask[:P], counts
+
+
+def decode_rows(payloads, img_seq_len=50, dim=2054, out=None, mask=None, key=b"feature", threads=4, max_seqs=None,
+                parse=True):
+    """Many TSV payloads in ONE C call with native threads (cpt_decode_tsv_rows): returns
+    (infos, feats (S, img_seq_len, dim), mask (S, img_seq_len), seqs_per_row, regions_per_seq) with S the total number
+    of proposal sequences; sequence order = row order, then box-list order inside the row.  ``parse=False`` returns the
+    stripped JSON texts instead of parsed objects (a driver may parse them on another process / later)."""
+    n = len(payloads)
+    payloads = [p.encode("utf-8") if isinstance(p, str) else p for p in payloads]
+    if max_seqs is None:
+        max_seqs = out.size(0) if out is not None else sum(len(p) // ((16 * dim) // 3) + 1 for p in payloads)
+    if out is None:
+        out = torch.empty((max_seqs, img_seq_len, dim), dtype=torch.float32)
+    if mask is None:
+        mask = torch.empty((max_seqs, img_seq_len), dtype=torch.int64)
+    assert out.is_contiguous() and mask.is_contiguous() and out.size(0) >= max_seqs and mask.size(0) >= max_seqs
+    rows = (C.c_char_p * max(n, 1))(*payloads)
+    lens = np.fromiter((len(p) for p in payloads), dtype=np.uint64, count=n) if n else np.zeros(1, np.uint64)
+    sbufs = [np.empty(len(p) + 1, dtype=np.uint8) for p in payloads]
+    sptr = np.fromiter((b.ctypes.data for b in sbufs), dtype=np.uint64, count=n) if n else np.zeros(1, np.uint64)
+    scap = lens + 1
+    slen = np.zeros(max(n, 1), dtype=np.uint64)
+    seqs_per_row = np.zeros(max(n, 1), dtype=np.int32)
+    regions = np.zeros(max(max_seqs, 1), dtype=np.int32)
+    L.check(L.lib().cpt_decode_tsv_rows(rows, lens.ctypes.data, n, key, dim, img_seq_len, max_seqs, out.data_ptr(),
+                                        mask.data_ptr(), sptr.ctypes.data, scap.ctypes.data, slen.ctypes.data,
+                                        seqs_per_row.ctypes.data, regions.ctypes.data, threads), "cpt_decode_tsv_rows")
+    infos = [sbufs[i][:int(slen[i])].tobytes() for i in range(n)]      # the row's JSON without the feature strings
+    if parse:
+        infos = [json.loads(b) for b in infos]
+    S = int(seqs_per_row[:n].sum())
+    return infos, out[:S], mask[:S], seqs_per_row[:n].tolist(), regions[:S].tolist()
+
+
+def decode_features(tsv, img_idx, img_seq_len=50, dim=2054):
+    """decode_features of refcoco_zsl_cpt_dataset.py:161-180: (img_name, od_labels, im_feats, caption, colors,
+    rect_lists); im_feats is the list of per-proposal (n_boxes, dim) tensors the reference returns (views of one
+    decoded buffer)."""
+    cols = tsv.seek_raw(img_idx)
+    img_name = cols[0].decode("utf-8").strip()
+    info, feats, _, counts = decode_row(cols[1].strip(), img_seq_len, dim)
+    objs, caption, colors, rect_lists = info["objects"]
+    im_feats = [feats[p, :c] for p, c in enumerate(counts)]
+    od_labels = [" ".join(o["class"] for o in boxlist) for boxlist in objs]
+    return img_name, od_labels, im_feats, caption, colors, rect_lists
+
+
+class RegionStager(object):
+    """Pinned host buffers + a side stream: decode batch i+1 on the host while batch i's features travel to the GPU
+    (the 26 MB/step host buffer of DESIGN.md section 7)."""
+
+    def __init__(self, max_seqs, img_seq_len=50, dim=2054, device="cuda:0", depth=2, threads=4):
+        self.dev = torch.device(device)
+        self.shape = (max_seqs, img_seq_len, dim)
+        self.threads = threads
+        self.host = [torch.empty(self.shape, dtype=torch.float32).pin_memory() for _ in range(depth)]
+        self.hmask = [torch.empty(self.shape[:2], dtype=torch.int64).pin_memory() for _ in range(depth)]
+        self.devb = [torch.empty(self.shape, dtype=torch.float32, device=self.dev) for _ in range(depth)]
+        self.dmask = [torch.empty(self.shape[:2], dtype=torch.int64, device=self.dev) for _ in range(depth)]
+        self.stream = torch.cuda.Stream(self.dev)
+        self.events = [None] * depth
+        self.i = 0
+
+    def stage(self, feature_lists):
+        """Decode + enqueue the H2D copy; returns (feats_dev, mask_dev, event).  The consumer stream must
+        ``wait_event(event)`` before reading."""
+        k = self.i % len(self.host)
+        self.i += 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()              # the previous copy out of this pinned buffer is done
+        P = len(feature_lists)
+        decode_regions(feature_lists, self.shape[1], self.shape[2], self.host[k][:P], self.hmask[k][:P], self.threads)
+        with torch.cuda.stream(self.stream):
+            self.devb[k][:P].copy_(self.host[k][:P], non_blocking=True)
+            self.dmask[k][:P].copy_(self.hmask[k][:P], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.events[k] = ev
+        return self.devb[k][:P], self.dmask[k][:P], ev

@@ -277,6 +277,45 @@ def vcr_nsp_case():
     np.savez_compressed(os.path.join(OUT, "tiny_vcr_nsp.npz"), **g)
 
 
+def tsv_rows_case():
+    """Section 8(f).2: two rows in the reference's predictions.tsv format (writer: zeroshot/inference_ref.py:157-191,
+    SURVEY Appendix B) with small random features, read back with the reference's TSVFile and decoded with the
+    reference's decode_features; the TSV itself and the decoded arrays are the fixture."""
+    import base64
+    from oscar.utils.tsv_file import TSVFile
+    import oscar.datasets.refcoco_zsl_cpt_dataset as D
+    rng = np.random.Generator(np.random.PCG64(2054))
+    tsv = os.path.join(OUT, "tiny_rows.tsv")
+    rows = []
+    for r, (P, nb) in enumerate(((3, (4, 2, 5)), (2, (1, 3)))):
+        objs = []
+        for p in range(P):
+            boxes = []
+            for j in range(nb[p]):
+                f = rng.standard_normal(2054).astype(np.float32)
+                f[:2048] = np.maximum(f[:2048], 0)
+                boxes.append({"rect": [float(v) for v in rng.integers(0, 400, 4)], "bbox_id": j,
+                              "class": ["dog", "man", "frisbee", "tree", "car"][j % 5], "conf": float(rng.random()),
+                              "feature": base64.b64encode(f.tobytes()).decode("utf-8")})
+            objs.append(boxes)
+        caption = 'the "feature": "dog" on the left\\' if r == 0 else "man in red"
+        rows.append(("img_%d.jpg" % r, json.dumps({"objects": [objs, caption, [["red"]] * P,
+                                                                [[[1, 2, 30, 40]]] * P]})))
+    with open(tsv, "w") as f:
+        for k, v in rows:
+            f.write(k + "\t" + v + "\n")
+    t = TSVFile(tsv, generate_lineidx=True)
+    g = {"n_rows": np.array(t.num_rows())}
+    for i in range(t.num_rows()):
+        img_name, od_labels, im_feats, caption, colors, rect_lists = D.ZSLColorFinetuneDataset.decode_features(None, t, i)
+        g["r%d_name" % i] = np.array(img_name)
+        g["r%d_caption" % i] = np.array(caption)
+        g["r%d_od_labels" % i] = np.array(od_labels)
+        g["r%d_counts" % i] = np.array([f.size(0) for f in im_feats])
+        g["r%d_feats" % i] = torch.cat(im_feats, 0).numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_rows_expected.npz"), **g)
+
+
 def caller_goldens():
     """a15 + iou: outputs of the reference helper functions on seeded inputs."""
     rng = np.random.Generator(np.random.PCG64(99))
@@ -300,6 +339,9 @@ def main():
     if "--only-vcr" in sys.argv:          # add the section 8(f).1 fixture without rewriting the others
         vcr_nsp_case()
         return
+    if "--only-tsv" in sys.argv:          # section 8(f).2 fixture
+        tsv_rows_case()
+        return
     meta = {"reference": "thunlp/CPT @ /root/reference (v1)",
             "third_party_restated": "huggingface/transformers@067923d3267325f525f4e46f357360c191ba562e (pytorch_transformers)",
             "torch": torch.__version__}
@@ -309,6 +351,7 @@ def main():
     meta["tiny_ckpt_vs_direct_maxabs"] = tiny_case()
     caller_goldens()
     vcr_nsp_case()
+    tsv_rows_case()
     base_case("base_cfg1_b2_r36", B=2, n_regions=36)                       # BASELINE config 1 shape
     base_case("base_cfg2_b4_r50", B=4, n_regions=50, with_grads=True)      # config 2 shape (+ grads for config 3)
     base_case("base_ragged_b3", B=3, n_regions=50, seed_b=3, vary=True)

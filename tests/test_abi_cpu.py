@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library builds, loads, and exports every entry point include/cpt_hip.h declares
+"""CPU: the C-ABI library builds, loads, and exports every entry point include/*.h declares
 (no compute calls without a GPU); the ctypes binding covers the same set."""
 import ctypes
 import os
@@ -10,9 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    src = open(os.path.join(ROOT, "include", "cpt_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(cpt_[a-z0-9_]+)\s*\(", src)))
+    names = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if h.endswith(".h"):
+            src = open(os.path.join(ROOT, "include", h)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names |= set(re.findall(r"\b(cpt_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_symbols_exported():

@@ -168,3 +168,24 @@ def test_vcr_nspcpt_golden(dev, golden_dir, mode):
     with pytest.raises(NotImplementedError):
         m.train()
         m(b["input_ids"], b["segment_ids"], b["attention_mask"], next_sentence_label=lab, img_feats=b["img_feats"])
+
+
+def test_region_stager_matches_host_decode(dev):
+    """Section 8(f).2: features decoded by the C decoder into pinned memory and staged on the side stream arrive on
+    the GPU bit-identical to the Python decode, and drive the model to the same logits as the host tensor."""
+    import base64
+    from cpt_amd import io
+    rng = np.random.default_rng(11)
+    counts = [50, 36, 0, 17]
+    data = [[np.maximum(rng.standard_normal(2054), 0).astype(np.float32) for _ in range(c)] for c in counts]
+    lists = [[base64.b64encode(a.tobytes()).decode() for a in seq] for seq in data]
+    st = io.RegionStager(max_seqs=8, device=str(dev), threads=2)
+    for _ in range(3):                                   # cycles through the pinned ring
+        feats, mask, ev = st.stage(lists)
+        torch.cuda.current_stream().wait_event(ev)
+        ref = torch.zeros(4, 50, 2054)
+        for p, seq in enumerate(data):
+            if seq:
+                ref[p, :len(seq)] = torch.from_numpy(np.stack(seq))
+        assert torch.equal(feats.cpu(), ref)
+        assert mask.cpu().sum(1).tolist() == counts

@@ -1,0 +1,117 @@
+"""CPU: the region-feature wire-format decoder (include/cpt_io.h, cpt_amd/io.py) against the
+fixture decoded by the reference's own TSVFile + decode_features, against the Python restatement (oracle/io_oracle.py)
+on random inputs, and on the edge cases (empty / full box lists, bad characters, wrong sizes)."""
+import base64
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from cpt_amd import io
+from oracle import io_oracle as IO
+
+
+def _b64(a):
+    return base64.b64encode(np.asarray(a, np.float32).tobytes()).decode("ascii")
+
+
+def test_oracle_matches_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_rows_expected.npz"))
+    tsv, idx = os.path.join(golden_dir, "tiny_rows.tsv"), os.path.join(golden_dir, "tiny_rows.lineidx")
+    for i in range(int(g["n_rows"])):
+        name, od, feats, caption, colors, rects = IO.decode_features(IO.tsv_seek(tsv, idx, i))
+        assert name == str(g["r%d_name" % i]) and caption == str(g["r%d_caption" % i])
+        assert od == list(g["r%d_od_labels" % i])
+        assert [f.size(0) for f in feats] == list(g["r%d_counts" % i])
+        assert np.array_equal(torch.cat(feats, 0).numpy(), g["r%d_feats" % i])
+
+
+def test_decoder_matches_reference_fixture(golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, "tiny_rows_expected.npz"))
+    src = os.path.join(golden_dir, "tiny_rows.tsv")
+    t = io.TSVFile(src)
+    assert len(t) == int(g["n_rows"])
+    for i in range(len(t)):
+        name, od, feats, caption, colors, rects = io.decode_features(t, i, img_seq_len=6)
+        assert name == str(g["r%d_name" % i]) and caption == str(g["r%d_caption" % i])
+        assert od == list(g["r%d_od_labels" % i])
+        assert [f.size(0) for f in feats] == list(g["r%d_counts" % i])
+        assert np.array_equal(torch.cat(feats, 0).numpy(), g["r%d_feats" % i])          # bit exact
+        assert t[i][0] == IO.tsv_seek(src, t.lineidx, i)[0] and t.seek_first_column(i) == name
+        # padded form + image part of the attention mask == the reference's torch.cat with zeros
+        cols = t.seek_raw(i)
+        info, padded, mask, counts = io.decode_row(cols[1].strip(), img_seq_len=6)
+        ref_p, ref_m = IO.pad_regions(IO.decode_features(IO.tsv_seek(src, t.lineidx, i))[2], 6)
+        assert torch.equal(padded, ref_p) and torch.equal(mask, ref_m)
+        assert all(o["feature"] == "" for bl in info["objects"][0] for o in bl)
+    # .lineidx generation == the one the reference's generate_lineidx_file wrote into the fixture
+    cp = str(tmp_path / "copy.tsv")
+    shutil.copy(src, cp)
+    t2 = io.TSVFile(cp, generate_lineidx=True)
+    assert open(t2.lineidx).read() == open(t.lineidx).read()
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_decode_regions_random_ragged(threads):
+    rng = np.random.default_rng(5)
+    counts = [0, 1, 50, 7, 50, 0, 13]
+    data = [[rng.standard_normal(2054).astype(np.float32) for _ in range(c)] for c in counts]
+    data[2][3][:5] = [np.nan, np.inf, -np.inf, -0.0, np.float32(1e-45)]          # every bit pattern survives
+    lists = [[_b64(a) for a in seq] for seq in data]
+    feats, mask = io.decode_regions(lists, img_seq_len=50, threads=threads)
+    ref_f, ref_m = IO.pad_regions([torch.Tensor(np.stack(s)) if s else torch.zeros(0, 2054) for s in data], 50)
+    assert feats.numpy().tobytes() == ref_f.numpy().tobytes()
+    assert torch.equal(mask, ref_m)
+    # other dims / paddings of the base64 tail ('=' and '==')
+    for dim in (1, 2, 3, 5, 38):
+        a = rng.standard_normal(dim).astype(np.float32)
+        assert io.b64_to_f32(_b64(a), dim).numpy().tobytes() == a.tobytes()
+    assert io.decode_regions([], img_seq_len=4)[0].shape == (0, 4, 2054)
+
+
+def test_decoder_rejects_bad_input():
+    good = _b64(np.arange(2054))
+    with pytest.raises(RuntimeError, match="outside the alphabet"):
+        io.b64_to_f32(good[:100] + "!" + good[101:])
+    with pytest.raises(RuntimeError, match="does not decode to 2054"):
+        io.b64_to_f32(_b64(np.arange(2053)))
+    with pytest.raises(RuntimeError, match="does not decode"):
+        io.b64_to_f32(good[:-1])
+    with pytest.raises(RuntimeError, match="do not fit max_regions"):
+        io.decode_regions([[good] * 5], img_seq_len=4)
+    with pytest.raises(RuntimeError, match="outside the alphabet"):          # error raised inside a worker thread
+        io.decode_regions([[good], [good], [good[:7] + "\n" + good[8:]], [good]], img_seq_len=2, threads=4)
+    row = json.dumps({"objects": [[[{"class": "a", "feature": good}]], "c", [["red"]], [[[0, 0, 1, 1]]]]})
+    with pytest.raises(RuntimeError, match="unterminated"):
+        io.decode_row(row[:-40].encode() if False else (row[:row.index(good) + 50]).encode())
+    info, feats, mask, counts = io.decode_row(row.encode(), img_seq_len=3)
+    assert counts == [1] and feats[0, 0, 7].item() == 7.0 and mask.tolist() == [[1, 0, 0]]
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_decode_rows_native_batch(golden_dir, threads):
+    """cpt_decode_tsv_rows: whole rows in one call, values grouped by their enclosing box list (empty lists kept)."""
+    g = np.load(os.path.join(golden_dir, "tiny_rows_expected.npz"))
+    t = io.TSVFile(os.path.join(golden_dir, "tiny_rows.tsv"))
+    payloads = [t.seek_raw(i)[1].strip() for i in range(len(t))]
+    rng = np.random.default_rng(3)
+    extra = [[rng.standard_normal(2054).astype(np.float32) for _ in range(c)] for c in (0, 2, 0, 1, 0)]
+    row3 = json.dumps({"objects": [[[{"rect": [[1, 2], [3, 4]], "class": "x", "feature": _b64(a)} for a in bl] for bl in extra],
+                                   "caption [with] brackets ]", [["red"]] * 5, [[[0, 0, 1, 1]]] * 5]})
+    infos, feats, mask, seqs_per_row, regions = io.decode_rows(payloads + [row3], img_seq_len=6, threads=threads)
+    assert seqs_per_row == [3, 2, 5]
+    assert regions == list(g["r0_counts"]) + list(g["r1_counts"]) + [0, 2, 0, 1, 0]
+    ref = np.concatenate([g["r0_feats"], g["r1_feats"]] + [np.stack(bl) for bl in extra if bl])
+    got = np.concatenate([feats[s, :c].numpy() for s, c in enumerate(regions) if c])
+    assert got.tobytes() == ref.tobytes()
+    assert mask.sum(1).tolist() == regions and float(feats[5, :].abs().max()) == 0.0
+    for s, c in enumerate(regions):
+        assert float(feats[s, c:].abs().max() if c < 6 else 0.0) == 0.0
+    assert infos[0]["objects"][1] == str(g["r0_caption"]) and infos[2]["objects"][1] == "caption [with] brackets ]"
+    with pytest.raises(RuntimeError, match="do not fit max_seqs"):
+        io.decode_rows(payloads, img_seq_len=6, max_seqs=4)
+    with pytest.raises(RuntimeError, match="do not fit max_regions"):
+        io.decode_rows(payloads, img_seq_len=4)
