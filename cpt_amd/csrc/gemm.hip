@@ -730,7 +730,11 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
                               {384, 192, 256, 645 /* MFMA-bound */},
                               {128, 192, 512, 460 /* two co-resident workgroups per CU: epilogue under the other's K loop */}};
         long best_cost = -1;
+        // residual-type epilogues do not fit the 168 (12 waves) / 128 (two workgroups per CU) register caps without
+        // scratch spills, and a spilling instance runs 3-5x slower: those shapes are not candidates for them
+        constexpr bool heavy_epi = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || EPI == CPT_EPI_LNPROD;
         for (int i = 0; i < 5; ++i) {
+            if (heavy_epi && (i == 3 || i == 4)) continue;
             const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
             const long cost = ((wgs + cand[i].slots - 1) / cand[i].slots) * cand[i].round_cost;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = i; }
