@@ -715,6 +715,7 @@ int g_gemm_variant = 3;      // 0: generic register-staged kernel only; 3: pipel
 #define CPT_CFG_128x192_OCC2 128, 192, 4, 2, 2, 1, 2, 2
 #define CPT_CFG_128x192_W4 128, 192, 2, 2, 2, 1, 2, 2     // 4 waves of 64x96, two workgroups per CU
 #define CPT_CFG_256x192 256, 192, 4, 2, 2, 1, 2, 1        // 8 waves of 64x96
+#define CPT_CFG_64x192 64, 192, 2, 2, 3                   // 4 waves of 32x96: twice the workgroups when M is small
 
 template <typename T, int EPI, typename OT>
 static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, const float* bias,
@@ -726,15 +727,17 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         // bound by LDS port time (LDS-DMA writes + fragment reads) unless the tile does >= 3.6 MFMA per KiB of
         // operands, and a launch takes ceil(workgroups / slots) rounds.
         struct Cand { int bm, bn, slots, round_cost; };   // round_cost ~ cycles for one round of `slots` workgroups
-        const Cand cand[5] = {{128, 192, 256, 320}, {192, 192, 256, 384}, {128, 384, 256, 512},
+        const Cand cand[8] = {{128, 192, 256, 320}, {192, 192, 256, 384}, {128, 384, 256, 512},
                               {384, 192, 256, 645 /* MFMA-bound */},
-                              {128, 192, 512, 460 /* two co-resident workgroups per CU: epilogue under the other's K loop */}};
+                              {128, 192, 512, 460 /* two co-resident workgroups per CU: epilogue under the other's K loop */},
+                              {0, 0, 1, 0}, {0, 0, 1, 0} /* 5, 6: experiment-only shapes */,
+                              {64, 192, 256, 200 /* small M: fills the chip with half-height tiles */}};
         long best_cost = -1;
         // residual-type epilogues do not fit the 168 (12 waves) / 128 (two workgroups per CU) register caps without
         // scratch spills, and a spilling instance runs 3-5x slower: those shapes are not candidates for them
         constexpr bool heavy_epi = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || EPI == CPT_EPI_LNPROD;
-        for (int i = 0; i < 5; ++i) {
-            if (heavy_epi && (i == 3 || i == 4)) continue;
+        for (int i = 0; i < 8; ++i) {
+            if (cand[i].bm == 0 || (heavy_epi && (i == 3 || i == 4))) continue;
             const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
             const long cost = ((wgs + cand[i].slots - 1) / cand[i].slots) * cand[i].round_cost;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = i; }
@@ -745,6 +748,7 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
     else if (variant == 15) pick = 4;
     else if (variant == 16) pick = 5;
     else if (variant == 17) pick = 6;
+    else if (variant == 18) pick = 7;
     switch (pick) {
         case 1: launch_pipe<T, EPI, OT, CPT_CFG_192x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         case 2: launch_pipe<T, EPI, OT, CPT_CFG_128x384>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
@@ -752,6 +756,7 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         case 4: launch_pipe<T, EPI, OT, CPT_CFG_128x192_OCC2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         case 5: launch_pipe<T, EPI, OT, CPT_CFG_128x192_W4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         case 6: launch_pipe<T, EPI, OT, CPT_CFG_256x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
+        case 7: launch_pipe<T, EPI, OT, CPT_CFG_64x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         default: launch_pipe<T, EPI, OT, CPT_CFG_128x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
     }
 }

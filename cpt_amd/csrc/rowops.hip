@@ -160,9 +160,41 @@ int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const fl
 }
 
 // ---- pad + cast: x[R][K] f32 -> out[R][Kp] T ---------------------------------------------------
+// One thread per 8 output elements: four 8-byte loads (rows of x are 8-byte aligned when K is even, e.g. the
+// 2054-float region features) and one 16-byte (bf16) / two 16-byte (f32) stores.
 template <typename T>
 __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__ x, T* __restrict__ out, int R, int K, int Kp) {
-    // one thread per pair of output elements; rows of x are only 8-byte aligned when K is even
+    const int cpr = Kp / 8;                                   // 8-element chunks per output row
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)R * cpr) return;
+    const int r = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
+    const float* src = x + (size_t)r * K + c;
+    float v[8];
+    if (c + 8 <= K && (K & 1) == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float2 t = *reinterpret_cast<const float2*>(src + 2 * e);
+            v[2 * e] = t.x; v[2 * e + 1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c + e < K ? src[e] : 0.f;
+    }
+    T* dst = out + (size_t)r * Kp + c;
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x8*>(dst) = o;
+    } else {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// generic fallback (Kp not a multiple of 8 or unaligned output): one thread per pair of output elements
+template <typename T>
+__global__ __launch_bounds__(256) void pad_cast_pairs_kernel(const float* __restrict__ x, T* __restrict__ out, int R, int K, int Kp) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int hp = Kp / 2;
     if (idx >= (size_t)R * hp) return;
@@ -175,11 +207,19 @@ __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__
 
 int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s) {
     if (R <= 0 || K <= 0 || Kp < K || Kp % 2) return CPT_ERR_SHAPE;
+    if (dtype != CPT_BF16 && dtype != CPT_F32) return CPT_ERR_DTYPE;
+    dim3 block(256);
+    if (Kp % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)x % 8) == 0) {
+        const size_t n = (size_t)R * (Kp / 8);
+        dim3 grid((unsigned)((n + 255) / 256));
+        if (dtype == CPT_BF16) pad_cast_kernel<bf16><<<grid, block, 0, s>>>(x, (bf16*)out, R, K, Kp);
+        else pad_cast_kernel<float><<<grid, block, 0, s>>>(x, (float*)out, R, K, Kp);
+        return CPT_OK;
+    }
     const size_t n = (size_t)R * (Kp / 2);
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (dtype == CPT_BF16) pad_cast_kernel<bf16><<<grid, block, 0, s>>>(x, (bf16*)out, R, K, Kp);
-    else if (dtype == CPT_F32) pad_cast_kernel<float><<<grid, block, 0, s>>>(x, (float*)out, R, K, Kp);
-    else return CPT_ERR_DTYPE;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == CPT_BF16) pad_cast_pairs_kernel<bf16><<<grid, block, 0, s>>>(x, (bf16*)out, R, K, Kp);
+    else pad_cast_pairs_kernel<float><<<grid, block, 0, s>>>(x, (float*)out, R, K, Kp);
     return CPT_OK;
 }
 
