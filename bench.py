@@ -33,7 +33,7 @@ def pmc_traffic_bytes(kernel):
     fn = os.path.join(ROOT, "profiles", "r01_pmc_bench_summary.json")
     try:
         d = json.load(open(fn))
-        fam = {"gemm_ffn_up": "gemm_ffn_up(+gelu)", "gemm_qkv": "gemm_qkv", "gemm_attn_out": "gemm_attn_out",
+        fam = {"gemm_ffn_up": "gemm_ffn_up(+gelu)", "gemm_qkv": "gemm_qkv_attn", "gemm_attn_out": "gemm_attn_out",
                "gemm_ffn_down": "gemm_ffn_down"}.get(kernel)
         if fam is None or fam not in d:
             return None

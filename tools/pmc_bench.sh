@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel (FFN-up GEMM) inside bench.py: separate --pmc passes as the guide prescribes.
 # usage (GPU box): tools/pmc_bench.sh gpurun_out/pmc_bench
-R=$PWD; O=$R/$1; mkdir -p $O
+R=$PWD; O=$R/$1; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ"; do
   n=$(echo $C | cut -d' ' -f1)
