@@ -83,6 +83,8 @@ _SIGS = {
     "cpt_attention": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_pad_cast": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_fold_ln_weights": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "cpt_select_regions": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
+    "cpt_argmax_columns": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     "cpt_gather_rows": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_ce_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "cpt_set_tuning": (C.c_int, [C.c_int, C.c_int]),

@@ -203,6 +203,16 @@ int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, c
     return check_launch(cpt::fold_ln_weights(W, gamma, beta, bias, Wf_bf16, colc, cold, N, K, (hipStream_t)stream), "cpt_fold_ln_weights");
 }
 
+int cpt_select_regions(const float* mask_logits, int V, const int64_t* color_ids, int C, const int32_t* query_first, int Q,
+                       int64_t none_id, int divide_by_none, int64_t* out_idx, float* out_score, void* stream) {
+    return check_launch(cpt::select_regions(mask_logits, V, color_ids, C, query_first, Q, none_id, divide_by_none, out_idx, out_score,
+                                            (hipStream_t)stream), "cpt_select_regions");
+}
+
+int cpt_argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids, int R, int64_t* out_idx, float* out_val, void* stream) {
+    return check_launch(cpt::argmax_columns(logits, V, ids, n_ids, R, out_idx, out_val, (hipStream_t)stream), "cpt_argmax_columns");
+}
+
 int cpt_gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H,
                     void* stream) {
     if (!src || !out) return fail(CPT_ERR_NULL, "cpt_gather_rows: null operand");

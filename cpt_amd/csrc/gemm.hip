@@ -444,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             sMask[tid] = mv;
         }
         __syncthreads();
-        if (wave < 4 && wave * 32 < Ls) {             // one attention wave per SIMD
+        if (wave < 4 && wave * 32 < Ls && !(abl & 32)) {   // one attention wave per SIMD (abl 32: projection only)
             const int q = wave * 32 + fr;
             bf16x8 fq[4];
 #pragma unroll

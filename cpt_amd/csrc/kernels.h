@@ -59,6 +59,9 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
 int gemm_qkv_attn(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
                   const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads,
                   int K, int config, hipStream_t s);
+int select_regions(const float* logits, int V, const int64_t* color_ids, int C, const int* query_first, int Q,
+                   int64_t none_id, int divide_by_none, int64_t* out_idx, float* out_score, hipStream_t s);
+int argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids, int R, int64_t* out_idx, float* out_val, hipStream_t s);
 int fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* colc,
                     float* cold, int N, int K, hipStream_t s);
 void set_splitk_target(int v);

@@ -320,4 +320,86 @@ int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlog
     return CPT_OK;
 }
 
+// ---- score extraction on the device (row a15 / SURVEY 8(f).3): only indices return to the host --------------
+// torch.argmax semantics: first maximum wins, NaN counts as the maximum.
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn != bn) return vn;                       // a NaN beats any number
+    if (!vn && v != bv) return v > bv;
+    return i < bi;                                 // equal (or both NaN): the earlier position
+}
+
+// One wave per query.  The query's proposal sequences are query_first[q] .. query_first[q+1]-1; sequence s contributes
+// the logits at its colour ids color_ids[s][0..C) (entries < 0 are padding) in order, optionally divided by its
+// "none" logit; the winner is the argmax position inside that concatenation.
+__global__ __launch_bounds__(64) void select_regions_kernel(const float* __restrict__ logits, int V, const int64_t* __restrict__ color_ids,
+                                                            int C, const int* __restrict__ query_first, int64_t none_id,
+                                                            int divide_by_none, int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int s0 = query_first[q], s1 = query_first[q + 1];
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    int base = 0;                                  // concatenation offset of the current sequence (uniform)
+    for (int s = s0; s < s1; ++s) {
+        int n = 0;                                 // valid colour ids of this sequence (padding is trailing)
+        while (n < C && color_ids[(size_t)s * C + n] >= 0) ++n;
+        const float* row = logits + (size_t)s * V;
+        const float none = divide_by_none ? row[none_id] : 1.0f;
+        for (int c = lane; c < n; c += 64) {
+            float v = row[color_ids[(size_t)s * C + c]];
+            if (divide_by_none) v = v / none;
+            if (bi == 0x7fffffff || better(v, base + c, bv, bi)) { bv = v; bi = base + c; }
+        }
+        base += n;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        out_idx[q] = bi == 0x7fffffff ? -1 : bi;
+        if (out_score) out_score[q] = bv;
+    }
+}
+
+int select_regions(const float* logits, int V, const int64_t* color_ids, int C, const int* query_first, int Q,
+                   int64_t none_id, int divide_by_none, int64_t* out_idx, float* out_score, hipStream_t s) {
+    if (Q <= 0 || V <= 0 || C <= 0 || none_id < 0 || none_id >= V) return CPT_ERR_SHAPE;
+    if (!logits || !color_ids || !query_first || !out_idx) return CPT_ERR_NULL;
+    select_regions_kernel<<<dim3(Q), dim3(64), 0, s>>>(logits, V, color_ids, C, query_first, none_id, divide_by_none, out_idx, out_score);
+    return CPT_OK;
+}
+
+// One wave per row: argmax over logits[row][ids[0..n_ids)] (gqa_cpt.py:598-601: answer scored at its first token)
+__global__ __launch_bounds__(64) void argmax_columns_kernel(const float* __restrict__ logits, int V, const int64_t* __restrict__ ids, int n_ids,
+                                                            int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const float* row = logits + (size_t)r * V;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < n_ids; c += 64) {
+        const float v = row[ids[c]];
+        if (bi == 0x7fffffff || better(v, c, bv, bi)) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        out_idx[r] = bi == 0x7fffffff ? -1 : bi;
+        if (out_val) out_val[r] = bv;
+    }
+}
+
+int argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids, int R, int64_t* out_idx, float* out_val, hipStream_t s) {
+    if (R <= 0 || V <= 0 || n_ids <= 0) return CPT_ERR_SHAPE;
+    if (!logits || !ids || !out_idx) return CPT_ERR_NULL;
+    argmax_columns_kernel<<<dim3(R), dim3(64), 0, s>>>(logits, V, ids, n_ids, out_idx, out_val);
+    return CPT_OK;
+}
+
 }  // namespace cpt

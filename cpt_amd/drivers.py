@@ -36,18 +36,13 @@ def val_queries(model, queries, none_id, device, few_shot=False, batch_queries=4
         with torch.no_grad():
             scores = model(cat["input_ids"], cat["segment_ids"], cat["attention_mask"], img_feats=cat["img_feats"],
                            mask_token_pos=cat["mask_token_pos"])[0]
-        # only the colour columns are needed on the host: gather them on the device first
-        ids = sorted({i for q in chunk for s in q["colors"] for i in s} | {none_id})
-        col = {v: j for j, v in enumerate(ids)}
-        small = scores[:, torch.tensor(ids, device=device)].float().cpu()
-        ptr = 0
-        for qi, q in enumerate(chunk):
-            P = q["input_ids"].size(0)
-            rows = small[ptr:ptr + P]
-            ptr += P
-            sets = [[col[i] for i in s] for s in q["colors"]]
-            idx, _, _ = scoring.select_region(rows, sets, q["rects"], col[none_id], few_shot=few_shot)
-            chosen[start - lo + qi] = idx
+        # colour gather + per-query argmax run on the device (cpt_select_regions): only indices leave the GPU
+        sets = [list(s) for q in chunk for s in q["colors"]]
+        first = [0]
+        for q in chunk:
+            first.append(first[-1] + q["input_ids"].size(0))
+        idx = scoring.select_regions_device(scores, sets, first, none_id, few_shot=few_shot)
+        chosen[start - lo:start - lo + len(chunk)] = idx
     allc = cdist.gather_fixed(chosen, len(queries), fill=-1).cpu().tolist()
     out = {}
     for gi, idx in enumerate(allc):

@@ -61,3 +61,44 @@ def nsp_choose(rel_scores, interval):
     logits = 1 - (rel_scores[:, :].softmax(-1)[:, 1].view(-1))
     n = rel_scores.size(0) // interval
     return logits, [int(logits[q * interval:(q + 1) * interval].argmax()) for q in range(n)]
+
+
+def select_regions_device(mask_scores, color_id_sets, query_first, none_id, few_shot=False, return_scores=False):
+    """Device-side region selection for a whole batch of queries (include/cpt_hip.h cpt_select_regions): the
+    (S, V) [MASK]-row logits stay on the GPU and only one index per query comes back.
+    mask_scores (S, V) CUDA fp32; color_id_sets: per sequence its colour-token ids; query_first: first sequence
+    index of every query plus the total (len Q+1).  Same result as ``select_region`` per query
+    (zeroshot/refcoco_cpt.py:224-246, fewshot/refcoco_cpt.py:277-295), torch.argmax tie-break included."""
+    from . import _lib as L
+    if not mask_scores.is_cuda:
+        raise RuntimeError("cpt_amd: select_regions_device needs the logits on the GPU (no CPU fallback)")
+    dev = mask_scores.device
+    S, V = mask_scores.shape
+    C = max(1, max((len(c) for c in color_id_sets), default=1))
+    ids = torch.full((S, C), -1, dtype=torch.int64)
+    for i, c in enumerate(color_id_sets):
+        if len(c):
+            ids[i, :len(c)] = torch.as_tensor(list(c), dtype=torch.int64)
+    ids = ids.to(dev)
+    qf = torch.as_tensor(list(query_first), dtype=torch.int32, device=dev)
+    Q = qf.numel() - 1
+    out = torch.empty(Q, dtype=torch.int64, device=dev)
+    sc = torch.empty(Q, dtype=torch.float32, device=dev) if return_scores else None
+    ms = mask_scores.contiguous()
+    L.check(L.lib().cpt_select_regions(ms.data_ptr(), V, ids.data_ptr(), C, qf.data_ptr(), Q, int(none_id), 1 if few_shot else 0,
+                                       out.data_ptr(), L.ptr(sc), L.stream_ptr()), "cpt_select_regions")
+    return (out, sc) if return_scores else out
+
+
+def argmax_columns_device(scores, ids):
+    """GQA answer scoring (gqa_cpt.py:598-601): argmax over the label-token columns, on the device."""
+    from . import _lib as L
+    if not scores.is_cuda:
+        raise RuntimeError("cpt_amd: argmax_columns_device needs the logits on the GPU (no CPU fallback)")
+    R, V = scores.shape
+    idt = torch.as_tensor(ids, dtype=torch.int64, device=scores.device).contiguous()
+    out = torch.empty(R, dtype=torch.int64, device=scores.device)
+    sc = scores.contiguous()
+    L.check(L.lib().cpt_argmax_columns(sc.data_ptr(), V, idt.data_ptr(), idt.numel(), R, out.data_ptr(), None, L.stream_ptr()),
+            "cpt_argmax_columns")
+    return out

@@ -236,6 +236,18 @@ int cpt_attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ct
 /* x[R][K] fp32 -> out[R][Kp] in `dtype`, zero-padded (region features / img weight, K=2054). */
 int cpt_pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, void* stream);
 
+/* Score extraction on the device: only indices go back to the host.
+ * cpt_select_regions: per query q, its proposal sequences are rows query_first[q] .. query_first[q+1]-1 of
+ * mask_logits [S][V]; sequence s contributes the logits at color_ids[s][0..C) (entries < 0 = trailing padding), in
+ * order, divided by its "none" logit when divide_by_none (fewshot/refcoco_cpt.py:291) or raw
+ * (zeroshot/refcoco_cpt.py:242); out_idx[q] = position of the maximum inside that concatenation with torch.argmax
+ * semantics (first maximum; NaN is maximal), -1 if the query has no colour; out_score[q] (may be NULL) its value.
+ * cpt_argmax_columns: out_idx[r] = argmax_j logits[r][ids[j]] (gqa_cpt.py:598-601). */
+int cpt_select_regions(const float* mask_logits, int V, const int64_t* color_ids, int C, const int32_t* query_first, int Q,
+                       int64_t none_id, int divide_by_none, int64_t* out_idx, float* out_score, void* stream);
+int cpt_argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids, int R, int64_t* out_idx, float* out_val,
+                       void* stream);
+
 /* Fold LayerNorm(gamma, beta) into the Linear (W [N][K] fp32, bias [N] or NULL) that consumes its output:
  * Wf = bf16(gamma[k] * W[n][k]), colc[n] = sum_k Wf[n][k], cold[n] = sum_k beta[k] W[n][k] + bias[n]. */
 int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,

@@ -199,3 +199,42 @@ def test_gemm_variants_agree(dev, variant):
             assert _stats("variant %d fp32" % variant, o32, ref) < 3e-5 * max(1.0, math.sqrt(K / 64))
     finally:
         L.check(L.lib().cpt_set_tuning(0, 3))
+
+
+def test_select_regions_device_matches_reference_rule(dev):
+    """Row a15 / 8(f).3 on the device: same index as the host rule of zeroshot/refcoco_cpt.py:224-246 (raw logits) and
+    fewshot/refcoco_cpt.py:277-295 (ratio to the "none" logit), including torch.argmax's first-max tie-break,
+    ragged colour sets, a query whose maximum sits in a later sequence, and NaN."""
+    from cpt_amd import scoring
+    from oracle import cpt_oracle as O
+    g = torch.Generator().manual_seed(3)
+    V, none_id = 3000, 2999
+    n_seq = [3, 1, 5, 2, 4]
+    sets, first = [], [0]
+    for n in n_seq:
+        for _ in range(n):
+            k = int(torch.randint(1, 6, (1,), generator=g))
+            sets.append([int(v) for v in torch.randperm(V - 1, generator=g)[:k]])
+        first.append(first[-1] + n)
+    S = first[-1]
+    scores = torch.randn(S, V, generator=g)
+    scores[:, none_id] = torch.rand(S, generator=g) + 0.5
+    # ties: two equal maxima in query 2 (first must win); NaN in query 3
+    scores[first[2] + 1, sets[first[2] + 1][0]] = 50.0
+    scores[first[2] + 3, sets[first[2] + 3][0]] = 50.0
+    scores[first[3] + 1, sets[first[3] + 1][0]] = float("nan")
+    sd = scores.to(dev)
+    for few in (False, True):
+        got, val = scoring.select_regions_device(sd, sets, first, none_id, few_shot=few, return_scores=True)
+        for q in range(len(n_seq)):
+            rows = scores[first[q]:first[q + 1]]
+            cs = sets[first[q]:first[q + 1]]
+            ref_idx, ref_sc = (O.select_region_fewshot if few else O.select_region_zeroshot)(rows, cs, none_id)
+            assert int(got[q]) == ref_idx, (few, q, int(got[q]), ref_idx)
+            if ref_sc[ref_idx] == ref_sc[ref_idx]:
+                assert float(val[q]) == float(ref_sc[ref_idx])          # bit-identical fp32 (IEEE division)
+    ids = [5, 17, 2998, 40, 41]
+    sc2 = torch.randn(7, V, generator=g)
+    sc2[3, 40] = sc2[3, 41] = 9.0
+    got = scoring.argmax_columns_device(sc2.to(dev), ids)
+    assert got.cpu().tolist() == sc2[:, ids].argmax(1).tolist()
