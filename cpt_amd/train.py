@@ -265,6 +265,69 @@ class FusedAdamW(object):
         eng.weights_updated(shadow_fresh=shadow is not None)
 
 
+    # ---- checkpointing: the reference saves no optimizer state (utils/save_model.py), so a few-shot
+    # run cannot resume; here the moments travel with the model, keyed by parameter NAME ------------------------------
+    def state_dict(self):
+        """{"state": {name: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...], "betas", "eps"}: the same
+        per-parameter entries as torch.optim.AdamW.state_dict(), as CPU tensors."""
+        self._ensure()
+        state = {}
+        for n, (off, num) in self.eng.offsets.items():
+            shape = tuple(self.eng._named()[n].shape) if hasattr(self.eng, "_named") else (num,)
+            state[n] = {"step": self.step_count,
+                        "exp_avg": self.m[off:off + num].view(shape).detach().cpu().clone(),
+                        "exp_avg_sq": self.v[off:off + num].view(shape).detach().cpu().clone()}
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        return {"state": state, "param_groups": groups, "betas": tuple(self.betas), "eps": self.eps,
+                "step_count": self.step_count}
+
+    def load_state_dict(self, sd):
+        self._ensure()
+        missing = [n for n in self.eng.offsets if n not in sd["state"]]
+        if missing:
+            raise RuntimeError("cpt_amd: optimizer state lacks %d parameters, e.g. %s" % (len(missing), missing[0]))
+        for n, (off, num) in self.eng.offsets.items():
+            e = sd["state"][n]
+            if e["exp_avg"].numel() != num:
+                raise RuntimeError("cpt_amd: optimizer state of %s has %d elements, expected %d" % (n, e["exp_avg"].numel(), num))
+            self.m[off:off + num].copy_(e["exp_avg"].reshape(-1))
+            self.v[off:off + num].copy_(e["exp_avg_sq"].reshape(-1))
+        self.step_count = int(sd.get("step_count", next(iter(sd["state"].values()))["step"]))
+        self.betas = tuple(sd.get("betas", self.betas))
+        self.eps = sd.get("eps", self.eps)
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in src.items() if k != "params"})
+
+
+def save_checkpoint(save_dir, model, optimizer=None, global_step=0, extra=None):
+    """HF-layout checkpoint (config.json + pytorch_model.bin via save_pretrained, as utils/save_model.py) PLUS
+    optimizer.pt and training_state.json, so that a few-shot run resumes where it stopped."""
+    import json
+    import os
+    os.makedirs(save_dir, exist_ok=True)
+    model.save_pretrained(save_dir)
+    if optimizer is not None:
+        torch.save(optimizer.state_dict(), os.path.join(save_dir, "optimizer.pt"))
+    with open(os.path.join(save_dir, "training_state.json"), "w") as f:
+        json.dump({"global_step": int(global_step), "extra": extra or {}}, f)
+
+
+def load_checkpoint(save_dir, model, optimizer=None):
+    """Loads weights in place (through the packed views, so the HIP path sees them) and the optimizer moments;
+    returns the saved global step."""
+    import json
+    import os
+    sd = torch.load(os.path.join(save_dir, "pytorch_model.bin"), map_location="cpu")
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    if [k for k in missing if "decoder.weight" not in k]:
+        raise RuntimeError("cpt_amd: checkpoint lacks parameters: %s" % missing[:3])
+    model.tie_weights()
+    if optimizer is not None:
+        optimizer.load_state_dict(torch.load(os.path.join(save_dir, "optimizer.pt"), map_location="cpu"))
+    p = os.path.join(save_dir, "training_state.json")
+    return json.load(open(p))["global_step"] if os.path.exists(p) else 0
+
+
 def build_optimizer(model, opts):
     """fewshot/refcoco_cpt.py:318-343 (opts.learning_rate, opts.weight_decay, opts.betas)."""
     return FusedAdamW(model, lr=opts.learning_rate, betas=tuple(opts.betas), weight_decay=opts.weight_decay)

@@ -180,3 +180,55 @@ def test_attention_backward_variants_agree(dev):
             continue
         rel, mx = _rel(grads[1][n], grads[0][n].cpu())
         assert rel < 3e-2, (n, rel, mx)
+
+
+def test_checkpoint_resume_reproduces_reference_trace(dev, golden_dir, tmp_path):
+    """save (weights in HF layout + AdamW moments + step) after step 1, load into a FRESH model and
+    optimizer, run steps 2-3: the losses and final parameters still match the reference's uninterrupted 3-step
+    trace, and the moments round-trip bit-exactly."""
+    from cpt_amd.train import build_optimizer, get_lr_sched, load_checkpoint, save_checkpoint
+    t = np.load(os.path.join(golden_dir, "tiny_train3.npz"))
+    g = np.load(os.path.join(golden_dir, "tiny_fwd_bwd.npz"))
+    cfg = cfgmod.tiny()
+    b = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+
+    class O(object):
+        learning_rate = float(t["lr0"])
+        weight_decay = float(t["wd"])
+        betas = (float(t["beta1"]), float(t["beta2"]))
+        warmup_steps = 1
+        num_train_steps = 3
+
+    def one_step(m, opt, step):
+        for gr in opt.param_groups:
+            gr["lr"] = get_lr_sched(step, O)
+        opt.zero_grad()
+        loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                    masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    m = _model(cfg, 1234, dev, "fp32")
+    opt = build_optimizer(m, O)
+    assert abs(one_step(m, opt, 0) - t["losses"][0]) < 2e-4
+    ck = str(tmp_path / "ckpt")
+    save_checkpoint(ck, m, opt, global_step=1)
+    assert sorted(os.listdir(ck)) == ["config.json", "optimizer.pt", "pytorch_model.bin", "training_state.json"]
+    m2 = _model(cfg, 999, dev, "fp32")                      # different weights: everything must come from the checkpoint
+    opt2 = build_optimizer(m2, O)
+    assert load_checkpoint(ck, m2, opt2) == 1
+    sd1, sd2 = opt.state_dict(), opt2.state_dict()
+    for n in sd1["state"]:
+        assert torch.equal(sd1["state"][n]["exp_avg"], sd2["state"][n]["exp_avg"])
+        assert torch.equal(sd1["state"][n]["exp_avg_sq"], sd2["state"][n]["exp_avg_sq"])
+    assert opt2.step_count == 1
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    for step in (1, 2):
+        assert abs(one_step(m2, opt2, step) - t["losses"][step]) < 2e-4
+    sd = m2.state_dict()
+    for k in t.files:
+        if k.startswith("after_"):
+            rel, mx = _rel(sd[k[6:]], t[k])
+            assert mx < 5e-5, (k, rel, mx)
