@@ -6,7 +6,8 @@
 // build runs with dropout disabled.
 //
 // gfx950 design: one 256-thread workgroup per (sequence, head, 128-query tile); the head's K
-// tile [L][64] (XOR-swizzled) and V^T tile [64][L] (+pad) are staged once in LDS; each of the 4
+// tile [L][64] (XOR-swizzled) and V tile (bf16: row-major, read back transposed by ds_read_b64_tr_b16 in
+// attn_core.h; fp32: V^T [64][L] + pad) are staged once in LDS; each of the 4
 // waves owns 32 query rows and keeps its whole score strip S^T = K.Q^T in MFMA accumulators
 // (sequence length <= 288, so no online softmax is needed).  Computing the TRANSPOSED scores puts
 // one query row per lane: the softmax row reduction is lane-local plus one cross-half shuffle,
@@ -103,14 +104,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     }
     __syncthreads();
     if (q0 >= L) return;   // whole wave has no query rows (uniform per wave)
-    if constexpr (LPT) {
+    if constexpr (LPT) {     // bf16: the shared core (attn_core.h); everything below is the fp32 parity path
         T* crow = ctx + ((size_t)b * L + min(q, L - 1)) * H + h * HD;
         T* prow = probs ? probs + (((size_t)b * heads + h) * L + min(q, L - 1)) * L : nullptr;
         attn_core_bf16<NKB>(fq, sK, sV, sMask, lane, q < L, crow, prow, L);
         return;
     }
 
-    // ---- S^T = K . Q^T : accumulator rows = keys, column (lane&31) = query ----
+    // ---- fp32: S^T = K . Q^T : accumulator rows = keys, column (lane&31) = query ----
     f32x16 st[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float s = st[kb][r] * (LPT ? 0.125f * LOG2E : 0.125f) + sMask[kb * 32 + key_of(r, fh)];
+            const float s = st[kb][r] * 0.125f + sMask[kb * 32 + key_of(r, fh)];
             st[kb][r] = s;
             mx = fmaxf(mx, s);
         }
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = LPT ? __builtin_amdgcn_exp2f(st[kb][r] - mx) : expf(st[kb][r] - mx);
+            const float p = expf(st[kb][r] - mx);
             st[kb][r] = p;
             sum += p;
         }
@@ -170,28 +171,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
 
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        if constexpr (sizeof(T) == 2) {
-            // O^T = V^T . P^T: two MFMA k-steps of 16 keys; operand slot j of half h <-> key 16*s + 4*h + (j&3) + 8*(j>>2).
-            // A operand = V^T (row = head-dim column db*32 + fr) by two transpose reads of 4 consecutive keys each,
-            // B operand = P^T (column = this lane's query): the probabilities already sit in that layout.
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pa;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pa[j] = (bf16)st[kb][8 * s2 + j];
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const unsigned char* vr = sV + (kb * 32 + 16 * s2 + 4 * fh + ((lane & 15) >> 2)) * VP16 +
-                                              (db * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-                    const bf16x4 lo = lds_read_tr16(vr);
-                    const bf16x4 hi = lds_read_tr16(vr + 8 * VP16);
-                    bf16x8 vb;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { vb[j] = lo[j]; vb[4 + j] = hi[j]; }
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pa, o[db], 0, 0, 0);
-                }
-            }
-        } else {
+        {
             // one v_mfma_f32_32x32x2_f32 per accumulator register: keys key_of(r,0) / key_of(r,1)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -208,23 +188,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     }
 
     // ---- store context rows (merge heads: column h*64 + d) ----
-    if constexpr (LPT) {
-        // O^T accumulators: register r <-> head-dim column db*32 + 8*(r>>2) + 4*fh + (r&3), lane&31 <-> query:
-        // four consecutive columns per register quad -> one 8-byte store
-        if (q < L) {
-            T* crow = ctx + ((size_t)b * L + q) * H + h * HD + 4 * fh;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 pk;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (bf16)o[db][4 * g + e];
-                    *reinterpret_cast<bf16x4*>(crow + db * 32 + 8 * g) = pk;
-                }
-        }
-        return;
-    }
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
