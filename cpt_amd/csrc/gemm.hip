@@ -462,8 +462,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     constexpr bool DO_GELU = EPI == CPT_EPI_GELU || EPI == CPT_EPI_LNCONS_GELU;
     const T* resid_lp = reinterpret_cast<const T*>(resid);      // EPI_RESID_LP: same rows, compute dtype
     const bool fold_resid = LNPROD && ex.g_in != nullptr;       // residual = LayerNorm(resid; st_in, g_in, b_in)
-    const bool vec_ok = (N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out) % 16 == 0) &&
-                        (!HAS_RESID || (ldr % 4 == 0 && ((uintptr_t)resid) % 16 == 0)) &&
+    // fp32 outputs without residual (e.g. the vocabulary decoder, ldo = 30522): rows are only 8-byte aligned, but 16-byte
+    // stores to dword-aligned addresses are legal (the HSA target runs in unaligned-access mode) -- no alignment demand.
+    // Everything else keeps natural alignment of its 8/16-byte accesses.
+    typedef f32x4 f32x4_u __attribute__((aligned(4)));
+    const bool out_ok = (sizeof(OT) == 4 && !HAS_RESID) ? true
+                        : ((N % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)out) % 16 == 0));
+    const bool vec_ok = out_ok && (!HAS_RESID || (ldr % 4 == 0 && ((uintptr_t)resid) % 16 == 0)) &&
                         (!bias || ((uintptr_t)bias) % 16 == 0);
     static_assert((16 * CH) % 64 == 0 && CH % 4 == 0, "slab read-back must fill whole waves");
     // row statistics -> (mean, rstd)
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
 #pragma unroll
                         for (int e = 0; e < 4; ++e) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, v[e]);
                     } else {
-                        *reinterpret_cast<f32x4*>(out + (size_t)row * ldo + col) = v;
+                        *reinterpret_cast<f32x4_u*>(out + (size_t)row * ldo + col) = v;
                     }
                     if constexpr (LNPROD) {
                         T* olp = reinterpret_cast<T*>(ex.out_lp) + (size_t)row * ldo + col;
