@@ -611,9 +611,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         else if constexpr (HAS_RESID) x += ax.r[it][e];
                         v[e] = x;
                     }
-                    if (abl & 16) {                      // ablation: finished values are not stored
-                        if (v[0] == 12345.678f) out[0] = from_f32<OT>(v[1] + v[2] + v[3]);
-                    } else if constexpr (sizeof(OT) == 2) {
+                    if constexpr (sizeof(OT) == 2) {
                         bf16x4 pk;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) pk[e] = (bf16)v[e];

@@ -277,7 +277,7 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *          per GEMM; fixed shapes 13 = 128x192 (3-stage), 11 = 192x192, 10 = 128x384, 14 = 384x192,
  *          15 = 128x192 two workgroups per CU, 16 = 128x192 with 4 waves of 64x96, 17 = 256x192,
  *          18 = 64x192 (small M)
- *   key 1  GEMM ablation bits: 1 no operand LDS-DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue, 16 no global stores,
+ *   key 1  GEMM ablation bits: 1 no operand LDS-DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue,
  *          32 fused QKV + attention kernel without its attention phase
  *   key 2  attention backward: 0 = generic fp32-math kernel, 1 (default) = MFMA kernel for bf16, L <= 128
  *   key 3  split-K target for the generic path
