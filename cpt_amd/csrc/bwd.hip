@@ -39,8 +39,47 @@ int transpose_cast(const void* in, int in_dtype, int ldi, void* out, int out_dty
 }
 
 // ---- column sums (bias gradients): out[c] += sum_r x[r][c] ----------------------------------------
+// 256 threads = 32 column groups (16 bytes each: 8 bf16 / 4 f32) x 8 row lanes; a block covers CS_ROWS rows of its
+// column span, reduces the 8 row lanes through LDS and issues one atomicAdd per column.
+constexpr int CS_ROWS = 128;
 template <typename TI>
-__global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ x, int ld, float* __restrict__ out, int R, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ x, int ld, float* __restrict__ out, int R, int C) {
+    constexpr int VE = 16 / (int)sizeof(TI);              // elements per 16-byte load
+    __shared__ float red[8][32 * VE + 1];
+    const int cg = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c0 = (blockIdx.x * 32 + cg) * VE;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    if (c0 + VE <= C) {
+        for (int r = r0 + ry; r < r1; r += 8) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(x + (size_t)r * ld + c0);
+            const TI* v = reinterpret_cast<const TI*>(&raw);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[e] += to_f32(v[e]);
+        }
+    } else {
+        for (int r = r0 + ry; r < r1; r += 8)
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+                if (c0 + e < C) acc[e] += to_f32(x[(size_t)r * ld + c0 + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) red[ry][cg * VE + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 32 * VE; c += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) t += red[y][c];
+        const int col = blockIdx.x * 32 * VE + c;
+        if (col < C) atomicAdd(&out[col], t);
+    }
+}
+
+// generic (rows not 16-byte aligned): one thread per column
+template <typename TI>
+__global__ __launch_bounds__(256) void colsum_scalar_kernel(const TI* __restrict__ x, int ld, float* __restrict__ out, int R, int C, int rows_per_block) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
@@ -51,39 +90,67 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ x, i
 
 int colsum(const void* x, int dtype, int ld, float* out, int R, int C, hipStream_t s) {
     if (R <= 0 || C <= 0) return CPT_ERR_SHAPE;
+    if (dtype != CPT_BF16 && dtype != CPT_F32) return CPT_ERR_DTYPE;
+    const int es = dtype == CPT_BF16 ? 2 : 4, ve = 16 / es;
+    if (((size_t)ld * es) % 16 == 0 && ((uintptr_t)x % 16) == 0) {
+        dim3 grid((C + 32 * ve - 1) / (32 * ve), (R + CS_ROWS - 1) / CS_ROWS), block(256);
+        if (dtype == CPT_BF16) colsum_kernel<bf16><<<grid, block, 0, s>>>((const bf16*)x, ld, out, R, C);
+        else colsum_kernel<float><<<grid, block, 0, s>>>((const float*)x, ld, out, R, C);
+        return CPT_OK;
+    }
     const int rpb = 64;
     dim3 grid((C + 255) / 256, (R + rpb - 1) / rpb), block(256);
-    if (dtype == CPT_BF16) colsum_kernel<bf16><<<grid, block, 0, s>>>((const bf16*)x, ld, out, R, C, rpb);
-    else if (dtype == CPT_F32) colsum_kernel<float><<<grid, block, 0, s>>>((const float*)x, ld, out, R, C, rpb);
-    else return CPT_ERR_DTYPE;
+    if (dtype == CPT_BF16) colsum_scalar_kernel<bf16><<<grid, block, 0, s>>>((const bf16*)x, ld, out, R, C, rpb);
+    else colsum_scalar_kernel<float><<<grid, block, 0, s>>>((const float*)x, ld, out, R, C, rpb);
     return CPT_OK;
 }
 
-// ---- GELU forward / backward on [n] elements ---------------------------------------------------
+// ---- GELU forward / backward on [n] elements: 16 bytes per thread --------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ u, T* __restrict__ h, size_t n) {
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    constexpr int VE = 16 / (int)sizeof(T);
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VE;
     if (i >= n) return;
+    if (i + VE <= n) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(u + i);
+        const T* v = reinterpret_cast<const T*>(&raw);
+        uint4 o;
+        T* w = reinterpret_cast<T*>(&o);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (i + e < n) h[i + e] = from_f32<T>(gelu_for<T>(to_f32(u[i + e])));
+        for (int e = 0; e < VE; ++e) w[e] = from_f32<T>(gelu_for<T>(to_f32(v[e])));
+        *reinterpret_cast<uint4*>(h + i) = o;
+    } else {
+        for (size_t e = i; e < n; ++e) h[e] = from_f32<T>(gelu_for<T>(to_f32(u[e])));
+    }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ u, T* __restrict__ du, size_t n) {
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    constexpr int VE = 16 / (int)sizeof(T);
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VE;
     if (i >= n) return;
+    if (i + VE <= n) {
+        const uint4 ra = *reinterpret_cast<const uint4*>(dh + i), rb = *reinterpret_cast<const uint4*>(u + i);
+        const T* a = reinterpret_cast<const T*>(&ra);
+        const T* b = reinterpret_cast<const T*>(&rb);
+        uint4 o;
+        T* w = reinterpret_cast<T*>(&o);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (i + e < n) du[i + e] = from_f32<T>(to_f32(dh[i + e]) * gelu_erf_grad(to_f32(u[i + e])));
+        for (int e = 0; e < VE; ++e) w[e] = from_f32<T>(to_f32(a[e]) * gelu_erf_grad(to_f32(b[e])));
+        *reinterpret_cast<uint4*>(du + i) = o;
+    } else {
+        for (size_t e = i; e < n; ++e) du[e] = from_f32<T>(to_f32(dh[e]) * gelu_erf_grad(to_f32(u[e])));
+    }
 }
 int gelu_fwd(const void* u, void* h, int dtype, size_t n, hipStream_t s) {
-    dim3 grid((unsigned)((n / 4 + 255) / 256 + 1)), block(256);
+    const size_t ve = dtype == CPT_BF16 ? 8 : 4;
+    dim3 grid((unsigned)(((n + ve - 1) / ve + 255) / 256)), block(256);
     if (dtype == CPT_BF16) gelu_fwd_kernel<bf16><<<grid, block, 0, s>>>((const bf16*)u, (bf16*)h, n);
     else gelu_fwd_kernel<float><<<grid, block, 0, s>>>((const float*)u, (float*)h, n);
     return CPT_OK;
 }
 int gelu_bwd(const void* dh, const void* u, void* du, int dtype, size_t n, hipStream_t s) {
-    dim3 grid((unsigned)((n / 4 + 255) / 256 + 1)), block(256);
+    const size_t ve = dtype == CPT_BF16 ? 8 : 4;
+    dim3 grid((unsigned)(((n + ve - 1) / ve + 255) / 256)), block(256);
     if (dtype == CPT_BF16) gelu_bwd_kernel<bf16><<<grid, block, 0, s>>>((const bf16*)dh, (const bf16*)u, (bf16*)du, n);
     else gelu_bwd_kernel<float><<<grid, block, 0, s>>>((const float*)dh, (const float*)u, (float*)du, n);
     return CPT_OK;
