@@ -135,10 +135,10 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dh,
         uint4 o;
         T* w = reinterpret_cast<T*>(&o);
 #pragma unroll
-        for (int e = 0; e < VE; ++e) w[e] = from_f32<T>(to_f32(a[e]) * gelu_erf_grad(to_f32(b[e])));
+        for (int e = 0; e < VE; ++e) w[e] = from_f32<T>(to_f32(a[e]) * gelu_grad_for<T>(to_f32(b[e])));
         *reinterpret_cast<uint4*>(du + i) = o;
     } else {
-        for (size_t e = i; e < n; ++e) du[e] = from_f32<T>(to_f32(dh[e]) * gelu_erf_grad(to_f32(u[e])));
+        for (size_t e = i; e < n; ++e) du[e] = from_f32<T>(to_f32(dh[e]) * gelu_grad_for<T>(to_f32(u[e])));
     }
 }
 int gelu_fwd(const void* u, void* h, int dtype, size_t n, hipStream_t s) {

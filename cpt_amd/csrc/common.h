@@ -66,12 +66,32 @@ __device__ __forceinline__ float gelu_fast(float x) {
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<bf16>(float x) { return gelu_fast(x); }
+template <typename T> __device__ __forceinline__ float gelu_grad_for(float x);
+// d/dx gelu of the bf16 training path: Phi(x) + x phi(x) with Phi from the same A&S 7.1.28 form as gelu_fast2
+// (r^16 already carries the factor 0.5: Phi = 1 - r^16 for x >= 0, r^16 for x < 0) and phi by one v_exp_f32;
+// |error| < 1e-6.  The fp32 parity path keeps libm (gelu_erf_grad).
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float ax = fabsf(x);
+    float p = fmaf(ax, 5.6212996640e-06f, 5.1055209009e-05f);
+    p = fmaf(p, ax, 3.9686137011e-05f);
+    p = fmaf(p, ax, 3.4227392389e-03f);
+    p = fmaf(p, ax, 2.2076998457e-02f);
+    p = fmaf(p, ax, 5.2075163037e-02f);
+    p = fmaf(p, ax, 1.0442737824e+00f);
+    float r = __builtin_amdgcn_rcpf(p);
+    r = r * r; r = r * r; r = r * r; r = r * r;
+    const float cdf = x >= 0.f ? 1.0f - r : r;
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+    return fmaf(x, pdf, cdf);
+}
 // d/dx gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+template <> __device__ __forceinline__ float gelu_grad_for<float>(float x) { return gelu_erf_grad(x); }
+template <> __device__ __forceinline__ float gelu_grad_for<bf16>(float x) { return gelu_grad_fast(x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
