@@ -99,7 +99,7 @@ FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
     w.imgp = take((size_t)B * Li * d.img_dim_pad * es);
     w.rows = take(hr * H * es);
     w.rows_f32 = take((size_t)B * H * 4);
-    w.stats = take((size_t)d.layers * 2 * M * 2 * 4);
+    w.stats = take((size_t)d.layers * 2 * cpt::ln_stat_slots(H) * M * 2 * 4);
     w.t1 = take(hr * H * 4);
     w.t2 = lp ? take(hr * H * 2) : take(hr * H * 4);
     w.pooled_f32 = take((size_t)B * H * 4);
@@ -296,15 +296,14 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     if (fold) {
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
         // producer GEMMs accumulate their row sums, the consumer GEMMs normalise in their epilogue.
-        float* stats = (float*)(ws + w.stats);
-        hipError_t e = hipMemsetAsync(stats, 0, (size_t)d.layers * 2 * M * 2 * sizeof(float), s);
-        if (e != hipSuccess) return fail(CPT_ERR_HIP - (int)e, "zero LayerNorm statistics: %s", hipGetErrorString(e));
+        float* stats = (float*)(ws + w.stats);         // [layers][2] tables of [M][slots][2] partial row sums (no zeroing needed)
+        const size_t tbl = (size_t)cpt::ln_stat_slots(H) * M * 2;
         for (int l = 0; l < d.layers; ++l) {
             const cpt_layer& y = m->layers[l];
             const cpt_layer_fold& f = m->fold[l];
-            float* st1 = stats + ((size_t)l * 2 + 0) * M * 2;
-            float* st2 = stats + ((size_t)l * 2 + 1) * M * 2;
-            const float* st2p = l > 0 ? stats + ((size_t)(l - 1) * 2 + 1) * M * 2 : nullptr;
+            float* st1 = stats + ((size_t)l * 2 + 0) * tbl;
+            float* st2 = stats + ((size_t)l * 2 + 1) * tbl;
+            const float* st2p = l > 0 ? stats + ((size_t)(l - 1) * 2 + 1) * tbl : nullptr;
             const cpt_layer* yp = l > 0 ? &m->layers[l - 1] : nullptr;
             if (fuse_attn) {
               Scope p(CPT_K_GEMM_QKV, s);      // QKV projection + attention, one kernel; q/k/v never reach HBM

@@ -151,10 +151,15 @@ constexpr int CPT_EPI_ATTN_LN = 10;    // internal: same, A operand is a pre-Lay
 // ---------------------------------------------------------------------------------------------
 // extra epilogue operands of the LayerNorm-folding modes (see cpt_abi.hip, "folded LayerNorm")
 struct EpiX {
-    const float* st_in;    // [M][2] row sums (sum, sum of squares) of the LayerNorm INPUT this GEMM reads / of the residual source
+    // Row statistics travel as PARTIAL sums, one slot per 96-column block of the producing GEMM: [M][slots][2]
+    // (sum, sum of squares).  Every producer wave owns exactly one slot per row (plain stores: no atomics, nothing to
+    // zero), and every reader adds the `parts` slots in index order, so the statistics are bit-reproducible.
+    const float* st_in;    // partial row sums of the LayerNorm INPUT this GEMM reads / of the residual source
+    int st_in_parts;       // number of slots in st_in
     const float* g_in;     // LNPROD: gain of the LayerNorm applied to the residual source on the fly (NULL: residual used as is)
     const float* b_in;
-    float* st_out;         // LNPROD: [M][2] row sums of this GEMM's output (atomically accumulated; caller zeroes)
+    float* st_out;         // LNPROD: partial row sums of this GEMM's output, slot = output column / 96
+    int st_out_slots;      // slots per row of st_out (ln_stat_slots of this GEMM's N)
     void* out_lp;          // LNPROD: copy of the output in the compute dtype
     const float* colc;     // LNCONS: c[n] = sum_k W'[n][k]  (W' = gain-folded weight as the MFMA sees it)
     const float* cold;     // LNCONS: d[n] = sum_k beta[k] W[n][k] + bias[n]
@@ -164,6 +169,37 @@ struct EpiX {
 };
 
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+// Sum of the partial row sums of `row` in slot order.  Table layout [M][slots][2] with `slots` = parts rounded up to
+// an even number (ln_stat_slots): the partial sums of one row are contiguous (64 bytes for hidden = 768), so a reader
+// fetches them as 16-byte pairs of slots in one unrolled, branch-free batch.  Slots past `parts` hold garbage and
+// are skipped by a select.
+template <int MAXQ>   // MAXQ 16-byte loads = 2*MAXQ slots
+__device__ __forceinline__ void sum_parts_n(const float* __restrict__ st, int parts, int slots, int row, float& sum, float& sq) {
+    const f32x4* base = reinterpret_cast<const f32x4*>(st + (size_t)row * slots * 2);
+    const int nq = slots >> 1;
+    f32x4 v[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) v[q] = base[min(q, nq - 1)];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const bool u0 = 2 * q < parts, u1 = 2 * q + 1 < parts;      // (select, not multiply: an unused slot may hold NaN)
+        sum += u0 ? v[q][0] : 0.f; sq += u0 ? v[q][1] : 0.f;
+        sum += u1 ? v[q][2] : 0.f; sq += u1 ? v[q][3] : 0.f;
+    }
+}
+__device__ __forceinline__ void sum_parts(const float* __restrict__ st, int parts, int row, float& sum, float& sq) {
+    const int slots = (parts + 1) & ~1;
+    sum = 0.f; sq = 0.f;
+    if (parts <= 8) sum_parts_n<4>(st, parts, slots, row, sum, sq);
+    else if (parts <= 12) sum_parts_n<6>(st, parts, slots, row, sum, sq);
+    else {
+        for (int p = 0; p < parts; ++p) {
+            const float2 v = *reinterpret_cast<const float2*>(st + ((size_t)row * slots + p) * 2);
+            sum += v.x; sq += v.y;
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1>
@@ -409,9 +445,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         const int trow = wm * 32 + fr;                // token row inside the tile
         float mu = 0.f, rs = 1.f;
         if constexpr (EPI == CPT_EPI_ATTN_LN) {
-            const float2 s2 = *reinterpret_cast<const float2*>(ex.st_in + 2 * (size_t)min(m0 + trow, M - 1));
-            mu = s2.x * ex.inv_h;
-            rs = rsqrtf(fmaxf(s2.y * ex.inv_h - mu * mu, 0.f) + ex.eps);
+            float sm, sq;
+            sum_parts(ex.st_in, ex.st_in_parts, min(m0 + trow, M - 1), sm, sq);
+            mu = sm * ex.inv_h;
+            rs = rsqrtf(fmaxf(sq * ex.inv_h - mu * mu, 0.f) + ex.eps);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -472,7 +509,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         (!bias || ((uintptr_t)bias) % 16 == 0);
     static_assert((16 * CH) % 64 == 0 && CH % 4 == 0, "slab read-back must fill whole waves");
     // row statistics -> (mean, rstd)
-    auto stats_of = [&](float sum, float sq, float& mu, float& rs) {
+    auto stats_of = [&](int row, float& mu, float& rs) {      // adds the partial sums of `row` in slot order
+        float sum, sq;
+        sum_parts(ex.st_in, ex.st_in_parts, row, sum, sq);
         mu = sum * ex.inv_h;
         rs = rsqrtf(fmaxf(sq * ex.inv_h - mu * mu, 0.f) + ex.eps);
     };
@@ -481,7 +520,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         float x;
         if constexpr (LNCONS) {
             float mu, rs;
-            stats_of(ex.st_in[2 * row], ex.st_in[2 * row + 1], mu, rs);
+            stats_of(row, mu, rs);
             x = rs * (a - mu * ex.colc[col]) + ex.cold[col];
         } else {
             x = a + (bias ? bias[col] : 0.f);
@@ -494,7 +533,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             float r = resid[(size_t)row * ldr + col];
             if (fold_resid) {
                 float mu, rs;
-                stats_of(ex.st_in[2 * row], ex.st_in[2 * row + 1], mu, rs);
+                stats_of(row, mu, rs);
                 r = (r - mu) * rs * ex.g_in[col] + ex.b_in[col];
             }
             x += r;
@@ -528,8 +567,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             if (lane < MI * 32) {
                 float2 ms = {0.f, 1.f};
                 if (LNCONS || fold_resid) {
-                    const float2 s2 = *reinterpret_cast<const float2*>(ex.st_in + 2 * (size_t)(wrow0 + lane));
-                    stats_of(s2.x, s2.y, ms.x, ms.y);
+                    stats_of(wrow0 + lane, ms.x, ms.y);
                 }
                 side_row[lane] = ms;
             }
@@ -635,6 +673,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         *reinterpret_cast<f32x4*>(slab + rr * CPW + ch * 16) = v;      // finished values back for the row sums
                     }
                 } else {
+                    f32x4 fin = {0.f, 0.f, 0.f, 0.f};                  // finished values; 0 outside the matrix
                     if (row < M) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -642,18 +681,17 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                                 const float x = finish1(v[e], row, col + e);
                                 if constexpr (EPI == CPT_EPI_ATOMIC && sizeof(OT) == 4) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, x);
                                 else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
-                                if constexpr (LNPROD) {
-                                    reinterpret_cast<T*>(ex.out_lp)[(size_t)row * ldo + col + e] = from_f32<T>(x);
-                                    atomicAdd(ex.st_out + 2 * (size_t)row, x);
-                                    atomicAdd(ex.st_out + 2 * (size_t)row + 1, x * x);
-                                }
+                                if constexpr (LNPROD) reinterpret_cast<T*>(ex.out_lp)[(size_t)row * ldo + col + e] = from_f32<T>(x);
+                                fin[e] = x;
                             }
                         }
                     }
+                    if constexpr (LNPROD) *reinterpret_cast<f32x4*>(slab + rr * CPW + ch * 16) = fin;
                 }
             }
-            if constexpr (LNPROD && FULL) {
-                // row sums of the finished slice: 4 lanes per row, CH/4 chunks each, two shuffles, 2 atomics per row
+            if constexpr (LNPROD) {
+                // row sums of the finished slice: 4 lanes per row, CH/4 chunks each, two shuffles, then ONE 8-byte store
+                // into this wave's own slot (column block wcol0 / 96) of the partial-sum table
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const int r16 = lane >> 2, part = lane & 3;
                 float sm = 0.f, sq = 0.f;
@@ -665,10 +703,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                 }
                 sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
                 sm += __shfl_xor(sm, 2, 64); sq += __shfl_xor(sq, 2, 64);
-                if (part == 0) {
-                    atomicAdd(ex.st_out + 2 * (size_t)(wrow0 + sl * 16 + r16), sm);
-                    atomicAdd(ex.st_out + 2 * (size_t)(wrow0 + sl * 16 + r16) + 1, sq);
-                }
+                static_assert(!LNPROD || WCOLS == 96, "statistics slots are 96 columns wide");
+                const int srow = wrow0 + sl * 16 + r16;
+                if (part == 0 && srow < M)
+                    *reinterpret_cast<float2*>(ex.st_out + 2 * ((size_t)srow * ex.st_out_slots + wcol0 / WCOLS)) = float2{sm, sq};
             }
             // (LDS operations of one wave execute in issue order: the next slice's writes cannot pass these reads)
         }
@@ -847,13 +885,16 @@ int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw,
 // ---- LayerNorm folded into the GEMMs around it (bf16 throughput path) -------------------------------
 // Producer: out_f32 = A.W^T + bias + R, where R = resid or LayerNorm(resid; st_in, g_in, b_in) computed on
 // the fly; also writes the bf16 copy and accumulates the row sums (sum, sum of squares) of out into st_out.
+int ln_stat_parts(int n_cols) { return (n_cols + 95) / 96; }     // 96-column blocks of an n_cols-wide producer
+int ln_stat_slots(int n_cols) { return (ln_stat_parts(n_cols) + 1) & ~1; }   // slots per row of its table [M][slots][2]
+
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
                  float* out_f32, void* out_lp, float* st_out, int ldo, int M, int N, int K, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
     if (!A || !W || !resid || !out_f32 || !out_lp || !st_out) return CPT_ERR_NULL;
     EpiX ex = {};
-    ex.st_in = st_in; ex.g_in = g_in; ex.b_in = b_in; ex.st_out = st_out; ex.out_lp = out_lp;
+    ex.st_in = st_in; ex.st_in_parts = ln_stat_parts(hidden); ex.g_in = g_in; ex.b_in = b_in; ex.st_out = st_out; ex.st_out_slots = ln_stat_slots(N); ex.out_lp = out_lp;
     ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
     launch_fast<bf16, CPT_EPI_LNPROD, float>(g_gemm_variant >= 3 ? g_gemm_variant : 3, (const bf16*)A, lda, (const bf16*)W, ldw, bias,
                                             resid, ldr, out_f32, ldo, M, N, K, s, &ex);
@@ -867,7 +908,7 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
     if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
     if (!A || !Wf || !st_in || !colc || !cold || !out_lp) return CPT_ERR_NULL;
     EpiX ex = {};
-    ex.st_in = st_in; ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
+    ex.st_in = st_in; ex.st_in_parts = ln_stat_parts(hidden); ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
     const int v = g_gemm_variant >= 3 ? g_gemm_variant : 3;
     if (gelu) launch_fast<bf16, CPT_EPI_LNCONS_GELU, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
     else launch_fast<bf16, CPT_EPI_LNCONS, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
@@ -899,7 +940,7 @@ int gemm_qkv_attn(const void* A, int lda, const void* W, int ldw, const float* b
     if (B <= 0 || L <= 0 || L > 128 || heads <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8 || ldo % 4) return CPT_ERR_SHAPE;
     if (!A || !W || !ctx || (st_in && (!colc || !cold))) return CPT_ERR_NULL;
     EpiX ex = {};
-    ex.st_in = st_in; ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
+    ex.st_in = st_in; ex.st_in_parts = ln_stat_parts(hidden); ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
     ex.mask = mask; ex.seq_len = L; ex.heads = heads;
     const int M = B * L, N = 3 * heads * 64;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W; bf16* c = (bf16*)ctx;

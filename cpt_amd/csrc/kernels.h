@@ -52,6 +52,8 @@ int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw,
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
                  float* out_f32, void* out_lp, float* st_out, int ldo, int M, int N, int K, hipStream_t s);
+int ln_stat_parts(int n_cols);      // 96-column blocks of a gemm_ln_prod of n_cols columns
+int ln_stat_slots(int n_cols);      // slots per row of the partial row-sum table [M][slots][2] it fills
 int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
                  float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s);
 // fused QKV projection + self-attention (bf16, L <= 128); st_in NULL: plain bias, else LayerNorm folded (colc/cold);

@@ -157,7 +157,7 @@ def test_config2_vs_oracle(dev, mode):
         got64 = m(D["input_ids"], D["segment_ids"], D["attention_mask"], img_feats=D["img_feats"],
                   mask_token_pos=D["mask_token_pos"])[0]
     assert torch.isfinite(got64).all()
-    assert _stats("B=64 rows 0..7 vs B=8", got64[:8], got.cpu()) < (1e-4 if mode == "fp32" else 2e-2)
+    assert _stats("B=64 rows 0..7 vs B=8", got64[:8], got.cpu()) < 1e-6          # observed: identical bits in both modes
 
 
 def test_bf16_folded_layernorm_and_fused_attention(dev):
@@ -202,3 +202,22 @@ def test_bf16_folded_layernorm_and_fused_attention(dev):
     # the all-row head's [MASK] rows are the [MASK]-row head's output
     r = res[(True, 1)]
     assert _stats("all-row head at [MASK]", r[1][torch.arange(6), pos], r[0]) < 2e-2
+
+
+def test_bf16_forward_is_bit_reproducible(dev):
+    """The fused bf16 encoder has no atomics on its data path (LayerNorm statistics travel as per-column-block partial
+    sums added in slot order): the same batch gives the same bits run after run, and a sequence's logits do not
+    depend on what else is in the batch."""
+    cfg = cfgmod.oscar_base()
+    m, _ = _model(cfg, 88, dev, "bf16")
+    b = _dev_batch(synth.make_batch(64, cfg, seed=5, vary_regions=True), dev)
+    outs = []
+    with torch.no_grad():
+        for _ in range(3):
+            outs.append(m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                          mask_token_pos=b["mask_token_pos"])[0].clone())
+        sub = {k: v[8:24].contiguous() for k, v in b.items()}
+        part = m(sub["input_ids"], sub["segment_ids"], sub["attention_mask"], img_feats=sub["img_feats"],
+                 mask_token_pos=sub["mask_token_pos"])[0]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0][8:24], part)
