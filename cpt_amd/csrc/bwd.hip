@@ -28,8 +28,52 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
     }
 }
 
+// bf16 -> bf16 fast path: a 64 x 64 tile goes to LDS row-major with 16-byte accesses (pitch 192 B, the conflict-free
+// pitch of the transpose read measured for attention's V), and comes back through ds_read_b64_tr_b16: two transpose
+// reads give a lane 8 consecutive input rows of ONE column = 16 contiguous bytes of an output row.  The four 16-lane
+// groups of a wave take adjacent row chunks of the same 16 output rows, so a store instruction writes 64-byte runs.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ in, int ldi, bf16* __restrict__ out,
+                                                             int ldo, int R, int C) {
+    constexpr int PITCH = 192;
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * PITCH];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256, rr = idx >> 3, ch = idx & 7;      // 64 rows x 8 chunks of 8 columns
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + rr < R && c0 + ch * 8 < C) v = *reinterpret_cast<const uint4*>(in + (size_t)(r0 + rr) * ldi + c0 + ch * 8);
+        *reinterpret_cast<uint4*>(tile + rr * PITCH + ch * 16) = v;
+    }
+    __syncthreads();
+    const int grp = lane >> 4, i16 = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c16 = wave, rchunk = it * 4 + grp;                      // 16 output rows (columns c16*16 ..), rows 8*rchunk ..
+        const unsigned char* p = tile + (rchunk * 8 + (i16 >> 2)) * PITCH + (c16 * 16 + 4 * (i16 & 3)) * 2;
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * PITCH));
+        const int oc = c0 + c16 * 16 + i16, orow0 = r0 + rchunk * 8;      // output row oc, columns orow0 .. orow0+7
+        if (oc < C && orow0 < ldo) {
+            uint4 o;
+            o.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+            o.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+            o.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+            o.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+            *reinterpret_cast<uint4*>(out + (size_t)oc * ldo + orow0) = o;
+        }
+    }
+}
+
 int transpose_cast(const void* in, int in_dtype, int ldi, void* out, int out_dtype, int ldo, int R, int C, hipStream_t s) {
     if (R <= 0 || C <= 0 || ldo < R || ldi < C) return CPT_ERR_SHAPE;
+    if (in_dtype == CPT_BF16 && out_dtype == CPT_BF16 && ldi % 8 == 0 && ldo % 8 == 0 && C % 8 == 0 &&
+        ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+        dim3 grid((C + 63) / 64, (ldo + 63) / 64), block(256);
+        transpose_bf16_kernel<<<grid, block, 0, s>>>((const bf16*)in, ldi, (bf16*)out, ldo, R, C);
+        return CPT_OK;
+    }
     dim3 grid((C + 63) / 64, (ldo + 63) / 64), block(256);
     if (in_dtype == CPT_F32 && out_dtype == CPT_F32) transpose_kernel<float, float><<<grid, block, 0, s>>>((const float*)in, ldi, (float*)out, ldo, R, C);
     else if (in_dtype == CPT_F32 && out_dtype == CPT_BF16) transpose_kernel<float, bf16><<<grid, block, 0, s>>>((const float*)in, ldi, (bf16*)out, ldo, R, C);
