@@ -189,3 +189,44 @@ def test_region_stager_matches_host_decode(dev):
                 ref[p, :len(seq)] = torch.from_numpy(np.stack(seq))
         assert torch.equal(feats.cpu(), ref)
         assert mask.cpu().sum(1).tolist() == counts
+
+
+@pytest.mark.parametrize("shape", [("base", 1, 70, 50), ("base", 5, 78, 50), ("base", 3, 28, 5), ("large", 3, 70, 50)])
+def test_fused_bf16_encoder_odd_shapes(dev, shape):
+    """The fused bf16 forms (folded LayerNorm, QKV + attention in one kernel) at the shapes the bench does not visit:
+    a single sequence (M < one tile), L = 128 exactly, L = 33 (last query block nearly empty), and 16 heads / H = 1024
+    (11 statistics slots: an odd count).  Fusing attention alone must not change a bit; the fully fused encoder
+    must stay inside the bf16 band of the fp32 parity mode."""
+    from cpt_amd import _lib as L
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    kind, B, Lt, Li = shape
+    cfg = cfgmod.oscar_base(num_hidden_layers=3) if kind == "base" else cfgmod.oscar_large(num_hidden_layers=2)
+    cfg.max_position_embeddings = max(cfg.max_position_embeddings, Lt)
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, 7, head="cpt"))
+    m.tie_weights()
+    m.to(dev).eval()
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, cfg, seed=9, max_seq_len=Lt, img_seq_len=Li, vary_regions=True).items()}
+
+    def run():
+        with torch.no_grad():
+            return m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                     mask_token_pos=b["mask_token_pos"])[0].float().cpu()
+    m.set_compute_dtype("fp32")
+    ref = run()
+    m.set_compute_dtype("bf16")
+    res = {}
+    try:
+        for fold, fuse in ((False, 0), (False, 1), (True, 0), (True, 1)):
+            m._engine().fold_ln = fold
+            L.check(L.lib().cpt_set_tuning(6, fuse), "cpt_set_tuning")
+            res[(fold, fuse)] = run()
+    finally:
+        L.lib().cpt_set_tuning(6, 1)
+    assert torch.equal(res[(False, 0)], res[(False, 1)])
+    assert torch.equal(res[(True, 0)], res[(True, 1)])
+    band = (res[(False, 0)] - ref).abs().max().item()
+    for k, v in res.items():
+        err = (v - ref).abs().max().item()
+        print(shape, k, "max |bf16 - fp32| = %.3e" % err)
+        assert err < max(2.5 * band, 0.05)
