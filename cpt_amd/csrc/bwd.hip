@@ -311,7 +311,7 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s) {
     if (R <= 0 || H % 4 || H > 256 * LNB_MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!dy || !x || !g || !dg || !db) return CPT_ERR_NULL;
-    const int rpb = R >= 4096 ? 16 : 8;
+    const int rpb = R >= 2048 ? 16 : 8;      // rows per block: fewer blocks = fewer dgamma/dbeta atomics (2*H per block)
     dim3 grid((R + rpb - 1) / rpb), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
 #define LNB(LPT, GI) ln_bwd_kernel<LPT, GI><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb)
