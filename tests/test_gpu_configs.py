@@ -56,6 +56,12 @@ def test_gqa_shape_answer_gather(dev, mode):
     assert err < (1e-3 if mode == "fp32" else 0.1)
     if mode == "fp32":
         assert (got.argmax(1) == ref.argmax(1)).all()
+    # the answer gather + argmax on the device (cpt_argmax_columns) picks what the host rule picks from the same logits
+    from cpt_amd import scoring
+    with torch.no_grad():
+        full = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"],
+                 mask_token_pos=d["mask_token_pos"])[0]
+    assert scoring.argmax_columns_device(full, ans.tolist()).cpu().tolist() == full[:, ans.to(dev)].argmax(1).cpu().tolist()
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
