@@ -11,11 +11,11 @@ LIB_PATH = os.path.join(HERE, "libcpt_hip.so")
 CPT_F32, CPT_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID = 0, 1, 2, 3
 OUT_SEQ, OUT_POOLED, OUT_MASK_LOGITS, OUT_ALL_LOGITS, OUT_LOSS, OUT_REL = 1, 2, 4, 8, 16, 32
-SAVE_FOR_BWD = 1024
 K_NAMES = ["gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up", "gemm_ffn_down",
            "embed_ln", "img_proj", "head", "op"]
 
 vp, i32, i64p, f32p = C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)      # cpt_bucket_fn (host callback of cpt_train_{fwd,bwd}_ex); None = NULL
 
 
 class Dims(C.Structure):
@@ -72,6 +72,9 @@ _SIGS = {
     "cpt_train_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int]),
     "cpt_train_fwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), vp, C.c_size_t, vp]),
     "cpt_train_bwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(ModelGrads), C.c_float, vp, C.c_size_t, vp]),
+    "cpt_train_fwd_ex": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), vp, C.c_size_t, vp, BUCKET_CB, vp]),
+    "cpt_train_bwd_ex": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(ModelGrads), C.c_float, vp, vp, C.c_size_t, vp,
+                                   BUCKET_CB, vp]),
     "cpt_adamw": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                             C.c_int, C.c_float, vp]),
     "cpt_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int,

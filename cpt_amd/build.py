@@ -11,6 +11,8 @@ LIB = os.path.join(HERE, "libcpt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result", "-I" + os.path.join(os.path.dirname(HERE), "include")]
+if os.environ.get("CPT_ABLATION"):          # diagnostic build: GEMM ablation bits live (tools/abl_sweep.sh)
+    FLAGS.append("-DCPT_ABLATION")
 
 
 def _sources():

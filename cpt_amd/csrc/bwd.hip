@@ -458,18 +458,20 @@ int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s)
 // out[r][c] = x[r][c] * scale / max(count,1) for c < C, 0 for C <= c < ldo; count read from device
 template <typename TO>
 __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ x, const float* __restrict__ loss_acc,
-                                                         float scale, TO* __restrict__ out, int R, int C, int ldo) {
+                                                         float scale, const float* __restrict__ dscale, TO* __restrict__ out,
+                                                         int R, int C, int ldo) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)R * ldo) return;
     const int r = (int)(idx / ldo), c = (int)(idx % ldo);
-    const float k = scale / fmaxf(loss_acc ? loss_acc[1] : 1.f, 1.f);
+    const float k = scale * (dscale ? dscale[0] : 1.f) / fmaxf(loss_acc ? loss_acc[1] : 1.f, 1.f);
     out[idx] = from_f32<TO>(c < C ? x[(size_t)r * C + c] * k : 0.f);
 }
-int scale_cast(const float* x, const float* loss_acc, float scale, void* out, int out_dtype, int R, int C, int ldo, hipStream_t s) {
+int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
+               hipStream_t s) {
     const size_t n = (size_t)R * ldo;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (out_dtype == CPT_BF16) scale_cast_kernel<bf16><<<grid, block, 0, s>>>(x, loss_acc, scale, (bf16*)out, R, C, ldo);
-    else scale_cast_kernel<float><<<grid, block, 0, s>>>(x, loss_acc, scale, (float*)out, R, C, ldo);
+    if (out_dtype == CPT_BF16) scale_cast_kernel<bf16><<<grid, block, 0, s>>>(x, loss_acc, scale, dscale, (bf16*)out, R, C, ldo);
+    else scale_cast_kernel<float><<<grid, block, 0, s>>>(x, loss_acc, scale, dscale, (float*)out, R, C, ldo);
     return CPT_OK;
 }
 

@@ -137,6 +137,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 1) { cpt::set_gemm_abl(value); return CPT_OK; }
     if (key == 2) { cpt::set_attn_bwd_variant(value); return CPT_OK; }
     if (key == 3) { cpt::set_splitk_target(value); return CPT_OK; }
+    if (key == 7) { cpt::set_gemm_skew(value); return CPT_OK; }
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
 }
 
@@ -254,7 +255,6 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         return fail(CPT_ERR_SHAPE, "cpt_model_fwd: CPT_OUT_LOSS needs a logits output");
     if ((flags & CPT_OUT_LOSS) && (!b->labels || !o->loss)) return fail(CPT_ERR_NULL, "cpt_model_fwd: labels/loss required for CPT_OUT_LOSS");
     if ((flags & CPT_OUT_REL) && (!m->w_rel || d.n_rel <= 0)) return fail(CPT_ERR_NULL, "cpt_model_fwd: model has no seq_relationship head");
-    if (flags & CPT_SAVE_FOR_BWD) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: CPT_SAVE_FOR_BWD not available in this build");
     const FwdLayout w = fwd_layout(d, B, Lt, Li, flags);
     if (workspace_bytes < w.total) return fail(CPT_ERR_WORKSPACE, "cpt_model_fwd: workspace %zu < required %zu bytes", workspace_bytes, w.total);
     if ((uintptr_t)workspace & 255) return fail(CPT_ERR_ALIGN, "cpt_model_fwd: workspace must be 256-byte aligned");

@@ -166,6 +166,7 @@ struct EpiX {
     float eps, inv_h;      // LayerNorm eps, 1 / hidden
     const int64_t* mask;   // ATTN: [B][L] attention mask (1 keep / 0 drop) or NULL
     int seq_len, heads;    // ATTN: tokens per sequence (<= 128), attention heads
+    int skew;              // two-workgroups-per-CU shapes: start delay of every second workgroup (see skew_start)
 };
 
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
@@ -206,8 +207,18 @@ template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, in
 __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_pipe_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
-    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace, int abl, EpiX ex) {
+    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace_arg, int abl_arg, EpiX ex) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses gfx950-only builtins/types (buffer rsrc, "v" asm): device pass only
+    // Ablation bits (cpt_set_tuning key 1) exist only in -DCPT_ABLATION builds: as run-time tests they put nine scalar
+    // branches into every K-loop iteration (measured: FFN-up +7 us), so the shipped kernels compile them away.
+#ifdef CPT_ABLATION
+    const int abl = abl_arg;
+    long long* __restrict__ trace = trace_arg;
+#else
+    constexpr int abl = 0;
+    constexpr long long* trace = nullptr;
+    (void)abl_arg; (void)trace_arg;
+#endif
     typedef typename FragOf<T>::type frag_t;
     constexpr int CE = Chunk<T>::N;
     constexpr int BK = ROWB / (int)sizeof(T);
@@ -225,6 +236,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    // Two co-resident workgroups per CU start together and would run their phases in lockstep (both in the K loop,
+    // then both in the epilogue): delaying every second one by about half a K loop puts one's epilogue (VALU, LDS,
+    // stores) under the other's MFMAs, and the offset persists through the later rounds.  skew: low byte = delay in
+    // units of 1024 cycles, bits 8.. = log2 of the block-id stride that separates the two co-resident workgroups.
+    if constexpr (OCC == 2) {
+        const int amount = ex.skew & 255, sh = ex.skew >> 8;
+        if (amount > 0 && ((blockIdx.x >> sh) & 1))
+            for (int i = 0; i < amount; ++i) __builtin_amdgcn_s_sleep(16);
+    }
 
     // XCD-first, then GROUP_M row tiles per group (see tile_of_block)
     constexpr bool ATTN = EPI == CPT_EPI_ATTN || EPI == CPT_EPI_ATTN_LN;
@@ -381,16 +401,20 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         if constexpr (FD == 4) {
             touch(0); CPT_SB(); ldfrag(slot, 2, 2); CPT_SB(); mma(0); CPT_SB();
             touch(1); CPT_SB(); ldfrag(slot, 3, 3); CPT_SB(); mma(1); CPT_SB();
+            // WAR safety by ORDERING, not by latency: this wave's last reads of tile t (k-steps 2, 3) are RETIRED
+            // (lgkmcnt wait placed by touch) before it arrives at the barrier, and no wave refills tile t's slot
+            // before every wave has arrived.  (Round 1 retired them after the refill had been issued.)
+            touch(2); touch(3); CPT_SB();
             if (more) {
                 if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1, min(nt, t + STAGES) - 1);
                 CPT_SB();
-                __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves; tile t's reads all issued
+                __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves; nobody still reads tile t
                 CPT_SB();
                 refill();
                 CPT_SB();
             }
-            touch(2); CPT_SB(); if (more) ldfrag(nslot, 0, 0); CPT_SB(); mma(2); CPT_SB();
-            touch(3); CPT_SB(); if (more) ldfrag(nslot, 1, 1); CPT_SB(); mma(3); CPT_SB();
+            if (more) ldfrag(nslot, 0, 0); CPT_SB(); mma(2); CPT_SB();
+            if (more) ldfrag(nslot, 1, 1); CPT_SB(); mma(3); CPT_SB();
         } else {
             touch(0); CPT_SB(); ldfrag(slot, 1, 1); CPT_SB(); mma(0); CPT_SB();
             touch(1); CPT_SB(); ldfrag(slot, 2, 0); CPT_SB(); mma(1); CPT_SB();
@@ -584,6 +608,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         // residual rows, loaded one slice ahead of their use
         struct Aux { f32x4 r[HAS_RESID ? NIT : 1]; };
         auto load_aux = [&](int sl, Aux& a) {
+            if (abl & 128) return;                    // ablation: no residual loads
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 64 + lane, rr = idx / CH, ch = idx % CH;
@@ -606,6 +631,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl) {
             const int i = sl >> 1, half = sl & 1;
+            if (!(abl & 256)) {                       // ablation 256: no slab writes
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -613,6 +639,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     const int rr = (r8 & 3) + 8 * (r8 >> 2) + 4 * (lane >> 5);
                     *reinterpret_cast<float*>(slab + rr * CPW + (j * 32 + (lane & 31)) * 4) = acc[i][j][half * 8 + r8];
                 }
+            } else { asm volatile("" :: "v"(acc[i][0][half * 8])); }
             if constexpr (FULL && HAS_RESID) {
                 if (sl + 1 < NSL) { if (sl & 1) load_aux(sl + 1, aux_a); else load_aux(sl + 1, aux_b); }
             }
@@ -624,6 +651,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                 const int row = wrow0 + sl * 16 + rr, col = wcol0 + ch * 4;
                 f32x4 v = *reinterpret_cast<const f32x4*>(slab + rr * CPW + ch * 16);
                 if constexpr (FULL) {
+                  if (!(abl & 16)) {                  // ablation 16: no finishing math
                     float2 ms = {0.f, 1.f};
                     f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (LNCONS || LNPROD) ms = side_row[sl * 16 + rr];
@@ -650,6 +678,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         else if constexpr (HAS_RESID) x += ax.r[it][e];
                         v[e] = x;
                     }
+                  }
+                  if (abl & 64) { asm volatile("" :: "v"(v)); } else {   // ablation 64: no global stores
                     if constexpr (sizeof(OT) == 2) {
                         bf16x4 pk;
 #pragma unroll
@@ -671,6 +701,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         } else {
                             *reinterpret_cast<f32x4*>(olp) = v;
                         }
+                    }
+                  }
+                    if constexpr (LNPROD) {
                         *reinterpret_cast<f32x4*>(slab + rr * CPW + ch * 16) = v;      // finished values back for the row sums
                     }
                 } else {
@@ -727,6 +760,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
 
 long long* g_gemm_trace = nullptr;
 extern int g_gemm_abl;
+int g_gemm_skew = 0;
+void set_gemm_skew(int v) { g_gemm_skew = v; }
 
 template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1>
 static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bias, const float* resid, int ldr,
@@ -739,10 +774,11 @@ static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bi
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         attr_done = true;
     }
-    const EpiX none = {};
+    EpiX e = {};
+    if (ex) e = *ex;
+    e.skew = g_gemm_skew;
     const int nwg = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN) * splitk;
-    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, g_gemm_trace, g_gemm_abl,
-                                                    ex ? *ex : none);
+    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, g_gemm_trace, g_gemm_abl, e);
     return CPT_OK;
 }
 
@@ -931,7 +967,9 @@ static int launch_qkv_attn(const bf16* A, int lda, const bf16* W, int ldw, const
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         attr_done = true;
     }
-    kern<<<dim3(B * ex.heads), dim3(512), LDS, s>>>(A, lda, W, ldw, bias, nullptr, 0, ctx, ldo, M, N, K, 1, g_gemm_trace, g_gemm_abl, ex);
+    EpiX e = ex;
+    e.skew = g_gemm_skew;
+    kern<<<dim3(B * ex.heads), dim3(512), LDS, s>>>(A, lda, W, ldw, bias, nullptr, 0, ctx, ldo, M, N, K, 1, g_gemm_trace, g_gemm_abl, e);
     return CPT_OK;
 }
 

@@ -41,7 +41,8 @@ int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int6
               int type_vocab, hipStream_t s);
 int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s);
 int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s);
-int scale_cast(const float* x, const float* loss_acc, float scale, void* out, int out_dtype, int R, int C, int ldo, hipStream_t s);
+int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
+               hipStream_t s);
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s);
 int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16, size_t n,
                float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s);
@@ -70,6 +71,7 @@ void set_splitk_target(int v);
 void set_attn_bwd_variant(int v);
 void set_gemm_variant(int v);
 void set_gemm_abl(int v);
+void set_gemm_skew(int v);
 void set_gemm_trace(void* p);
 
 }  // namespace cpt

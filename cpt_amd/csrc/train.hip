@@ -108,6 +108,11 @@ size_t cpt_train_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li) {
 
 int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
                   size_t workspace_bytes, void* stream) {
+    return cpt_train_fwd_ex(m, b, o, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
+                     size_t workspace_bytes, void* stream, cpt_bucket_fn before_bucket, void* user) {
     if (!m || !b || !o || !workspace) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: null argument");
     const cpt_dims& d = m->dims;
     const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li);
@@ -121,7 +126,11 @@ int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     float* x_f32 = (float*)(ws + w.x_f32);
     float* a_f32 = (float*)(ws + w.a_f32);
     auto LB = [&](int l, size_t off) { return (void*)(ws + w.layer0 + (size_t)l * w.layer_stride + off); };
+    // parameter buckets (data-parallel training): the host callback runs BEFORE the first launch that reads the
+    // bucket's parameters, so the caller can make `stream` wait for that bucket's all-gather (include/cpt_hip.h)
+    auto need = [&](int bucket) { if (before_bucket) before_bucket(user, bucket); };
 
+    need(0);
     TRY(cpt::embed_ln(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g,
                       m->emb_ln_b, d.ln_eps, x_f32, LB(0, w.o_xin), dt, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, s), "embed_ln");
     if (Li > 0) {
@@ -134,6 +143,7 @@ int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     }
     for (int l = 0; l < d.layers; ++l) {
         const cpt_layer& y = m->layers[l];
+        need(1 + l);
         void* xin = LB(l, w.o_xin);
         void* xnext = l + 1 < d.layers ? LB(l + 1, w.o_xin) : (void*)(ws + w.xout);
         TRY(cpt::gemm(dt, CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
@@ -149,6 +159,7 @@ int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     void* rows = ws + w.rows;
     float* uh = (float*)(ws + w.uh);
     void* t2 = ws + w.t2;
+    need(d.layers + 1);
     TRY(cpt::gather_rows(ws + w.xout, dt, b->mask_pos, rows, B, L, H, s), "gather([MASK])");
     TRY(cpt::gemm(dt, CPT_EPI_NONE, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, uh, CPT_F32, H, B, H, H, s), "gemm(head transform)");
     TRY(cpt::layernorm_rows_ex(uh, m->tr_ln_g, m->tr_ln_b, d.ln_eps, dt == CPT_F32 ? (float*)t2 : nullptr,
@@ -164,6 +175,11 @@ int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
 
 int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
                   void* workspace, size_t workspace_bytes, void* stream) {
+    return cpt_train_bwd_ex(m, b, g, loss_scale, nullptr, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale, const float* loss_scale_dev,
+                     void* workspace, size_t workspace_bytes, void* stream, cpt_bucket_fn grads_ready, void* user) {
     if (!m || !b || !g || !workspace) return abi_fail(CPT_ERR_NULL, "cpt_train_bwd: null argument");
     const cpt_dims& d = m->dims;
     const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li);
@@ -206,7 +222,7 @@ int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads*
     float* duh = (float*)(ws + w.duh);
     void* duh_lp = ws + w.duh_lp;
     float* drows = (float*)(ws + w.drows);
-    TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, dl_lp, dt, B, V, Vp, s), "scale(dlogits)");
+    TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, loss_scale_dev, dl_lp, dt, B, V, Vp, s), "scale(dlogits)");
     TRY(cpt::colsum(dl_lp, dt, Vp, g->b_dec, B, V, s), "colsum(cls.bias)");
     rc = dgrad(dl_lp, Vp, Vp, m->w_dec, H, V, H, B, nullptr, dt2, CPT_F32, "dgrad(decoder)");
     if (rc) return rc;
@@ -223,6 +239,10 @@ int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads*
     hipError_t e = hipMemsetAsync(dx, 0, (size_t)M * H * 4, s);
     if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero dx: %s", hipGetErrorString(e));
     TRY(cpt::scatter_rows_add(drows, b->mask_pos, dx, B, L, H, s), "scatter([MASK] rows)");
+    // gradient buckets: the host callback runs right AFTER the last launch that writes the bucket's gradients has
+    // been enqueued on `stream` (the tied word-embedding table belongs to bucket 0: its lookup gradient comes last)
+    auto ready = [&](int bucket) { if (grads_ready) grads_ready(user, bucket); };
+    ready(d.layers + 1);
 
     // ---- encoder layers, last to first -----------------------------------------------------------
     const void* dpre_in = dt == CPT_BF16 ? dpre_lp : (const void*)dpre;
@@ -258,6 +278,7 @@ int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads*
         if (rc) return rc;
         rc = dgrad(dbig, 3 * H, 3 * H, y.w_qkv, H, 3 * H, H, M, dpre, dx, CPT_F32, "dgrad(qkv)+residual");
         if (rc) return rc;
+        ready(1 + l);
     }
 
     // ---- region projection and text embeddings ----------------------------------------------------
@@ -278,6 +299,7 @@ int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads*
     TRY(cpt::embed_bwd(dx, b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g,
                        d.ln_eps, g->word_emb, g->pos_emb, g->type_emb, g->emb_ln_g, g->emb_ln_b, B, Lt, L, H, d.vocab, d.max_pos,
                        d.type_vocab, s), "embed_bwd");
+    ready(0);
     return CPT_OK;
 }
 

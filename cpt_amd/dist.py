@@ -76,3 +76,188 @@ def broadcast_(flat, src=0):
     if world > 1:
         dist.broadcast(flat, src)
     return flat
+
+
+class ShardedGradSync(object):
+    """Bucketed, overlapped gradient synchronisation for the flat buffers of the training step.
+
+    The reference wraps the model in DistributedDataParallel (fewshot/refcoco_cpt.py:516-522): 25 MB buckets of an
+    all-reduce that overlaps backward, then every rank runs the whole optimizer.  On the MI355X node a ring
+    all-reduce of the 447 MB gradient is bound by ONE xGMI link (2*(7/8)*447 MB / 153 GB/s = 5.1 ms); reduce-scatter
+    + all-gather uses all seven links of the fully connected mesh (2*(447/8) MB / 153 GB/s = 0.73 ms), and between the
+    two every rank only owns 1/N of the AdamW work (ZeRO-1): this class does that, per parameter bucket
+    (engine.bucket_of: embeddings | one per encoder layer | head), so that
+
+      backward :  bucket k's reduce-scatter starts on the communication stream as soon as cpt_train_bwd_ex reports its
+                  gradients complete (head first, layer N-1 .. 0, embeddings last) and runs under the remaining backward;
+      step     :  AdamW on this rank's shard of every bucket, then the buckets' all-gathers are queued in FORWARD
+                  order (embeddings, layer 0 ..) on the communication stream;
+      forward  :  cpt_train_fwd_ex asks for bucket k right before its first use -> the compute stream waits for that
+                  all-gather only, so the parameter all-gather overlaps the next forward.
+
+    buckets: {k: (lo, hi)} element ranges of the flat buffers, (hi - lo) % world == 0.  Works on CPU tensors with gloo
+    (tests) and on device tensors with RCCL ("nccl") or gloo; collectives are torch.distributed's.
+    wire: None = fp32 gradients on the wire, torch.bfloat16 = gradients cast to bf16 for the reduce-scatter
+    (half the bytes; the sum is then a bf16 sum).
+    """
+
+    def __init__(self, buckets, device, wire=None, group=None):
+        self.rank, self.world = rank_world()
+        self.group = group
+        self.buckets = dict(buckets)
+        self.order = sorted(self.buckets)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.wire = wire
+        for k, (lo, hi) in self.buckets.items():
+            if (hi - lo) % self.world:
+                raise ValueError("bucket %d has %d elements, not a multiple of world size %d" % (k, hi - lo, self.world))
+        # this rank's shard of bucket k lives at [soff[k], soff[k] + n_k / world) of the shard-sized buffers
+        self.soff, o = {}, 0
+        for k in self.order:
+            lo, hi = self.buckets[k]
+            self.soff[k] = o
+            o += (hi - lo) // self.world
+        self.shard_elems = o
+        self.gshard = torch.zeros(o, device=self.device, dtype=torch.float32)    # reduced gradient shards
+        self.pstage = torch.empty(o, device=self.device, dtype=torch.float32)    # updated parameter shards (all-gather source)
+        self.wire_full = self.wire_shard = None
+        self.comm = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._rs = {}          # bucket -> (work, event) of a reduce-scatter in flight
+        self._ag = {}          # bucket -> (work, event) of an all-gather in flight
+        self.reduced = set()
+
+    # -- ranges ------------------------------------------------------------------------------------------------
+    def shard_range(self, k):
+        """(lo, hi) of this rank's shard of bucket k inside the FLAT buffers."""
+        lo, hi = self.buckets[k]
+        n = (hi - lo) // self.world
+        return lo + self.rank * n, lo + (self.rank + 1) * n
+
+    def shard_view(self, buf, k):
+        lo, hi = self.buckets[k]
+        n = (hi - lo) // self.world
+        return buf[self.soff[k]: self.soff[k] + n]
+
+    # -- backward: reduce-scatter -------------------------------------------------------------------------------
+    def begin_backward(self):
+        if self._rs and self.cuda:       # a previous backward's reduce-scatters were never consumed by a step()
+            for _w, done in self._rs.values():
+                if done is not None:
+                    torch.cuda.current_stream(self.device).wait_event(done)
+        self.reduced = set()
+        self._rs = {}
+
+    def grads_ready(self, grad, k):
+        """Bucket k of the flat gradient `grad` is final on the current stream: start its reduce-scatter (sum)."""
+        if k in self.reduced:
+            return
+        self.reduced.add(k)
+        lo, hi = self.buckets[k]
+        out = self.shard_view(self.gshard, k)
+        if self.world == 1:
+            out.copy_(grad[lo:hi])
+            return
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                work = self._reduce_scatter(grad, k, lo, hi, out)
+                if work is not None:
+                    work.wait()        # RCCL: the communication stream waits for the collective (no host block)
+                done = torch.cuda.Event()
+                done.record(self.comm)
+            self._rs[k] = (None, done)
+        else:
+            self._rs[k] = (self._reduce_scatter(grad, k, lo, hi, out), None)
+
+    def _reduce_scatter(self, grad, k, lo, hi, out):
+        if self.wire is None:
+            return dist.reduce_scatter_tensor(out, grad[lo:hi], group=self.group, async_op=True)
+        if self.wire_full is None:
+            self.wire_full = torch.empty(max(h - l for l, h in self.buckets.values()) if not self.cuda else grad.numel(),
+                                         device=self.device, dtype=self.wire)
+            self.wire_shard = torch.empty(self.shard_elems, device=self.device, dtype=self.wire)
+        src = self.wire_full[lo:hi] if self.cuda else self.wire_full[: hi - lo]
+        src.copy_(grad[lo:hi])
+        wout = self.shard_view(self.wire_shard, k)
+        work = dist.reduce_scatter_tensor(wout, src, group=self.group, async_op=True)
+        if not self.cuda:
+            work.wait()
+            out.copy_(wout)
+            return None
+        work.wait()            # stream-level dependency on the communication stream, not a host wait
+        out.copy_(wout)
+        return None
+
+    def finish_reduce(self, grad):
+        """All buckets reduced and visible to the current stream (buckets whose callback never came are reduced now)."""
+        for k in self.order:
+            if k not in self.reduced:
+                self.grads_ready(grad, k)
+        for k, (work, done) in self._rs.items():
+            if work is not None:
+                work.wait()
+            if done is not None:
+                torch.cuda.current_stream(self.device).wait_event(done)
+        self._rs = {}
+
+    # -- step: sharded update + all-gather ------------------------------------------------------------------------
+    def all_gather_params(self, flat, after_update=None):
+        """Queue the all-gather of every bucket of `flat` (this rank's shard already updated in place), buckets in
+        forward order.  after_update(k) runs on the current stream before bucket k is sent (unused by default)."""
+        self._ag = {}
+        if self.world == 1:
+            return
+        for k in self.order:
+            lo, hi = self.buckets[k]
+            slo, shi = self.shard_range(k)
+            stage = self.shard_view(self.pstage, k)
+            stage.copy_(flat[slo:shi])
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.comm):
+                    self.comm.wait_event(ev)
+                    work = dist.all_gather_into_tensor(flat[lo:hi], stage, group=self.group, async_op=True)
+                    work.wait()
+                    done = torch.cuda.Event()
+                    done.record(self.comm)
+                self._ag[k] = (None, done)
+            else:
+                self._ag[k] = (dist.all_gather_into_tensor(flat[lo:hi], stage, group=self.group, async_op=True), None)
+
+    def params_pending(self):
+        return bool(self._ag)
+
+    def wait_params(self, k=None):
+        """The current stream may read bucket k's parameters (k None: all buckets) after this returns."""
+        ks = self.order if k is None else [k]
+        for kk in ks:
+            ent = self._ag.pop(kk, None)
+            if ent is None:
+                continue
+            work, done = ent
+            if work is not None:
+                work.wait()
+            if done is not None:
+                torch.cuda.current_stream(self.device).wait_event(done)
+
+    # -- optimizer-state helpers -----------------------------------------------------------------------------------
+    def gather_full(self, shard_buf, total):
+        """Full flat tensor from per-rank shard buffers (checkpointing the sharded AdamW moments)."""
+        full = torch.zeros(total, device=self.device, dtype=shard_buf.dtype)
+        for k in self.order:
+            lo, hi = self.buckets[k]
+            sv = self.shard_view(shard_buf, k).contiguous()
+            if self.world == 1:
+                full[lo:hi].copy_(sv)
+            else:
+                dist.all_gather_into_tensor(full[lo:hi], sv, group=self.group)
+        return full
+
+    def scatter_full(self, full, shard_buf):
+        for k in self.order:
+            slo, shi = self.shard_range(k)
+            self.shard_view(shard_buf, k).copy_(full[slo:shi])

@@ -47,7 +47,8 @@ def val_queries(model, queries, none_id, device, few_shot=False, batch_queries=4
     out = {}
     for gi, idx in enumerate(allc):
         rects = [r for rs in queries[gi]["rects"] for r in rs]
-        out[gi] = (idx, rects[idx])
+        # a query none of whose proposal sequences carries a colour has no prediction (idx -1): never index rects[-1]
+        out[gi] = (idx, rects[idx] if 0 <= idx < len(rects) else None)
     return out
 
 

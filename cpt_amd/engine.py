@@ -17,9 +17,23 @@ from .synth import param_specs
 ALIGN = 64  # elements
 
 
+BUCKET_ALIGN = 512  # elements: every parameter bucket splits evenly over 1, 2, 4 or 8 ranks into 64-element-aligned shards
+
+
+def bucket_of(name, n_layers):
+    """Data-parallel bucket of a parameter (include/cpt_hip.h, cpt_train_bwd_ex): 0 = embedding tables, their
+    LayerNorm and the region projection; 1 + l = encoder layer l; n_layers + 1 = pooler + task head."""
+    if name.startswith("bert.encoder.layer."):
+        return 1 + int(name.split(".")[3])
+    if name.startswith(("bert.pooler.", "cls.")):
+        return n_layers + 1
+    return 0
+
+
 def pack_order(cfg, head):
-    """Parameter names in flat-buffer order: as param_specs, but q/k/v weights adjacent, then
-    q/k/v biases adjacent (fused QKV GEMM reads them as [3H][H] and [3H])."""
+    """Parameter names in flat-buffer order: grouped by data-parallel bucket (each bucket is one contiguous range, so
+    its gradients reduce-scatter as ONE message), inside a layer q/k/v weights adjacent, then q/k/v biases adjacent
+    (the fused QKV GEMM reads them as [3H][H] and [3H])."""
     names = [n for n, _, kind in param_specs(cfg, head) if kind != "tied"]
     final = []
     for n in names:
@@ -30,7 +44,8 @@ def pack_order(cfg, head):
             final += [p + "query.weight", p + "key.weight", p + "value.weight",
                       p + "query.bias", p + "key.bias", p + "value.bias"]
         final.append(n)
-    return final
+    nl = cfg.num_hidden_layers
+    return sorted(final, key=lambda n: bucket_of(n, nl))     # stable: registration order inside a bucket
 
 
 class PackedModel(object):
@@ -52,6 +67,7 @@ class PackedModel(object):
         self.fold_ln = True         # bf16 inference: fold the encoder LayerNorms into the GEMMs around them
         self._fold = None
         self._fold_stale = True
+        self.pending = None         # data-parallel optimizer whose parameter all-gather is still in flight (train.FusedAdamW)
 
     # ---- packing -------------------------------------------------------------------------
     def _named(self):
@@ -86,9 +102,19 @@ class PackedModel(object):
                 raise RuntimeError("cpt_amd: parameter %s is %s; master weights must be fp32" % (n, p.dtype))
         total = 0
         self.offsets = {}
+        nl = self.cfg.num_hidden_layers
+        starts = {}
         for n, p in named.items():
+            k = bucket_of(n, nl)
+            if k not in starts:                       # a new bucket starts on a BUCKET_ALIGN boundary
+                total = (total + BUCKET_ALIGN - 1) // BUCKET_ALIGN * BUCKET_ALIGN
+                starts[k] = total
             self.offsets[n] = (total, p.numel())
             total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        total = (total + BUCKET_ALIGN - 1) // BUCKET_ALIGN * BUCKET_ALIGN
+        # [lo, hi) element range of bucket k in the flat parameter / gradient / moment buffers (gaps hold zeros)
+        ks = sorted(starts)
+        self.buckets = {k: (starts[k], starts[ks[i + 1]] if i + 1 < len(ks) else total) for i, k in enumerate(ks)}
         flat = torch.zeros(total, device=dev, dtype=torch.float32)
         for n, p in named.items():
             off, num = self.offsets[n]
@@ -113,6 +139,8 @@ class PackedModel(object):
     def refresh_shadow(self, force=False):
         """bf16 copy of the flat buffer + zero-padded img weight; redone whenever a parameter
         was written in place (load_state_dict, an optimizer step done outside this engine)."""
+        if self.pending is not None:
+            self.complete_pending()
         sig = self._versions()
         if self._sig is None:
             self._sig = {}
@@ -141,6 +169,40 @@ class PackedModel(object):
                 self._desc = {}
             L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_f32.data_ptr(), L.CPT_F32, H, D, Dp, st),
                     "cpt_pad_cast(w_img)")
+
+    def invalidate(self):
+        """Tell the engine the parameters were written behind its back.  In-place writes through ``.data``
+        (``p.data.copy_/mul_/normal_``, which init_weights-style code uses) do not bump the Parameter's version
+        counter, so the bf16 shadow, the LayerNorm-folded weights and the padded img_embedding copy would go stale
+        silently; load_state_dict / optimizer paths are detected automatically, anything else calls this."""
+        self._sig = None
+        self._fold_stale = True
+
+    def complete_pending(self, bucket=None):
+        """Data parallel: make the current stream wait for the parameter all-gather the last optimizer step queued
+        (bucket None: all of it) and refresh the copies derived from those parameters."""
+        opt = self.pending
+        if opt is None:
+            return
+        opt._params_arrived(bucket)
+
+    def refresh_bucket_shadow(self, k):
+        """bf16 shadow (and the padded img_embedding copy for bucket 0) of ONE parameter bucket."""
+        lo, hi = self.buckets[k]
+        st = L.stream_ptr()
+        cfg = self.cfg
+        H, D = cfg.hidden_size, cfg.img_feature_dim
+        Dp = (D + 63) // 64 * 64
+        if self.dtype == "bf16" and self.flat_lp is not None:
+            L.check(L.lib().cpt_pad_cast(self.flat.data_ptr() + lo * 4, self.flat_lp.data_ptr() + lo * 2, L.CPT_BF16, 1, hi - lo,
+                                         hi - lo, st), "cpt_pad_cast(shadow bucket)")
+        if k == 0:
+            w_img = self.view("bert.img_embedding.weight")
+            if self.dtype == "bf16" and getattr(self, "img_pad_lp", None) is not None:
+                L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_lp.data_ptr(), L.CPT_BF16, H, D, Dp, st), "cpt_pad_cast(w_img)")
+            elif self.dtype != "bf16" and getattr(self, "img_pad_f32", None) is not None:
+                L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_f32.data_ptr(), L.CPT_F32, H, D, Dp, st), "cpt_pad_cast(w_img)")
+        self._fold_stale = True
 
     def weights_updated(self, shadow_fresh=False):
         """Called after the fused optimizer wrote the flat buffer through raw pointers (which does

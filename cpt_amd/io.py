@@ -209,7 +209,16 @@ def decode_features(tsv, img_idx, img_seq_len=50, dim=2054):
 
 class RegionStager(object):
     """Pinned host buffers + a side stream: decode batch i+1 on the host while batch i's features travel to the GPU
-    (the 26 MB/step host buffer of DESIGN.md section 7)."""
+    (the 26 MB/step host buffer of DESIGN.md section 7).
+
+    Slot k (= call number mod depth) is reused every `depth` calls, and BOTH directions of the dependency are tracked:
+      copy -> consumer : stage() returns an event; the consumer stream must ``wait_event(event)`` before reading;
+      consumer -> copy : before slot k's device buffer is overwritten, the side stream waits for the event the
+                         consumer recorded after ITS last read of that slot -- pass the consumer stream to stage()
+                         (default: the current stream) and call ``release(slot)`` once the forward that reads the
+                         slot has been enqueued, or use ``stage_and_wait`` which does wait + release bookkeeping for
+                         the common "one forward per staged batch" loop.  Without that event a fast host could
+                         overwrite batch i's features while pad_cast of batch i is still reading them."""
 
     def __init__(self, max_seqs, img_seq_len=50, dim=2054, device="cuda:0", depth=2, threads=4):
         self.dev = torch.device(device)
@@ -220,22 +229,51 @@ class RegionStager(object):
         self.devb = [torch.empty(self.shape, dtype=torch.float32, device=self.dev) for _ in range(depth)]
         self.dmask = [torch.empty(self.shape[:2], dtype=torch.int64, device=self.dev) for _ in range(depth)]
         self.stream = torch.cuda.Stream(self.dev)
-        self.events = [None] * depth
+        self.events = [None] * depth          # H2D copy of slot k done
+        self.consumed = [None] * depth        # consumer's reads of slot k done
+        self.unreleased = [False] * depth
         self.i = 0
+        self.last_slot = None
 
-    def stage(self, feature_lists):
+    def release(self, slot=None, stream=None):
+        """Record "the consumer has finished reading `slot`" on the consumer stream (call after enqueueing the forward)."""
+        k = self.last_slot if slot is None else slot
+        if k is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(stream if stream is not None else torch.cuda.current_stream(self.dev))
+        self.consumed[k] = ev
+        self.unreleased[k] = False
+
+    def stage(self, feature_lists, consumer_stream=None):
         """Decode + enqueue the H2D copy; returns (feats_dev, mask_dev, event).  The consumer stream must
-        ``wait_event(event)`` before reading."""
+        ``wait_event(event)`` before reading and ``release()`` the slot after its reads are enqueued."""
         k = self.i % len(self.host)
         self.i += 1
         if self.events[k] is not None:
             self.events[k].synchronize()              # the previous copy out of this pinned buffer is done
+        if self.unreleased[k]:
+            # the consumer never told us when it finished with this slot: fall back to "everything enqueued on its
+            # stream so far" (safe, possibly later than necessary)
+            self.release(k, consumer_stream)
         P = len(feature_lists)
         decode_regions(feature_lists, self.shape[1], self.shape[2], self.host[k][:P], self.hmask[k][:P], self.threads)
         with torch.cuda.stream(self.stream):
+            if self.consumed[k] is not None:
+                self.stream.wait_event(self.consumed[k])      # write-after-read: the model is done with this slot
             self.devb[k][:P].copy_(self.host[k][:P], non_blocking=True)
             self.dmask[k][:P].copy_(self.hmask[k][:P], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.events[k] = ev
+        self.unreleased[k] = True
+        self.last_slot = k
         return self.devb[k][:P], self.dmask[k][:P], ev
+
+    def stage_and_wait(self, feature_lists, stream=None):
+        """stage() + make `stream` (default: current) wait for the copy; the caller enqueues its forward and then calls
+        ``release()``."""
+        st = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        feats, mask, ev = self.stage(feature_lists, st)
+        st.wait_event(ev)
+        return feats, mask

@@ -122,6 +122,17 @@ class _EngineMixin(object):
         self._engine().dtype = dtype
         return self
 
+    def invalidate_packed(self):
+        """Call after writing parameters in place through ``.data`` (see PackedModel.invalidate)."""
+        self._engine().invalidate()
+        return self
+
+    def state_dict(self, *args, **kwargs):
+        eng = self.__dict__.get("_cpt_engine")
+        if eng is not None and eng.pending is not None:
+            eng.complete_pending()          # data parallel: a parameter all-gather may still be in flight
+        return super().state_dict(*args, **kwargs)
+
 
 class BertImgModel(_EngineMixin, BertPreTrainedModel):
     """modeling_bert.py:150-279."""

@@ -44,6 +44,8 @@ class _TrainState(object):
         self.gdesc = None
         self.ws = None
         self.saved = None
+        self.gen = 0            # stamps every training forward: a backward may only consume ITS forward's activations
+        self.sync = None        # dist.ShardedGradSync when an optimizer runs this engine data-parallel
 
     def ensure(self):
         eng = self.eng
@@ -139,10 +141,28 @@ class _MLMLoss(torch.autograd.Function):
         o = L.Outputs(logits=logits.data_ptr(), loss=loss_acc.data_ptr())
         bt = L.Batch(B=B, Lt=Lt, Li=Li, input_ids=ids.data_ptr(), token_type=L.ptr(seg), position_ids=L.ptr(pos),
                      attn_mask=L.ptr(mask), img_feats=L.ptr(feats), mask_pos=mpos.data_ptr(), labels=labels.data_ptr())
+        if st.saved is not None and st.ws is not None:
+            # the activations of an earlier training forward are still waiting for their backward; the workspace is
+            # per engine, so this forward overwrites them (their backward will raise instead of using the wrong ones)
+            pass
         ws = st.workspace(B, Lt, Li)
-        L.check(L.lib().cpt_train_fwd(C.byref(m), C.byref(bt), C.byref(o), ws.data_ptr(), ws.numel(), L.stream_ptr()),
-                "cpt_train_fwd")
-        st.saved = (bt, tensors)          # keep the input tensors alive until backward
+        errs = []
+
+        def before_bucket(_user, k):
+            # data parallel: bucket k's parameter all-gather (queued by the last optimizer step) must have landed,
+            # and its bf16 shadow / padded copies must be current, before the first kernel that reads it
+            try:
+                eng.complete_pending(k)
+            except Exception as e:          # never let an exception cross the C frame
+                errs.append(e)
+        cb = L.BUCKET_CB(before_bucket) if eng.pending is not None else None
+        L.check(L.lib().cpt_train_fwd_ex(C.byref(m), C.byref(bt), C.byref(o), ws.data_ptr(), ws.numel(), L.stream_ptr(),
+                                         cb, None), "cpt_train_fwd")
+        if errs:
+            raise errs[0]
+        st.gen += 1
+        ctx.gen = st.gen
+        st.saved = (bt, tensors, st.gen)          # keep the input tensors alive until backward
         ctx.logits = logits
         ctx.mark_non_differentiable(logits)
         return loss_acc[0] / loss_acc[1], logits
@@ -153,7 +173,11 @@ class _MLMLoss(torch.autograd.Function):
         st = _state(eng)
         if st.saved is None:
             raise RuntimeError("cpt_amd: backward called twice (activations of the training forward were released)")
-        bt, tensors = st.saved
+        bt, tensors, gen = st.saved
+        if gen != ctx.gen:
+            raise RuntimeError("cpt_amd: backward of a stale training forward: the engine keeps the activations of the LATEST "
+                               "training forward only (one workspace per model); call backward() before the next "
+                               "training forward of the same model")
         st.ensure()
         m, _ = eng.descriptor()
         views = _named_grad_views(eng, st)
@@ -162,8 +186,26 @@ class _MLMLoss(torch.autograd.Function):
             keep = st.grad.clone()
         st.grad.zero_()
         g, _ = st.gdesc
-        L.check(L.lib().cpt_train_bwd(C.byref(m), C.byref(bt), C.byref(g), float(grad_loss), st.ws.data_ptr(), st.ws.numel(),
-                                      L.stream_ptr()), "cpt_train_bwd")
+        sync = st.sync if not accumulate else None
+        errs = []
+
+        def grads_ready(_user, k):
+            try:
+                sync.grads_ready(st.grad, k)
+            except Exception as e:
+                errs.append(e)
+        if sync is not None:
+            sync.begin_backward()
+            cb = L.BUCKET_CB(grads_ready)
+        else:
+            cb = None
+            if st.sync is not None:
+                st.sync.begin_backward()          # accumulation step: buckets are reduced in optimizer.step()
+        gl = grad_loss.to(torch.float32).contiguous()          # device scalar: no host synchronisation between fwd and bwd
+        L.check(L.lib().cpt_train_bwd_ex(C.byref(m), C.byref(bt), C.byref(g), 1.0, gl.data_ptr(), st.ws.data_ptr(), st.ws.numel(),
+                                         L.stream_ptr(), cb, None), "cpt_train_bwd")
+        if errs:
+            raise errs[0]
         if accumulate:
             st.grad.add_(keep)
         for p, v in views:
@@ -181,7 +223,8 @@ def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels,
                                   "exactly one labelled position per row: pass it as mask_token_pos)")
     eng = model._engine()
     eng.ensure_packed()
-    eng.refresh_shadow()
+    if eng.pending is None:          # (data parallel: a pending parameter all-gather is awaited bucket by bucket in the forward)
+        eng.refresh_shadow()
     st = _state(eng)
     st.ensure()
 
@@ -204,13 +247,23 @@ def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels,
 
 
 class FusedAdamW(object):
-    """torch.optim.AdamW semantics (decoupled decay, bias correction, eps outside the sqrt) as ONE
-    kernel over the flat parameter / gradient / moment buffers; also refreshes the bf16 shadow.
-    Exposes ``param_groups`` with the reference's four groups so ``param_group['lr'] = ...``
-    scheduling code (fewshot/refcoco_cpt.py:237-243) keeps working; with data parallelism the flat
-    gradient is all-reduced once (sum) and averaged inside the update."""
+    """torch.optim.AdamW semantics (decoupled decay, bias correction, eps outside the sqrt) as ONE kernel over the
+    flat parameter / gradient / moment buffers; also refreshes the bf16 shadow.  Exposes ``param_groups`` with the
+    reference's four groups so ``param_group['lr'] = ...`` scheduling code (fewshot/refcoco_cpt.py:237-243) keeps
+    working.
 
-    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+    Data parallel (torch.distributed initialised with world size > 1; the reference's DistributedDataParallel wrap at
+    fewshot/refcoco_cpt.py:516-522 is replaced by this optimizer, do NOT also wrap the model in DDP):
+      * construction broadcasts rank 0's flat parameters (what DDP does at wrap time);
+      * backward reduce-scatters each parameter bucket as soon as its gradients are complete, on a side stream,
+        under the rest of backward (dist.ShardedGradSync);
+      * step() runs AdamW on this rank's 1/N shard of every bucket (moments are sharded: 1/N of the state per GPU)
+        and queues the parameter all-gather, which the next forward waits for bucket by bucket.
+      ``p.grad`` views hold this rank's LOCAL gradients (the averaged ones exist only as shards); use
+      ``clip_grad_norm_`` below instead of torch.nn.utils.clip_grad_norm_.
+    grad_wire: None (fp32 on the wire) or "bf16" (gradients cast to bf16 for the reduce-scatter: half the bytes)."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_wire=None):
         self.model = model
         self.eng = model._engine()
         self.betas = betas
@@ -221,13 +274,30 @@ class FusedAdamW(object):
                              {"lr": lr, "weight_decay": 0.0, "params": []}]
         self.step_count = 0
         self.m = self.v = self.code = None
+        self.grad_wire = {None: None, "fp32": None, "bf16": torch.bfloat16}[grad_wire]
+        self.sync = None
+        self._clip = 1.0
+        self._stale_shadow = set()
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if self.world > 1 and next(model.parameters()).is_cuda:
+            self._ensure()
 
     def _ensure(self):
         eng = self.eng
         eng.ensure_packed()
-        if self.m is None or self.m.numel() != eng.flat.numel() or self.m.device != eng.flat.device:
-            self.m = torch.zeros_like(eng.flat)
-            self.v = torch.zeros_like(eng.flat)
+        dev = eng.flat.device
+        if self.world > 1 and (self.sync is None or self.sync.device != dev):
+            from . import dist as cdist
+            self.sync = cdist.ShardedGradSync(eng.buckets, dev, wire=self.grad_wire)
+            cdist.broadcast_(eng.flat, 0)             # replicas start from rank 0's parameters
+            eng.weights_updated()
+            _state(eng).sync = self.sync
+            self.m = None
+        n_state = self.sync.shard_elems if self.sync is not None else eng.flat.numel()
+        if self.m is None or self.m.numel() != n_state or self.m.device != dev:
+            self.m = torch.zeros(n_state, device=dev, dtype=torch.float32)
+            self.v = torch.zeros(n_state, device=dev, dtype=torch.float32)
             code = torch.zeros(eng.flat.numel(), dtype=torch.uint8)
             for n in eng.offsets:
                 off, num = eng.offsets[n]
@@ -238,45 +308,102 @@ class FusedAdamW(object):
                 else:
                     c = 1
                 code[off:off + num] = c
-            self.code = code.to(eng.flat.device)
+            code = code.to(dev)
+            if self.sync is not None:
+                sh = torch.zeros(n_state, device=dev, dtype=torch.uint8)
+                self.sync.scatter_full(code, sh)
+                code = sh
+            self.code = code
 
     def zero_grad(self, set_to_none=True):
         for p in self.model.parameters():
             p.grad = None
 
+    def clip_grad_norm_(self, max_norm):
+        """Global-norm clipping of the AVERAGED gradient (gqa_cpt.py:454 clips at 1.0; the RefCOCO path does not clip).
+        Call between backward() and step(); the coefficient is folded into the update.  Returns the norm (a host
+        float: this synchronises)."""
+        self._ensure()
+        st = _state(self.eng)
+        if self.sync is not None:
+            import torch.distributed as dist
+            self.sync.finish_reduce(st.grad)
+            sq = (self.sync.gshard.double() ** 2).sum() / float(self.world) ** 2
+            dist.all_reduce(sq)
+        else:
+            sq = (st.grad.double() ** 2).sum()
+        norm = float(sq.sqrt())
+        self._clip = min(1.0, max_norm / (norm + 1e-6))
+        return norm
+
+    def _adamw(self, p_ptr, g_ptr, m_ptr, v_ptr, code_ptr, shadow_ptr, n, lr, wd, scale):
+        L.check(L.lib().cpt_adamw(p_ptr, g_ptr, m_ptr, v_ptr, code_ptr, shadow_ptr, n, lr, self.betas[0], self.betas[1], self.eps,
+                                  wd, self.step_count, scale, L.stream_ptr()), "cpt_adamw")
+
     def step(self):
-        import torch.distributed as dist
         eng = self.eng
         self._ensure()
         st = _state(eng)
         if st.grad is None:
             raise RuntimeError("cpt_amd: optimizer.step() before any backward")
-        scale = 1.0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(st.grad)                     # ONE collective over all 111.68 M gradients
-            scale = 1.0 / dist.get_world_size()
         self.step_count += 1
         lr = self.param_groups[2]["lr"]
         wd = self.param_groups[2]["weight_decay"]
-        shadow = eng.flat_lp.data_ptr() if (eng.dtype == "bf16" and eng.flat_lp is not None) else None
-        L.check(L.lib().cpt_adamw(eng.flat.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                  self.code.data_ptr(), shadow, eng.flat.numel(), lr, self.betas[0], self.betas[1], self.eps,
-                                  wd, self.step_count, scale, L.stream_ptr()), "cpt_adamw")
-        eng.weights_updated(shadow_fresh=shadow is not None)
+        lp = eng.dtype == "bf16" and eng.flat_lp is not None
+        if self.sync is None:
+            shadow = eng.flat_lp.data_ptr() if lp else None
+            self._adamw(eng.flat.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.code.data_ptr(), shadow,
+                        eng.flat.numel(), lr, wd, self._clip)
+            self._clip = 1.0
+            eng.weights_updated(shadow_fresh=shadow is not None)
+            return
+        # data parallel: summed gradient shards -> AdamW on the shard (mean folded in as 1/world) -> all-gather
+        sync = self.sync
+        if eng.pending is not None:
+            eng.complete_pending()
+        sync.finish_reduce(st.grad)
+        for k in sync.order:
+            slo, shi = sync.shard_range(k)
+            so = sync.soff[k]
+            self._adamw(eng.flat.data_ptr() + slo * 4, sync.gshard.data_ptr() + so * 4, self.m.data_ptr() + so * 4,
+                        self.v.data_ptr() + so * 4, self.code.data_ptr() + so, None, shi - slo, lr, wd, self._clip / self.world)
+        self._clip = 1.0
+        sync.all_gather_params(eng.flat)
+        self._stale_shadow = set(sync.order)
+        eng.pending = self
 
+    def _params_arrived(self, bucket=None):
+        """engine.complete_pending: bucket's all-gather has landed on the current stream -> refresh its derived copies."""
+        ks = list(self.sync.order) if bucket is None else [bucket]
+        for k in ks:
+            if k in self._stale_shadow:
+                self.sync.wait_params(k)
+                self.eng.refresh_bucket_shadow(k)
+                self._stale_shadow.discard(k)
+        if not self._stale_shadow:
+            self.eng.pending = None
+            self.eng._sig = {self.eng.dtype: self.eng._versions()}
 
     # ---- checkpointing (SURVEY 8(f).4): the reference saves no optimizer state (utils/save_model.py), so a few-shot
     # run cannot resume; here the moments travel with the model, keyed by parameter NAME ------------------------------
+    def _full_moments(self):
+        if self.sync is None:
+            return self.m, self.v
+        n = self.eng.flat.numel()
+        return self.sync.gather_full(self.m, n), self.sync.gather_full(self.v, n)
+
     def state_dict(self):
         """{"state": {name: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...], "betas", "eps"}: the same
-        per-parameter entries as torch.optim.AdamW.state_dict(), as CPU tensors."""
+        per-parameter entries as torch.optim.AdamW.state_dict(), as CPU tensors (data parallel: a collective call,
+        the sharded moments are gathered)."""
         self._ensure()
+        m, v = self._full_moments()
         state = {}
         for n, (off, num) in self.eng.offsets.items():
             shape = tuple(self.eng._named()[n].shape) if hasattr(self.eng, "_named") else (num,)
             state[n] = {"step": self.step_count,
-                        "exp_avg": self.m[off:off + num].view(shape).detach().cpu().clone(),
-                        "exp_avg_sq": self.v[off:off + num].view(shape).detach().cpu().clone()}
+                        "exp_avg": m[off:off + num].view(shape).detach().cpu().clone(),
+                        "exp_avg_sq": v[off:off + num].view(shape).detach().cpu().clone()}
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
         return {"state": state, "param_groups": groups, "betas": tuple(self.betas), "eps": self.eps,
                 "step_count": self.step_count}
@@ -286,12 +413,19 @@ class FusedAdamW(object):
         missing = [n for n in self.eng.offsets if n not in sd["state"]]
         if missing:
             raise RuntimeError("cpt_amd: optimizer state lacks %d parameters, e.g. %s" % (len(missing), missing[0]))
+        n_all = self.eng.flat.numel()
+        dev = self.eng.flat.device
+        m = torch.zeros(n_all, device=dev) if self.sync is not None else self.m
+        v = torch.zeros(n_all, device=dev) if self.sync is not None else self.v
         for n, (off, num) in self.eng.offsets.items():
             e = sd["state"][n]
             if e["exp_avg"].numel() != num:
                 raise RuntimeError("cpt_amd: optimizer state of %s has %d elements, expected %d" % (n, e["exp_avg"].numel(), num))
-            self.m[off:off + num].copy_(e["exp_avg"].reshape(-1))
-            self.v[off:off + num].copy_(e["exp_avg_sq"].reshape(-1))
+            m[off:off + num].copy_(e["exp_avg"].reshape(-1))
+            v[off:off + num].copy_(e["exp_avg_sq"].reshape(-1))
+        if self.sync is not None:
+            self.sync.scatter_full(m, self.m)
+            self.sync.scatter_full(v, self.v)
         self.step_count = int(sd.get("step_count", next(iter(sd["state"].values()))["step"]))
         self.betas = tuple(sd.get("betas", self.betas))
         self.eps = sd.get("eps", self.eps)

@@ -142,9 +142,8 @@ enum {
     CPT_OUT_MASK_LOGITS = 4,/* prediction scores of the [MASK] rows only [B][V] fp32 */
     CPT_OUT_ALL_LOGITS = 8, /* prediction scores of every position [B][L][V] (modeling_rec.py:143) */
     CPT_OUT_LOSS = 16,      /* CrossEntropy(ignore_index=-1) (modeling_rec.py:147-150) */
-    CPT_OUT_REL = 32,       /* cls.seq_relationship(pooled) [B][n_rel] (modeling_vcr.py NSPCPT) */
-    CPT_SAVE_FOR_BWD = 1024 /* keep per-layer activations in the workspace for cpt_model_bwd */
-};
+    CPT_OUT_REL = 32        /* cls.seq_relationship(pooled) [B][n_rel] (modeling_vcr.py NSPCPT) */
+};  /* (training keeps its activations through cpt_train_fwd / cpt_train_bwd below, not through a flag here) */
 
 typedef struct {
     float* seq;          /* CPT_OUT_SEQ */
@@ -192,6 +191,26 @@ int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
  * (vector gradients are accumulated with atomics); uses the workspace cpt_train_fwd filled. */
 int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* Data-parallel fine-tuning (the reference wraps the model in DistributedDataParallel, whose bucketed gradient
+ * all-reduce overlaps backward: Oscar/oscar/fewshot/refcoco_cpt.py:516-522).  The parameters form
+ * dims.layers + 2 BUCKETS: 0 = embedding tables + embeddings.LayerNorm + region projection (+ its LayerNorm),
+ * 1 + l = encoder layer l, dims.layers + 1 = pooler + MLM head.  The _ex forms call back on the HOST, from inside
+ * the call, on the calling thread:
+ *   cpt_train_fwd_ex: before_bucket(user, k) BEFORE the first launch that reads bucket k's parameters is enqueued
+ *                     (order 0, 1 .. layers, layers + 1) -- the caller makes `stream` wait for k's parameter all-gather;
+ *   cpt_train_bwd_ex: grads_ready(user, k) AFTER the last launch that writes bucket k's gradients is enqueued
+ *                     (order layers + 1, layers .. 1, 0) -- the caller records an event on `stream` and starts
+ *                     bucket k's reduce-scatter on its communication stream while backward continues.
+ * The library itself owns no communicator: collectives stay in torch.distributed (RCCL).  NULL callbacks = the plain forms. */
+typedef void (*cpt_bucket_fn)(void* user, int bucket);
+int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
+                     size_t workspace_bytes, void* stream, cpt_bucket_fn before_bucket, void* user);
+/* loss_scale_dev (optional): DEVICE scalar multiplied into loss_scale -- autograd's incoming gradient of the loss
+ * without a host synchronisation. */
+int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
+                     const float* loss_scale_dev, void* workspace, size_t workspace_bytes, void* stream,
+                     cpt_bucket_fn grads_ready, void* user);
+
 /* torch.optim.AdamW update (fewshot/refcoco_cpt.py:343,249) over flat buffers of n fp32 elements
  * (n % 4 == 0).  code[i]: 0 = no gradient on this path (skipped), 1 = weight decay, 2 = no decay
  * (fewshot/refcoco_cpt.py:320-338).  grad is multiplied by grad_scale first (1/world after a

@@ -1,7 +1,7 @@
 /* cpt_io.h -- C ABI of the region-feature wire-format decoder, host side.
  *
  * The reference stores the VinVL region features of every (image, proposal) pair as base64 text of
- * float32[2054] inside a JSON object on one TSV line (writer: Oscar/oscar/zeroshot/inference_ref.py:157-191)
+ * float32[2054] inside a JSON object on one TSV line (writer: prompt_feat/maskrcnn_benchmark/engine/inference_ref.py:157-191)
  * and decodes them per box in Python: json.loads -> base64.b64decode -> np.frombuffer -> np.stack -> torch.Tensor
  * -> zero-pad to img_seq_len rows (Oscar/oscar/datasets/refcoco_zsl_cpt_dataset.py:161-180 and :119-120).
  * At the GPU's rate (3e4 sequences/s x 0.55 MB of base64 each) that Python path is the bottleneck.  These entry

@@ -195,6 +195,24 @@ def test_region_stager_matches_host_decode(dev):
                 ref[p, :len(seq)] = torch.from_numpy(np.stack(seq))
         assert torch.equal(feats.cpu(), ref)
         assert mask.cpu().sum(1).tolist() == counts
+        st.release()
+    # write-after-read: a slow consumer and a host that runs `depth` batches ahead -- the side stream must
+    # not overwrite slot k before the consumer's reads of it (enqueued behind a long kernel) have run
+    outs, refs = [], []
+    for it in range(6):
+        data_it = [[np.full(2054, 100.0 * it + p + 0.25 * j, dtype=np.float32) for j in range(c)] for p, c in enumerate(counts)]
+        lists_it = [[base64.b64encode(a.tobytes()).decode() for a in seq] for seq in data_it]
+        feats, mask = st.stage_and_wait(lists_it)
+        torch.cuda._sleep(40_000_000)                     # ~20 ms of consumer-stream work ahead of the read
+        outs.append(feats.clone())
+        st.release()
+        r = torch.zeros(4, 50, 2054)
+        for p, seq in enumerate(data_it):
+            if seq:
+                r[p, :len(seq)] = torch.from_numpy(np.stack(seq))
+        refs.append(r)
+    for o, r in zip(outs, refs):
+        assert torch.equal(o.cpu(), r)
 
 
 @pytest.mark.parametrize("shape", [("base", 1, 70, 50), ("base", 5, 78, 50), ("base", 3, 28, 5), ("large", 3, 70, 50)])

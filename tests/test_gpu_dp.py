@@ -1,0 +1,131 @@
+"""GPU: the PRODUCT data-parallel training step (train.FusedAdamW with world_size 2: rank-0 broadcast at construction,
+per-bucket reduce-scatter started from cpt_train_bwd_ex's callbacks on a side stream, sharded cpt_adamw, parameter
+all-gather awaited bucket by bucket inside cpt_train_fwd_ex) against a single-process step on the concatenated batch.
+Both ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device; the collectives are the same
+torch.distributed calls).  Reference: DistributedDataParallel at /root/reference/Oscar/oscar/fewshot/refcoco_cpt.py:516-522."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from cpt_amd import config as cfgmod
+from cpt_amd import synth
+
+pytestmark = pytest.mark.gpu
+STEPS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(cfg, seed, dev, mode, wire=None):
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    from cpt_amd.train import FusedAdamW
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, seed, head="cpt"))
+    m.tie_weights()
+    m.to(dev).train()
+    m.set_compute_dtype(mode)
+    opt = FusedAdamW(m, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.01, grad_wire=wire)
+    return m, opt
+
+
+def _run(m, opt, b, rows, steps=STEPS):
+    losses = []
+    d = {k: v[rows] for k, v in b.items()}
+    for _ in range(steps):
+        opt.zero_grad()
+        loss, _ = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"],
+                    masked_lm_labels=d["colors"], mask_token_pos=d["mask_token_pos"])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    return losses
+
+
+def _worker(rank, world, port, tmp, mode, wire):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        cfg = cfgmod.tiny()
+        m, opt = _make(cfg, 1234 + 17 * rank, dev, mode, wire)      # rank 1 starts from OTHER weights: the broadcast must fix that
+        assert opt.sync is not None and opt.m.numel() * world == m._engine().flat.numel()      # moments are sharded
+        b = {k: v.to(dev) for k, v in synth.make_batch(4, cfg, seed=5, max_seq_len=20, img_seq_len=6).items()}
+        per = 4 // world
+        losses = _run(m, opt, b, slice(rank * per, (rank + 1) * per))
+        m.eval()
+        with torch.no_grad():                                        # a parameter all-gather is still pending here
+            logits = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                       mask_token_pos=b["mask_token_pos"])[0]
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        osd = opt.state_dict()                                       # collective: gathers the sharded moments
+        torch.save({"sd": sd, "losses": losses, "logits": logits.cpu(), "opt": osd}, os.path.join(tmp, "r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,wire", [("fp32", None), ("bf16", None), ("fp32", "bf16")])
+def test_product_dp_step_world2_matches_single_process(mode, wire):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(world, _free_port(), tmp, mode, wire), nprocs=world, join=True)
+        r = [torch.load(os.path.join(tmp, "r%d.pt" % i)) for i in range(world)]
+    dev = torch.device("cuda:0")
+    cfg = cfgmod.tiny()
+    m, opt = _make(cfg, 1234, dev, mode)
+    b = {k: v.to(dev) for k, v in synth.make_batch(4, cfg, seed=5, max_seq_len=20, img_seq_len=6).items()}
+    losses = _run(m, opt, b, slice(0, 4))
+    m.eval()
+    with torch.no_grad():
+        logits = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                   mask_token_pos=b["mask_token_pos"])[0].cpu()
+    exact = mode == "fp32" and wire is None
+    ptol, ltol = (1e-6, 1e-5) if exact else (4e-3, 5e-2)
+    # replicas identical to each other bit for bit, and equal to the single-process run on the concatenated batch
+    for k, v in m.state_dict().items():
+        assert torch.equal(r[0]["sd"][k], r[1]["sd"][k]), k
+        err = (r[0]["sd"][k] - v.cpu()).abs().max().item()
+        assert err < ptol, (k, err)
+    assert torch.equal(r[0]["logits"], r[1]["logits"])
+    assert (r[0]["logits"] - logits).abs().max().item() < (1e-4 if exact else 0.15)
+    for s in range(STEPS):
+        mean = 0.5 * (r[0]["losses"][s] + r[1]["losses"][s])        # equal labelled-row counts per rank
+        assert abs(mean - losses[s]) < ltol, (s, mean, losses[s])
+    ref = opt.state_dict()
+    for k in ref["state"]:
+        e = (r[0]["opt"]["state"][k]["exp_avg"] - ref["state"][k]["exp_avg"]).abs().max().item()
+        assert e < (1e-6 if exact else 1e-2), (k, e)
+    assert r[0]["opt"]["step_count"] == STEPS
+
+
+def test_stale_training_forward_raises():
+    """loss_a = model(a); loss_b = model(b); loss_a.backward() must not consume b's activations."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    cfg = cfgmod.tiny()
+    m, opt = _make(cfg, 1234, dev, "fp32")
+    b = {k: v.to(dev) for k, v in synth.make_batch(4, cfg, seed=5, max_seq_len=20, img_seq_len=6).items()}
+
+    def fwd(rows):
+        d = {k: v[rows] for k, v in b.items()}
+        return m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"],
+                 masked_lm_labels=d["colors"], mask_token_pos=d["mask_token_pos"])[0]
+    la = fwd(slice(0, 2))
+    lb = fwd(slice(2, 4))
+    with pytest.raises(RuntimeError, match="stale training forward"):
+        la.backward()
+    lb.backward()                                                   # the latest forward still has its activations
