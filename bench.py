@@ -290,7 +290,7 @@ def main():
                 "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": ("Oscar-base CPT few-shot training step (fwd+bwd+grad all-reduce+AdamW), batch %d/GPU, "
-                                        "50 regions, seq_len 120, %s, dropout off" % (B, args.dtype)) if train else
+                                        "50 regions, seq_len 120, %s, dropout %.2g" % (B, args.dtype, cfg.hidden_dropout_prob)) if train else
                                        "Oscar-base CPT RefCOCO inference, batch %d/GPU, 50 regions, seq_len 120, %s, "
                                        "[MASK]-row logits%s" % (B, args.dtype, " (all-row head)" if args.all_rows else ""),
                            "global_batch": B * n_gpus, "seq_len": 120, "parallelism": "dp%d" % n_gpus,

@@ -15,7 +15,8 @@ K_NAMES = ["gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up",
            "embed_ln", "img_proj", "head", "op"]
 
 vp, i32, i64p, f32p = C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p
-BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)      # cpt_bucket_fn (host callback of cpt_train_{fwd,bwd}_ex); None = NULL
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)      # cpt_bucket_fn (host callback of cpt_train_{fwd,bwd}_ex)
+NULL_CB = C.cast(None, BUCKET_CB)                        # "no callback"
 
 
 class Dims(C.Structure):
@@ -59,6 +60,10 @@ class ModelGrads(C.Structure):
                [(n, C.c_void_p) for n in ("w_tr", "b_tr", "tr_ln_g", "tr_ln_b", "b_dec")]
 
 
+class Dropout(C.Structure):
+    _fields_ = [("p_hidden", C.c_float), ("p_attn", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64)]
+
+
 class Outputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("seq", "pooled", "logits", "loss", "rel")]
 
@@ -72,9 +77,11 @@ _SIGS = {
     "cpt_train_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int]),
     "cpt_train_fwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), vp, C.c_size_t, vp]),
     "cpt_train_bwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(ModelGrads), C.c_float, vp, C.c_size_t, vp]),
-    "cpt_train_fwd_ex": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), vp, C.c_size_t, vp, BUCKET_CB, vp]),
+    "cpt_train_fwd_ex": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), vp, C.c_size_t, vp, BUCKET_CB, vp,
+                                   C.POINTER(Dropout)]),
     "cpt_train_bwd_ex": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(ModelGrads), C.c_float, vp, vp, C.c_size_t, vp,
-                                   BUCKET_CB, vp]),
+                                   BUCKET_CB, vp, C.POINTER(Dropout)]),
+    "cpt_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_adamw": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                             C.c_int, C.c_float, vp]),
     "cpt_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int,

@@ -35,7 +35,7 @@ __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >>
 template <typename T, int NKB>
 __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
-    T* __restrict__ probs, int B, int L, int heads) {
+    T* __restrict__ probs, int B, int L, int heads, DropSpec dr) {
     typedef typename FragOf<T>::type frag_t;
     constexpr int CE = Chunk<T>::N;
     constexpr int NC = HD / CE;                       // chunks per K row
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     if constexpr (LPT) {     // bf16: the shared core (attn_core.h); everything below is the fp32 parity path
         T* crow = ctx + ((size_t)b * L + min(q, L - 1)) * H + h * HD;
         T* prow = probs ? probs + (((size_t)b * heads + h) * L + min(q, L - 1)) * L : nullptr;
-        attn_core_bf16<NKB>(fq, sK, sV, sMask, lane, q < L, crow, prow, L);
+        attn_core_bf16<NKB>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)blockIdx.x, min(q, L - 1));
         return;
     }
 
@@ -150,6 +150,17 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[kb][r] *= inv;
+    if (dr.thresh != 0) {   // training: dropout on the probabilities (modeling_bert.py:57), same mask function as the bf16 core
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bool keep[4];
+                drop_attn_row4(dr, (uint32_t)blockIdx.x, min(q, L - 1), kb * 8 + 2 * g + fh, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st[kb][4 * g + j] = keep[j] ? st[kb][4 * g + j] * dr.scale : 0.f;
+            }
+    }
 
     if (probs && q < L) {   // [B][heads][L][L], saved for the backward pass only
         T* pr = probs + (((size_t)b * heads + h) * L + q) * L;
@@ -205,7 +216,7 @@ static size_t att_lds_bytes() {
 }
 
 template <typename T, int NKB>
-static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s) {
+static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s) {
     const size_t lds = att_lds_bytes<T, NKB>();
     auto kern = attention_kernel<T, NKB>;
     if (lds > 64 * 1024) {
@@ -213,24 +224,26 @@ static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* pro
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
     }
     dim3 grid(B * heads, (L + 127) / 128), block(ATT_THREADS);
-    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads);
+    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads, dr);
     return CPT_OK;
 }
 
 template <typename T>
-static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s) {
-    if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, s);
-    if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, s);
-    if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, s);
-    if (L <= 288) return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, s);
+static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s) {
+    if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, dr, s);
+    if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, dr, s);
+    if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, dr, s);
+    if (L <= 288) return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, dr, s);
     return CPT_ERR_SHAPE;
 }
 
-int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s) {
+int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s,
+              const DropSpec* drop) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
     if (!qkv || !ctx) return CPT_ERR_NULL;
-    if (dtype == CPT_BF16) return att_dispatch<bf16>(qkv, attn_mask, ctx, probs, B, L, heads, s);
-    if (dtype == CPT_F32) return att_dispatch<float>(qkv, attn_mask, ctx, probs, B, L, heads, s);
+    const DropSpec dr = drop ? *drop : DropSpec{};
+    if (dtype == CPT_BF16) return att_dispatch<bf16>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s);
+    if (dtype == CPT_F32) return att_dispatch<float>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s);
     return CPT_ERR_DTYPE;
 }
 

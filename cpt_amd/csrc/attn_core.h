@@ -3,6 +3,7 @@
 //   ctx[q][:] = softmax(Q K^T / 8 + mask) V        (modeling_bert.py:42-67 of the reference, per sequence and head)
 #pragma once
 #include "common.h"
+#include "dropout.h"
 
 namespace cpt {
 
@@ -36,7 +37,7 @@ __device__ __forceinline__ int att_key_of(int r, int h) { return (r & 3) + 8 * (
 template <int NKB>
 __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsigned char* sK, const unsigned char* sV,
                                                const float* sMask, int lane, bool valid, bf16* ctx_row,
-                                               bf16* probs_row, int L) {
+                                               bf16* probs_row, int L, const DropSpec& dr = DropSpec{}, uint32_t bh = 0, int q = 0) {
     const int fr = lane & 31, fh = lane >> 5;
     // S^T = K . Q^T : accumulator rows = keys, column (lane&31) = query
     f32x16 st[NKB];
@@ -76,6 +77,18 @@ __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsi
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[kb][r] *= inv;
+    // training: dropout on the probabilities (modeling_bert.py:57); bh = sequence * heads + head, q = this lane's query
+    if (dr.thresh != 0) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bool keep[4];
+                drop_attn_row4(dr, bh, q, kb * 8 + 2 * g + fh, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st[kb][4 * g + j] = keep[j] ? st[kb][4 * g + j] * dr.scale : 0.f;
+            }
+    }
 
     if (probs_row && valid) {   // [B][heads][L][L], saved for the backward pass only
 #pragma unroll

@@ -475,13 +475,77 @@ int scale_cast(const float* x, const float* loss_acc, float scale, const float* 
     return CPT_OK;
 }
 
+// ---- hidden dropout as a row pass: y = dropout(x) (+ resid), optional low-precision copy ------------------------------
+// Forward of the reference's hidden dropouts (BertEmbeddings / modeling_bert.py:266 / BertSelfOutput / BertOutput) and,
+// with resid = NULL, their backward.  4 elements per thread = one Philox call (dropout.h).
+template <typename TL>
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ x, const float* __restrict__ resid, float* __restrict__ y,
+                                                           TL* __restrict__ y_lp, size_t n4, DropSpec d) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    bool keep[4];
+    drop_hidden4(d, i, keep);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * d.scale : 0.f;
+    if (resid) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(resid + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    if (y) *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    if (y_lp) {
+        if constexpr (sizeof(TL) == 2) {
+            bf16x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16)v[e];
+            *reinterpret_cast<bf16x4*>(y_lp + i * 4) = pk;
+        } else {
+            *reinterpret_cast<f32x4*>(y_lp + i * 4) = v;
+        }
+    }
+}
+int dropout_rows(const float* x, const float* resid, float* y, void* y_lp, int lp_dtype, int R, int H, const DropSpec& d, hipStream_t s) {
+    if (R <= 0 || H <= 0 || H % 4) return CPT_ERR_SHAPE;
+    if (!x || (!y && !y_lp)) return CPT_ERR_NULL;
+    const size_t n4 = (size_t)R * H / 4;
+    dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+    if (y_lp && lp_dtype == CPT_BF16) dropout_rows_kernel<bf16><<<grid, block, 0, s>>>(x, resid, y, (bf16*)y_lp, n4, d);
+    else dropout_rows_kernel<float><<<grid, block, 0, s>>>(x, resid, y, (float*)y_lp, n4, d);
+    return CPT_OK;
+}
+
+// keep-mask export for the tests / the oracle: kind 0 = hidden site [n0 rows][n1 columns]; kind 1 = attention site
+// [n0 = sequences * heads][n1 = queries][n2 = keys].  out[...] = 1 keep, 0 drop.
+__global__ __launch_bounds__(256) void dropout_mask_kernel(int kind, unsigned char* __restrict__ out, size_t n, int n1, int n2, DropSpec d) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (kind == 0) {
+        bool keep[4];
+        drop_hidden4(d, i >> 2, keep);
+        out[i] = keep[i & 3] ? 1 : 0;
+    } else {
+        const int k = (int)(i % n2), q = (int)((i / n2) % n1);
+        const uint32_t bh = (uint32_t)(i / ((size_t)n1 * n2));
+        out[i] = drop_attn_one(d, bh, q, k) ? 1 : 0;
+    }
+}
+int dropout_mask(int kind, unsigned char* out, int n0, int n1, int n2, const DropSpec& d, hipStream_t s) {
+    if (!out) return CPT_ERR_NULL;
+    if (n0 <= 0 || n1 <= 0 || (kind == 1 && n2 <= 0) || (kind != 0 && kind != 1)) return CPT_ERR_SHAPE;
+    const size_t n = kind == 0 ? (size_t)n0 * n1 : (size_t)n0 * n1 * n2;
+    dropout_mask_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(kind, out, n, n1, n2, d);
+    return CPT_OK;
+}
+
 // ---- attention backward (generic, fp32 math on LDS tiles; one workgroup per (sequence, head)) ----
 // Recomputes P = softmax(QK^T/8 + mask) per 32-query block, then
 //   dV += P^T dO,  dP = dO V^T,  dS = P (dP - rowsum(dP P)),  dQ = dS K / 8,  dK += dS^T Q / 8.
 constexpr int AB_QB = 32, AB_D = 64;
 template <typename T, int MAXE>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
-                                                       const T* __restrict__ dctx, T* __restrict__ dqkv, int B, int L, int heads) {
+                                                       const T* __restrict__ dctx, T* __restrict__ dqkv, int B, int L, int heads,
+                                                       DropSpec dr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LP1 = L + 1;
     float* sK = reinterpret_cast<float*>(smem);          // [L][65]
@@ -491,6 +555,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     float* sP = sO + AB_QB * 65;                          // [32][L+1]
     float* sS = sP + AB_QB * LP1;                         // [32][L+1]  (dP then dS)
     float* sM = sS + AB_QB * LP1;                         // [L] additive mask
+    float* sW = sM + L;                                   // [32][L+1] dropout multipliers (0 or 1/(1-p)); only with dropout
+    const bool drop = dr.thresh != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const int H = heads * AB_D;
@@ -530,6 +596,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
                 dp += sO[i * 65 + d] * sV[j * 65 + d];
             }
             sP[i * LP1 + j] = s * 0.125f + sM[j];
+            if (drop) {      // dp arrives as the gradient of the DROPPED probabilities: d/dP = mask / (1-p) times it
+                const float wgt = drop_attn_one(dr, (uint32_t)blockIdx.x, min(q0 + i, L - 1), j) ? dr.scale : 0.f;
+                sW[i * LP1 + j] = wgt;
+                dp *= wgt;
+            }
             sS[i * LP1 + j] = dp;
         }
         __syncthreads();
@@ -567,7 +638,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
                     float ak = 0.f, av = 0.f;
                     for (int i = 0; i < nq; ++i) {
                         ak += sS[i * LP1 + j] * sQ[i * 65 + d];
-                        av += sP[i * LP1 + j] * sO[i * 65 + d];
+                        av += (drop ? sP[i * LP1 + j] * sW[i * LP1 + j] : sP[i * LP1 + j]) * sO[i * 65 + d];
                     }
                     accK[k] += ak;
                     accV[k] += av;
@@ -600,7 +671,8 @@ __device__ __forceinline__ int kq_off(int row, int chunk) { return row * 128 + (
 
 template <int NKB>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
-                                                            const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int B, int L, int heads) {
+                                                            const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int B, int L, int heads,
+                                                            DropSpec dr) {
     constexpr int LP = NKB * 32;
     constexpr int TROW = LP * 2 + 8;                  // bytes per transposed-tile row (pad: conflict-free b64 reads)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -703,6 +775,18 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
             for (int r = 0; r < 16; ++r) { const float e = expf(st[kb][r] - mx); st[kb][r] = e; sum += e; }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+        if (dr.thresh != 0) {       // dp is the gradient of the DROPPED probabilities: times mask / (1-p) (same mask as forward)
+            const int qd = min(qb * 32 + fr, L - 1);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bool keep[4];
+                    drop_attn_row4(dr, (uint32_t)blockIdx.x, qd, kb * 8 + 2 * g + fh, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dp[kb][4 * g + j] = keep[j] ? dp[kb][4 * g + j] * dr.scale : 0.f;
+                }
+        }
         float dd = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
@@ -756,12 +840,25 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
                 sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sQ, qb * 32 + fr, ks), rowfrag(sK, kb * 32 + fr, ks), sb, 0, 0, 0);
                 db_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sO, qb * 32 + fr, ks), rowfrag(sV, kb * 32 + fr, ks), db_, 0, 0, 0);
             }
+            float wgt[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wgt[r] = 1.f;
+            if (dr.thresh != 0) {   // lane = key, register quads = 4 consecutive queries
+                const int kd = min(kb * 32 + fr, L - 1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bool keep[4];
+                    drop_attn_col4(dr, (uint32_t)blockIdx.x, qb * 8 + 2 * g + fh, kd, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wgt[4 * g + j] = keep[j] ? dr.scale : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 const float p = expf(sb[r] * 0.125f + mk - sM[q]) * sLi[q];
-                sb[r] = p;
-                db_[r] = p * (db_[r] - sD[q]);
+                sb[r] = p * wgt[r];                                   // dropped probabilities -> dV
+                db_[r] = p * (db_[r] * wgt[r] - sD[q]);               // dS -> dK
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -788,7 +885,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
 }
 
 template <int NKB>
-static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s) {
+static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int heads, const DropSpec& dr,
+                                hipStream_t s) {
     constexpr int LP = NKB * 32;
     const size_t lds = (size_t)4 * LP * 128 + (size_t)3 * 64 * (LP * 2 + 8) + (size_t)4 * LP * sizeof(float);
     auto k = attn_bwd_mfma_kernel<NKB>;
@@ -798,21 +896,23 @@ static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         done = true;
     }
-    k<<<dim3(B * heads), dim3(256), lds, s>>>((const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, heads);
+    k<<<dim3(B * heads), dim3(256), lds, s>>>((const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, heads, dr);
     return CPT_OK;
 }
 
 int g_attn_bwd_variant = 1;      // 1: MFMA kernel for bf16 when L <= 128; 0: generic kernel always
 void set_attn_bwd_variant(int v) { g_attn_bwd_variant = v; }
 
-int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s) {
+int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
+                  const DropSpec* drop) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
+    const DropSpec dr = drop ? *drop : DropSpec{};
     if (dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L <= 128) {
-        if (L <= 32) return attn_bwd_mfma_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, s);
-        if (L <= 64) return attn_bwd_mfma_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, s);
-        return attn_bwd_mfma_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, s);
+        if (L <= 32) return attn_bwd_mfma_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
+        if (L <= 64) return attn_bwd_mfma_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
+        return attn_bwd_mfma_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
     }
-    const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + 2 * AB_QB * (L + 1) + L) * sizeof(float);
+    const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + (dr.thresh ? 3 : 2) * AB_QB * (L + 1) + L) * sizeof(float);
     if (lds > 160 * 1024) return CPT_ERR_SHAPE;            // L <= ~176 in this round (RefCOCO L = 120)
     dim3 grid(B * heads), block(256);
     hipError_t e;
@@ -822,7 +922,7 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
         if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)             \
             return CPT_ERR_HIP - (int)e;                                                                              \
-        k<<<grid, block, lds, s>>>((const TT*)qkv, attn_mask, (const TT*)dctx, (TT*)dqkv, B, L, heads);               \
+        k<<<grid, block, lds, s>>>((const TT*)qkv, attn_mask, (const TT*)dctx, (TT*)dqkv, B, L, heads, dr);           \
     } while (0)
     if (dtype == CPT_BF16) { if (L <= 128) ABK(bf16, 32); else ABK(bf16, 44); }
     else if (dtype == CPT_F32) { if (L <= 128) ABK(float, 32); else ABK(float, 44); }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/cpt_hip.h"
+#include "dropout.h"
 
 namespace cpt {
 
@@ -19,7 +20,7 @@ int layernorm_rows(const float* x, const float* g, const float* bta, float eps, 
                    hipStream_t s);
 
 int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B,
-              int L, int heads, hipStream_t s);
+              int L, int heads, hipStream_t s, const DropSpec* drop = nullptr);
 
 int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s);
 
@@ -43,7 +44,13 @@ int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, in
 int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s);
 int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
                hipStream_t s);
-int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s);
+int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
+                  const DropSpec* drop = nullptr);
+// y = dropout(x) (+ resid): x, y fp32 [R][H] (in place allowed), y_lp optional copy in lp_dtype; element index of the mask =
+// row * H + col.  Forward of the hidden dropouts and, with resid = NULL, their backward (the mask applied to a gradient).
+int dropout_rows(const float* x, const float* resid, float* y, void* y_lp, int lp_dtype, int R, int H, const DropSpec& d, hipStream_t s);
+// keep-mask export (tests): kind 0 hidden [R][H]; kind 1 attention [BH][L][L]; out = 1 keep / 0 drop
+int dropout_mask(int kind, unsigned char* out, int n0, int n1, int n2, const DropSpec& d, hipStream_t s);
 int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16, size_t n,
                float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s);
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,

@@ -21,7 +21,7 @@ struct TrainLayout {
     size_t x_f32, a_f32, layer0, layer_stride;
     size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2;     // offsets inside a layer block
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
-    size_t dx, dpre, da, dpre_lp, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp;
+    size_t dx, dpre, da, dpre_lp, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
     size_t total;
     int Mp, Bp, Vp, Rp;
 };
@@ -71,6 +71,8 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li) {
     w.drows = take((size_t)B * H * 4);
     w.dimg = take(R * H * 4);
     w.dimg_lp = take(R * H * es);
+    w.dmask = take(M * H * 4);        // dropout: masked gradient of a dense output (the unmasked one feeds the residual path)
+    w.dmask_lp = take(M * H * es);
     w.total = o;
     return w;
 }
@@ -91,6 +93,30 @@ int check_common(const cpt_model* m, const cpt_batch* b, void* ws, size_t ws_byt
     return CPT_OK;
 }
 
+// Dropout sites of the model (counter word 3 of the Philox stream, dropout.h): 0 = embeddings (text and region rows,
+// after their LayerNorms); layer l: 1 + 3l attention probabilities, 2 + 3l BertSelfOutput, 3 + 3l BertOutput.
+cpt::DropSpec drop_spec(const cpt_dropout* d, int site, bool attn) {
+    cpt::DropSpec s = {};
+    if (!d) return s;
+    const double p = attn ? d->p_attn : d->p_hidden;
+    if (!(p > 0.0)) return s;
+    s.k0 = (uint32_t)d->seed; s.k1 = (uint32_t)(d->seed >> 32);
+    s.step = (uint32_t)d->step; s.site = (uint32_t)site;
+    const double full = attn ? 65536.0 : 4294967296.0;
+    double t = p * full;
+    if (t < 1.0) t = 1.0;
+    if (t > full - 1.0) t = full - 1.0;
+    s.thresh = (uint32_t)(t + 0.5);
+    s.scale = (float)(1.0 / (1.0 - (double)s.thresh / full));      // exact effective rate: E[mask * scale] = 1
+    return s;
+}
+int check_drop(const cpt_dropout* d, const char* who) {
+    if (!d) return CPT_OK;
+    if (!(d->p_hidden >= 0.f && d->p_hidden < 1.f) || !(d->p_attn >= 0.f && d->p_attn < 1.f))
+        return abi_fail(CPT_ERR_SHAPE, "%s: dropout probabilities must be in [0, 1)", who);
+    return CPT_OK;
+}
+
 }  // namespace
 
 #define TRY(expr, what)                        \
@@ -108,12 +134,14 @@ size_t cpt_train_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li) {
 
 int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
                   size_t workspace_bytes, void* stream) {
-    return cpt_train_fwd_ex(m, b, o, workspace, workspace_bytes, stream, nullptr, nullptr);
+    return cpt_train_fwd_ex(m, b, o, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr);
 }
 
 int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
-                     size_t workspace_bytes, void* stream, cpt_bucket_fn before_bucket, void* user) {
+                     size_t workspace_bytes, void* stream, cpt_bucket_fn before_bucket, void* user, const cpt_dropout* drop) {
     if (!m || !b || !o || !workspace) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: null argument");
+    if (int rcd = check_drop(drop, "cpt_train_fwd")) return rcd;
+    const bool ph = drop && drop->p_hidden > 0.f, pa = drop && drop->p_attn > 0.f;
     const cpt_dims& d = m->dims;
     const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li);
     int rc = check_common(m, b, workspace, workspace_bytes, w, "cpt_train_fwd");
@@ -141,17 +169,30 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
                       B * Li, H, d.img_dim_pad, s), "gemm(img_embedding)");
         TRY(cpt::layernorm_rows(imgpre, m->img_ln_g, m->img_ln_b, d.img_ln_eps, x_f32, LB(0, w.o_xin), dt, B * Li, H, Li, L, Lt, s), "layernorm(img)");
     }
+    if (ph)   // BertEmbeddings' dropout on the text rows and modeling_bert.py:266 on the region rows: one pass over all rows
+        TRY(cpt::dropout_rows(x_f32, nullptr, x_f32, LB(0, w.o_xin), dt, M, H, drop_spec(drop, 0, false), s), "dropout(embeddings)");
     for (int l = 0; l < d.layers; ++l) {
         const cpt_layer& y = m->layers[l];
         need(1 + l);
         void* xin = LB(l, w.o_xin);
         void* xnext = l + 1 < d.layers ? LB(l + 1, w.o_xin) : (void*)(ws + w.xout);
         TRY(cpt::gemm(dt, CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
-        TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s), "attention");
+        const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
+        TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention");
+        if (ph) {   // LN(dropout(dense(ctx)) + x): the residual add moves from the GEMM epilogue into the dropout pass
+            TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, nullptr, 0, LB(l, w.o_pre1), CPT_F32, H, M, H, H, s), "gemm(attn out)");
+            TRY(cpt::dropout_rows((const float*)LB(l, w.o_pre1), x_f32, (float*)LB(l, w.o_pre1), nullptr, dt, M, H, drop_spec(drop, 2 + 3 * l, false), s),
+                "dropout(attn out)+residual");
+        } else
         TRY(cpt::gemm(dt, CPT_EPI_RESID, LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, x_f32, H, LB(l, w.o_pre1), CPT_F32, H, M, H, H, s), "gemm(attn out)");
         TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, s), "layernorm(attn)");
         TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_a), H, y.w_in, H, y.b_in, nullptr, 0, LB(l, w.o_u), dt, I, M, I, H, s), "gemm(ffn up)");
         TRY(cpt::gelu_fwd(LB(l, w.o_u), LB(l, w.o_h), dt, (size_t)M * I, s), "gelu");
+        if (ph) {
+            TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, 0, LB(l, w.o_pre2), CPT_F32, H, M, H, I, s), "gemm(ffn down)");
+            TRY(cpt::dropout_rows((const float*)LB(l, w.o_pre2), a_f32, (float*)LB(l, w.o_pre2), nullptr, dt, M, H, drop_spec(drop, 3 + 3 * l, false), s),
+                "dropout(ffn down)+residual");
+        } else
         TRY(cpt::gemm(dt, CPT_EPI_RESID, LB(l, w.o_h), I, y.w_out, I, y.b_out, a_f32, H, LB(l, w.o_pre2), CPT_F32, H, M, H, I, s), "gemm(ffn down)");
         TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, s), "layernorm(ffn)");
     }
@@ -175,12 +216,14 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
 
 int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
                   void* workspace, size_t workspace_bytes, void* stream) {
-    return cpt_train_bwd_ex(m, b, g, loss_scale, nullptr, workspace, workspace_bytes, stream, nullptr, nullptr);
+    return cpt_train_bwd_ex(m, b, g, loss_scale, nullptr, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr);
 }
 
 int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale, const float* loss_scale_dev,
-                     void* workspace, size_t workspace_bytes, void* stream, cpt_bucket_fn grads_ready, void* user) {
+                     void* workspace, size_t workspace_bytes, void* stream, cpt_bucket_fn grads_ready, void* user, const cpt_dropout* drop) {
     if (!m || !b || !g || !workspace) return abi_fail(CPT_ERR_NULL, "cpt_train_bwd: null argument");
+    if (int rcd = check_drop(drop, "cpt_train_bwd")) return rcd;
+    const bool ph = drop && drop->p_hidden > 0.f, pa = drop && drop->p_attn > 0.f;
     const cpt_dims& d = m->dims;
     const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li);
     int rc = check_common(m, b, workspace, workspace_bytes, w, "cpt_train_bwd");
@@ -245,14 +288,20 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     ready(d.layers + 1);
 
     // ---- encoder layers, last to first -----------------------------------------------------------
-    const void* dpre_in = dt == CPT_BF16 ? dpre_lp : (const void*)dpre;
+    // with hidden dropout the gradient that enters a dense layer is the masked one (dmask); the unmasked one (dpre)
+    // keeps feeding the residual path
+    float* dmask = (float*)(ws + w.dmask);
+    void* dmask_lp = ws + w.dmask_lp;
+    const void* dpre_in = ph ? (dt == CPT_BF16 ? (const void*)dmask_lp : (const void*)dmask) : (dt == CPT_BF16 ? (const void*)dpre_lp : (const void*)dpre);
+    const float* dpre_f = ph ? dmask : dpre;
     for (int l = d.layers - 1; l >= 0; --l) {
         const cpt_layer& y = m->layers[l];
         const cpt_layer_grads& gy = g->layers[l];
         // x_out = LN2(pre2); pre2 = h W_out^T + b_out + a
         TRY(cpt::ln_bwd(dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln2_g, gy.ln2_b,
                         M, H, M, 0, 0, 0, s), "ln_bwd(ffn)");
-        TRY(cpt::colsum(dpre, CPT_F32, H, gy.b_out, M, H, s), "colsum(b_out)");
+        if (ph) TRY(cpt::dropout_rows(dpre, nullptr, dmask, dt == CPT_BF16 ? dmask_lp : nullptr, dt, M, H, drop_spec(drop, 3 + 3 * l, false), s), "dropout_bwd(ffn down)");
+        TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_out, M, H, s), "colsum(b_out)");
         rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_h), I, I, M, Mp, gy.w_out, I, "wgrad(ffn down)");
         if (rc) return rc;
         rc = dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)");
@@ -267,12 +316,14 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         // a = LN1(pre1); pre1 = ctx W_ao^T + b_ao + x_in
         TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln1_g, gy.ln1_b,
                         M, H, M, 0, 0, 0, s), "ln_bwd(attn)");
-        TRY(cpt::colsum(dpre, CPT_F32, H, gy.b_ao, M, H, s), "colsum(b_ao)");
+        if (ph) TRY(cpt::dropout_rows(dpre, nullptr, dmask, dt == CPT_BF16 ? dmask_lp : nullptr, dt, M, H, drop_spec(drop, 2 + 3 * l, false), s), "dropout_bwd(attn out)");
+        TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_ao, M, H, s), "colsum(b_ao)");
         rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_ctx), H, H, M, Mp, gy.w_ao, H, "wgrad(attn out)");
         if (rc) return rc;
         rc = dgrad(dpre_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
         if (rc) return rc;
-        TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s), "attention_bwd");
+        const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
+        TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention_bwd");
         TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
         rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)");
         if (rc) return rc;
@@ -282,6 +333,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     }
 
     // ---- region projection and text embeddings ----------------------------------------------------
+    if (ph) TRY(cpt::dropout_rows(dx, nullptr, dx, nullptr, dt, M, H, drop_spec(drop, 0, false), s), "dropout_bwd(embeddings)");
     if (Li > 0) {
         const int R = B * Li;
         float* dimg = (float*)(ws + w.dimg);
@@ -301,6 +353,14 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
                        d.type_vocab, s), "embed_bwd");
     ready(0);
     return CPT_OK;
+}
+
+int cpt_dropout_mask(const cpt_dropout* drop, int site, int is_attn, unsigned char* out, int n0, int n1, int n2, void* stream) {
+    if (!drop || !out) return abi_fail(CPT_ERR_NULL, "cpt_dropout_mask: null argument");
+    if (int rcd = check_drop(drop, "cpt_dropout_mask")) return rcd;
+    const cpt::DropSpec sp = drop_spec(drop, site, is_attn != 0);
+    if (sp.thresh == 0) return abi_fail(CPT_ERR_SHAPE, "cpt_dropout_mask: the dropout probability of this site is 0");
+    return abi_check(cpt::dropout_mask(is_attn ? 1 : 0, out, n0, n1, n2, sp, (hipStream_t)stream), "cpt_dropout_mask");
 }
 
 int cpt_adamw(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16,

@@ -7,8 +7,9 @@ Counterparts of the reference's few-shot driver pieces:
   * ``build_optimizer`` (:318-343, torch.optim.AdamW with 4 groups) -> ``build_optimizer`` /
     ``FusedAdamW`` (one cpt_adamw launch over the flat parameter buffer).
   * ``get_lr_sched`` / ``warmup_linear`` (Oscar/oscar/utils/optim_sched.py:16-20,39-45).
-Dropout is not applied in the HIP training path (the reference trains with p=0.1; bitwise parity
-under dropout is impossible, gradient parity is tested with dropout disabled).
+Dropout (the reference trains with --drop_out 0.1) is applied when the module is in training mode: counter-based masks
+regenerated in backward (csrc/dropout.h); gradient parity against the reference is tested with dropout disabled
+(bit-identical to the dropout-free kernels) and, with dropout on, against the oracle fed the exported masks.
 """
 import ctypes as C
 
@@ -45,6 +46,8 @@ class _TrainState(object):
         self.ws = None
         self.saved = None
         self.gen = 0            # stamps every training forward: a backward may only consume ITS forward's activations
+        self.drop_seed = None   # Philox key of the dropout masks (default: torch.initial_seed() mixed with the rank)
+        self.drop_step = 0      # counter word: one fresh mask set per training forward
         self.sync = None        # dist.ShardedGradSync when an optimizer runs this engine data-parallel
 
     def ensure(self):
@@ -128,7 +131,7 @@ def _named_grad_views(eng, st):
 
 class _MLMLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, trigger, eng, tensors):
+    def forward(ctx, trigger, eng, tensors, drop):
         ctx.eng = eng
         st = _state(eng)
         ids, seg, mask, pos, feats, mpos, labels = tensors
@@ -155,14 +158,14 @@ class _MLMLoss(torch.autograd.Function):
                 eng.complete_pending(k)
             except Exception as e:          # never let an exception cross the C frame
                 errs.append(e)
-        cb = L.BUCKET_CB(before_bucket) if eng.pending is not None else None
+        cb = L.BUCKET_CB(before_bucket) if eng.pending is not None else L.NULL_CB
         L.check(L.lib().cpt_train_fwd_ex(C.byref(m), C.byref(bt), C.byref(o), ws.data_ptr(), ws.numel(), L.stream_ptr(),
-                                         cb, None), "cpt_train_fwd")
+                                         cb, None, C.byref(drop) if drop is not None else None), "cpt_train_fwd")
         if errs:
             raise errs[0]
         st.gen += 1
         ctx.gen = st.gen
-        st.saved = (bt, tensors, st.gen)          # keep the input tensors alive until backward
+        st.saved = (bt, tensors, st.gen, drop)    # keep the input tensors alive until backward; same masks in backward
         ctx.logits = logits
         ctx.mark_non_differentiable(logits)
         return loss_acc[0] / loss_acc[1], logits
@@ -173,7 +176,7 @@ class _MLMLoss(torch.autograd.Function):
         st = _state(eng)
         if st.saved is None:
             raise RuntimeError("cpt_amd: backward called twice (activations of the training forward were released)")
-        bt, tensors, gen = st.saved
+        bt, tensors, gen, drop = st.saved
         if gen != ctx.gen:
             raise RuntimeError("cpt_amd: backward of a stale training forward: the engine keeps the activations of the LATEST "
                                "training forward only (one workspace per model); call backward() before the next "
@@ -198,12 +201,12 @@ class _MLMLoss(torch.autograd.Function):
             sync.begin_backward()
             cb = L.BUCKET_CB(grads_ready)
         else:
-            cb = None
+            cb = L.NULL_CB
             if st.sync is not None:
                 st.sync.begin_backward()          # accumulation step: buckets are reduced in optimizer.step()
         gl = grad_loss.to(torch.float32).contiguous()          # device scalar: no host synchronisation between fwd and bwd
         L.check(L.lib().cpt_train_bwd_ex(C.byref(m), C.byref(bt), C.byref(g), 1.0, gl.data_ptr(), st.ws.data_ptr(), st.ws.numel(),
-                                         L.stream_ptr(), cb, None), "cpt_train_bwd")
+                                         L.stream_ptr(), cb, None, C.byref(drop) if drop is not None else None), "cpt_train_bwd")
         if errs:
             raise errs[0]
         if accumulate:
@@ -211,7 +214,7 @@ class _MLMLoss(torch.autograd.Function):
         for p, v in views:
             p.grad = v
         st.saved = None
-        return None, None, None
+        return None, None, None, None
 
 
 def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels, position_ids, img_feats, mask_token_pos):
@@ -242,8 +245,33 @@ def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels,
                prep(img_feats, torch.float32, "img_feats"), prep(mask_token_pos, torch.int64, "mask_token_pos"),
                prep(labels, torch.int64, "labels"))
     trigger = torch.zeros((), device=eng.flat.device, requires_grad=True)
-    loss, logits = _MLMLoss.apply(trigger, eng, tensors)
+    loss, logits = _MLMLoss.apply(trigger, eng, tensors, dropout_for(model, st))
     return (loss, logits)
+
+
+def dropout_for(model, st):
+    """The cpt_dropout of this training forward: config.hidden_dropout_prob / attention_probs_dropout_prob when the
+    module is in training mode (nn.Dropout semantics: identity in eval), a key derived from torch's seed and the rank
+    (so `torch.manual_seed(args.seed)` of the reference drivers, zeroshot/refcoco_cpt.py:376, controls it and ranks draw
+    different masks), and a counter that advances with every training forward.  None = no dropout."""
+    cfg = model.config
+    ph = float(getattr(cfg, "hidden_dropout_prob", 0.0) or 0.0) if model.training else 0.0
+    pa = float(getattr(cfg, "attention_probs_dropout_prob", 0.0) or 0.0) if model.training else 0.0
+    if ph <= 0.0 and pa <= 0.0:
+        return None
+    if st.drop_seed is None:
+        import torch.distributed as dist
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        st.drop_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+    st.drop_step += 1
+    return L.Dropout(p_hidden=ph, p_attn=pa, seed=st.drop_seed, step=st.drop_step)
+
+
+def set_dropout_seed(model, seed, step=0):
+    """Pin the dropout stream of `model` (tests, reproducible runs): masks become a function of (seed, forward count)."""
+    st = _state(model._engine())
+    st.drop_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    st.drop_step = int(step)
 
 
 class FusedAdamW(object):

@@ -166,7 +166,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
  * Few-shot training step (Oscar/oscar/fewshot/refcoco_cpt.py:231-249): forward that keeps the
  * activations, backward into caller-owned fp32 gradient tensors laid out like the parameters,
  * fused AdamW.  [MASK]-rows mode only (the loss of modeling_rec.py:147-150 sees only those rows).
- * Dropout is not applied (identity), see DESIGN.md.
+ * The plain forms run without dropout; the _ex forms below take the dropout description.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {           /* gradients of cpt_layer, all fp32, same shapes */
     float* w_qkv; float* b_qkv; float* w_ao; float* b_ao; float* ln1_g; float* ln1_b;
@@ -203,13 +203,33 @@ int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads*
  *                     bucket k's reduce-scatter on its communication stream while backward continues.
  * The library itself owns no communicator: collectives stay in torch.distributed (RCCL).  NULL callbacks = the plain forms. */
 typedef void (*cpt_bucket_fn)(void* user, int bucket);
+
+/* Dropout of the training step (reference: nn.Dropout at modeling_bert.py:57 on the attention probabilities, :266 on the
+ * region embeddings, and inside BertEmbeddings / BertSelfOutput / BertOutput; p = config.hidden_dropout_prob /
+ * attention_probs_dropout_prob, --drop_out 0.1 in fewshot/refcoco_cpt.py:387,509-512).  Masks are never stored: forward
+ * and backward regenerate them from Philox4x32-10 keyed by `seed` with the counter (element block, step, site), so a mask
+ * is a pure function of (seed, step, site, element) whatever the tile shapes or the number of GPUs.  Pass the SAME
+ * struct to the forward and the backward of a step; ranks of a data-parallel job use different seeds (their batches
+ * differ).  NULL, or both probabilities 0, runs exactly the dropout-free kernels.  The rate actually applied is p rounded
+ * to 2^-32 (hidden) / 2^-16 (attention), and kept values are scaled by 1 / (1 - that rate). */
+typedef struct {
+    float p_hidden;      /* embeddings, region embeddings, BertSelfOutput, BertOutput */
+    float p_attn;        /* attention probabilities */
+    uint64_t seed;
+    uint64_t step;       /* training step: a fresh mask every step */
+} cpt_dropout;
+/* Keep-mask of one dropout site (tests / oracle): site 0 = embeddings; layer l: 1 + 3l attention probabilities,
+ * 2 + 3l BertSelfOutput, 3 + 3l BertOutput.  is_attn 0: out[n0 = rows][n1 = hidden]; 1: out[n0 = B*heads][n1 = L][n2 = L].
+ * out[i] = 1 keep / 0 drop. */
+int cpt_dropout_mask(const cpt_dropout* drop, int site, int is_attn, unsigned char* out, int n0, int n1, int n2, void* stream);
+
 int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
-                     size_t workspace_bytes, void* stream, cpt_bucket_fn before_bucket, void* user);
+                     size_t workspace_bytes, void* stream, cpt_bucket_fn before_bucket, void* user, const cpt_dropout* drop);
 /* loss_scale_dev (optional): DEVICE scalar multiplied into loss_scale -- autograd's incoming gradient of the loss
  * without a host synchronisation. */
 int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
                      const float* loss_scale_dev, void* workspace, size_t workspace_bytes, void* stream,
-                     cpt_bucket_fn grads_ready, void* user);
+                     cpt_bucket_fn grads_ready, void* user, const cpt_dropout* drop);
 
 /* torch.optim.AdamW update (fewshot/refcoco_cpt.py:343,249) over flat buffers of n fp32 elements
  * (n % 4 == 0).  code[i]: 0 = no gradient on this path (skipped), 1 = weight decay, 2 = no decay

@@ -77,8 +77,16 @@ def image_embeddings(sd, cfg, img_feats, prefix="bert."):
     return y
 
 
-def self_attention(sd, cfg, x, ext_mask, p):
-    """CaptionBertSelfAttention.forward, modeling_bert.py:30-70."""
+def _drop(x, drop, key):
+    """nn.Dropout in training mode with a GIVEN mask: ``drop[key]`` is the multiplier tensor (0 or 1/(1-p)), broadcastable
+    to x.  drop None / key absent = eval mode (identity)."""
+    if drop is None or key not in drop:
+        return x
+    return x * drop[key].to(x.dtype).view(x.shape)
+
+
+def self_attention(sd, cfg, x, ext_mask, p, drop=None, layer=0):
+    """CaptionBertSelfAttention.forward, modeling_bert.py:30-70 (dropout on the probabilities: :57)."""
     B, L, H = x.shape
     nh = cfg["num_attention_heads"]
     d = H // nh
@@ -90,27 +98,27 @@ def self_attention(sd, cfg, x, ext_mask, p):
     v = v.view(B, L, nh, d).permute(0, 2, 1, 3)
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d)
     s = s + ext_mask
-    pr = torch.softmax(s, dim=-1)
+    pr = _drop(torch.softmax(s, dim=-1), drop, ("attn", layer))
     ctx = torch.matmul(pr, v)
     return ctx.permute(0, 2, 1, 3).contiguous().view(B, L, H)
 
 
-def encoder_layer(sd, cfg, x, ext_mask, i, prefix="bert."):
+def encoder_layer(sd, cfg, x, ext_mask, i, prefix="bert.", drop=None):
     """CaptionBertLayer.forward modeling_bert.py:139-147; CaptionBertAttention
     82-87; BertSelfOutput / BertIntermediate / BertOutput (third-party)."""
     p = "%sencoder.layer.%d." % (prefix, i)
     eps = cfg["layer_norm_eps"]
-    ctx = self_attention(sd, cfg, x, ext_mask, p + "attention.self.")
+    ctx = self_attention(sd, cfg, x, ext_mask, p + "attention.self.", drop, i)
     a = F.linear(ctx, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
-    a = layer_norm(a + x, sd[p + "attention.output.LayerNorm.weight"],
+    a = layer_norm(_drop(a, drop, ("ao", i)) + x, sd[p + "attention.output.LayerNorm.weight"],
                    sd[p + "attention.output.LayerNorm.bias"], eps)
     h = gelu_erf(F.linear(a, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
     o = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
-    return layer_norm(o + a, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
+    return layer_norm(_drop(o, drop, ("out", i)) + a, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
 
 
 def bert_img_forward(sd, cfg, input_ids, token_type_ids=None, attention_mask=None,
-                     position_ids=None, img_feats=None, prefix="bert.", all_hidden=False):
+                     position_ids=None, img_feats=None, prefix="bert.", all_hidden=False, drop=None):
     """BertImgModel.forward, modeling_bert.py:199-279 -> (sequence_output, pooled_output[, hiddens])."""
     if attention_mask is None:
         attention_mask = torch.ones_like(input_ids)
@@ -118,9 +126,10 @@ def bert_img_forward(sd, cfg, input_ids, token_type_ids=None, attention_mask=Non
     x = text_embeddings(sd, cfg, input_ids, token_type_ids, position_ids, prefix)
     if img_feats is not None:
         x = torch.cat((x, image_embeddings(sd, cfg, img_feats, prefix)), 1)   # :269
+    x = _drop(x, drop, "emb")        # BertEmbeddings' dropout (text rows) and modeling_bert.py:266 (region rows)
     hiddens = [x]
     for i in range(cfg["num_hidden_layers"]):                                   # :100-126
-        x = encoder_layer(sd, cfg, x, ext, i, prefix)
+        x = encoder_layer(sd, cfg, x, ext, i, prefix, drop)
         hiddens.append(x)
     pooled = torch.tanh(F.linear(x[:, 0], sd[prefix + "pooler.dense.weight"],
                                  sd[prefix + "pooler.dense.bias"]))             # :275
@@ -140,7 +149,7 @@ def lm_head(sd, cfg, x, prefix="cls."):
 
 def rec_mlm_cpt_forward(sd, cfg, input_ids, token_type_ids=None, attention_mask=None,
                         masked_lm_labels=None, position_ids=None, img_feats=None,
-                        mask_rows_only=None):
+                        mask_rows_only=None, drop=None):
     """REC_MLM_CPT.forward, modeling_rec.py:137-152.
 
     ``mask_rows_only``: optional LongTensor (B,) of [MASK] positions; when given
@@ -148,7 +157,7 @@ def rec_mlm_cpt_forward(sd, cfg, input_ids, token_type_ids=None, attention_mask=
     keeps exactly those rows (zeroshot/refcoco_cpt.py:219, fewshot/refcoco_cpt.py:268).
     """
     seq, _ = bert_img_forward(sd, cfg, input_ids, token_type_ids, attention_mask,
-                              position_ids, img_feats)
+                              position_ids, img_feats, drop=drop)
     if mask_rows_only is not None:
         rows = seq[torch.arange(seq.size(0)), mask_rows_only]
         scores = lm_head(sd, cfg, rows)
@@ -261,8 +270,8 @@ def adamw_step(p, g, m, v, step, lr, beta1, beta2, eps, wd):
     return p, m, v
 
 
-def train_step_grads(sd, cfg, batch, names=None):
-    """loss.backward() of fewshot/refcoco_cpt.py:231-248 with dropout disabled:
+def train_step_grads(sd, cfg, batch, names=None, drop=None):
+    """loss.backward() of fewshot/refcoco_cpt.py:231-248 with dropout disabled (or, with ``drop``, with the given masks):
     returns (loss, {name: grad}).  The tied decoder/word-embedding tensor gets the
     sum of both contributions, exactly as autograd does for the shared Parameter."""
     tied = sd["cls.decoder.weight"].data_ptr() == sd["bert.embeddings.word_embeddings.weight"].data_ptr()
@@ -280,7 +289,63 @@ def train_step_grads(sd, cfg, batch, names=None):
     loss, _ = rec_mlm_cpt_forward(work, cfg, batch["input_ids"], batch["segment_ids"],
                                   batch["attention_mask"], masked_lm_labels=labels,
                                   img_feats=batch["img_feats"],
-                                  mask_rows_only=batch["mask_token_pos"])
+                                  mask_rows_only=batch["mask_token_pos"], drop=drop)
     loss.backward()
     grads = {k: (t.grad if t.grad is not None else None) for k, t in leaves.items()}
     return loss.detach(), grads
+
+
+# ---- dropout masks: CPU restatement of the counter scheme of cpt_amd/csrc/dropout.h (to pin the exported masks) --------
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11) on numpy uint32 arrays -> four uint32 arrays."""
+    import numpy as np
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & 0xFFFFFFFF for c in (c0, c1, c2, c3))
+    k0 = np.uint64(k0 & 0xFFFFFFFF)
+    k1 = np.uint64(k1 & 0xFFFFFFFF)
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ k0
+        n1 = p1 & mask
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ k1
+        n3 = p0 & mask
+        c0, c1, c2, c3 = n0 & mask, n1, n2 & mask, n3
+        k0 = (k0 + W0) & mask
+        k1 = (k1 + W1) & mask
+    return [c.astype(np.uint32) for c in (c0, c1, c2, c3)]
+
+
+def dropout_thresh_scale(p, attn):
+    full = 65536.0 if attn else 4294967296.0
+    t = min(max(p * full, 1.0), full - 1.0)
+    thresh = int(t + 0.5)
+    return thresh, 1.0 / (1.0 - thresh / full)
+
+
+def dropout_keep_hidden(seed, step, site, R, H, p):
+    """keep mask [R][H] (uint8) of a hidden dropout site: element e = r*H + c, one Philox call per 4 consecutive elements."""
+    import numpy as np
+    thresh, _ = dropout_thresh_scale(p, False)
+    n4 = R * H // 4
+    e4 = np.arange(n4, dtype=np.uint64)
+    u = philox4x32_10(e4 & 0xFFFFFFFF, e4 >> np.uint64(32), np.full(n4, step), np.full(n4, site), seed & 0xFFFFFFFF, seed >> 32)
+    keep = np.stack([w >= np.uint32(thresh) for w in u], 1).reshape(R, H)
+    return keep.astype(np.uint8)
+
+
+def dropout_keep_attn(seed, step, site, BH, L, p):
+    """keep mask [BH][L][L] of an attention dropout site: 4 x 4 blocks of the (query, key) plane, two calls per block
+    (query rows 0-1 / 2-3), eight 16-bit uniforms each, index (q & 1) * 4 + (k & 3)."""
+    import numpy as np
+    thresh, _ = dropout_thresh_scale(p, True)
+    bh, q, k = np.meshgrid(np.arange(BH, dtype=np.uint64), np.arange(L, dtype=np.uint64), np.arange(L, dtype=np.uint64), indexing="ij")
+    c0 = ((q >> np.uint64(2)) << np.uint64(16)) | ((k >> np.uint64(2)) << np.uint64(1)) | ((q >> np.uint64(1)) & np.uint64(1))
+    u = philox4x32_10(c0.ravel(), bh.ravel(), np.full(c0.size, step), np.full(c0.size, site), seed & 0xFFFFFFFF, seed >> 32)
+    idx = ((q & np.uint64(1)) * np.uint64(4) + (k & np.uint64(3))).ravel().astype(np.int64)
+    words = np.stack(u, 1)                                         # [n][4]
+    w = words[np.arange(idx.size), idx >> 1]
+    u16 = (w >> ((idx & 1) * 16).astype(np.uint32)) & np.uint32(0xFFFF)
+    return (u16 >= np.uint32(thresh)).reshape(BH, L, L).astype(np.uint8)

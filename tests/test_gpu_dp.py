@@ -29,6 +29,7 @@ def _free_port():
 def _make(cfg, seed, dev, mode, wire=None):
     from cpt_amd.modeling_rec import REC_MLM_CPT
     from cpt_amd.train import FusedAdamW
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0      # ranks draw different masks: compare without dropout
     m = REC_MLM_CPT(cfg)
     m.load_state_dict(synth.init_state_dict(cfg, seed, head="cpt"))
     m.tie_weights()

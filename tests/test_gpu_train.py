@@ -20,8 +20,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _model(cfg, seed, dev, dtype):
+def _model(cfg, seed, dev, dtype, dropout=0.0):
     from cpt_amd.modeling_rec import REC_MLM_CPT
+    # the reference goldens are generated with dropout disabled (oracle/make_golden.py); dropout tests pass their own rate
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = dropout
     m = REC_MLM_CPT(cfg)
     m.load_state_dict(synth.init_state_dict(cfg, seed, head="cpt"))
     m.tie_weights()

@@ -155,3 +155,14 @@ def test_vcr_nsp_cpt_golden(golden_dir):
     logits, preds = O.nsp_choose(rel, interval)
     np.testing.assert_allclose(logits.numpy(), g["choice_logits"], atol=1e-5, rtol=0)
     assert preds == list(g["preds"])
+
+
+def test_philox_known_answer_vectors():
+    """The oracle's Philox4x32-10 (which pins the dropout masks the HIP kernels regenerate) against the published
+    Random123 known-answer vectors (kat_vectors: philox4x32 10 rounds)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10([ctr[0]], [ctr[1]], [ctr[2]], [ctr[3]], key[0], key[1])
+        assert tuple(int(g[0]) for g in got) == want
