@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune", default="", help="debug: comma list of key=value passed to cpt_set_tuning")
     ap.add_argument("--no-check", action="store_true", help="debug: skip the finite-output check (ablation runs)")
+    ap.add_argument("--workload", default="refcoco", choices=["refcoco", "gqa", "vcr"],
+                    help="refcoco: BASELINE configs[1] (default; the headline metric).  gqa: configs[3] shape, Oscar-base L=165+45, "
+                         "default batch 256.  vcr: configs[4], Oscar-large 24 layers, NSP-CPT head, L=165+100, default batch 32")
     ap.add_argument("--print-launch", action="store_true", help="print the multi-rank launch command instead of running it")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="train mode: gradient dtype on the wire")
     args = ap.parse_args()
@@ -209,17 +212,38 @@ def main():
     for kv in [t for t in args.tune.split(",") if t]:
         k, v = kv.split("=")
         _lib.check(_lib.lib().cpt_set_tuning(int(k), int(v)), "cpt_set_tuning")
-    cfg = cfgmod.oscar_base()
     seed = 88
-    model = REC_MLM_CPT(cfg)
-    model.load_state_dict(synth.init_state_dict(cfg, seed, head="cpt", randomize_all=False))
-    model.tie_weights()
-    model.to(dev).eval().set_compute_dtype(args.dtype)
     train = args.mode == "train"
+    Lt, Li = 70, 50
+    if args.workload == "vcr":
+        from cpt_amd.modeling_bert import BertImgForPreTraining
+        from cpt_amd.modeling_vcr import NSPCPT
+        cfg = cfgmod.oscar_large()
+        Lt, Li = 165, 100
+        pre = BertImgForPreTraining(cfg)
+        pre.load_state_dict(synth.init_state_dict(cfg, seed, head="pretrain", randomize_all=False))
+        pre.tie_weights()
+        model = NSPCPT(cfg)
+        model.copy_from_pretraining_model(pre)
+        if args.batch == 64:
+            args.batch = 32
+        if train or args.all_rows:
+            raise SystemExit("--workload vcr is an inference workload (NSP-CPT scoring head)")
+    else:
+        cfg = cfgmod.oscar_base()
+        if args.workload == "gqa":
+            Lt, Li = 165, 45
+            if args.batch == 64:
+                args.batch = 256
+        model = REC_MLM_CPT(cfg)
+        model.load_state_dict(synth.init_state_dict(cfg, seed, head="cpt", randomize_all=False))
+        model.tie_weights()
+    model.to(dev).eval().set_compute_dtype(args.dtype)
     if train and args.batch == 64:
         args.batch = 32
     B = args.batch
-    b = {k: v.to(dev) for k, v in synth.make_batch(B, cfg, seed=seed + rank).items()}
+    Lseq = Lt + Li
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, cfg, seed=seed + rank, max_seq_len=Lt, img_seq_len=Li).items()}
     if train:
         from cpt_amd.train import FusedAdamW
         model.train()
@@ -236,6 +260,8 @@ def main():
             opt.step()                      # world > 1: sharded AdamW + parameter all-gather (reduce-scatter ran under backward)
             return logits
         with torch.no_grad():
+            if args.workload == "vcr":
+                return model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"])[0]
             return model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
                          mask_token_pos=mpos)[0]
 
@@ -269,7 +295,7 @@ def main():
             step()
         prof = engine.profile_read()
         _lib.lib().cpt_prof_enable(0)
-        M, H, I = B * 120, cfg.hidden_size, cfg.intermediate_size
+        M, H, I = B * Lseq, cfg.hidden_size, cfg.intermediate_size
         breakdown = {k: round(t / args.steps, 4) for k, (t, n) in prof.items() if n}
         gem = {k: prof[k] for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn_up", "gemm_ffn_down") if prof[k][1]}
         dom = max(gem, key=lambda k: gem[k][0])
@@ -278,7 +304,7 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4),
-                "traffic": pmc_traffic_bytes(dom) if (B == 64 and args.dtype == "bf16") else None,
+                "traffic": pmc_traffic_bytes(dom) if (B == 64 and args.dtype == "bf16" and args.workload == "refcoco") else None,
                 "avg_launch_ms": round(avg_ms, 5),
                 "flop_per_launch": gemm_flops(dom, M, H, I)}
     if world > 1:
@@ -291,14 +317,20 @@ def main():
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": ("Oscar-base CPT few-shot training step (fwd+bwd+grad all-reduce+AdamW), batch %d/GPU, "
                                         "50 regions, seq_len 120, %s, dropout %.2g" % (B, args.dtype, cfg.hidden_dropout_prob)) if train else
-                                       "Oscar-base CPT RefCOCO inference, batch %d/GPU, 50 regions, seq_len 120, %s, "
-                                       "[MASK]-row logits%s" % (B, args.dtype, " (all-row head)" if args.all_rows else ""),
-                           "global_batch": B * n_gpus, "seq_len": 120, "parallelism": "dp%d" % n_gpus,
+                                       {"refcoco": "Oscar-base CPT RefCOCO inference, batch %d/GPU, 50 regions, seq_len 120, %s, [MASK]-row logits%s",
+                                        "gqa": "Oscar-base CPT GQA inference (BASELINE configs[3] shape), batch %d/GPU, 45 regions, seq_len 165+45, %s, "
+                                               "[MASK]-row logits%s",
+                                        "vcr": "Oscar-large (24 layers, hidden 1024) VCR NSP-CPT scoring (BASELINE configs[4]), batch %d/GPU, "
+                                               "100 regions, seq_len 165+100, %s, relation scores%s"}[args.workload]
+                                       % (B, args.dtype, " (all-row head)" if args.all_rows else ""),
+                           "global_batch": B * n_gpus, "seq_len": Lseq, "parallelism": "dp%d" % n_gpus,
                            "weights": "random-init N(0,0.02), seed 88"},
                 "roofline": roof, "kernel_ms_per_step": breakdown}
-        if n_gpus == 1 and not args.no_roofline and not train:
+        if args.workload != "refcoco":
+            line["metric"] = "prompted (image,query) pairs/sec, %s workload (not the headline configuration)" % args.workload
+        if n_gpus == 1 and not args.no_roofline and not train and args.workload == "refcoco":
             line["hbm_kernels"] = hbm_kernels(cfg, B, dev)
-        if n_gpus == 1 and not args.no_cpu and not train:
+        if n_gpus == 1 and not args.no_cpu and not train and args.workload == "refcoco":
             line["cpu_baseline"] = cpu_baseline(cfg, seed, min(usable_cores(), 64))
         else:
             line["cpu_baseline"] = None

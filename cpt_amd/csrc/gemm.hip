@@ -753,7 +753,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long* t = trace + (size_t)blockIdx.x * 8;
         t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = tr3; t[4] = clock64();
-        t[5] = 0; t[6] = 0; t[7] = 0;
+        t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13
+        t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        t[7] = blockIdx.x;
     }
 #endif
 }

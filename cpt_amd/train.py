@@ -9,7 +9,7 @@ Counterparts of the reference's few-shot driver pieces:
   * ``get_lr_sched`` / ``warmup_linear`` (Oscar/oscar/utils/optim_sched.py:16-20,39-45).
 Dropout (the reference trains with --drop_out 0.1) is applied when the module is in training mode: counter-based masks
 regenerated in backward (csrc/dropout.h); gradient parity against the reference is tested with dropout disabled
-(bit-identical to the dropout-free kernels) and, with dropout on, against the oracle fed the exported masks.
+(bit-identical to the dropout-free kernels) and, with dropout on, against a CPU restatement fed the exported masks.
 """
 import ctypes as C
 

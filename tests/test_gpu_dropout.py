@@ -114,6 +114,8 @@ def test_loss_and_gradients_match_oracle_with_the_same_masks(dev, mode, Lt, Li):
         got = prm.grad.double().cpu().flatten()
         rf = g.double().flatten()
         rel = float((got - rf).norm() / (rf.norm() + 1e-30))
+        if float(rf.abs().max()) < 1e-6 and float(got.abs().max()) < (1e-5 if mode == "fp32" else 1e-3):
+            continue          # key bias: its true gradient is 0 (softmax is shift-invariant), both sides hold rounding noise
         worst = max(worst, rel)
         assert rel < gtol, (name, rel)
     print("dropout %s L=%d: loss %.5f (oracle %.5f), worst relative gradient error %.2e" % (mode, Lt + Li, loss.item(), float(ref_loss), worst))
@@ -128,11 +130,13 @@ def test_p0_is_bit_identical_and_seed_reproduces(dev):
         for _ in range(steps):
             for prm in m.parameters():
                 prm.grad = None
-            loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
-                        mask_token_pos=b["mask_token_pos"])
+            loss, logits = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
+                             mask_token_pos=b["mask_token_pos"])
             loss.backward()
-            out.append((loss.detach().clone(), m.bert.encoder.layer[0].attention.self.query.weight.grad.clone(),
-                        m.bert.embeddings.word_embeddings.weight.grad.clone()))
+            # tensors whose bits are run-to-run deterministic: the [MASK]-row logits and GEMM-produced weight gradients (the
+            # scalar loss, the embedding-table and LayerNorm gain/bias gradients are accumulated with fp32 atomics)
+            out.append((logits.detach().clone(), m.bert.encoder.layer[0].attention.self.query.weight.grad.clone(),
+                        m.bert.encoder.layer[1].intermediate.dense.weight.grad.clone()))
         return out
     for mode in ("fp32", "bf16"):
         m0 = _model(cfgmod.tiny(), dev, mode, 0.0)

@@ -12,7 +12,8 @@ from cpt_amd import config as cfgmod
 from cpt_amd import synth
 
 pytestmark = pytest.mark.gpu
-FP32_TOL = 1e-3
+FP32_TOL = 1e-3          # north_star: [MASK] colour-token logits within 1e-3 of the fp32 reference CPU path
+BF16_TOL = 0.04          # bf16 throughput mode: max |d logit| observed 1.0-1.6e-2 on logits of range +-2.2 (<= 0.04)
 
 
 @pytest.fixture(scope="module")
@@ -123,7 +124,7 @@ def test_base_golden_mask_logits(dev, golden_dir, name, mode):
         assert abs(loss.item() - float(g["loss"])) < 1e-3
         assert _stats("pooled", pooled.cpu()[:, ::13], g["pooled_sample"]) < 1e-3
     else:
-        assert err < 0.15
+        assert err < BF16_TOL
         top2 = ref_col.topk(2, -1).values
         margin = top2[:, 0] - top2[:, 1]
         same = got_col.argmax(-1) == ref_col.argmax(-1)
@@ -147,7 +148,7 @@ def test_config2_vs_oracle(dev, mode):
         got = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"],
                 mask_token_pos=d["mask_token_pos"])[0]
     err = _stats("config2 B=8 %s" % mode, got, ref)
-    assert err < (FP32_TOL if mode == "fp32" else 0.15)
+    assert err < (FP32_TOL if mode == "fp32" else BF16_TOL)
     # full size: sequences are independent, so the first 8 rows of a B=64 batch must reproduce
     big = synth.make_batch(64, cfg, seed=21)
     for k in big:
@@ -189,7 +190,7 @@ def test_bf16_folded_layernorm_and_fused_attention(dev):
                 seq, pooled = m.bert(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])
             res[(fold, fuse)] = (rows.cpu(), allr.cpu(), seq.cpu(), pooled.cpu())
             err = _stats("fold=%s fuse=%d [MASK] logits vs oracle" % (fold, fuse), rows, ref)
-            assert err < 0.15
+            assert err < BF16_TOL
     finally:
         L.lib().cpt_set_tuning(6, 1)
     pos = b["mask_token_pos"]
@@ -198,7 +199,7 @@ def test_bf16_folded_layernorm_and_fused_attention(dev):
         if key == (False, 0):
             continue
         for i, nm in enumerate(("mask rows", "all rows", "seq", "pooled")):
-            assert _stats("%s vs kernel-per-op: %s" % (key, nm), r[i], base[i]) < (0.15 if i < 2 else 0.1)
+            assert _stats("%s vs kernel-per-op: %s" % (key, nm), r[i], base[i]) < (2 * BF16_TOL if i < 2 else 0.1)
     # the all-row head's [MASK] rows are the [MASK]-row head's output
     r = res[(True, 1)]
     assert _stats("all-row head at [MASK]", r[1][torch.arange(6), pos], r[0]) < 2e-2
