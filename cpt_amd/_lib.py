@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcpt_hip.so")
+LIB_PATH = os.environ.get("CPT_LIB_PATH") or os.path.join(HERE, "libcpt_hip.so")     # (CPT_LIB_PATH: developer A/B builds, tools/ only)
 
 CPT_F32, CPT_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID = 0, 1, 2, 3
@@ -93,6 +93,9 @@ _SIGS = {
     "cpt_attention": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_pad_cast": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_fold_ln_weights": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "cpt_gemm_ln_cons": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_gemm_ln_prod": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, vp]),
     "cpt_select_regions": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
     "cpt_argmax_columns": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     "cpt_gather_rows": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -138,6 +138,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 2) { cpt::set_attn_bwd_variant(value); return CPT_OK; }
     if (key == 3) { cpt::set_splitk_target(value); return CPT_OK; }
     if (key == 7) { cpt::set_gemm_skew(value); return CPT_OK; }
+    if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
 }
 
@@ -197,6 +198,18 @@ int cpt_attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ct
 int cpt_pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, void* stream) {
     if (!x || !out) return fail(CPT_ERR_NULL, "cpt_pad_cast: null operand");
     return check_launch(cpt::pad_cast(x, out, dtype, R, K, Kp, (hipStream_t)stream), "cpt_pad_cast");
+}
+
+int cpt_gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
+                     float eps, int hidden, int gelu, void* out, int ldo, int M, int N, int K, void* stream) {
+    return check_launch(cpt::gemm_ln_cons(A, lda, Wf, ldw, st_in, colc, cold, eps, hidden, gelu, out, ldo, M, N, K, (hipStream_t)stream), "cpt_gemm_ln_cons");
+}
+
+int cpt_gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr, const float* st_in,
+                     const float* g_in, const float* b_in, float eps, int hidden, float* out_f32, void* out_lp, float* st_out, int ldo,
+                     int M, int N, int K, void* stream) {
+    return check_launch(cpt::gemm_ln_prod(A, lda, W, ldw, bias, resid, ldr, st_in, g_in, b_in, eps, hidden, out_f32, out_lp, st_out, ldo,
+                                          M, N, K, (hipStream_t)stream), "cpt_gemm_ln_prod");
 }
 
 int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,

@@ -248,6 +248,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
 
     // XCD-first, then GROUP_M row tiles per group (see tile_of_block)
     constexpr bool ATTN = EPI == CPT_EPI_ATTN || EPI == CPT_EPI_ATTN_LN;
+    // LayerNorm-folding epilogues of the bf16 encoder run straight from the accumulator registers (see "direct epilogue")
+    // The LayerNorm PRODUCER keeps the slab epilogue: its residual loads and fp32 stores are row-per-lane in the direct form
+    // (32 rows x 32 B per instruction instead of 1 KB runs), measured slower on MI355X (attn-out 24.7 -> 28.2 us, FFN-down
+    // 51.5 -> 55.3 us; tools/epi_bench.hip: 7.0 vs 5.3 us for the fp32 tile stores alone).  The direct code path below still
+    // handles it (DIRECT_LNPROD) for A/B runs.
+    constexpr bool DIRECT_LNPROD = false;
+    constexpr bool DIRECT = ((EPI == CPT_EPI_LNPROD && DIRECT_LNPROD) || EPI == CPT_EPI_LNCONS || EPI == CPT_EPI_LNCONS_GELU) && sizeof(T) == 2;
     int m0, n0, split;
     int att_b = 0, att_h = 0;
     if constexpr (ATTN) {
@@ -286,7 +293,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     static_assert((TBM / 8) % NW == 0, "A pieces must split evenly over the waves");
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
-    unsigned voff[G];
+    // G <= 6: one VGPR per piece, computed once.  Bigger tiles (registers go to the accumulators): the offsets are rebuilt at
+    // every issue from the piece's row (2 VALU per 1 KiB piece); with an even wave count the swizzle term is the same for
+    // every piece of a lane.
+    constexpr bool VOFF_ARRAY = G <= 6 || ATTN;
+    static_assert(VOFF_ARRAY || NW % 2 == 0, "rebuilt offsets need an even wave count");
+    const int rbase = wave * 8 + (lane >> 3);
+    const unsigned c16 = (unsigned)(((lane & 7) ^ ((rbase >> 1) & 7)) * 16);
+    unsigned voff[VOFF_ARRAY ? G : 1];
+    if constexpr (!VOFF_ARRAY) voff[0] = 0;
+    else
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int g = i * NW + wave;
@@ -306,8 +322,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         for (int i = 0; i < G; ++i) {
             const int g = i * NW + wave;
             auto lds = (__attribute__((address_space(3))) void*)(smem + slot * STAGE_BYTES + g * 1024);
-            if (i < GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lds, 16, voff[i], soff, 0, 0);
-            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lds, 16, voff[i], soff, 0, 0);
+            unsigned vo;
+            if constexpr (VOFF_ARRAY) vo = voff[i];
+            else if (i < GA) vo = (unsigned)min(m0 + rbase + i * NW * 8, M - 1) * (unsigned)(lda * (int)sizeof(T)) + c16;
+            else vo = (unsigned)min(n0 + rbase + i * NW * 8 - TBM, N - 1) * (unsigned)(ldw * (int)sizeof(T)) + c16;
+            if (i < GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lds, 16, vo, soff, 0, 0);
+            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lds, 16, vo, soff, 0, 0);
         }
     };
 
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if constexpr (ATTN) mfma_chunk(acc[i][j], fb[pb][j], fa[pb][i]);   // transposed tile: lane = token, registers = output columns
+                if constexpr (ATTN || DIRECT) mfma_chunk(acc[i][j], fb[pb][j], fa[pb][i]);   // transposed tile: lane = row (token), registers = output columns
                 else mfma_chunk(acc[i][j], fa[pb][i], fb[pb][j]);
             }
     };
@@ -415,6 +435,23 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             }
             if (more) ldfrag(nslot, 0, 0); CPT_SB(); mma(2); CPT_SB();
             if (more) ldfrag(nslot, 1, 1); CPT_SB(); mma(3); CPT_SB();
+        } else if constexpr (FD == 1) {
+            // one fragment buffer (big tiles at four waves per SIMD, where registers go to the accumulators and the other
+            // three waves of the SIMD cover this wave's LDS latency): read k-step ks+1 right after the MFMAs of ks issue
+            touch(0); CPT_SB(); mma(0); CPT_SB(); ldfrag(slot, 1, 0); CPT_SB();
+            touch(0); CPT_SB(); mma(0); CPT_SB(); ldfrag(slot, 2, 0); CPT_SB();
+            touch(0); CPT_SB(); mma(0); CPT_SB(); ldfrag(slot, 3, 0); CPT_SB();
+            touch(0); CPT_SB();                    // this wave's reads of tile t are all retired
+            if (more) {
+                if (MAIN) wait_vmcnt<(STAGES - 2) * G>(); else wait_tile(t + 1, min(nt, t + STAGES) - 1);
+                CPT_SB();
+                __builtin_amdgcn_s_barrier();      // tile t+1 visible to all waves; nobody still reads tile t
+                CPT_SB();
+                refill();
+                CPT_SB();
+            }
+            mma(0); CPT_SB();
+            if (more) { ldfrag(nslot, 0, 0); CPT_SB(); }
         } else {
             touch(0); CPT_SB(); ldfrag(slot, 1, 1); CPT_SB(); mma(0); CPT_SB();
             touch(1); CPT_SB(); ldfrag(slot, 2, 0); CPT_SB(); mma(1); CPT_SB();
@@ -452,9 +489,139 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     constexpr int NIT = (16 * CH + 63) / 64;          // read-back iterations per slice
     constexpr int NSL = MI * 2;                       // 16-row slices per wave
     constexpr int SIDE = MI * 32 * 8 + 2 * WCOLS * 4; // per-wave side area: (mean, rstd) per row + two column vectors
-    static_assert((16 * CPW + SIDE) * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
-    static_assert(MI * 32 <= 64 && CH <= 64, "side area is filled by one wave pass");
+    static_assert(DIRECT || (16 * CPW + SIDE) * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
+    static_assert(DIRECT || (MI * 32 <= 64 && CH <= 64), "side area is filled by one wave pass");
     if (split != 0) bias = nullptr;                   // split-K: the bias is added once
+    if constexpr (DIRECT) {
+        // ---- direct epilogue: the accumulators are TRANSPOSED (operands swapped in mma): lane = output row
+        // (wrow0 + 32 i + (lane & 31)), register quad g of block j = the four consecutive columns
+        // wcol0 + 32 j + 8 g + 4 (lane >> 5) + [0, 4).  Per-row LayerNorm statistics are therefore per-lane scalars, the
+        // per-column vectors come from a 1 KB per-wave LDS side area as 16-byte broadcasts, every output quad is
+        // finished in registers and leaves as 16-byte stores (fp32 quads as they are; bf16 quads of the two half-waves
+        // paired by v_permlane32_swap).  No slab round trip, no LDS waits in the math, all quads independent.
+        constexpr bool LNPROD = EPI == CPT_EPI_LNPROD;
+        constexpr bool GELU = EPI == CPT_EPI_LNCONS_GELU;
+        static_assert(NW * 3 * NJ * 32 * 4 <= STAGES * STAGE_BYTES, "side areas must fit in the ring");
+        const int wrow0 = m0 + wm * (MI * 32), wcol0 = n0 + wn * (NJ * 32);
+        constexpr int WC = NJ * 32;
+        const bool fold_resid = LNPROD && ex.g_in != nullptr;
+        float* sd = reinterpret_cast<float*>(smem) + wave * (3 * WC);
+        // operand loads are issued ahead of the barrier that frees the ring
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0;
+        if constexpr (LNPROD) v1 = f32x4{1.f, 1.f, 1.f, 1.f};
+        {
+            const int c = wcol0 + lane * 4;
+            if (lane < WC / 4 && c < N) {
+                if constexpr (LNPROD) {
+                    if (bias) v0 = *reinterpret_cast<const f32x4*>(bias + c);
+                    if (fold_resid) { v1 = *reinterpret_cast<const f32x4*>(ex.g_in + c); v2 = *reinterpret_cast<const f32x4*>(ex.b_in + c); }
+                } else {
+                    v0 = *reinterpret_cast<const f32x4*>(ex.colc + c);
+                    v1 = *reinterpret_cast<const f32x4*>(ex.cold + c);
+                }
+            }
+        }
+        // row statistics -> (mean, rstd) of row block i; block 0 ahead of the barrier, the others inside the row loop
+        // (one block's 64 bytes of partial sums in flight at a time: registers belong to the accumulators here)
+        auto row_stats = [&](int i, float& m_o, float& r_o) {
+            m_o = 0.f; r_o = 1.f;
+            if (!LNPROD || fold_resid) {
+                float sum, sq;
+                sum_parts(ex.st_in, ex.st_in_parts, min(wrow0 + i * 32 + fr, M - 1), sum, sq);
+                m_o = sum * ex.inv_h;
+                r_o = rsqrtf(fmaxf(sq * ex.inv_h - m_o * m_o, 0.f) + ex.eps);
+            }
+        };
+        float mu0, rs0;
+        row_stats(0, mu0, rs0);
+        __syncthreads();                              // every wave is done reading the operand ring
+        if (trace) tr3 = clock64();
+        if (lane < WC / 4) {
+            *reinterpret_cast<f32x4*>(sd + lane * 4) = v0;
+            *reinterpret_cast<f32x4*>(sd + WC + lane * 4) = v1;
+            if constexpr (LNPROD) *reinterpret_cast<f32x4*>(sd + 2 * WC + lane * 4) = v2;
+        }
+        // (LDS operations of one wave execute in issue order: its reads below see these writes)
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        T* out_lp = LNPROD ? reinterpret_cast<T*>(ex.out_lp) : reinterpret_cast<T*>(out);
+        auto run = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wrow0 + i * 32 + fr;
+                const bool rok = FULL || row < M;
+                const size_t rowc = (size_t)(FULL ? row : min(row, M - 1));
+                f32x4 rq[LNPROD ? NJ * 4 : 1];
+                if constexpr (LNPROD) {
+                    if (!(abl & 128)) {
+#pragma unroll
+                    for (int q = 0; q < NJ * 4; ++q) {
+                        const int c = wcol0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * fh;
+                        rq[q] = *reinterpret_cast<const f32x4*>(resid + rowc * ldr + (FULL ? c : min(c, N - 4)));
+                    }
+                    }
+                }
+                float sm = 0.f, sq = 0.f;
+                float m_i = mu0, r_i = rs0;
+                if (i > 0) row_stats(i, m_i, r_i);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        u32x2 pk[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int g = 2 * gp + h;
+                            const int lc = j * 32 + 8 * g + 4 * fh, c = wcol0 + lc;
+                            const bool cok = FULL || c < N;
+                            f32x4 x;
+                            if constexpr (LNPROD) {
+                                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sd + lc);
+                                const f32x4 g4 = *reinterpret_cast<const f32x4*>(sd + WC + lc);
+                                const f32x4 t4 = *reinterpret_cast<const f32x4*>(sd + 2 * WC + lc);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    x[e] = acc[i][j][4 * g + e] + b4[e] + ((rq[j * 4 + g][e] - m_i) * r_i * g4[e] + t4[e]);
+                                if (rok && cok && !(abl & 64)) *reinterpret_cast<f32x4*>(out + (size_t)row * ldo + c) = x;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { sm += cok ? x[e] : 0.f; sq += cok ? x[e] * x[e] : 0.f; }
+                            } else {
+                                const f32x4 c4 = *reinterpret_cast<const f32x4*>(sd + lc);
+                                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + WC + lc);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) x[e] = r_i * (acc[i][j][4 * g + e] - m_i * c4[e]) + d4[e];
+                                if constexpr (GELU) {
+                                    if (!(abl & 16)) {
+                                    const f32x2 g0 = gelu_fast2(f32x2{x[0], x[1]}), g1 = gelu_fast2(f32x2{x[2], x[3]});
+                                    x = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                                    }
+                                }
+                            }
+                            bf16x4 p4;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) p4[e] = (bf16)x[e];
+                            pk[h] = __builtin_bit_cast(u32x2, p4);
+                        }
+                        // half-wave exchange: lanes 0-31 end up with columns [16 gp, 16 gp + 8) of block j, lanes 32-63 with the next 8
+                        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                        const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+                        const int c8 = wcol0 + j * 32 + 16 * gp + 8 * fh;
+                        if (rok && (FULL || c8 < N) && !(abl & 64)) *reinterpret_cast<u32x4*>(out_lp + (size_t)row * ldo + c8) = w;
+                    }
+                if constexpr (LNPROD) {
+                    sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+                    static_assert(!LNPROD || WC == 96, "statistics slots are 96 columns wide");
+                    if (fh == 0 && rok)
+                        *reinterpret_cast<float2*>(ex.st_out + 2 * ((size_t)row * ex.st_out_slots + wcol0 / WC)) = float2{sm, sq};
+                }
+            }
+        };
+        if (abl & 8) { if (acc[0][0][0] == 12345.678f) out[0] = from_f32<OT>(1.f); }     // ablation: no epilogue
+        else if (wrow0 + MI * 32 <= M && wcol0 + WC <= N) run(std::true_type{});
+        else run(std::false_type{});
+    } else {
     __syncthreads();                                  // every wave is done reading the operand ring
     if (trace) tr3 = clock64();
     if constexpr (ATTN) {
@@ -749,6 +916,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     else if (vec_ok && wrow0 + MI * 32 <= M && wcol0 + WCOLS <= N) epilogue(std::true_type{});
     else epilogue(std::false_type{});
     }   // !ATTN
+    }   // !DIRECT
     if (trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long* t = trace + (size_t)blockIdx.x * 8;
@@ -761,6 +929,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
 }
 
 long long* g_gemm_trace = nullptr;
+int g_trace_epi = -1, g_trace_k = 0;       // diagnostic builds: stamp only launches of this epilogue / this K (-1 / 0: all)
+void set_gemm_trace_filter(int epi, int k) { g_trace_epi = epi == 255 ? -1 : epi; g_trace_k = k; }
 extern int g_gemm_abl;
 int g_gemm_skew = 0;
 void set_gemm_skew(int v) { g_gemm_skew = v; }
@@ -780,7 +950,8 @@ static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bi
     if (ex) e = *ex;
     e.skew = g_gemm_skew;
     const int nwg = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN) * splitk;
-    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, g_gemm_trace, g_gemm_abl, e);
+    long long* tr = ((g_trace_epi < 0 || g_trace_epi == EPI) && (g_trace_k == 0 || g_trace_k == K)) ? g_gemm_trace : nullptr;
+    kern<<<dim3(nwg), dim3(WM * WN * 64), LDS, s>>>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, tr, g_gemm_abl, e);
     return CPT_OK;
 }
 
@@ -796,6 +967,7 @@ int g_gemm_variant = 3;      // 0: generic register-staged kernel only; 3: pipel
 #define CPT_CFG_128x192_W4 128, 192, 2, 2, 2, 1, 2, 2     // 4 waves of 64x96, two workgroups per CU
 #define CPT_CFG_256x192 256, 192, 4, 2, 2, 1, 2, 1        // 8 waves of 64x96
 #define CPT_CFG_64x192 64, 192, 2, 2, 3                   // 4 waves of 32x96: twice the workgroups when M is small
+#define CPT_CFG_384x256 384, 256, 4, 2, 2, 1, 1, 1        // 8 waves of 96x128 (192 accumulator registers), the whole LDS as a 2-stage ring
 
 template <typename T, int EPI, typename OT>
 static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, const float* bias,
@@ -807,16 +979,18 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         // bound by LDS port time (LDS-DMA writes + fragment reads) unless the tile does >= 3.6 MFMA per KiB of
         // operands, and a launch takes ceil(workgroups / slots) rounds.
         struct Cand { int bm, bn, slots, round_cost; };   // round_cost ~ cycles for one round of `slots` workgroups
-        const Cand cand[8] = {{128, 192, 256, 320}, {192, 192, 256, 384}, {128, 384, 256, 512},
+        constexpr bool big_ok = EPI == CPT_EPI_LNCONS_GELU;   // 384x256 exists for the direct FFN-up epilogue only
+        const Cand cand[9] = {{128, 192, 256, 320}, {192, 192, 256, 384}, {128, 384, 256, 512},
                               {384, 192, 256, 645 /* MFMA-bound */},
                               {128, 192, 512, 460 /* two co-resident workgroups per CU: epilogue under the other's K loop */},
                               {0, 0, 1, 0}, {0, 0, 1, 0} /* 5, 6: experiment-only shapes */,
-                              {64, 192, 256, 200 /* small M: fills the chip with half-height tiles */}};
+                              {64, 192, 256, 200 /* small M: fills the chip with half-height tiles */},
+                              {big_ok ? 384 : 0, 256, 256, 860 /* MFMA-bound, 26 B of operands per MFMA cycle */}};
         long best_cost = -1;
         // residual-type epilogues do not fit the 168 (12 waves) / 128 (two workgroups per CU) register caps without
         // scratch spills, and a spilling instance runs 3-5x slower: those shapes are not candidates for them
         constexpr bool heavy_epi = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || EPI == CPT_EPI_LNPROD;
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 9; ++i) {
             if (cand[i].bm == 0 || (heavy_epi && (i == 3 || i == 4))) continue;
             const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
             const long cost = ((wgs + cand[i].slots - 1) / cand[i].slots) * cand[i].round_cost;
@@ -829,6 +1003,11 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
     else if (variant == 16) pick = 5;
     else if (variant == 17) pick = 6;
     else if (variant == 18) pick = 7;
+    else if (variant == 19) pick = 8;
+    if constexpr (EPI == CPT_EPI_LNCONS_GELU) {
+        if (pick == 8) { launch_pipe<T, EPI, OT, CPT_CFG_384x256>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); return; }
+    }
+    if (pick == 8) pick = 0;
     switch (pick) {
         case 1: launch_pipe<T, EPI, OT, CPT_CFG_192x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         case 2: launch_pipe<T, EPI, OT, CPT_CFG_128x384>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
@@ -932,6 +1111,9 @@ int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bi
                  float* out_f32, void* out_lp, float* st_out, int ldo, int M, int N, int K, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
     if (!A || !W || !resid || !out_f32 || !out_lp || !st_out) return CPT_ERR_NULL;
+    // direct epilogue: 16-byte accesses on rows of the outputs, the residual and the column vectors
+    if (N % 8 || ldo % 8 || ldr % 4 || (((uintptr_t)out_f32 | (uintptr_t)out_lp | (uintptr_t)resid | (uintptr_t)bias | (uintptr_t)g_in | (uintptr_t)b_in) & 15))
+        return CPT_ERR_ALIGN;
     EpiX ex = {};
     ex.st_in = st_in; ex.st_in_parts = ln_stat_parts(hidden); ex.g_in = g_in; ex.b_in = b_in; ex.st_out = st_out; ex.st_out_slots = ln_stat_slots(N); ex.out_lp = out_lp;
     ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
@@ -946,9 +1128,14 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
                  float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
     if (!A || !Wf || !st_in || !colc || !cold || !out_lp) return CPT_ERR_NULL;
+    if (N % 8 || ldo % 8 || (((uintptr_t)out_lp | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
     EpiX ex = {};
     ex.st_in = st_in; ex.st_in_parts = ln_stat_parts(hidden); ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
     const int v = g_gemm_variant >= 3 ? g_gemm_variant : 3;
+    if (gelu && (v == 3 || v == 20) && ffn_up_2pass_supported(M, N, K)) {
+        void* tr = ((g_trace_epi < 0 || g_trace_epi == CPT_EPI_LNCONS_GELU) && (g_trace_k == 0 || g_trace_k == K)) ? (void*)g_gemm_trace : nullptr;
+        return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, tr, g_gemm_abl, s);
+    }
     if (gelu) launch_fast<bf16, CPT_EPI_LNCONS_GELU, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
     else launch_fast<bf16, CPT_EPI_LNCONS, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
     return CPT_OK;
@@ -971,7 +1158,8 @@ static int launch_qkv_attn(const bf16* A, int lda, const bf16* W, int ldw, const
     }
     EpiX e = ex;
     e.skew = g_gemm_skew;
-    kern<<<dim3(B * ex.heads), dim3(512), LDS, s>>>(A, lda, W, ldw, bias, nullptr, 0, ctx, ldo, M, N, K, 1, g_gemm_trace, g_gemm_abl, e);
+    long long* tr = (g_trace_epi < 0 || g_trace_epi == EPI) ? g_gemm_trace : nullptr;
+    kern<<<dim3(B * ex.heads), dim3(512), LDS, s>>>(A, lda, W, ldw, bias, nullptr, 0, ctx, ldo, M, N, K, 1, tr, g_gemm_abl, e);
     return CPT_OK;
 }
 

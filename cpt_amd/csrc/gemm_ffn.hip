@@ -1,0 +1,377 @@
+// FFN-up (BertIntermediate: dense + GELU, /root/reference/Oscar/oscar/modeling/modeling_bert.py:144 -> third-party
+// BertIntermediate) of the bf16 fused encoder as ONE kernel with its epilogue software-pipelined under the K loop:
+//   out[M][N] = gelu( rstd[m] * (A.Wf^T - mean[m] * colc[n]) + cold[n] )        (LayerNorm folded, see gemm.hip / DESIGN.md 5c)
+//
+// Why a dedicated kernel (measured on MI355X, tools/gemm_cu_timeline.py): with 128x192 tiles the K loop is bound by the
+// CU's LDS-DMA path (40 KB of operands per 768 MFMA cycles) and the GELU epilogue (about as many VALU issue cycles as
+// the MFMAs take matrix cycles) ran after it, un-overlapped.  Here one workgroup owns a 384 x 256 output tile and computes
+// it as TWO passes of 192 x 256 (56 KB of operands per 1536 MFMA cycles): pass 1's K loop carries pass 0's finished
+// accumulators in a second register set and retires them -- LayerNorm fold, GELU, bf16 pack, 16-byte stores -- one
+// register-quad pair per K-tile, in the issue slots the matrix pipe leaves free.  Only the second half's epilogue is
+// exposed.  240 workgroups at M = 7680, N = 3072: one per CU, one round.
+//
+// Layout: 8 waves as 2 (M) x 4 (N), wave tile 96 x 64 = 3 x 2 MFMA 32x32x16 blocks with SWAPPED operands, so the
+// accumulators are transposed (lane = output row, register quad = 4 consecutive columns; gemm.hip "direct epilogue").
+// LDS rings (LDS-DMA, source-side XOR swizzle, counted vmcnt): three stages of 56 KB do not fit beside the side data, and with two the single tile in flight exposed the
+// whole L2/MALL latency every K-tile (2720 cycles per K-tile measured, MFMA time 1536).  So the operands ride rings of
+// different depth: A half-tiles (24 KB) 2 deep, W tiles (32 KB) 3 deep -- the W tile of K-tile t+3 is requested two
+// iterations ahead, only the 24 KB A half-tile of t+2 has to arrive within one.  Plus the tile's 256-column c/d vectors
+// and its 384 rows' (mean, rstd): 149 KB.
+#include "common.h"
+#include "kernels.h"
+
+namespace cpt {
+namespace {
+
+constexpr int RB = 128;                       // bytes per operand-tile row (64 bf16)
+constexpr int HM = 192, TN = 256, TM = 2 * HM;
+constexpr int NWV = 8;
+constexpr int A_SLOT = HM * RB, W_SLOT = TN * RB;            // 24 KB, 32 KB
+constexpr int NA = 2, NW_ = 3;                                // ring depths: A half-tiles 2, W tiles 3 (see "rings" below)
+constexpr int GA = HM / 8 / NWV, GW = TN / 8 / NWV;           // LDS-DMA pieces (1 KiB = 8 rows) per wave per tile: 3 of A, 4 of W
+constexpr int MI = 3, NJ = 2;
+constexpr int W_RING = NA * A_SLOT, SIDE_C = W_RING + NW_ * W_SLOT, SIDE_D = SIDE_C + TN * 4, SIDE_ST = SIDE_D + TN * 4,
+              LDS_BYTES = SIDE_ST + TM * 8;                   // 48 + 96 + 5 KB
+static_assert(GA * 8 * NWV == HM && GW * 8 * NWV == TN && LDS_BYTES <= 160 * 1024, "tile must split evenly over the waves and fit the LDS");
+
+__device__ __forceinline__ int ldsoff(int row, int chunk) { return row * RB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>       // K-tiles per pass: K = 64 NT
+__global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                                                              bf16* __restrict__ out, int ldo, int M, int N,
+                                                              const float* __restrict__ st_in, int st_parts, const float* __restrict__ colc,
+                                                              const float* __restrict__ cold, float eps, float inv_h,
+                                                              long long* __restrict__ trace_arg, int abl_arg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifdef CPT_ABLATION
+    long long* __restrict__ trace = trace_arg;
+    const int abl = abl_arg;          // diagnostic build: 1 no operand DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue under pass 1
+#else
+    constexpr long long* trace = nullptr;
+    constexpr int abl = 0;
+    (void)trace_arg; (void)abl_arg;
+#endif
+    long long tr0 = 0, tr1 = 0, tr2 = 0, trp = 0, s_wait = 0, s_bar = 0, s_dma = 0, ta = 0, tb = 0, tc = 0;
+    if (trace) tr0 = clock64();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // XCD-first tile order, 4 row tiles per group (as gemm.hip)
+    int m0, n0;
+    {
+        const int tm = (M + TM - 1) / TM, tn = N / TN;
+        const int nwg = tm * tn, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int gm = 4, per_group = gm * tn;
+        const int g = lid / per_group, first_m = g * gm;
+        const int gsz = min(tm - first_m, gm);
+        const int in_g = lid - g * per_group;
+        m0 = (first_m + in_g % gsz) * TM;
+        n0 = (in_g / gsz) * TN;
+    }
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
+    const int rbase = wave * 8 + (lane >> 3);
+    const unsigned c16 = (unsigned)(((lane & 7) ^ ((rbase >> 1) & 7)) * 16);
+    // K-tile `it` of the 2 NT-tile stream (pass = it / NT): A half-tile into A slot `sa`, W tile into W slot `sw`
+    auto stage_a = [&](int sa, int it) {
+        if (abl & 1) return;
+        const int pass = it >= NT ? 1 : 0;
+        const int soff = (it - pass * NT) * 64 * 2;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            auto lds = (__attribute__((address_space(3))) void*)(smem + sa * A_SLOT + (i * NWV + wave) * 1024);
+            const unsigned vo = (unsigned)min(m0 + pass * HM + rbase + i * NWV * 8, M - 1) * (unsigned)(lda * 2) + c16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lds, 16, vo, soff, 0, 0);
+        }
+    };
+    auto stage_w = [&](int sw, int it) {
+        if (abl & 1) return;
+        const int pass = it >= NT ? 1 : 0;
+        const int soff = (it - pass * NT) * 64 * 2;
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            auto lds = (__attribute__((address_space(3))) void*)(smem + W_RING + sw * W_SLOT + (i * NWV + wave) * 1024);
+            const unsigned vo = (unsigned)min(n0 + rbase + i * NWV * 8, N - 1) * (unsigned)(ldw * 2) + c16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lds, 16, vo, soff, 0, 0);
+        }
+    };
+
+    // side data (the tile's column vectors and row statistics): the global loads go FIRST, so that the compiler's wait for
+    // them does not drain the operand DMA issued behind them
+    float* side_c = reinterpret_cast<float*>(smem + SIDE_C);
+    float* side_d = reinterpret_cast<float*>(smem + SIDE_D);
+    float2* side_st = reinterpret_cast<float2*>(smem + SIDE_ST);
+    f32x4 cd = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) cd = *reinterpret_cast<const f32x4*>(colc + n0 + tid * 4);
+    else if (tid < 128) cd = *reinterpret_cast<const f32x4*>(cold + n0 + (tid - 64) * 4);
+    float2 ms_mine = {0.f, 1.f};
+    if (tid < TM) {
+        const int row = min(m0 + tid, M - 1);
+        const int slots = (st_parts + 1) & ~1, nq = slots >> 1;
+        const f32x4* base = reinterpret_cast<const f32x4*>(st_in + (size_t)row * slots * 2);
+        f32x4 v[6];                                // up to 12 slots (hidden <= 1152), all loads in flight together
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = base[min(q, nq - 1)];
+        float sum = 0.f, sq = 0.f;                 // slot order: bit-reproducible (gemm.hip sum_parts)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const bool u0 = 2 * q < st_parts, u1 = 2 * q + 1 < st_parts;
+            sum += u0 ? v[q][0] : 0.f; sq += u0 ? v[q][1] : 0.f;
+            sum += u1 ? v[q][2] : 0.f; sq += u1 ? v[q][3] : 0.f;
+        }
+        const float mu = sum * inv_h;
+        ms_mine = float2{mu, rsqrtf(fmaxf(sq * inv_h - mu * mu, 0.f) + eps)};
+    }
+    __builtin_amdgcn_sched_barrier(0);             // (loads stay ahead of the DMA in program order: the compiler's counted wait for them passes the DMA)
+    stage_a(0, 0); stage_w(0, 0);
+    stage_a(1, 1); stage_w(1, 1);
+    stage_w(2, 2);
+    if (tid < 64) *reinterpret_cast<f32x4*>(side_c + tid * 4) = cd;
+    else if (tid < 128) *reinterpret_cast<f32x4*>(side_d + (tid - 64) * 4) = cd;
+    if (tid < TM) side_st[tid] = ms_mine;
+
+    f32x16 acc0[MI][NJ], acc1[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+
+    // Fragments: A blocks single-buffered, each re-read for the next k-step right after the MFMAs that used it have been
+    // issued; the two W blocks (used by all three A blocks) double-buffered and read a whole k-step ahead.  With two waves
+    // per SIMD and 192 accumulator registers this is what keeps LDS latency off the matrix pipe (one buffer for all five:
+    // 2840 cycles per K-tile measured; MFMA time 1536).
+    bf16x8 fa[MI], fb[2][NJ];
+    // fragment addresses: every row this lane reads is (multiple of 16) + fr, so the swizzle term (row >> 1) & 7 is the lane
+    // constant (fr >> 1) & 7: one base per operand, the blocks 32 rows apart sit at immediate offsets
+    const unsigned abase = (unsigned)(wm * 96 + fr) * RB, wbase = (unsigned)W_RING + (unsigned)(wn * 64 + fr) * RB;
+    const unsigned sx = (unsigned)((fr >> 1) & 7);
+    auto coff = [&](int ks) { return (((unsigned)(ks * 2 + fh)) ^ sx) << 4; };
+    auto rd_a = [&](int i, int sa, int ks) { if (abl & 2) return; fa[i] = *reinterpret_cast<const bf16x8*>(smem + abase + coff(ks) + (unsigned)(sa * A_SLOT) + i * 32 * RB); };
+    auto rd_b = [&](int b, int sw, int ks) {
+        if (abl & 2) return;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[b][j] = *reinterpret_cast<const bf16x8*>(smem + wbase + coff(ks) + (unsigned)(sw * W_SLOT) + j * 32 * RB);
+    };
+#define CPT_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef CPT_STAGGER
+#define CPT_STAGGER 0
+#endif
+    // experiment: the second wave of every SIMD (waves 4-7) leaves each K-tile barrier CPT_STAGGER x 64 clocks late
+#define CPT_STAG() do { if (CPT_STAGGER > 0 && wave >= 4) __builtin_amdgcn_s_sleep(CPT_STAGGER); } while (0)
+#define CPT_T(x) asm volatile("" : "+v"(x))
+    // one k-step on accumulator set ACC with W buffer B; the fragments of k-step (NSLOT, NKS) are fetched meanwhile if MORE
+#define CPT_MF(D, X, Y) do { if (!(abl & 4)) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X, Y, D, 0, 0, 0); } while (0)
+#define CPT_KSTEP(ACC, B, NSA, NSW, NKS, MORE)                                                                              \
+    do {                                                                                                                  \
+        if (MORE) { rd_b((B) ^ 1, NSW, NKS); CPT_SB(); }                                                                  \
+        CPT_T(fa[0]); CPT_T(fb[B][0]); CPT_T(fb[B][1]); CPT_SB();                                                         \
+        CPT_MF(ACC[0][0], fb[B][0], fa[0]);                         \
+        CPT_MF(ACC[0][1], fb[B][1], fa[0]); CPT_SB();               \
+        if (MORE) { rd_a(0, NSA, NKS); CPT_SB(); }                                                                        \
+        CPT_T(fa[1]); CPT_SB();                                                                                           \
+        CPT_MF(ACC[1][0], fb[B][0], fa[1]);                         \
+        CPT_MF(ACC[1][1], fb[B][1], fa[1]); CPT_SB();               \
+        if (MORE) { rd_a(1, NSA, NKS); CPT_SB(); }                                                                        \
+        CPT_T(fa[2]); CPT_SB();                                                                                           \
+        CPT_MF(ACC[2][0], fb[B][0], fa[2]);                         \
+        CPT_MF(ACC[2][1], fb[B][1], fa[2]); CPT_SB();               \
+        if (MORE) { rd_a(2, NSA, NKS); CPT_SB(); }                                                                        \
+    } while (0)
+    // all fragment reads of the current tile retired (before the barrier that frees its slot)
+#define CPT_RETIRE(B) do { CPT_T(fa[0]); CPT_T(fa[1]); CPT_T(fa[2]); CPT_T(fb[B][0]); CPT_T(fb[B][1]); CPT_SB(); } while (0)
+
+    // ---- epilogue pieces: pair p (0..11) of a pass = row block i = p / 4, column block j = (p / 2) % 2, quad pair gp = p % 2
+    auto epi_quad = [&](const f32x16& a, int pass, int p, int h) -> u32x2 {
+        const int i = p >> 2, j = (p >> 1) & 1, g = 2 * (p & 1) + h;
+        // The side data is read with inline-asm ds_read: for an LDS load it can see, hipcc waits vmcnt(0) first whenever an
+        // LDS-DMA is in flight (it cannot tell the side area from the ring), which drained the operand pipeline once per
+        // K-tile (measured: +1070 cycles per K-tile of pass 1).  The wait below also retires the older fragment reads.
+        const int lc = wn * 64 + j * 32 + 8 * g + 4 * fh;
+        float2 ms; f32x4 c4, d4;
+#ifndef CPT_SIDE_MODE
+#define CPT_SIDE_MODE 0
+#endif
+#if CPT_SIDE_MODE == 0
+        ms = side_st[pass * HM + wm * 96 + i * 32 + fr];
+        c4 = *reinterpret_cast<const f32x4*>(side_c + lc);
+        d4 = *reinterpret_cast<const f32x4*>(side_d + lc);
+#else
+#if CPT_SIDE_MODE == 2
+        wait_vm<0>();
+#endif
+        asm volatile("ds_read_b64 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ms), "=&v"(c4), "=&v"(d4)
+                     : "v"((unsigned)(SIDE_ST + (pass * HM + wm * 96 + i * 32 + fr) * 8)), "v"((unsigned)(SIDE_C + lc * 4)), "v"((unsigned)(SIDE_D + lc * 4))
+                     : "memory");
+#if CPT_SIDE_MODE == 3
+        {   // debug: the same values through compiler-visible loads; mismatches counted in the last trace slot
+            const float2 ms2 = side_st[pass * HM + wm * 96 + i * 32 + fr];
+            const f32x4 c42 = *reinterpret_cast<const f32x4*>(side_c + lc);
+            const f32x4 d42 = *reinterpret_cast<const f32x4*>(side_d + lc);
+            bool bad = __float_as_uint(ms2.x) != __float_as_uint(ms.x) || __float_as_uint(ms2.y) != __float_as_uint(ms.y);
+            for (int e = 0; e < 4; ++e) bad = bad || __float_as_uint(c42[e]) != __float_as_uint(c4[e]) || __float_as_uint(d42[e]) != __float_as_uint(d4[e]);
+            if (bad && trace) atomicAdd(reinterpret_cast<unsigned long long*>(trace) + 4096 * 8 - 1, 1ull);
+        }
+#endif
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = ms.y * (a[4 * g + e] - ms.x * c4[e]) + d4[e];
+        const f32x2 g0 = gelu_fast2(f32x2{x[0], x[1]}), g1 = gelu_fast2(f32x2{x[2], x[3]});
+        bf16x4 p4 = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
+        return __builtin_bit_cast(u32x2, p4);
+    };
+    auto epi_store = [&](int pass, int p, u32x2 k0, u32x2 k1) {
+        const int i = p >> 2, j = (p >> 1) & 1, gp = p & 1;
+        // half-wave exchange: lanes 0-31 get columns [16 gp, 16 gp + 8) of the block, lanes 32-63 the next 8 (guide T21)
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(k0[0], k1[0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(k0[1], k1[1], false, false);
+        const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+        const int row = m0 + pass * HM + wm * 96 + i * 32 + fr;
+        const int col = n0 + wn * 64 + j * 32 + 16 * gp + 8 * fh;
+        if (row < M) *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + col) = w;
+    };
+
+    // issued so far per wave: A0 W0 A1 W1 W2 = 3 4 3 4 4 pieces; tile 0 is complete when at most 11 are outstanding
+    wait_vm<GA + 2 * GW>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // side data written
+    __builtin_amdgcn_s_barrier();                               // tile 0 and the side data visible to every wave
+    if (trace) tr1 = clock64();
+    CPT_SB();
+    rd_b(0, 0, 0); rd_a(0, 0, 0); rd_a(1, 0, 0); rd_a(2, 0, 0);
+    CPT_SB();
+
+    // Steady state of iteration `it` (K-tile it of 2 NT): after its last fragment reads are retired, wait for tile it+1
+    // (A half-tile it+1 was issued one iteration ago together with, and ahead of, W tile it+2, which may stay in flight: 4
+    // pieces, plus the epilogue store of this iteration), barrier, then request A(it+2) into the A slot just freed and
+    // W(it+3) into the W slot just freed.  k-steps 0..3 of a tile use W fragment buffers 0, 1, 0, 1.
+    // ---- pass 0: rows [m0, m0 + 192)
+    int sa = 0, sw = 0;
+    for (int kt = 0; kt < NT; ++kt) {
+        const int sw1 = sw == NW_ - 1 ? 0 : sw + 1;
+        CPT_KSTEP(acc0, 0, sa, sw, 1, true);
+        CPT_KSTEP(acc0, 1, sa, sw, 2, true);
+        CPT_KSTEP(acc0, 0, sa, sw, 3, true);
+        if (trace) ta = clock64();
+        CPT_RETIRE(1);                             // this wave's reads of the tile are retired
+        wait_vm<GW>();                             // tile kt+1 landed (W(kt+2) may still be in flight)
+        CPT_SB();
+        if (trace) tb = clock64();
+        __builtin_amdgcn_s_barrier();              // ... for every wave; nobody still reads tile kt's slots
+        CPT_STAG();
+        CPT_SB();
+        if (trace) tc = clock64();
+        stage_a(sa, kt + 2);                       // (kt + 3 < 2 NT always holds in pass 0: NT >= 3)
+        stage_w(sw, kt + 3);
+        CPT_SB();
+        if (trace) { const long long td = clock64(); s_wait += tb - ta; s_bar += tc - tb; s_dma += td - tc; }
+        CPT_KSTEP(acc0, 1, sa ^ 1, sw1, 0, true);
+        sa ^= 1; sw = sw1;
+    }
+    if (trace) trp = clock64();
+    // ---- pass 1: rows [m0 + 192, m0 + 384); pass 0's accumulators retire under it, one quad pair per K-tile
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        constexpr int NP = MI * NJ * 2;            // 12 pairs
+        const int it = NT + kt;
+        const int a_s = it & 1, w_s = it % NW_, w_s1 = (it + 1) % NW_;
+        const bool epi = kt < NP && !(abl & 8);
+        const bool more = kt + 1 < NT;
+        u32x2 k0 = {0, 0}, k1 = {0, 0};
+        CPT_KSTEP(acc1, 0, a_s, w_s, 1, true);
+        if (epi) { k0 = epi_quad(acc0[(kt % NP) >> 2][((kt % NP) >> 1) & 1], 0, kt % NP, 0); CPT_SB(); }
+        CPT_KSTEP(acc1, 1, a_s, w_s, 2, true);
+        if (epi) { k1 = epi_quad(acc0[(kt % NP) >> 2][((kt % NP) >> 1) & 1], 0, kt % NP, 1); CPT_SB(); }
+        CPT_KSTEP(acc1, 0, a_s, w_s, 3, true);
+        if (epi) { epi_store(0, kt % NP, k0, k1); CPT_SB(); }
+        if (trace) ta = clock64();
+        CPT_RETIRE(1);
+        if (more) {
+            // Loads younger than A(it+1): the 4 pieces of W(it+2), if it exists.  Loads complete in issue order, stores do NOT
+            // keep order with loads on gfx950 (one vmcnt for both): the epilogue's stores must not be counted as "younger
+            // ops that may stay in flight" -- a store that completes early would let an older DMA piece slip through.  At
+            // most GW outstanding => every load older than W(it+2) has landed, whatever the stores did.
+            if (kt + 2 < NT) wait_vm<GW>(); else wait_vm<0>();
+            CPT_SB();
+            if (trace) tb = clock64();
+            __builtin_amdgcn_s_barrier();
+            CPT_STAG();
+            CPT_SB();
+            if (trace) tc = clock64();
+            if (kt + 2 < NT) stage_a(a_s, it + 2);
+            if (kt + 3 < NT) stage_w(w_s, it + 3);
+            CPT_SB();
+            if (trace) { const long long td = clock64(); s_wait += tb - ta; s_bar += tc - tb; s_dma += td - tc; }
+        }
+        CPT_KSTEP(acc1, 1, a_s ^ 1, w_s1, 0, more);
+    }
+    if (trace) tr2 = clock64();
+    // pairs of pass 0 that did not fit under pass 1 (NT < 12), then pass 1's own epilogue (exposed)
+#pragma unroll
+    for (int p = NT; p < MI * NJ * 2; ++p) {
+        const u32x2 k0 = epi_quad(acc0[p >> 2][(p >> 1) & 1], 0, p, 0), k1 = epi_quad(acc0[p >> 2][(p >> 1) & 1], 0, p, 1);
+        epi_store(0, p, k0, k1);
+    }
+#pragma unroll
+    for (int p = 0; p < MI * NJ * 2; ++p) {
+        const u32x2 k0 = epi_quad(acc1[p >> 2][(p >> 1) & 1], 1, p, 0), k1 = epi_quad(acc1[p >> 2][(p >> 1) & 1], 1, p, 1);
+        epi_store(1, p, k0, k1);
+    }
+#undef CPT_SB
+#undef CPT_T
+#undef CPT_KSTEP
+#undef CPT_RETIRE
+    if (trace && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* t = trace + (size_t)blockIdx.x * 8;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = trp; t[4] = clock64();
+        t[5] = s_wait; t[6] = s_bar; t[7] = s_dma;         // wave 0: sums over the K-tiles (fragment retire + vmcnt wait, barrier, DMA issue)
+    }
+#endif
+}
+
+template <int NT>
+int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int ldo, int M, int N, const float* st_in, int st_parts,
+                 const float* colc, const float* cold, float eps, float inv_h, long long* trace, int abl, hipStream_t s) {
+    auto kern = ffn_up_2pass_kernel<NT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+        attr_done = true;
+    }
+    const int nwg = ((M + TM - 1) / TM) * (N / TN);
+    kern<<<dim3(nwg), dim3(512), LDS_BYTES, s>>>(A, lda, W, ldw, out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, trace, abl);
+    return CPT_OK;
+}
+
+}  // namespace
+
+// 1 = this shape runs on the two-pass kernel
+int ffn_up_2pass_supported(int M, int N, int K) {
+    return (K == 768 || K == 1024) && N % TN == 0 && M >= TM;
+}
+
+int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
+                      float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s) {
+    if (!ffn_up_2pass_supported(M, N, K)) return CPT_ERR_SHAPE;
+    if (lda % 8 || ldw % 8 || ldo % 8 || (((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)out | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
+    const float inv_h = 1.0f / (float)hidden;
+    if (K == 768) return launch_2pass<12>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);
+    return launch_2pass<16>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);
+}
+
+}  // namespace cpt

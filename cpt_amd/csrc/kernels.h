@@ -79,6 +79,11 @@ void set_attn_bwd_variant(int v);
 void set_gemm_variant(int v);
 void set_gemm_abl(int v);
 void set_gemm_skew(int v);
+// FFN-up as one 384 x 256 two-pass kernel with its epilogue pipelined under the second pass (gemm_ffn.hip)
+int ffn_up_2pass_supported(int M, int N, int K);
+int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
+                      float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s);
 void set_gemm_trace(void* p);
+void set_gemm_trace_filter(int epi, int k);
 
 }  // namespace cpt

@@ -105,3 +105,32 @@ def ce_rows(logits, labels, want_grad=False):
     L.check(L.lib().cpt_ce_rows(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), L.ptr(d), R, V,
                                 L.stream_ptr()), "cpt_ce_rows")
     return (loss, d) if want_grad else loss
+
+
+def ln_stat_slots(hidden):
+    """Slots per row of the partial row-sum table of a `hidden`-wide LayerNorm producer (96-column blocks, rounded up to even)."""
+    parts = (hidden + 95) // 96
+    return (parts + 1) & ~1
+
+
+def row_stats_table(x, hidden=None):
+    """Partial row sums [M][slots][2] (sum, sum of squares per 96-column block) of fp32 x[M][hidden], as gemm_ln_prod writes them."""
+    M, H = x.shape
+    slots = ln_stat_slots(H)
+    st = torch.zeros((M, slots, 2), device=x.device, dtype=torch.float32)
+    for p in range((H + 95) // 96):
+        blk = x[:, p * 96:(p + 1) * 96].float()
+        st[:, p, 0] = blk.sum(1)
+        st[:, p, 1] = (blk * blk).sum(1)
+    return st
+
+
+def gemm_ln_cons(a, wf, st_in, colc, cold, eps, hidden, gelu):
+    """[gelu]( rstd * (a @ wf.T - mean * colc) + cold ): bf16 a[M,K], wf[N,K]; st_in from row_stats_table / gemm_ln_prod."""
+    _need_cuda(a, wf, st_in, colc, cold)
+    M, K = a.shape
+    N = wf.size(0)
+    out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    L.check(L.lib().cpt_gemm_ln_cons(a.data_ptr(), a.stride(0), wf.data_ptr(), wf.stride(0), st_in.data_ptr(), colc.data_ptr(), cold.data_ptr(),
+                                     float(eps), hidden, 1 if gelu else 0, out.data_ptr(), out.stride(0), M, N, K, L.stream_ptr()), "cpt_gemm_ln_cons")
+    return out

@@ -292,6 +292,19 @@ int cpt_argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids
 int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,
                         float* colc, float* cold, int N, int K, void* stream);
 
+/* The two GEMM forms of the fused bf16 encoder, as stand-alone operators (bf16 operands, fp32 accumulate).
+ * Row statistics travel as partial sums: st[M][slots][2] (sum, sum of squares), one slot per 96-column block of the
+ * `hidden`-wide producer, slots = number of blocks rounded up to even; readers add the slots in index order.
+ *   consumer:  out = [gelu]( LayerNorm(A; st_in) . W^T + bias ), with the LayerNorm folded: Wf = gamma (.) W in bf16,
+ *              colc / cold from cpt_fold_ln_weights; BertIntermediate (modeling_bert.py:144) and the Q|K|V projections.
+ *   producer:  out_f32 = A . W^T + bias + R, R = resid or LayerNorm(resid; st_in, g_in, b_in) when g_in != NULL; also writes
+ *              the bf16 copy and st_out (partial row sums of out_f32); BertSelfOutput / BertOutput (:85-86, :145). */
+int cpt_gemm_ln_cons(const void* A_bf16, int lda, const void* Wf_bf16, int ldw, const float* st_in, const float* colc,
+                     const float* cold, float eps, int hidden, int gelu, void* out_bf16, int ldo, int M, int N, int K, void* stream);
+int cpt_gemm_ln_prod(const void* A_bf16, int lda, const void* W_bf16, int ldw, const float* bias, const float* resid, int ldr,
+                     const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, float* out_f32,
+                     void* out_bf16, float* st_out, int ldo, int M, int N, int K, void* stream);
+
 /* out[b][:] = src[b*L + pos[b]][:] (pos NULL = row 0): the [MASK] rows
  * (zeroshot/refcoco_cpt.py:219) and the [CLS] rows of BertPooler. */
 int cpt_gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H,

@@ -238,3 +238,39 @@ def test_select_regions_device_matches_reference_rule(dev):
     sc2[3, 40] = sc2[3, 41] = 9.0
     got = scoring.argmax_columns_device(sc2.to(dev), ids)
     assert got.cpu().tolist() == sc2[:, ids].argmax(1).tolist()
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(7680 // 4, 3072, 768, 3), (1000, 3072, 768, 3), (500, 512, 1024, 3), (100, 3072, 768, 3),
+                                           (1000, 3072, 768, 15), (1000, 2304, 768, 14), (640, 1024, 1024, 19), (300, 200, 128, 3)])
+def test_gemm_ln_consumer(dev, M, N, K, variant):
+    """The LayerNorm-consumer GEMM of the fused bf16 encoder, gelu( LayerNorm(x) . W^T + bias ) with the LayerNorm folded
+    (modeling_bert.py:144 + the LayerNorm of :86 before it), on every kernel that serves it: the two-pass 384 x 256 FFN-up
+    kernel (gemm_ffn.hip; K = 768 and 1024, full and ragged row tiles), the direct-epilogue 128 x 192 / 384 x 192 / 384 x 256
+    tile shapes of gemm.hip, and shapes that fall back to guarded edge tiles.  Reference: fp64 on the bf16-rounded operands."""
+    from cpt_amd import ops, _lib as L
+    rng = _rng(5 + M + K)
+    x = _t(rng, M, K, scale=1.3) + 0.4
+    W = _t(rng, N, K, scale=0.04)
+    gamma, beta, bias = 1.0 + _t(rng, K, scale=0.1), _t(rng, K, scale=0.1), _t(rng, N, scale=0.1)
+    eps = 1e-12
+    a = x.to(torch.bfloat16)
+    wf = (W * gamma).to(torch.bfloat16)
+    colc = wf.float().sum(1)                              # as the MFMA sees the folded weight
+    cold = (W.double() @ beta.double() + bias.double()).float()
+    st = ops.row_stats_table(x.to(dev))
+    mu = x.double().mean(1, keepdim=True)
+    rs = 1.0 / torch.sqrt(x.double().var(1, unbiased=False, keepdim=True) + eps)
+    for gelu in (True, False):
+        pre = rs * (a.double() @ wf.double().T - mu * colc.double()) + cold.double()
+        ref = pre * 0.5 * (1.0 + torch.erf(pre / math.sqrt(2.0))) if gelu else pre
+        try:
+            L.check(L.lib().cpt_set_tuning(0, variant))
+            got = ops.gemm_ln_cons(a.to(dev), wf.to(dev), st, colc.to(dev), cold.to(dev), eps, K, gelu).float().cpu()
+            again = ops.gemm_ln_cons(a.to(dev), wf.to(dev), st, colc.to(dev), cold.to(dev), eps, K, gelu).float().cpu()
+        finally:
+            L.check(L.lib().cpt_set_tuning(0, 3))
+        assert torch.equal(got, again)                    # no run-to-run variation (counted-vmcnt pipeline)
+        d = (got.double() - ref).abs()
+        tol = 2.0 ** -8 * ref.abs() + 2e-3                # bf16 output rounding (half an ulp = 2^-9 relative) + fp32 accumulation
+        print("ln-consumer %dx%dx%d variant %d gelu=%d: max|d| %.3e (ref absmax %.2f)" % (M, N, K, variant, gelu, d.max().item(), ref.abs().max().item()))
+        assert bool((d <= tol).all()), (d - tol).max().item()
