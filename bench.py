@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}      # MI355X_MICROARCH.md: dense MFMA peaks
 
 
 def pmc_traffic_bytes(kernel):
@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--all-rows", action="store_true", help="vocabulary head on all 120 rows, as the reference computes it")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: BASELINE configs[1] (default, the headline metric); train: few-shot step "

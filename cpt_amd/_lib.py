@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPT_LIB_PATH") or os.path.join(HERE, "libcpt_hip.so")     # (CPT_LIB_PATH: developer A/B builds, tools/ only)
 
-CPT_F32, CPT_BF16 = 0, 1
+CPT_F32, CPT_BF16, CPT_BF16X3 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID = 0, 1, 2, 3
 OUT_SEQ, OUT_POOLED, OUT_MASK_LOGITS, OUT_ALL_LOGITS, OUT_LOSS, OUT_REL = 1, 2, 4, 8, 16, 32
 K_NAMES = ["gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up", "gemm_ffn_down",
@@ -96,6 +96,7 @@ _SIGS = {
     "cpt_gemm_ln_cons": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_gemm_ln_prod": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int,
                                    C.c_int, C.c_int, vp]),
+    "cpt_split3": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_select_regions": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
     "cpt_argmax_columns": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     "cpt_gather_rows": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -44,20 +44,32 @@ __device__ __forceinline__ float erf_fast(float x) {
 // One v_rcp_f32 and no exp; everything else is fma/mul, written on float pairs so that it compiles to the packed
 // fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32).  |gelu error| < 1e-6 absolute over all x (checked against
 // scipy erf on 2M points, tests/test_gpu_ops.py checks the kernel): four orders below bf16 resolution.
+// (Every multiply-add is an EXPLICIT fma: the same sequence of roundings in every kernel that inlines this, whatever the
+// compiler's contraction choices in that context -- rows of a batch must not depend on which tile shape served them.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-    f32x2 p = ax * 5.6212996640e-06f + 5.1055209009e-05f;
-    p = p * ax + 3.9686137011e-05f;
-    p = p * ax + 3.4227392389e-03f;
-    p = p * ax + 2.2076998457e-02f;
-    p = p * ax + 5.2075163037e-02f;
-    p = p * ax + 1.0442737824e+00f;
+    f32x2 p = __builtin_elementwise_fma(ax, splat2(5.6212996640e-06f), splat2(5.1055209009e-05f));
+    p = __builtin_elementwise_fma(p, ax, splat2(3.9686137011e-05f));
+    p = __builtin_elementwise_fma(p, ax, splat2(3.4227392389e-03f));
+    p = __builtin_elementwise_fma(p, ax, splat2(2.2076998457e-02f));
+    p = __builtin_elementwise_fma(p, ax, splat2(5.2075163037e-02f));
+    p = __builtin_elementwise_fma(p, ax, splat2(1.0442737824e+00f));
     f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
     r = r * r; r = r * r; r = r * r; r = r * r;
     const f32x2 m = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
-    return m - ax * r;
+    return __builtin_elementwise_fma(-ax, r, m);
 }
+// Folded LayerNorm, shared by every kernel that applies it, with explicit fma for the same reason:
+//   (mean, rstd) from a row's sums;   x = rstd * (acc - mean * c) + d
+__device__ __forceinline__ void ln_mean_rstd(float sum, float sq, float inv_h, float eps, float& mu, float& rs) {
+    mu = sum * inv_h;
+    rs = rsqrtf(fmaxf(fmaf(-mu, mu, sq * inv_h), 0.f) + eps);
+}
+__device__ __forceinline__ float ln_fold(float acc, float mu, float rs, float c, float d) { return fmaf(rs, fmaf(-mu, c, acc), d); }
+//   LayerNorm applied on the fly to a stored pre-LayerNorm value (the producers' residual):  (r - mean) * rstd * gain + shift
+__device__ __forceinline__ float ln_apply(float r, float mu, float rs, float g, float b) { return fmaf((r - mu) * rs, g, b); }
 __device__ __forceinline__ float gelu_fast(float x) {
     const f32x2 g = gelu_fast2(f32x2{x, x});
     return g[0];

@@ -77,7 +77,7 @@ struct Scope {
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FwdLayout {
-    size_t x_f32, x_lp, qkv, ctx, pre, a_f32, a_lp, ffn, imgp, rows, rows_f32, t1, t2, pooled_f32, pooled_lp, stats, loss, total;
+    size_t x_f32, x_lp, qkv, ctx, pre, a_f32, a_lp, ffn, imgp, rows, rows_f32, t1, t2, pooled_f32, pooled_lp, stats, loss, split, total;
 };
 
 FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
@@ -105,6 +105,14 @@ FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
     w.pooled_f32 = take((size_t)B * H * 4);
     w.pooled_lp = lp ? take((size_t)B * H * 2) : w.pooled_f32;
     w.loss = take(256);
+    // bf16x3: the split copy [rows][3K] bf16 of whichever GEMM input is current (largest: the FFN-down input, M x 3I)
+    w.split = 0;
+    if (d.dtype == CPT_BF16X3) {
+        size_t mx = M * 3 * (size_t)(d.inter > d.hidden ? d.inter : d.hidden);
+        const size_t im = (size_t)B * Li * 3 * d.img_dim_pad;
+        if (im > mx) mx = im;
+        w.split = take(mx * 2);
+    }
     w.total = o;
     return w;
 }
@@ -195,6 +203,11 @@ int cpt_attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ct
     return check_launch(cpt::attention(dtype, qkv, attn_mask, ctx, probs, B, L, heads, (hipStream_t)stream), "cpt_attention");
 }
 
+int cpt_split3(const float* x, int ld, void* out, int R, int K, int weight_order, void* stream) {
+    if (!x || !out) return fail(CPT_ERR_NULL, "cpt_split3: null operand");
+    return check_launch(cpt::split3(x, ld, out, R, K, weight_order, (hipStream_t)stream), "cpt_split3");
+}
+
 int cpt_pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, void* stream) {
     if (!x || !out) return fail(CPT_ERR_NULL, "cpt_pad_cast: null operand");
     return check_launch(cpt::pad_cast(x, out, dtype, R, K, Kp, (hipStream_t)stream), "cpt_pad_cast");
@@ -258,7 +271,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     if (B <= 0 || Lt <= 0 || Li < 0) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: bad batch shape B=%d Lt=%d Li=%d", B, Lt, Li);
     if (d.heads <= 0 || H != d.heads * 64) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: hidden %d / heads %d: head_dim must be 64", H, d.heads);
     if (L > 288) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: sequence length %d > 288 not supported", L);
-    if (d.dtype != CPT_F32 && d.dtype != CPT_BF16) return fail(CPT_ERR_DTYPE, "cpt_model_fwd: dtype %d", d.dtype);
+    if (d.dtype != CPT_F32 && d.dtype != CPT_BF16 && d.dtype != CPT_BF16X3) return fail(CPT_ERR_DTYPE, "cpt_model_fwd: dtype %d", d.dtype);
     if (d.img_dim_pad < d.img_dim || d.img_dim_pad % 8) return fail(CPT_ERR_ALIGN, "cpt_model_fwd: img_dim_pad %d must be >= img_dim and a multiple of 8", d.img_dim_pad);
     if (Li > 0 && !b->img_feats) return fail(CPT_ERR_NULL, "cpt_model_fwd: img_feats is NULL with Li=%d", Li);
     if ((flags & (CPT_OUT_MASK_LOGITS | CPT_OUT_ALL_LOGITS)) == (CPT_OUT_MASK_LOGITS | CPT_OUT_ALL_LOGITS))
@@ -273,8 +286,19 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     if ((uintptr_t)workspace & 255) return fail(CPT_ERR_ALIGN, "cpt_model_fwd: workspace must be 256-byte aligned");
 
     unsigned char* ws = (unsigned char*)workspace;
-    const int dt = d.dtype;
+    // bf16x3 parity mode: everything outside the GEMMs runs as in fp32 mode; a GEMM splits its fp32 input into the
+    // [rows][hi | hi | lo] bf16 copy and runs the bf16 MFMA kernel over K' = 3K against the [N][hi | lo | hi] weights
+    const bool x3 = d.dtype == CPT_BF16X3;
+    const int dt = x3 ? CPT_F32 : d.dtype;
     const bool lp = dt == CPT_BF16;
+    void* splitbuf = ws + w.split;
+    auto gm = [&](int epi, const void* A, int lda, const void* W, int K, const float* bias, const float* resid, int ldr, void* out,
+                  int out_dt, int ldo, int Mr, int N) -> int {
+        if (!x3) return cpt::gemm(dt, epi, A, lda, W, K, bias, resid, ldr, out, out_dt, ldo, Mr, N, K, s);
+        const int rc = cpt::split3((const float*)A, lda, splitbuf, Mr, K, 0, s);
+        if (rc != CPT_OK) return rc;
+        return cpt::gemm(CPT_BF16, epi, splitbuf, 3 * K, W, 3 * K, bias, resid, ldr, out, CPT_F32, ldo, Mr, N, 3 * K, s);
+    };
     float* x_f32 = (float*)(ws + w.x_f32);
     void* x_lp = ws + w.x_lp;
     void* qkv = ws + w.qkv;
@@ -296,8 +320,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         Scope p(CPT_K_IMG, s);
         void* imgp = ws + w.imgp;
         TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
-        TRY(cpt::gemm(dt, CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, pre,
-                      CPT_F32, H, B * Li, H, d.img_dim_pad, s), "gemm(img_embedding)");
+        TRY(gm(CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, pre, CPT_F32, H, B * Li, H), "gemm(img_embedding)");
         const bool iln = d.use_img_ln && m->img_ln_g;
         TRY(cpt::layernorm_rows(pre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, x_f32,
                                 lp ? x_lp : nullptr, dt, B * Li, H, Li, L, Lt, s), "layernorm(img)");
@@ -355,20 +378,20 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                                  B, L, d.heads, H, g_fuse_attn, s), "gemm(qkv)+attention");
         } else {
         { Scope p(CPT_K_GEMM_QKV, s);
-          TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)"); }
+          TRY(gm(CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H), "gemm(qkv)"); }
         { Scope p(CPT_K_ATTN, s);
           TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s), "attention"); }
         }
         const bool lpr = lp && g_lp_resid;                       // residual operand read as bf16, fp32 copy not written
         const bool last = l + 1 == d.layers;
         { Scope p(CPT_K_GEMM_AO, s);
-          TRY(cpt::gemm(dt, lpr ? 5 : CPT_EPI_RESID, ctx, H, y.w_ao, H, y.b_ao, lpr ? (const float*)x_lp : x_f32, H, pre, CPT_F32, H, M, H, H, s), "gemm(attn out)"); }
+          TRY(gm(lpr ? 5 : CPT_EPI_RESID, ctx, H, y.w_ao, H, y.b_ao, lpr ? (const float*)x_lp : x_f32, H, pre, CPT_F32, H, M, H), "gemm(attn out)"); }
         { Scope p(CPT_K_LN, s);
           TRY(cpt::layernorm_rows(pre, y.ln1_g, y.ln1_b, d.ln_eps, lpr ? nullptr : a_f32, lp ? a_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(attn)"); }
         { Scope p(CPT_K_GEMM_FFN1, s);
-          TRY(cpt::gemm(dt, CPT_EPI_GELU, a_lp, H, y.w_in, H, y.b_in, nullptr, 0, ffn, dt, I, M, I, H, s), "gemm(ffn up)"); }
+          TRY(gm(CPT_EPI_GELU, a_lp, H, y.w_in, H, y.b_in, nullptr, 0, ffn, dt, I, M, I), "gemm(ffn up)"); }
         { Scope p(CPT_K_GEMM_FFN2, s);
-          TRY(cpt::gemm(dt, lpr ? 5 : CPT_EPI_RESID, ffn, I, y.w_out, I, y.b_out, lpr ? (const float*)a_lp : a_f32, H, pre, CPT_F32, H, M, H, I, s), "gemm(ffn down)"); }
+          TRY(gm(lpr ? 5 : CPT_EPI_RESID, ffn, I, y.w_out, I, y.b_out, lpr ? (const float*)a_lp : a_f32, H, pre, CPT_F32, H, M, H), "gemm(ffn down)"); }
         { Scope p(CPT_K_LN, s);
           TRY(cpt::layernorm_rows(pre, y.ln2_g, y.ln2_b, d.ln_eps, (lpr && !(last && (flags & CPT_OUT_SEQ))) ? nullptr : x_f32, lp ? x_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(ffn)"); }
     }
@@ -391,7 +414,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
             TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, rows, dt, B, H, B, 0, 0, s), "layernorm([CLS] rows)");
         } else
         TRY(cpt::gather_rows(x_lp, dt, nullptr, rows, B, L, H, s), "gather([CLS])");
-        TRY(cpt::gemm(dt, CPT_EPI_TANH, rows, H, m->w_pool, H, m->b_pool, nullptr, 0, pooled, CPT_F32, H, B, H, H, s), "gemm(pooler)");
+        TRY(gm(CPT_EPI_TANH, rows, H, m->w_pool, H, m->b_pool, nullptr, 0, pooled, CPT_F32, H, B, H), "gemm(pooler)");
         if (flags & CPT_OUT_REL) {
             if (!o->rel) return fail(CPT_ERR_NULL, "cpt_model_fwd: rel output is NULL");
             const void* pin = pooled;
@@ -400,7 +423,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                 TRY(cpt::layernorm_rows(pooled, nullptr, nullptr, 0.f, nullptr, plp, dt, B, H, B, 0, 0, s), "cast(pooled)");
                 pin = plp;
             }
-            TRY(cpt::gemm(dt, CPT_EPI_NONE, pin, H, m->w_rel, H, m->b_rel, nullptr, 0, o->rel, CPT_F32, d.n_rel, B, d.n_rel, H, s), "gemm(seq_relationship)");
+            TRY(gm(CPT_EPI_NONE, pin, H, m->w_rel, H, m->b_rel, nullptr, 0, o->rel, CPT_F32, d.n_rel, B, d.n_rel), "gemm(seq_relationship)");
         }
     }
     // (a11,a12) MLM head on the [MASK] rows (or every row), optional CE loss
@@ -424,9 +447,9 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         }
         float* t1 = (float*)(ws + w.t1);
         void* t2 = ws + w.t2;
-        TRY(cpt::gemm(dt, CPT_EPI_GELU, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, t1, CPT_F32, H, R, H, H, s), "gemm(head transform)");
+        TRY(gm(CPT_EPI_GELU, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, t1, CPT_F32, H, R, H), "gemm(head transform)");
         TRY(cpt::layernorm_rows(t1, m->tr_ln_g, m->tr_ln_b, d.ln_eps, lp ? nullptr : (float*)t2, lp ? t2 : nullptr, dt, R, H, R, 0, 0, s), "layernorm(head)");
-        TRY(cpt::gemm(dt, CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, R, d.vocab, H, s), "gemm(decoder)");
+        TRY(gm(CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, R, d.vocab), "gemm(decoder)");
         if (flags & CPT_OUT_LOSS) {
             hipError_t e = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);
             if (e != hipSuccess) return fail(CPT_ERR_HIP - (int)e, "zero loss: %s", hipGetErrorString(e));

@@ -528,8 +528,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             if (!LNPROD || fold_resid) {
                 float sum, sq;
                 sum_parts(ex.st_in, ex.st_in_parts, min(wrow0 + i * 32 + fr, M - 1), sum, sq);
-                m_o = sum * ex.inv_h;
-                r_o = rsqrtf(fmaxf(sq * ex.inv_h - m_o * m_o, 0.f) + ex.eps);
+                ln_mean_rstd(sum, sq, ex.inv_h, ex.eps, m_o, r_o);
             }
         };
         float mu0, rs0;
@@ -582,7 +581,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                                 const f32x4 t4 = *reinterpret_cast<const f32x4*>(sd + 2 * WC + lc);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    x[e] = acc[i][j][4 * g + e] + b4[e] + ((rq[j * 4 + g][e] - m_i) * r_i * g4[e] + t4[e]);
+                                    x[e] = acc[i][j][4 * g + e] + b4[e] + ln_apply(rq[j * 4 + g][e], m_i, r_i, g4[e], t4[e]);
                                 if (rok && cok && !(abl & 64)) *reinterpret_cast<f32x4*>(out + (size_t)row * ldo + c) = x;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { sm += cok ? x[e] : 0.f; sq += cok ? x[e] * x[e] : 0.f; }
@@ -590,7 +589,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                                 const f32x4 c4 = *reinterpret_cast<const f32x4*>(sd + lc);
                                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + WC + lc);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) x[e] = r_i * (acc[i][j][4 * g + e] - m_i * c4[e]) + d4[e];
+                                for (int e = 0; e < 4; ++e) x[e] = ln_fold(acc[i][j][4 * g + e], m_i, r_i, c4[e], d4[e]);
                                 if constexpr (GELU) {
                                     if (!(abl & 16)) {
                                     const f32x2 g0 = gelu_fast2(f32x2{x[0], x[1]}), g1 = gelu_fast2(f32x2{x[2], x[3]});
@@ -639,8 +638,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         if constexpr (EPI == CPT_EPI_ATTN_LN) {
             float sm, sq;
             sum_parts(ex.st_in, ex.st_in_parts, min(m0 + trow, M - 1), sm, sq);
-            mu = sm * ex.inv_h;
-            rs = rsqrtf(fmaxf(sq * ex.inv_h - mu * mu, 0.f) + ex.eps);
+            ln_mean_rstd(sm, sq, ex.inv_h, ex.eps, mu, rs);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -654,7 +652,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     const f32x4 c4 = *reinterpret_cast<const f32x4*>(ex.colc + gcol);
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(ex.cold + gcol);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = rs * (acc[0][j][4 * g + e] - mu * c4[e]) + d4[e];
+                    for (int e = 0; e < 4; ++e) x[e] = ln_fold(acc[0][j][4 * g + e], mu, rs, c4[e], d4[e]);
                 } else {
                     const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + gcol) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -704,8 +702,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     auto stats_of = [&](int row, float& mu, float& rs) {      // adds the partial sums of `row` in slot order
         float sum, sq;
         sum_parts(ex.st_in, ex.st_in_parts, row, sum, sq);
-        mu = sum * ex.inv_h;
-        rs = rsqrtf(fmaxf(sq * ex.inv_h - mu * mu, 0.f) + ex.eps);
+        ln_mean_rstd(sum, sq, ex.inv_h, ex.eps, mu, rs);
     };
     // element-wise finish shared by the guarded path: a = accumulator, returns the output value
     auto finish1 = [&](float a, int row, int col) {
@@ -713,7 +710,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         if constexpr (LNCONS) {
             float mu, rs;
             stats_of(row, mu, rs);
-            x = rs * (a - mu * ex.colc[col]) + ex.cold[col];
+            x = ln_fold(a, mu, rs, ex.colc[col], ex.cold[col]);
         } else {
             x = a + (bias ? bias[col] : 0.f);
         }
@@ -726,23 +723,30 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             if (fold_resid) {
                 float mu, rs;
                 stats_of(row, mu, rs);
-                r = (r - mu) * rs * ex.g_in[col] + ex.b_in[col];
+                r = ln_apply(r, mu, rs, ex.g_in[col], ex.b_in[col]);
             }
             x += r;
         }
         return x;
     };
-    // FULL (interior sub-tile, aligned pointers): one basic block, no guards, so the compiler's vmcnt
-    // bookkeeping is exact and stores issue back to back.  Otherwise the guarded element-wise path.
-    auto epilogue = [&](auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    // Three instances.  MODE 1 (interior sub-tile, aligned pointers): one basic block, no guards, so the compiler's vmcnt
+    // bookkeeping is exact and stores issue back to back.  MODE 2 (sub-tile that crosses the matrix edge, aligned pointers,
+    // N % 4 == 0): the SAME vector arithmetic with clamped load addresses and predicated stores -- a row must get the
+    // same bits whether its sub-tile is interior or not (round 1's element-wise edge path differed in the last bit for
+    // the LayerNorm producers when M % 32 != 0).  MODE 0: element-wise path for unaligned operands / ragged quads.
+    auto epilogue = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool FULL = MODE != 0;             // vector path
+        constexpr bool GUARD = MODE == 2;
+        auto ccol = [&](int c) { return GUARD ? min(c, N - 4) : c; };
+        auto crow = [&](int r) { return GUARD ? min(r, M - 1) : r; };
         // per-column operands: the column chunk of read-back iteration `it` is ((it*64 + lane) % CH), which
         // repeats with period P = CH / gcd(64, CH) in `it` -- P register sets serve all NIT iterations
         constexpr int P = CH / gcd_c(64, CH);
         f32x4 bv[P], cv[LNCONS ? P : 1];
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            const int col = wcol0 + ((q * 64 + lane) % CH) * 4;
+            const int col = ccol(wcol0 + ((q * 64 + lane) % CH) * 4);
             if constexpr (LNCONS) {
                 bv[q] = FULL ? *reinterpret_cast<const f32x4*>(ex.cold + col) : f32x4{0.f, 0.f, 0.f, 0.f};
                 cv[q] = FULL ? *reinterpret_cast<const f32x4*>(ex.colc + col) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -759,14 +763,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             if (lane < MI * 32) {
                 float2 ms = {0.f, 1.f};
                 if (LNCONS || fold_resid) {
-                    stats_of(wrow0 + lane, ms.x, ms.y);
+                    stats_of(crow(wrow0 + lane), ms.x, ms.y);
                 }
                 side_row[lane] = ms;
             }
             if constexpr (LNPROD) {
                 if (lane < CH) {
-                    const f32x4 g4 = fold_resid ? *reinterpret_cast<const f32x4*>(ex.g_in + wcol0 + lane * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
-                    const f32x4 t4 = fold_resid ? *reinterpret_cast<const f32x4*>(ex.b_in + wcol0 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 g4 = fold_resid ? *reinterpret_cast<const f32x4*>(ex.g_in + ccol(wcol0 + lane * 4)) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    const f32x4 t4 = fold_resid ? *reinterpret_cast<const f32x4*>(ex.b_in + ccol(wcol0 + lane * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(side_g + lane * 4) = g4;
                     *reinterpret_cast<f32x4*>(side_t + lane * 4) = t4;
                 }
@@ -779,9 +783,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 64 + lane, rr = idx / CH, ch = idx % CH;
-                const int row = wrow0 + sl * 16 + rr;
+                const int row = crow(wrow0 + sl * 16 + rr);
                 if constexpr (HAS_RESID) {
-                    const size_t off = (size_t)row * ldr + wcol0 + ch * 4;
+                    const size_t off = (size_t)row * ldr + ccol(wcol0 + ch * 4);
                     if constexpr (EPI == CPT_EPI_RESID_LP && sizeof(T) == 2) {
                         const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(resid_lp + off);
                         a.r[it] = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
@@ -829,7 +833,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     const float mu = ms.x, rs = ms.y;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if constexpr (LNCONS) v[e] = rs * (v[e] - mu * cv[it % P][e]) + bv[it % P][e];
+                        if constexpr (LNCONS) v[e] = ln_fold(v[e], mu, rs, cv[it % P][e], bv[it % P][e]);
                         else v[e] = v[e] + bv[it % P][e];
                     }
                     if constexpr (DO_GELU && sizeof(T) == 2) {        // bf16 path: packed-fp32 fast GELU on pairs
@@ -841,12 +845,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         float x = v[e];
                         if constexpr (DO_GELU && sizeof(T) != 2) x = gelu_for<T>(x);
                         if (EPI == CPT_EPI_TANH) x = tanhf(x);
-                        if constexpr (LNPROD) x += (ax.r[it][e] - mu) * rs * g4[e] + t4[e];     // mu=0, rs=1, g=1, b=0 when not folded
+                        if constexpr (LNPROD) x += ln_apply(ax.r[it][e], mu, rs, g4[e], t4[e]);     // mu=0, rs=1, g=1, b=0 when not folded
                         else if constexpr (HAS_RESID) x += ax.r[it][e];
                         v[e] = x;
                     }
                   }
-                  if (abl & 64) { asm volatile("" :: "v"(v)); } else {   // ablation 64: no global stores
+                  const bool in_mat = !GUARD || (row < M && col < N);
+                  if (abl & 64) { asm volatile("" :: "v"(v)); } else if (in_mat) {   // ablation 64: no global stores
                     if constexpr (sizeof(OT) == 2) {
                         bf16x4 pk;
 #pragma unroll
@@ -871,6 +876,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     }
                   }
                     if constexpr (LNPROD) {
+                        if (GUARD && !in_mat) v = f32x4{0.f, 0.f, 0.f, 0.f};           // outside the matrix: nothing to sum
                         *reinterpret_cast<f32x4*>(slab + rr * CPW + ch * 16) = v;      // finished values back for the row sums
                     }
                 } else {
@@ -913,8 +919,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         }
     };
     if (abl & 8) { if (acc[0][0][0] == 12345.678f) out[0] = from_f32<OT>(1.f); }     // ablation: no epilogue
-    else if (vec_ok && wrow0 + MI * 32 <= M && wcol0 + WCOLS <= N) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    else if (vec_ok && wrow0 + MI * 32 <= M && wcol0 + WCOLS <= N) epilogue(std::integral_constant<int, 1>{});
+    else if (vec_ok && N % 4 == 0 && N >= 4 && EPI != CPT_EPI_ATOMIC) epilogue(std::integral_constant<int, 2>{});
+    else epilogue(std::integral_constant<int, 0>{});
     }   // !ATTN
     }   // !DIRECT
     if (trace && tid == 0) {
@@ -1132,7 +1139,7 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
     EpiX ex = {};
     ex.st_in = st_in; ex.st_in_parts = ln_stat_parts(hidden); ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
     const int v = g_gemm_variant >= 3 ? g_gemm_variant : 3;
-    if (gelu && (v == 3 || v == 20) && ffn_up_2pass_supported(M, N, K)) {
+    if (gelu && ((v == 3 && ffn_up_2pass_preferred(M, N, K)) || (v == 20 && ffn_up_2pass_legal(M, N, K)))) {     // variant 20: forced (tests)
         void* tr = ((g_trace_epi < 0 || g_trace_epi == CPT_EPI_LNCONS_GELU) && (g_trace_k == 0 || g_trace_k == K)) ? (void*)g_gemm_trace : nullptr;
         return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, tr, g_gemm_abl, s);
     }

@@ -129,8 +129,9 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
             sum += u0 ? v[q][0] : 0.f; sq += u0 ? v[q][1] : 0.f;
             sum += u1 ? v[q][2] : 0.f; sq += u1 ? v[q][3] : 0.f;
         }
-        const float mu = sum * inv_h;
-        ms_mine = float2{mu, rsqrtf(fmaxf(sq * inv_h - mu * mu, 0.f) + eps)};
+        float mu, rs;
+        ln_mean_rstd(sum, sq, inv_h, eps, mu, rs);
+        ms_mine = float2{mu, rs};
     }
     __builtin_amdgcn_sched_barrier(0);             // (loads stay ahead of the DMA in program order: the compiler's counted wait for them passes the DMA)
     stage_a(0, 0); stage_w(0, 0);
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
         __builtin_amdgcn_sched_barrier(0);
         f32x4 x;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = ms.y * (a[4 * g + e] - ms.x * c4[e]) + d4[e];
+        for (int e = 0; e < 4; ++e) x[e] = ln_fold(a[4 * g + e], ms.x, ms.y, c4[e], d4[e]);
         const f32x2 g0 = gelu_fast2(f32x2{x[0], x[1]}), g1 = gelu_fast2(f32x2{x[2], x[3]});
         bf16x4 p4 = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
         return __builtin_bit_cast(u32x2, p4);
@@ -360,14 +361,18 @@ int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int 
 
 }  // namespace
 
-// 1 = this shape runs on the two-pass kernel
-int ffn_up_2pass_supported(int M, int N, int K) {
-    return (K == 768 || K == 1024) && N % TN == 0 && M >= TM;
+// shapes the two-pass kernel can run / shapes it is the better choice for
+int ffn_up_2pass_legal(int M, int N, int K) { return (K == 768 || K == 1024) && N % TN == 0 && M >= TM; }
+int ffn_up_2pass_preferred(int M, int N, int K) {
+    if (!ffn_up_2pass_legal(M, N, K)) return 0;
+    // one workgroup per CU per round: worth it only when the 384 x 256 tiles fill most of the 256 CUs (B = 64 x L = 120:
+    // 240 tiles); below that the 128 x 192 two-per-CU shape has 4x the workgroups
+    return (long)((M + TM - 1) / TM) * (N / TN) >= 192;
 }
 
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
                       float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s) {
-    if (!ffn_up_2pass_supported(M, N, K)) return CPT_ERR_SHAPE;
+    if (!ffn_up_2pass_legal(M, N, K)) return CPT_ERR_SHAPE;
     if (lda % 8 || ldw % 8 || ldo % 8 || (((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)out | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
     const float inv_h = 1.0f / (float)hidden;
     if (K == 768) return launch_2pass<12>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);

@@ -23,6 +23,7 @@ int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, v
               int L, int heads, hipStream_t s, const DropSpec* drop = nullptr);
 
 int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s);
+int split3(const float* x, int ld, void* out_bf16, int R, int K, int weight_order, hipStream_t s);
 
 int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H,
                 hipStream_t s);
@@ -80,7 +81,8 @@ void set_gemm_variant(int v);
 void set_gemm_abl(int v);
 void set_gemm_skew(int v);
 // FFN-up as one 384 x 256 two-pass kernel with its epilogue pipelined under the second pass (gemm_ffn.hip)
-int ffn_up_2pass_supported(int M, int N, int K);
+int ffn_up_2pass_legal(int M, int N, int K);
+int ffn_up_2pass_preferred(int M, int N, int K);
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
                       float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s);
 void set_gemm_trace(void* p);

@@ -223,6 +223,31 @@ int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStre
     return CPT_OK;
 }
 
+// ---- split-operand copies of the bf16x3 parity mode: hi = bf16(x), lo = bf16(x - hi); row layout hi | hi | lo (activations)
+// or hi | lo | hi (weights), so that one bf16 GEMM over K' = 3K gives hi.hi + hi.lo + lo.hi ------------------------------------
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int ld, bf16* __restrict__ out, int R, int K, int worder) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // one 4-element chunk per thread
+    const int kc = K / 4;
+    if (i >= (size_t)R * kc) return;
+    const int r = (int)(i / kc), c = (int)(i % kc) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * ld + c);
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
+    bf16* o = out + (size_t)r * 3 * K + c;
+    *reinterpret_cast<bf16x4*>(o) = hi;
+    *reinterpret_cast<bf16x4*>(o + K) = worder ? lo : hi;
+    *reinterpret_cast<bf16x4*>(o + 2 * K) = worder ? hi : lo;
+}
+
+int split3(const float* x, int ld, void* out, int R, int K, int weight_order, hipStream_t s) {
+    if (R <= 0 || K <= 0 || K % 4 || ld % 4 || ld < K) return CPT_ERR_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 7)) return CPT_ERR_ALIGN;
+    const size_t n = (size_t)R * (K / 4);
+    split3_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(x, ld, (bf16*)out, R, K, weight_order);
+    return CPT_OK;
+}
+
 // ---- fold a LayerNorm (gamma, beta) into the Linear that consumes its output ------------------------
 // Wf[n][k] = bf16(gamma[k] * W[n][k]);  colc[n] = sum_k float(Wf[n][k]) (what the MFMA will see);
 // cold[n] = sum_k beta[k] * W[n][k] + bias[n].  One wave per output row n.

@@ -169,6 +169,50 @@ class PackedModel(object):
                 self._desc = {}
             L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_f32.data_ptr(), L.CPT_F32, H, D, Dp, st),
                     "cpt_pad_cast(w_img)")
+            if self.dtype == "bf16x3":
+                self._build_x3(st)
+
+    def _x3_matrices(self):
+        """(key, first parameter name, rows, cols) of every matrix the forward multiplies by (Q|K|V stacked as one)."""
+        cfg = self.cfg
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        out = []
+        for i in range(cfg.num_hidden_layers):
+            p = "bert.encoder.layer.%d." % i
+            out += [(p + "qkv", p + "attention.self.query.weight", 3 * H, H), (p + "ao", p + "attention.output.dense.weight", H, H),
+                    (p + "in", p + "intermediate.dense.weight", I, H), (p + "out", p + "output.dense.weight", H, I)]
+        out.append(("pool", "bert.pooler.dense.weight", H, H))
+        if self.head == "nsp":
+            out.append(("rel", "cls.weight", getattr(cfg, "num_contrast_classes", 2), H))
+        if self.head in ("cpt", "pretrain"):
+            hp = "cls." if self.head == "cpt" else "cls.predictions."
+            out.append(("tr", hp + "transform.dense.weight", H, H))
+            out.append(("dec", "bert.embeddings.word_embeddings.weight", cfg.vocab_size, H))
+        if self.head == "pretrain":
+            out.append(("rel", "cls.seq_relationship.weight", getattr(cfg, "num_contrast_classes", 2), H))
+        return out
+
+    def _build_x3(self, st):
+        """bf16x3 parity mode: [N][hi | lo | hi] bf16 split copies of the weight matrices (include/cpt_hip.h cpt_split3)."""
+        cfg = self.cfg
+        H, D = cfg.hidden_size, cfg.img_feature_dim
+        Dp = (D + 63) // 64 * 64
+        mats = self._x3_matrices()
+        total = sum(n * 3 * k for _, _, n, k in mats) + H * 3 * Dp
+        dev = self.flat.device
+        if getattr(self, "x3_buf", None) is None or self.x3_buf.device != dev or self.x3_buf.numel() != total:
+            self.x3_buf = torch.empty(total, device=dev, dtype=torch.bfloat16)
+            self._desc = {}
+        self.x3_off = {}
+        off = 0
+        base = self.x3_buf.data_ptr()
+        for key, pname, n, k in mats:
+            src = self.flat.data_ptr() + self.offsets[pname][0] * 4
+            L.check(L.lib().cpt_split3(src, k, base + off * 2, n, k, 1, st), "cpt_split3(%s)" % key)
+            self.x3_off[key] = off
+            off += n * 3 * k
+        L.check(L.lib().cpt_split3(self.img_pad_f32.data_ptr(), Dp, base + off * 2, H, Dp, 1, st), "cpt_split3(w_img)")
+        self.x3_off["img"] = off
 
     def invalidate(self):
         """Tell the engine the parameters were written behind its back.  In-place writes through ``.data``
@@ -276,11 +320,18 @@ class PackedModel(object):
             return self._desc[key]
         cfg = self.cfg
         lp = self.dtype == "bf16"
+        x3 = self.dtype == "bf16x3"
         esz = 2 if lp else 4
         mat_base = (self.flat_lp if lp else self.flat).data_ptr()
         vec_base = self.flat.data_ptr()
+        x3_key = {}
+        if x3:
+            for key, pname, _, _ in self._x3_matrices():
+                x3_key.setdefault(pname, key)
 
         def mat(n):
+            if x3:
+                return self.x3_buf.data_ptr() + self.x3_off[x3_key[n]] * 2
             return mat_base + self.offsets[n][0] * esz
 
         def vec(n):
@@ -292,7 +343,7 @@ class PackedModel(object):
                    max_pos=cfg.max_position_embeddings, type_vocab=cfg.type_vocab_size,
                    use_img_ln=1 if getattr(cfg, "use_img_layernorm", None) else 0,
                    n_rel=getattr(cfg, "num_contrast_classes", 2) if self.head in ("pretrain", "nsp") else 0,
-                   dtype=L.CPT_BF16 if lp else L.CPT_F32, ln_eps=cfg.layer_norm_eps,
+                   dtype=L.CPT_BF16 if lp else (L.CPT_BF16X3 if x3 else L.CPT_F32), ln_eps=cfg.layer_norm_eps,
                    img_ln_eps=getattr(cfg, "img_layer_norm_eps", cfg.layer_norm_eps))
         layers = (L.Layer * cfg.num_hidden_layers)()
         for i in range(cfg.num_hidden_layers):
@@ -317,7 +368,7 @@ class PackedModel(object):
         m.type_emb = vec("bert.embeddings.token_type_embeddings.weight")
         m.emb_ln_g = vec("bert.embeddings.LayerNorm.weight")
         m.emb_ln_b = vec("bert.embeddings.LayerNorm.bias")
-        m.w_img = (self.img_pad_lp if lp else self.img_pad_f32).data_ptr()
+        m.w_img = (self.x3_buf.data_ptr() + self.x3_off["img"] * 2) if x3 else (self.img_pad_lp if lp else self.img_pad_f32).data_ptr()
         m.b_img = vec("bert.img_embedding.bias")
         if d.use_img_ln:
             m.img_ln_g = vec("bert.LayerNorm.weight")

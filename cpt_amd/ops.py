@@ -134,3 +134,19 @@ def gemm_ln_cons(a, wf, st_in, colc, cold, eps, hidden, gelu):
     L.check(L.lib().cpt_gemm_ln_cons(a.data_ptr(), a.stride(0), wf.data_ptr(), wf.stride(0), st_in.data_ptr(), colc.data_ptr(), cold.data_ptr(),
                                      float(eps), hidden, 1 if gelu else 0, out.data_ptr(), out.stride(0), M, N, K, L.stream_ptr()), "cpt_gemm_ln_cons")
     return out
+
+
+def gemm_ln_prod(a, w, bias, resid, st_in=None, g_in=None, b_in=None, eps=1e-12, hidden=None):
+    """out = a @ w.T + bias + R with R = resid, or LayerNorm(resid; st_in, g_in, b_in) when g_in is given.
+    Returns (out_f32, out_bf16, st_out) -- st_out = partial row sums of out (the table the next consumer reads)."""
+    _need_cuda(a, w, bias, resid)
+    M, K = a.shape
+    N = w.size(0)
+    hidden = hidden or N
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    out_lp = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    st_out = torch.zeros((M, ln_stat_slots(N), 2), device=a.device, dtype=torch.float32)
+    L.check(L.lib().cpt_gemm_ln_prod(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), L.ptr(bias), resid.data_ptr(), resid.stride(0),
+                                     L.ptr(st_in), L.ptr(g_in), L.ptr(b_in), float(eps), hidden, out.data_ptr(), out_lp.data_ptr(),
+                                     st_out.data_ptr(), out.stride(0), M, N, K, L.stream_ptr()), "cpt_gemm_ln_prod")
+    return out, out_lp, st_out

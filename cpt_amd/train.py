@@ -225,6 +225,8 @@ def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels,
         raise NotImplementedError("cpt_amd: training needs mask_token_pos (the (B, L) label grid of the reference has "
                                   "exactly one labelled position per row: pass it as mask_token_pos)")
     eng = model._engine()
+    if eng.dtype not in ("fp32", "bf16"):
+        raise NotImplementedError("cpt_amd: training runs in 'fp32' or 'bf16' compute mode ('%s' is an inference mode)" % eng.dtype)
     eng.ensure_packed()
     if eng.pending is None:          # (data parallel: a pending parameter all-gather is awaited bucket by bucket in the forward)
         eng.refresh_shadow()

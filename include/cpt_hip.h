@@ -18,7 +18,11 @@
  *   - dtype: CPT_F32 runs every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32; parity mode, matches
  *     the reference CPU path to ~1e-5); CPT_BF16 feeds bf16 operands to v_mfma_f32_32x32x16_bf16
  *     with fp32 accumulation and keeps the residual stream, LayerNorm, softmax, GELU and all
- *     reductions in fp32 (throughput mode).
+ *     reductions in fp32 (throughput mode); CPT_BF16X3 (cpt_model_fwd only) is the parity mode at MFMA-bf16 rates:
+ *     every GEMM operand is split into bf16 hi + lo parts and the product a.w is computed as hi.hi + hi.lo + lo.hi
+ *     (three bf16 MFMA terms, fp32 accumulate; relative error ~2^-16 per product instead of 2^-8), laid out as ONE bf16
+ *     GEMM over a tripled K: activations [M][hi | hi | lo], weights [N][hi | lo | hi] (cpt_split3).  Everything
+ *     outside the GEMMs runs as in CPT_F32 mode.
  */
 #ifndef CPT_HIP_H
 #define CPT_HIP_H
@@ -31,7 +35,7 @@ extern "C" {
 
 #define CPT_ABI_VERSION 1
 
-enum { CPT_F32 = 0, CPT_BF16 = 1 };
+enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2 };
 enum { CPT_EPI_NONE = 0, CPT_EPI_GELU = 1, CPT_EPI_TANH = 2, CPT_EPI_RESID = 3 };
 enum {
     CPT_OK = 0,
@@ -68,7 +72,7 @@ typedef struct {
     int32_t type_vocab;    /* config.type_vocab_size */
     int32_t use_img_ln;    /* config.use_img_layernorm */
     int32_t n_rel;         /* rows of cls.seq_relationship (num_contrast_classes), 0 if absent */
-    int32_t dtype;         /* CPT_F32 | CPT_BF16 */
+    int32_t dtype;         /* CPT_F32 | CPT_BF16 | CPT_BF16X3 (matrices then are [N][3K] bf16 split copies, cpt_split3) */
     float ln_eps;          /* config.layer_norm_eps */
     float img_ln_eps;      /* config.img_layer_norm_eps */
 } cpt_dims;
@@ -304,6 +308,11 @@ int cpt_gemm_ln_cons(const void* A_bf16, int lda, const void* Wf_bf16, int ldw, 
 int cpt_gemm_ln_prod(const void* A_bf16, int lda, const void* W_bf16, int ldw, const float* bias, const float* resid, int ldr,
                      const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, float* out_f32,
                      void* out_bf16, float* st_out, int ldo, int M, int N, int K, void* stream);
+
+/* Split-operand copy for CPT_BF16X3: x fp32 [R][K] (leading dimension ld) -> out bf16 [R][3K] holding, per row, the blocks
+ * hi | hi | lo (weight_order 0: activations) or hi | lo | hi (weight_order 1: nn.Linear weights), hi = bf16(x),
+ * lo = bf16(x - hi).  A bf16 GEMM of the two over K' = 3K is x.w to ~2^-16 relative. */
+int cpt_split3(const float* x, int ld, void* out_bf16, int R, int K, int weight_order, void* stream);
 
 /* out[b][:] = src[b*L + pos[b]][:] (pos NULL = row 0): the [MASK] rows
  * (zeroshot/refcoco_cpt.py:219) and the [CLS] rows of BertPooler. */

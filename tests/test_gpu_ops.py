@@ -240,7 +240,7 @@ def test_select_regions_device_matches_reference_rule(dev):
     assert got.cpu().tolist() == sc2[:, ids].argmax(1).tolist()
 
 
-@pytest.mark.parametrize("M,N,K,variant", [(7680 // 4, 3072, 768, 3), (1000, 3072, 768, 3), (500, 512, 1024, 3), (100, 3072, 768, 3),
+@pytest.mark.parametrize("M,N,K,variant", [(7680, 3072, 768, 3), (1000, 3072, 768, 20), (500, 512, 1024, 20), (100, 3072, 768, 3),
                                            (1000, 3072, 768, 15), (1000, 2304, 768, 14), (640, 1024, 1024, 19), (300, 200, 128, 3)])
 def test_gemm_ln_consumer(dev, M, N, K, variant):
     """The LayerNorm-consumer GEMM of the fused bf16 encoder, gelu( LayerNorm(x) . W^T + bias ) with the LayerNorm folded
@@ -274,3 +274,60 @@ def test_gemm_ln_consumer(dev, M, N, K, variant):
         tol = 2.0 ** -8 * ref.abs() + 2e-3                # bf16 output rounding (half an ulp = 2^-9 relative) + fp32 accumulation
         print("ln-consumer %dx%dx%d variant %d gelu=%d: max|d| %.3e (ref absmax %.2f)" % (M, N, K, variant, gelu, d.max().item(), ref.abs().max().item()))
         assert bool((d <= tol).all()), (d - tol).max().item()
+
+
+def test_ln_consumer_kernels_are_bit_identical(dev):
+    """Which kernel serves the FFN-up GEMM depends on the batch size (two-pass 384 x 256 tiles when they fill the chip,
+    128 x 192 two-per-CU tiles otherwise, 384 x 256 single pass as an option): every one of them must produce the same BITS,
+    or rows of a batch would depend on the batch they sit in (the accumulation order over K and the epilogue arithmetic
+    -- explicit fma -- are the same by construction)."""
+    from cpt_amd import ops, _lib as L
+    rng = _rng(99)
+    M, N, K = 7680, 3072, 768
+    x = _t(rng, M, K, scale=1.3) + 0.4
+    a = x.to(torch.bfloat16).to(dev)
+    st = ops.row_stats_table(x.to(dev))
+    wf = _t(rng, N, K, scale=0.04).to(torch.bfloat16).to(dev)
+    colc = wf.float().sum(1).contiguous()
+    cold = _t(rng, N, scale=0.1).to(dev)
+    outs = {}
+    try:
+        for v in (3, 15, 19, 20):
+            L.check(L.lib().cpt_set_tuning(0, v))
+            outs[v] = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, True)
+            # the first 960 rows as their own (small) problem: other tile shape choices, ragged last tiles
+            outs[(v, "small")] = ops.gemm_ln_cons(a[:960], wf, st[:960], colc, cold, 1e-12, K, True)
+    finally:
+        L.check(L.lib().cpt_set_tuning(0, 3))
+    for v in (15, 19, 20):
+        assert torch.equal(outs[3], outs[v]), "variant %d differs from the default" % v
+    for v in (3, 15, 19, 20):
+        assert torch.equal(outs[3][:960], outs[(v, "small")]), "variant %d, 960-row problem" % v
+
+
+@pytest.mark.parametrize("Mbig,Msmall", [(7680, 840), (7680, 120), (1000, 77)])
+def test_operators_are_batch_invariant(dev, Mbig, Msmall):
+    """Rows [0, Msmall) of a big problem equal the same rows run as their own problem, bit for bit, for the four GEMM forms of
+    the fused encoder -- also when Msmall is not a multiple of the 32-row wave sub-tile, where the guarded per-element
+    epilogue finishes the last rows (round 1 only ever compared multiples of 32 and missed a contraction difference there)."""
+    from cpt_amd import ops
+    rng = _rng(Mbig + Msmall)
+    H, I = 768, 3072
+    x = (_t(rng, Mbig, H, scale=1.2) + 0.3).to(dev)
+    a = x.to(torch.bfloat16)
+    st = ops.row_stats_table(x)
+    for N, gelu in ((3 * H, False), (I, True)):
+        wf = _t(rng, N, H, scale=0.03).to(torch.bfloat16).to(dev)
+        colc = wf.float().sum(1).contiguous()
+        cold = _t(rng, N, scale=0.1).to(dev)
+        big = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, H, gelu)
+        small = ops.gemm_ln_cons(a[:Msmall].contiguous(), wf, st[:Msmall].contiguous(), colc, cold, 1e-12, H, gelu)
+        assert torch.equal(big[:Msmall], small), "consumer N=%d" % N
+    for K in (H, I):
+        ak = _t(rng, Mbig, K).to(torch.bfloat16).to(dev)
+        w = _t(rng, H, K, scale=0.03).to(torch.bfloat16).to(dev)
+        bias, g, bt = _t(rng, H, scale=0.1).to(dev), (1 + _t(rng, H, scale=0.1)).to(dev), _t(rng, H, scale=0.1).to(dev)
+        o1 = ops.gemm_ln_prod(ak, w, bias, x, st, g, bt, 1e-12, H)
+        o2 = ops.gemm_ln_prod(ak[:Msmall].contiguous(), w, bias, x[:Msmall].contiguous(), st[:Msmall].contiguous(), g, bt, 1e-12, H)
+        for nm, p, q in zip(("fp32", "bf16", "row sums"), o1, o2):
+            assert torch.equal(p[:Msmall], q), "producer K=%d: %s" % (K, nm)

@@ -1,0 +1,113 @@
+"""GPU race screen of the pipelined GEMM kernels: the LDS-DMA operand rings are synchronised by
+counted s_waitcnt vmcnt + one raw s_barrier per K-tile, i.e. by ORDERING; a mistake there shows up as rare wrong tiles
+that depend on memory timing.  Every tile configuration the hot path uses is launched hundreds of times back to back
+while a second stream thrashes HBM / L2 / MALL, and every result must equal the first launch bit for bit (no kernel on
+the inference path uses atomics, so bitwise equality is the specification)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+LAUNCHES = 500
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _screen(dev, launch, n=LAUNCHES, ring=4):
+    """launch(slot) -> tuple of output tensors written into per-slot buffers.  Runs n launches under memory pressure and
+    compares every result with the first one (slots rotate so a result is checked before its buffer is reused)."""
+    side = torch.cuda.Stream(device=dev)
+    junk_a = torch.empty(192 * 1024 * 1024 // 4, device=dev)
+    junk_b = torch.empty_like(junk_a)
+    ref = [t.clone() for t in launch(0)]
+    torch.cuda.synchronize()
+    bad = torch.zeros((), device=dev, dtype=torch.int64)
+    stop = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(n // 4 + 1):                # ~0.1 ms per copy pair: runs alongside the whole screen
+            junk_b.copy_(junk_a)
+            junk_a.copy_(junk_b)
+        stop.record(side)
+    for i in range(n):
+        outs = launch(i % ring)
+        for o, r in zip(outs, ref):
+            bad += (o.view(torch.int16 if o.dtype == torch.bfloat16 else torch.int32) != r.view(torch.int16 if r.dtype == torch.bfloat16 else torch.int32)).any().long()
+    torch.cuda.synchronize()
+    return int(bad.item())
+
+
+@pytest.mark.parametrize("variant,M,N,K,epi", [(3, 7680, 768, 768, "resid"), (3, 7680, 768, 3072, "resid"), (14, 7680, 2304, 768, "none"),
+                                               (15, 7680, 3072, 768, "gelu"), (10, 1920, 3072, 768, "gelu"), (11, 1920, 768, 768, "none"),
+                                               (18, 640, 768, 2112, "none")])
+def test_gemm_ring_race_screen(dev, variant, M, N, K, epi):
+    from cpt_amd import ops, _lib as L
+    torch.manual_seed(variant + K)
+    a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device=dev)
+    r = torch.randn(M, N, device=dev) if epi == "resid" else None
+    code = {"resid": L.EPI_RESID, "gelu": L.EPI_GELU, "none": L.EPI_NONE}[epi]
+    odt = torch.float32 if epi == "resid" else torch.bfloat16
+    try:
+        L.check(L.lib().cpt_set_tuning(0, variant))
+        bad = _screen(dev, lambda s: (ops.gemm(a, w, b, epi=code, resid=r, out_dtype=odt),), n=LAUNCHES if K < 3000 else 300)
+    finally:
+        L.check(L.lib().cpt_set_tuning(0, 3))
+    assert bad == 0, "%d of the launches differed from the first one" % bad
+
+
+@pytest.mark.parametrize("variant,M,N,K", [(3, 7680, 3072, 768), (20, 2000, 4096, 1024), (15, 7680, 3072, 768), (19, 7680, 3072, 768), (14, 7680, 2304, 768)])
+def test_ln_consumer_race_screen(dev, variant, M, N, K):
+    """Two-pass FFN-up kernel (variant 3, K = 768 and 1024 incl. a ragged last row tile) and the direct-epilogue tile shapes."""
+    from cpt_amd import ops, _lib as L
+    torch.manual_seed(variant + K)
+    x = torch.randn(M, K, device=dev) + 0.2
+    a = x.to(torch.bfloat16)
+    st = ops.row_stats_table(x)
+    wf = (torch.randn(N, K, device=dev) * 0.04).to(torch.bfloat16)
+    colc = wf.float().sum(1).contiguous()
+    cold = torch.randn(N, device=dev) * 0.1
+    try:
+        L.check(L.lib().cpt_set_tuning(0, variant))
+        bad = _screen(dev, lambda s: (ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, True),))
+    finally:
+        L.check(L.lib().cpt_set_tuning(0, 3))
+    assert bad == 0, "%d of the launches differed from the first one" % bad
+
+
+@pytest.mark.parametrize("K", [768, 3072])
+def test_ln_producer_race_screen(dev, K):
+    """attn-out / FFN-down form: + bias + LayerNorm-on-the-fly residual, fp32 + bf16 outputs + partial row sums."""
+    from cpt_amd import ops
+    M, N = 7680, 768
+    torch.manual_seed(K)
+    a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.03).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev) * 0.1
+    resid = torch.randn(M, N, device=dev)
+    st_in = ops.row_stats_table(resid)
+    g, bt = 1.0 + 0.1 * torch.randn(N, device=dev), 0.1 * torch.randn(N, device=dev)
+    bad = _screen(dev, lambda s: ops.gemm_ln_prod(a, w, bias, resid, st_in, g, bt, 1e-12, N), n=LAUNCHES if K < 3000 else 300)
+    assert bad == 0, "%d of the launches differed from the first one" % bad
+
+
+def test_fused_qkv_attention_race_screen(dev):
+    """The whole bf16 forward (fused QKV + attention kernel, producers, consumers, head) 200 times under memory pressure."""
+    from cpt_amd import config as cfgmod, synth
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    cfg = cfgmod.oscar_base()
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, 88, head="cpt", randomize_all=False))
+    m.tie_weights()
+    m.to(dev).eval().set_compute_dtype("bf16")
+    b = {k: v.to(dev) for k, v in synth.make_batch(64, cfg, seed=3, vary_regions=True).items()}
+
+    def fwd(_):
+        with torch.no_grad():
+            return (m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"])[0].clone(),)
+    bad = _screen(dev, fwd, n=200)
+    assert bad == 0, "%d of the forwards differed from the first one" % bad
