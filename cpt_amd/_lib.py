@@ -57,7 +57,7 @@ class LayerGrads(C.Structure):
 class ModelGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "w_img", "b_img",
                                           "img_ln_g", "img_ln_b")] + [("layers", C.POINTER(LayerGrads))] + \
-               [(n, C.c_void_p) for n in ("w_tr", "b_tr", "tr_ln_g", "tr_ln_b", "b_dec")]
+               [(n, C.c_void_p) for n in ("w_tr", "b_tr", "tr_ln_g", "tr_ln_b", "b_dec", "w_pool", "b_pool", "w_rel", "b_rel")]
 
 
 class Dropout(C.Structure):

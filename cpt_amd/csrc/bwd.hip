@@ -442,6 +442,23 @@ int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, in
     return CPT_OK;
 }
 
+// dx = dy * (1 - y^2), y = tanh(.) as saved by the forward (BertPooler, third-party); optional copy in lp_dtype
+template <typename TL>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                                       TL* __restrict__ dx_lp, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = dy[i] * (1.0f - y[i] * y[i]);
+    dx[i] = v;
+    if (dx_lp) dx_lp[i] = from_f32<TL>(v);
+}
+int tanh_bwd(const float* dy, const float* y, float* dx, void* dx_lp, int lp_dtype, size_t n, hipStream_t s) {
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (lp_dtype == CPT_BF16) tanh_bwd_kernel<bf16><<<grid, block, 0, s>>>(dy, y, dx, (bf16*)dx_lp, n);
+    else tanh_bwd_kernel<float><<<grid, block, 0, s>>>(dy, y, dx, (float*)dx_lp, n);
+    return CPT_OK;
+}
+
 // dst[R][K] += src[R][Kp]  (drop the zero padding of the img weight gradient)
 __global__ __launch_bounds__(256) void unpad_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int K, int Kp) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;

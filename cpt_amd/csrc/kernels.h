@@ -42,6 +42,7 @@ int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int6
               float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,
               int type_vocab, hipStream_t s);
 int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s);
+int tanh_bwd(const float* dy, const float* y, float* dx, void* dx_lp, int lp_dtype, size_t n, hipStream_t s);
 int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s);
 int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
                hipStream_t s);

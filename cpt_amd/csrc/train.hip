@@ -84,10 +84,12 @@ int check_common(const cpt_model* m, const cpt_batch* b, void* ws, size_t ws_byt
     if (d.dtype != CPT_F32 && d.dtype != CPT_BF16) return abi_fail(CPT_ERR_DTYPE, "%s: dtype %d", who, d.dtype);
     if (d.img_dim_pad < d.img_dim || d.img_dim_pad % 64) return abi_fail(CPT_ERR_ALIGN, "%s: img_dim_pad must be a multiple of 64 for training", who);
     if (d.hidden % 64 || d.inter % 64) return abi_fail(CPT_ERR_ALIGN, "%s: hidden/intermediate sizes must be multiples of 64", who);
-    if (!b->mask_pos || !b->labels) return abi_fail(CPT_ERR_NULL, "%s: mask_pos and labels are required", who);
+    const bool nsp = !m->w_tr && !m->w_dec && m->w_pool && m->w_rel && d.n_rel > 0;
+    if (!b->labels || (!nsp && !b->mask_pos)) return abi_fail(CPT_ERR_NULL, "%s: labels (and, for the MLM head, mask_pos) are required", who);
     if (b->Li > 0 && !b->img_feats) return abi_fail(CPT_ERR_NULL, "%s: img_feats is NULL", who);
     if (b->Li > 0 && !(d.use_img_ln && m->img_ln_g)) return abi_fail(CPT_ERR_SHAPE, "%s: training without use_img_layernorm is not implemented", who);
-    if (!m->w_tr || !m->w_dec) return abi_fail(CPT_ERR_NULL, "%s: model has no MLM head", who);
+    if (!nsp && (!m->w_tr || !m->w_dec)) return abi_fail(CPT_ERR_NULL, "%s: model has neither the MLM head nor the NSP head (pooler + seq_relationship)", who);
+    if (nsp && d.n_rel > 64) return abi_fail(CPT_ERR_SHAPE, "%s: n_rel %d > 64", who, d.n_rel);
     if (ws_bytes < w.total) return abi_fail(CPT_ERR_WORKSPACE, "%s: workspace %zu < required %zu bytes", who, ws_bytes, w.total);
     if ((uintptr_t)ws & 255) return abi_fail(CPT_ERR_ALIGN, "%s: workspace must be 256-byte aligned", who);
     return CPT_OK;
@@ -146,7 +148,8 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li);
     int rc = check_common(m, b, workspace, workspace_bytes, w, "cpt_train_fwd");
     if (rc) return rc;
-    if (!o->logits || !o->loss) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: logits and loss outputs are required");
+    const bool nsp = !m->w_tr && !m->w_dec;
+    if (!o->loss || (nsp ? !o->rel : !o->logits)) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: loss and logits (NSP head: rel) outputs are required");
     hipStream_t s = (hipStream_t)stream;
     const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, dt = d.dtype;
     if (L > 288) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: sequence length %d > 288", L);
@@ -201,6 +204,23 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     float* uh = (float*)(ws + w.uh);
     void* t2 = ws + w.t2;
     need(d.layers + 1);
+    if (nsp) {
+        // NSPCPT: pooled = tanh([CLS] W_pool^T + b_pool) (kept in `uh`), rel = pooled W_rel^T + b_rel, CE over n_rel classes
+        TRY(cpt::gather_rows(ws + w.xout, dt, nullptr, rows, B, L, H, s), "gather([CLS])");
+        TRY(cpt::gemm(dt, CPT_EPI_TANH, rows, H, m->w_pool, H, m->b_pool, nullptr, 0, uh, CPT_F32, H, B, H, H, s), "gemm(pooler)");
+        const void* pin = uh;
+        if (dt == CPT_BF16) {
+            TRY(cpt::layernorm_rows(uh, nullptr, nullptr, 0.f, nullptr, t2, dt, B, H, B, 0, 0, s), "cast(pooled)");
+            pin = t2;
+        }
+        TRY(cpt::gemm(dt, CPT_EPI_NONE, pin, H, m->w_rel, H, m->b_rel, nullptr, 0, o->rel, CPT_F32, d.n_rel, B, d.n_rel, H, s), "gemm(seq_relationship)");
+        hipError_t e2 = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);
+        if (e2 != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e2, "zero loss: %s", hipGetErrorString(e2));
+        TRY(cpt::ce_rows(o->rel, b->labels, o->loss, (float*)(ws + w.dlogits), B, d.n_rel, s), "ce_rows(rel)");
+        e2 = hipMemcpyAsync(ws + w.loss, o->loss, 2 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e2 != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e2, "save loss: %s", hipGetErrorString(e2));
+        return CPT_OK;
+    }
     TRY(cpt::gather_rows(ws + w.xout, dt, b->mask_pos, rows, B, L, H, s), "gather([MASK])");
     TRY(cpt::gemm(dt, CPT_EPI_NONE, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, uh, CPT_F32, H, B, H, H, s), "gemm(head transform)");
     TRY(cpt::layernorm_rows_ex(uh, m->tr_ln_g, m->tr_ln_b, d.ln_eps, dt == CPT_F32 ? (float*)t2 : nullptr,
@@ -265,6 +285,26 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     float* duh = (float*)(ws + w.duh);
     void* duh_lp = ws + w.duh_lp;
     float* drows = (float*)(ws + w.drows);
+    const bool nsp = !m->w_tr && !m->w_dec;
+    if (nsp) {
+        if (!g->w_pool || !g->b_pool || !g->w_rel || !g->b_rel) return abi_fail(CPT_ERR_NULL, "cpt_train_bwd: NSP head needs the w_pool / b_pool / w_rel / b_rel gradient tensors");
+        const int NR = d.n_rel, NRp = 64;
+        const float* pooled = (const float*)(ws + w.uh);
+        const void* pin = dt == CPT_BF16 ? (const void*)(ws + w.t2) : (const void*)pooled;
+        TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, loss_scale_dev, dl_lp, dt, B, NR, NRp, s), "scale(drel)");
+        TRY(cpt::colsum(dl_lp, dt, NRp, g->b_rel, B, NR, s), "colsum(cls.bias)");
+        rc = dgrad(dl_lp, NRp, NRp, m->w_rel, H, NR, H, B, nullptr, dt2, CPT_F32, "dgrad(seq_relationship)");
+        if (rc) return rc;
+        rc = wgrad(dl_lp, dt, NRp, NR, pin, H, H, B, Bp, g->w_rel, H, "wgrad(seq_relationship)");
+        if (rc) return rc;
+        TRY(cpt::tanh_bwd(dt2, pooled, duh, dt == CPT_BF16 ? duh_lp : nullptr, dt, (size_t)B * H, s), "tanh_bwd(pooler)");
+        const void* dpo = dt == CPT_BF16 ? (const void*)duh_lp : (const void*)duh;
+        TRY(cpt::colsum(duh, CPT_F32, H, g->b_pool, B, H, s), "colsum(pooler bias)");
+        rc = wgrad(dpo, dt, H, H, ws + w.rows, H, H, B, Bp, g->w_pool, H, "wgrad(pooler)");
+        if (rc) return rc;
+        rc = dgrad(dpo, H, H, m->w_pool, H, H, H, B, nullptr, drows, CPT_F32, "dgrad(pooler)");
+        if (rc) return rc;
+    } else {
     TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, loss_scale_dev, dl_lp, dt, B, V, Vp, s), "scale(dlogits)");
     TRY(cpt::colsum(dl_lp, dt, Vp, g->b_dec, B, V, s), "colsum(cls.bias)");
     rc = dgrad(dl_lp, Vp, Vp, m->w_dec, H, V, H, B, nullptr, dt2, CPT_F32, "dgrad(decoder)");
@@ -279,9 +319,10 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     if (rc) return rc;
     rc = dgrad(duh_in, H, H, m->w_tr, H, H, H, B, nullptr, drows, CPT_F32, "dgrad(head transform)");
     if (rc) return rc;
+    }
     hipError_t e = hipMemsetAsync(dx, 0, (size_t)M * H * 4, s);
     if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero dx: %s", hipGetErrorString(e));
-    TRY(cpt::scatter_rows_add(drows, b->mask_pos, dx, B, L, H, s), "scatter([MASK] rows)");
+    TRY(cpt::scatter_rows_add(drows, nsp ? nullptr : b->mask_pos, dx, B, L, H, s), "scatter([MASK] / [CLS] rows)");
     // gradient buckets: the host callback runs right AFTER the last launch that writes the bucket's gradients has
     // been enqueued on `stream` (the tied word-embedding table belongs to bucket 0: its lookup gradient comes last)
     auto ready = [&](int bucket) { if (grads_ready) grads_ready(user, bucket); };

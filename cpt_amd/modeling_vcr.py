@@ -7,8 +7,9 @@ constructor, ``copy_from_pretraining_model`` (``self.cls`` BECOMES the pre-train
 order and outputs ``(loss?, seq_relationship_score)``.  The encoder is the same HIP path as REC_MLM_CPT; the head
 is the C ABI's CPT_OUT_REL output (pooler GEMM + tanh, then Linear(H, num_contrast_classes)).
 
-Inference and loss evaluation only: the reference fine-tunes this head too (fewshot/vcr_nsp_cpt.py:425-470);
-the HIP backward of this build covers the MLM head (REC_MLM_CPT), not this one, and says so loudly.
+Fine-tuning (fewshot/vcr_nsp_cpt.py:425-470) runs through the same HIP training step as REC_MLM_CPT with the NSP head
+(pooler + tanh + Linear(H, 3) + cross entropy) in place of the MLM head: cpt_train_fwd / cpt_train_bwd select it when the
+model carries w_pool / w_rel and no MLM head.
 """
 import torch
 from torch import nn
@@ -50,8 +51,10 @@ class NSPCPT(_EngineMixin, BertPreTrainedModel):
             raise RuntimeError("cpt_amd: NSPCPT needs copy_from_pretraining_model() first (cls must be the "
                                "seq_relationship Linear, modeling_vcr.py:90-92)")
         if torch.is_grad_enabled() and next_sentence_label is not None and self.cls.weight.requires_grad:
-            raise NotImplementedError("cpt_amd: NSPCPT fine-tuning (backward through the relation head) is not "
-                                      "built; evaluate under torch.no_grad()")
+            # few-shot fine-tuning (fewshot/vcr_nsp_cpt.py:425-470): loss with gradients through the HIP backward
+            from .train import mlm_loss_with_grad
+            return mlm_loss_with_grad(self, input_ids, token_type_ids, attention_mask, next_sentence_label.view(-1),
+                                      position_ids, img_feats, None)
         out = self._engine().forward(input_ids, token_type_ids, attention_mask, position_ids, img_feats, flags=L.OUT_REL)
         rel = out["rel"]
         outputs = (rel,)

@@ -23,6 +23,12 @@ NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")       # fewshot/refcoc
 NO_GRAD_PREFIXES = ("bert.pooler.", "cls.seq_relationship.")
 
 
+def no_grad_prefixes(head):
+    """Parameters outside the loss's graph: the MLM heads never touch the pooler / relation head; the NSP-CPT head
+    (NSPCPT, modeling_vcr.py:115-129) trains every parameter it holds."""
+    return () if head == "nsp" else NO_GRAD_PREFIXES
+
+
 def warmup_linear(step, warmup_step, tot_step):
     if step < warmup_step:
         return step / warmup_step
@@ -90,12 +96,18 @@ class _TrainState(object):
                 g.img_ln_g = gp("bert.LayerNorm.weight")
                 g.img_ln_b = gp("bert.LayerNorm.bias")
             g.layers = C.cast(layers, C.POINTER(L.LayerGrads))
-            hp = "cls." if eng.head == "cpt" else "cls.predictions."
-            g.w_tr = gp(hp + "transform.dense.weight")
-            g.b_tr = gp(hp + "transform.dense.bias")
-            g.tr_ln_g = gp(hp + "transform.LayerNorm.weight")
-            g.tr_ln_b = gp(hp + "transform.LayerNorm.bias")
-            g.b_dec = gp(hp + "bias")
+            if eng.head == "nsp":
+                g.w_pool = gp("bert.pooler.dense.weight")
+                g.b_pool = gp("bert.pooler.dense.bias")
+                g.w_rel = gp("cls.weight")
+                g.b_rel = gp("cls.bias")
+            else:
+                hp = "cls." if eng.head == "cpt" else "cls.predictions."
+                g.w_tr = gp(hp + "transform.dense.weight")
+                g.b_tr = gp(hp + "transform.dense.bias")
+                g.tr_ln_g = gp(hp + "transform.LayerNorm.weight")
+                g.tr_ln_b = gp(hp + "transform.LayerNorm.bias")
+                g.b_dec = gp(hp + "bias")
             self.gdesc = (g, layers)
 
     def workspace(self, B, Lt, Li):
@@ -120,8 +132,9 @@ def _state(eng):
 def _named_grad_views(eng, st):
     named = eng._named()
     out = []
+    skip = no_grad_prefixes(eng.head)
     for n, p in named.items():
-        if n.startswith(NO_GRAD_PREFIXES):
+        if skip and n.startswith(skip):
             out.append((p, None))
         else:
             off, num = eng.offsets[n]
@@ -139,11 +152,15 @@ class _MLMLoss(torch.autograd.Function):
         Li = feats.size(1) if feats is not None else 0
         m, _ = eng.descriptor()
         dev = eng.flat.device
-        logits = torch.empty((B, eng.cfg.vocab_size), device=dev, dtype=torch.float32)
         loss_acc = torch.empty(2, device=dev, dtype=torch.float32)
-        o = L.Outputs(logits=logits.data_ptr(), loss=loss_acc.data_ptr())
+        if eng.head == "nsp":       # relation scores of the pooled [CLS] instead of vocabulary logits of the [MASK] row
+            logits = torch.empty((B, m.dims.n_rel), device=dev, dtype=torch.float32)
+            o = L.Outputs(rel=logits.data_ptr(), loss=loss_acc.data_ptr())
+        else:
+            logits = torch.empty((B, eng.cfg.vocab_size), device=dev, dtype=torch.float32)
+            o = L.Outputs(logits=logits.data_ptr(), loss=loss_acc.data_ptr())
         bt = L.Batch(B=B, Lt=Lt, Li=Li, input_ids=ids.data_ptr(), token_type=L.ptr(seg), position_ids=L.ptr(pos),
-                     attn_mask=L.ptr(mask), img_feats=L.ptr(feats), mask_pos=mpos.data_ptr(), labels=labels.data_ptr())
+                     attn_mask=L.ptr(mask), img_feats=L.ptr(feats), mask_pos=L.ptr(mpos), labels=labels.data_ptr())
         if st.saved is not None and st.ws is not None:
             # the activations of an earlier training forward are still waiting for their backward; the workspace is
             # per engine, so this forward overwrites them (their backward will raise instead of using the wrong ones)
@@ -220,11 +237,13 @@ class _MLMLoss(torch.autograd.Function):
 def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels, position_ids, img_feats, mask_token_pos):
     """(loss, prediction_scores) with autograd history, as REC_MLM_CPT.forward returns them
     (modeling_rec.py:147-152).  ``mask_token_pos`` is required: the loss only sees the [MASK] rows
-    (fewshot/refcoco_cpt.py:231-233 puts -1 everywhere else)."""
-    if mask_token_pos is None:
+    (fewshot/refcoco_cpt.py:231-233 puts -1 everywhere else).  For NSPCPT (head "nsp", modeling_vcr.py:115-129)
+    ``labels`` are the (B,) next-sentence labels (-1 ignored), ``mask_token_pos`` is None and the second result is
+    the (B, num_contrast_classes) relation scores."""
+    eng = model._engine()
+    if mask_token_pos is None and eng.head != "nsp":
         raise NotImplementedError("cpt_amd: training needs mask_token_pos (the (B, L) label grid of the reference has "
                                   "exactly one labelled position per row: pass it as mask_token_pos)")
-    eng = model._engine()
     if eng.dtype not in ("fp32", "bf16"):
         raise NotImplementedError("cpt_amd: training runs in 'fp32' or 'bf16' compute mode ('%s' is an inference mode)" % eng.dtype)
     eng.ensure_packed()
@@ -331,7 +350,7 @@ class FusedAdamW(object):
             code = torch.zeros(eng.flat.numel(), dtype=torch.uint8)
             for n in eng.offsets:
                 off, num = eng.offsets[n]
-                if n.startswith(NO_GRAD_PREFIXES):
+                if no_grad_prefixes(eng.head) and n.startswith(no_grad_prefixes(eng.head)):
                     c = 0
                 elif any(nd in n for nd in NO_DECAY):
                     c = 2

@@ -177,18 +177,23 @@ typedef struct {           /* gradients of cpt_layer, all fp32, same shapes */
     float* w_in; float* b_in; float* w_out; float* b_out; float* ln2_g; float* ln2_b;
 } cpt_layer_grads;
 
-typedef struct {           /* gradients of cpt_model (pooler / seq_relationship get none on this path) */
+typedef struct {           /* gradients of cpt_model: the MLM-head fields (w_tr .. b_dec) or the NSP-head fields (w_pool .. b_rel) */
     float* word_emb;       /* [V][H]: tied table, decoder + embedding-lookup contributions */
     float* pos_emb; float* type_emb; float* emb_ln_g; float* emb_ln_b;
     float* w_img;          /* [H][img_dim] (unpadded) */
     float* b_img; float* img_ln_g; float* img_ln_b;
     const cpt_layer_grads* layers;   /* HOST array */
     float* w_tr; float* b_tr; float* tr_ln_g; float* tr_ln_b; float* b_dec;
+    float* w_pool; float* b_pool;    /* NSP head (model without w_tr / w_dec but with w_pool and w_rel): bert.pooler.dense */
+    float* w_rel; float* b_rel;      /* ... and the relation Linear [n_rel][H] (NSPCPT.cls, modeling_vcr.py:90-92) */
 } cpt_model_grads;
 
 size_t cpt_train_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li);
 /* forward: o->logits [B][V] and o->loss[2] = {sum of row losses, labelled-row count} are written;
- * b->mask_pos and b->labels ([B], -1 = ignored) are required. */
+ * b->mask_pos and b->labels ([B], -1 = ignored) are required.
+ * A model WITHOUT the MLM head (w_tr, w_dec NULL) but with w_pool and w_rel trains the NSP-CPT head instead
+ * (NSPCPT.forward, modeling_vcr.py:115-129; fewshot/vcr_nsp_cpt.py:425-470): pooled [CLS] -> tanh -> Linear(H, n_rel) ->
+ * CrossEntropyLoss(ignore_index=-1) over b->labels [B]; o->rel [B][n_rel] is written instead of o->logits, b->mask_pos is not used. */
 int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
                   size_t workspace_bytes, void* stream);
 /* backward of loss = loss_scale * mean over labelled rows; g's tensors must be zero on entry

@@ -171,9 +171,73 @@ def test_vcr_nspcpt_golden(dev, golden_dir, mode):
     assert (logits - torch.from_numpy(g["choice_logits"])).abs().max().item() < tol
     if mode == "fp32":
         assert preds == list(g["preds"])
-    with pytest.raises(NotImplementedError):
-        m.train()
-        m(b["input_ids"], b["segment_ids"], b["attention_mask"], next_sentence_label=lab, img_feats=b["img_feats"])
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_vcr_nspcpt_finetune_gradients(dev, golden_dir, mode):
+    """NSPCPT fine-tuning (fewshot/vcr_nsp_cpt.py:425-470): loss.backward() through the HIP training step with the NSP head
+    against the gradients the reference's own NSPCPT produced under autograd (fixture), every other gradient against
+    the oracle's autograd, and a few AdamW steps that must lower the loss."""
+    from cpt_amd.modeling_bert import BertImgForPreTraining
+    from cpt_amd.modeling_vcr import NSPCPT
+    from cpt_amd import scoring
+    from cpt_amd.train import FusedAdamW
+    from oracle import cpt_oracle as O
+    g = np.load(os.path.join(golden_dir, "tiny_vcr_nsp.npz"))
+    cfg = cfgmod.tiny()
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0
+    pre = BertImgForPreTraining(cfg)
+    sd0 = synth.init_state_dict(cfg, 4321, head="pretrain")
+    pre.load_state_dict(sd0)
+    pre.tie_weights()
+    m = NSPCPT(cfg)
+    m.copy_from_pretraining_model(pre)
+    m.to(dev).train().set_compute_dtype(mode)
+    b = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    lab = scoring.nsp_choice_labels([2, 0], int(g["interval"]), 8, device=dev)
+    loss, rel = m(b["input_ids"], b["segment_ids"], b["attention_mask"], next_sentence_label=lab, img_feats=b["img_feats"])
+    loss.backward()
+    ltol, gtol = (1e-5, 2e-4) if mode == "fp32" else (5e-3, 8e-2)
+    assert abs(loss.item() - float(g["loss"])) < ltol
+    assert (rel.detach().cpu() - torch.from_numpy(g["rel"])).abs().max().item() < (2e-5 if mode == "fp32" else 5e-3)
+    named = dict(m.named_parameters())
+
+    def rel_err(name, ref):
+        got = named[name].grad.double().cpu().flatten()
+        ref = torch.as_tensor(ref).double().flatten()
+        return float((got - ref).norm() / (ref.norm() + 1e-30))
+    # the reference's own autograd (oracle/make_golden.py: vcr_nsp_case)
+    for name, key in (("cls.weight", "grad_cls_weight"), ("cls.bias", "grad_cls_bias"), ("bert.pooler.dense.weight", "grad_pooler_weight"),
+                      ("bert.encoder.layer.0.attention.self.query.weight", "grad_q0_weight")):
+        assert rel_err(name, g[key]) < gtol, name
+    # everything else: the oracle's autograd on the same inputs
+    osd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    ob = {k: v.cpu() for k, v in b.items()}
+    oloss, _ = O.nsp_cpt_forward(osd, cfg.to_dict(), ob["input_ids"], ob["segment_ids"], ob["attention_mask"], ob["img_feats"],
+                                 next_sentence_label=lab.cpu(), w_key="cls.weight", b_key="cls.bias")
+    oloss.backward()
+    worst = 0.0
+    for name, prm in named.items():
+        ref = osd[name].grad
+        if ref is None or prm.grad is None:
+            assert ref is None or float(ref.abs().max()) == 0.0, name
+            continue
+        if float(ref.abs().max()) < 1e-6 and float(prm.grad.abs().max()) < (1e-5 if mode == "fp32" else 1e-3):
+            continue                     # key bias: true gradient 0 (softmax is shift-invariant), rounding noise on both sides
+        e = rel_err(name, ref)
+        worst = max(worst, e)
+        assert e < gtol, (name, e)
+    print("NSPCPT %s: loss %.5f, worst relative gradient error %.2e" % (mode, loss.item(), worst))
+    # a few optimizer steps
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=0.01)
+    losses = [loss.item()]
+    for _ in range(4):
+        opt.step()
+        opt.zero_grad()
+        loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], next_sentence_label=lab, img_feats=b["img_feats"])
+        loss.backward()
+        losses.append(loss.item())
+    assert losses[-1] < 0.7 * losses[0], losses
 
 
 def test_region_stager_matches_host_decode(dev):
