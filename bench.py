@@ -29,10 +29,10 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}      # MI355
 
 def pmc_traffic_bytes(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_pmc_bench_summary.json, produced by tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in
+    (profiles/r02_pmc_bench_summary.json, produced by tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in
     separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams on gfx950).
     None when the summary is absent or the batch differs from the profiled one."""
-    fn = os.path.join(ROOT, "profiles", "r01_pmc_bench_summary.json")
+    fn = os.path.join(ROOT, "profiles", "r02_pmc_bench_summary.json")
     try:
         d = json.load(open(fn))
         fam = {"gemm_ffn_up": "gemm_ffn_up(+gelu)", "gemm_qkv": "gemm_qkv_attn", "gemm_attn_out": "gemm_attn_out",

@@ -8,6 +8,8 @@ import sys
 
 
 def family(name, prev):
+    if "ffn_up_2pass_kernel" in name:
+        return "gemm_ffn_up(+gelu)"                     # gemm_ffn.hip: the two-pass 384 x 256 FFN-up kernel
     if "gemm_pipe_kernel" in name:
         # template arguments: <T, EPI, OT, ...>; EPI 0 none, 1 gelu, 3 resid, 6 LN producer, 7/8 LN consumer (+gelu), 9/10 fused QKV + attention
         if "Li9EDF16b" in name or "Li10EDF16b" in name:
