@@ -6,8 +6,9 @@ The hot path shards over independent (query x proposal) sequences (SURVEY.md sec
     the argmax is per query), NO collective inside the model; one fixed-shape gather of the chosen
     indices / scores at the end -- replaces the pickled-dict all_gather of
     /root/reference/Oscar/oscar/utils/comm.py:102-142 (called from zeroshot/refcoco_cpt.py:256).
-  * training: replicated weights, ONE sum all-reduce over the flat gradient buffer per step
-    (instead of DDP's 25 MB buckets over 200 tensors), averaged inside the fused AdamW.
+  * training: replicated weights; per parameter bucket a reduce-scatter of the flat gradient under backward, AdamW on
+    the 1/N shard, an all-gather of the updated parameters under the next forward (ShardedGradSync below; replaces
+    DistributedDataParallel's bucketed all-reduce + replicated optimizer, fewshot/refcoco_cpt.py:516-522).
 """
 import os
 
