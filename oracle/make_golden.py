@@ -316,6 +316,90 @@ def tsv_rows_case():
     np.savez_compressed(os.path.join(OUT, "tiny_rows_expected.npz"), **g)
 
 
+PROMPT_VOCAB = (["[PAD]"] + ["[unused%d]" % i for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] +
+                ["the", "a", "dog", "man", "woman", "on", "left", "right", "in", "red", "blue", "green", "is", "color", ".", ",",
+                 "fr", "##is", "##bee", "tree", "car", "none", "shirt", "black", "of", "and", "standing", "next", "to", "big",
+                 "small", "##s", "##ing", "holding", "traffic", "light", "feature", ":", "\"", "\\", "person", "hat"])
+
+
+def prompt_tokenizer(tmpdir):
+    """A WordPiece tokenizer over a small vocabulary laid out like bert-base-uncased ([MASK] = 103, which the reference
+    hard-codes at refcoco_zsl_cpt_dataset.py:116).  The reference takes any object with tokenize / convert_tokens_to_ids."""
+    from transformers import BertTokenizer
+    vf = os.path.join(tmpdir, "vocab.txt")
+    with open(vf, "w") as f:
+        f.write("\n".join(PROMPT_VOCAB) + "\n")
+    return BertTokenizer(vf, do_lower_case=True)
+
+
+def prompt_case():
+    """Section 8(f).2, prompt assembly: the reference's own templates, tokenize() and ZSLColorFinetuneDataset.__getitem__
+    (refcoco_zsl_cpt_dataset.py:18-54, 85-159, 211-302) on a three-row predictions file with varied colours / rectangles /
+    annotated boxes, in evaluation and in few-shot (sampling) mode.  The data set object is built without its __init__
+    (which wants the RefCOCO annotation tree on disk); everything __getitem__ touches is set by hand."""
+    import base64
+    import random
+    import tempfile
+    from oscar.utils.tsv_file import TSVFile
+    import oscar.datasets.refcoco_zsl_cpt_dataset as D
+    rng = np.random.Generator(np.random.PCG64(70))
+    tmp = tempfile.mkdtemp()
+    tok = prompt_tokenizer(tmp)
+    g = {"vocab": np.array(PROMPT_VOCAB)}
+    # (a) templates + tokenize() alone, incl. both truncation branches and the no-text_b form
+    cases = [("the dog on the left", "dog man frisbee", 4, 1), ("man in red shirt standing next to the big tree and the small car " * 3, "tree car " * 20, 7, 2),
+             ("a woman holding a frisbee", "", 0, 3), ("the person", "red traffic light hat " * 12, 50, 1), ("dogs, trees and cars.", "zebra car", 2, 2)]
+    for i, (cap, tb, nf, t) in enumerate(cases):
+        text_a = D.tmp_list[t](cap, 0)
+        ids, msk, seg, lab = D.tokenize(tok, text_a=text_a, text_b=tb, img_feat=torch.zeros(nf, 2054), max_img_seq_len=50,
+                                        max_seq_a_len=40, max_seq_len=70, cls_token_segment_id=0, pad_token_segment_id=0,
+                                        sequence_a_segment_id=0, sequence_b_segment_id=1)
+        g["tok%d_in" % i] = np.array([cap, tb, str(nf), str(t)])
+        g["tok%d_text_a" % i] = np.array(text_a)
+        g["tok%d_ids" % i], g["tok%d_mask" % i], g["tok%d_seg" % i], g["tok%d_lab" % i] = ids.numpy(), msk.numpy(), seg.numpy(), lab.numpy()
+    for t in (4, 5, 6):
+        g["tmpl%d" % t] = np.array([D.tmp_list[t]("man in red shirt", [3, 10]), D.tmp_list[t]("man in red", [10])])
+    # (b) whole rows
+    tsv = os.path.join(OUT, "tiny_prompt_rows.tsv")
+    spec = [("17", "The dog on the left.", (("red", "blue"), ("red",), ("green", "red")),
+             (([10, 10, 110, 110], [200, 200, 260, 260]), ([12, 8, 108, 112],), ([300, 0, 320, 40], [0, 0, 50, 50])), [10, 10, 101, 101]),
+            ("23", "man in red shirt.", (("red",), ("red",)), (([5, 5, 25, 25],), ([100, 100, 150, 180],)), [100, 100, 51, 81]),
+            ("31", "a woman holding a frisbee", (("blue",), ("blue", "green"), ("blue",), ("blue",)),
+             (([0, 0, 10, 10],), ([50, 50, 90, 90], [52, 48, 92, 95]), ([400, 400, 420, 420],), ([51, 51, 89, 91],)), [50, 50, 41, 41])]
+    rows, anns, dets = [], {}, {}
+    for name, cap, colors, rects, gtb in spec:
+        objs = []
+        for pi, cs in enumerate(colors):
+            boxes = []
+            for j in range(len(cs)):
+                f = rng.standard_normal(2054).astype(np.float32)
+                boxes.append({"rect": [float(v) for v in rects[pi][j]], "bbox_id": j, "class": "x", "conf": 0.5,
+                              "feature": base64.b64encode(f.tobytes()).decode("utf-8")})
+            objs.append(boxes)
+        rows.append((name, json.dumps({"objects": [objs, cap, [list(c) for c in colors], [[list(r) for r in rs] for rs in rects]]})))
+        anns[name] = {"id": int(name), "bbox": gtb}
+        dets[name] = ["dog", "man", "frisbee", "traffic light", "person"][: len(colors) + 1]
+    with open(tsv, "w") as f:
+        for k, v in rows:
+            f.write(k + "\t" + v + "\n")
+    g["anns"] = np.array(json.dumps(anns))
+    g["dets"] = np.array(json.dumps(dets))
+    for is_train in (False, True):
+        ds = object.__new__(D.ZSLColorFinetuneDataset)
+        ds.tokenizer, ds.txt_seq_len, ds.img_seq_len = tok, 70, 50
+        ds.corpus_tsvfile = TSVFile(tsv, generate_lineidx=True)
+        ds.anns_dic, ds.det_dic, ds.is_train, ds.template = anns, dets, is_train, D.tmp_list[2]
+        random.seed(1234)
+        for i in range(len(rows)):
+            img_name, feats, ids, msk, seg, mpos, gts, colors, rects = ds[i]
+            k = "%s%d_" % ("tr" if is_train else "ev", i)
+            g[k + "ids"], g[k + "mask"], g[k + "seg"] = torch.stack(ids).numpy(), torch.stack(msk).numpy(), torch.stack(seg).numpy()
+            g[k + "mpos"], g[k + "gts"] = np.array(mpos), np.array(gts)
+            g[k + "nfeat"] = np.array([f.size(0) for f in feats])           # padded to img_seq_len by the reference
+            g[k + "feat_sum"] = np.array([float(f.double().sum()) for f in feats])
+    np.savez_compressed(os.path.join(OUT, "tiny_prompts.npz"), **g)
+
+
 def caller_goldens():
     """a15 + iou: outputs of the reference helper functions on seeded inputs."""
     rng = np.random.Generator(np.random.PCG64(99))
@@ -336,6 +420,9 @@ def caller_goldens():
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-prompts" in sys.argv:      # add the prompt-assembly fixture without rewriting the others
+        prompt_case()
+        return
     if "--only-vcr" in sys.argv:          # add the section 8(f).1 fixture without rewriting the others
         vcr_nsp_case()
         return
@@ -351,6 +438,7 @@ def main():
     meta["tiny_ckpt_vs_direct_maxabs"] = tiny_case()
     caller_goldens()
     vcr_nsp_case()
+    prompt_case()
     tsv_rows_case()
     base_case("base_cfg1_b2_r36", B=2, n_regions=36)                       # BASELINE config 1 shape
     base_case("base_cfg2_b4_r50", B=4, n_regions=50, with_grads=True)      # config 2 shape (+ grads for config 3)
