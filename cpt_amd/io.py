@@ -167,24 +167,32 @@ def decode_rows(payloads, img_seq_len=50, dim=2054, out=None, mask=None, key=b"f
     (infos, feats (S, img_seq_len, dim), mask (S, img_seq_len), seqs_per_row, regions_per_seq) with S the total number
     of proposal sequences; sequence order = row order, then box-list order inside the row.  ``parse=False`` returns the
     stripped JSON texts instead of parsed objects (a driver may parse them on another process / later)."""
-    n = len(payloads)
     payloads = [p.encode("utf-8") if isinstance(p, str) else p for p in payloads]
+    n = len(payloads)
+    rows = (C.c_char_p * max(n, 1))(*payloads)
+    lens = np.fromiter((len(p) for p in payloads), dtype=np.uint64, count=n) if n else np.zeros(1, np.uint64)
+    return decode_rows_at(rows, lens, n, img_seq_len, dim, out, mask, key, threads, max_seqs, parse)
+
+
+def decode_rows_at(rows, lens, n, img_seq_len=50, dim=2054, out=None, mask=None, key=b"feature", threads=4, max_seqs=None,
+                   parse=True):
+    """decode_rows on row texts given by ADDRESS: ``rows`` a ctypes array of n pointers (c_char_p / c_void_p), ``lens``
+    their byte lengths (uint64 array).  Lets a caller decode straight out of a memory-mapped predictions file without
+    materialising 4 MB ``bytes`` objects per row (DecodePool's workers)."""
     if max_seqs is None:
-        max_seqs = out.size(0) if out is not None else sum(len(p) // ((16 * dim) // 3) + 1 for p in payloads)
+        max_seqs = out.size(0) if out is not None else int(sum(int(l) // ((16 * dim) // 3) + 1 for l in lens[:n]))
     if out is None:
         out = torch.empty((max_seqs, img_seq_len, dim), dtype=torch.float32)
     if mask is None:
         mask = torch.empty((max_seqs, img_seq_len), dtype=torch.int64)
     assert out.is_contiguous() and mask.is_contiguous() and out.size(0) >= max_seqs and mask.size(0) >= max_seqs
-    rows = (C.c_char_p * max(n, 1))(*payloads)
-    lens = np.fromiter((len(p) for p in payloads), dtype=np.uint64, count=n) if n else np.zeros(1, np.uint64)
-    sbufs = [np.empty(len(p) + 1, dtype=np.uint8) for p in payloads]
+    sbufs = [np.empty(int(lens[i]) + 1, dtype=np.uint8) for i in range(n)]
     sptr = np.fromiter((b.ctypes.data for b in sbufs), dtype=np.uint64, count=n) if n else np.zeros(1, np.uint64)
     scap = lens + 1
     slen = np.zeros(max(n, 1), dtype=np.uint64)
     seqs_per_row = np.zeros(max(n, 1), dtype=np.int32)
     regions = np.zeros(max(max_seqs, 1), dtype=np.int32)
-    L.check(L.lib().cpt_decode_tsv_rows(rows, lens.ctypes.data, n, key, dim, img_seq_len, max_seqs, out.data_ptr(),
+    L.check(L.lib().cpt_decode_tsv_rows(C.cast(rows, C.POINTER(C.c_char_p)), lens.ctypes.data, n, key, dim, img_seq_len, max_seqs, out.data_ptr(),
                                         mask.data_ptr(), sptr.ctypes.data, scap.ctypes.data, slen.ctypes.data,
                                         seqs_per_row.ctypes.data, regions.ctypes.data, threads), "cpt_decode_tsv_rows")
     infos = [sbufs[i][:int(slen[i])].tobytes() for i in range(n)]      # the row's JSON without the feature strings
@@ -277,3 +285,154 @@ class RegionStager(object):
         feats, mask, ev = self.stage(feature_lists, st)
         st.wait_event(ev)
         return feats, mask
+
+
+# ---- worker processes + shared pinned ring -------------------------------------------------------------------------
+# The reference feeds its model from torch DataLoader worker PROCESSES (zeroshot/refcoco_cpt.py: DataLoader(num_workers=...)),
+# each decoding rows in Python and pickling (P, 50, 2054) tensors back to the main process.  One Python process cannot keep
+# up with the HIP forward (decode + json + launch contend for the interpreter: 9 k sequences/s, profiles/r01_io_decode.json),
+# so the decode moves to worker processes here too -- but they write the decoded features straight into a ring of SHARED,
+# PINNED host buffers (one batch per slot): nothing is pickled but the rows' small JSON, and the main process only issues the
+# H2D copy of a finished slot and the forward.
+
+def _pool_worker(tsv_path, img_seq_len, dim, threads, feats, masks, tasks, results, my_slots):
+    import mmap
+    for k in my_slots:                  # map this worker's slots now: first-touch page faults stay out of the steady state
+        feats[k].zero_()
+        masks[k].zero_()
+    tsv = TSVFile(tsv_path)
+    tsv._ensure_lineidx_loaded()
+    offs = tsv._lineidx
+    fp = open(tsv_path, "rb")
+    size = os.fstat(fp.fileno()).st_size
+    mm = mmap.mmap(fp.fileno(), 0, access=mmap.ACCESS_READ)      # rows are decoded in place out of the page cache
+    base = np.frombuffer(mm, dtype=np.uint8).ctypes.data
+    ws = b" \t\r\n"
+    while True:
+        job = tasks.get()
+        if job is None:
+            return
+        ticket, slot, rows = job
+        try:
+            n = len(rows)
+            ptrs = (C.c_void_p * max(n, 1))()
+            lens = np.zeros(max(n, 1), dtype=np.uint64)
+            names = []
+            for j, i in enumerate(rows):
+                lo = offs[i]                                      # (IndexError for a row that does not exist: reported below)
+                hi = offs[i + 1] if i + 1 < len(offs) else size
+                tab = mm.find(b"\t", lo, hi)
+                if tab < 0:
+                    raise ValueError("row %d has no tab-separated payload" % i)
+                names.append(mm[lo:tab].decode("utf-8").strip())
+                lo = tab + 1                                      # (two-column rows, as inference_ref.py writes them: name \t json;
+                #  scanning 4 MB for a further tab with mmap.find costs more than the decode itself)
+                while hi > lo and mm[hi - 1:hi] in (b" ", b"\t", b"\r", b"\n"):
+                    hi -= 1
+                while lo < hi and mm[lo:lo + 1] in (b" ", b"\t", b"\r", b"\n"):
+                    lo += 1
+                if hi - lo < 2 or mm[hi - 1:hi] != b"}":
+                    raise ValueError("row %d: the payload column is not one JSON object" % i)
+                ptrs[j] = base + lo
+                lens[j] = hi - lo
+            infos, f, m, seqs_per_row, regions = decode_rows_at(ptrs, lens, n, img_seq_len, dim, out=feats[slot], mask=masks[slot],
+                                                                threads=threads, max_seqs=feats.size(1), parse=False)
+            results.put((ticket, slot, names, infos, seqs_per_row, regions, None))
+        except Exception as e:          # the main process re-raises
+            results.put((ticket, slot, None, None, None, None, "%s: %s" % (type(e).__name__, e)))
+
+
+class DecodePool(object):
+    """``workers`` processes decode whole batches of TSV rows into a ring of ``slots`` shared pinned buffers.
+
+        pool = DecodePool(tsv_path, max_seqs=64, workers=4, slots=6)
+        for rows in batches: pool.submit(rows)                 # row indices of one batch; up to `slots` in flight
+        slot, names, infos, seqs_per_row, regions = pool.next()  # in submission order
+        feats, mask = pool.feats[slot][:S], pool.masks[slot][:S]   # pinned host views: copy H2D, then pool.release(slot)
+
+    ``infos`` are the rows' JSON texts WITHOUT the feature strings (bytes; json.loads them where the captions are needed,
+    e.g. prompts.PromptBuilder).  A slot is reused only after ``release(slot)``: call it once the H2D copy out of the slot
+    has completed (e.g. after the copy event's synchronize())."""
+
+    def __init__(self, tsv_path, max_seqs, img_seq_len=50, dim=2054, workers=4, slots=None, threads=2, pin=None):
+        import torch.multiprocessing as mp
+        ctx = mp.get_context("spawn")               # never fork a process that holds a HIP context
+        self.slots = slots or 2 * workers
+        if self.slots < workers:
+            raise ValueError("DecodePool: at least one slot per worker")
+        self.feats = torch.empty((self.slots, max_seqs, img_seq_len, dim), dtype=torch.float32).share_memory_()
+        self.masks = torch.empty((self.slots, max_seqs, img_seq_len), dtype=torch.int64).share_memory_()
+        self.pinned = False
+        if pin is None:
+            pin = torch.cuda.is_available()
+        if pin:                                      # page-lock the shared pages for the DMA engine (hipHostRegister)
+            rt = torch.cuda.cudart()
+            for t in (self.feats, self.masks):
+                rc = rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
+                if int(rc) != 0:
+                    raise RuntimeError("cpt_amd.io: hipHostRegister of the shared ring failed (%s)" % rc)
+            self.pinned = True
+        # slot k always belongs to worker k % workers (own task queue): a process only ever maps and touches its own slots
+        self.workers = workers
+        self.tasks, self.results = [ctx.Queue() for _ in range(workers)], ctx.Queue()
+        self.procs = [ctx.Process(target=_pool_worker, args=(tsv_path, img_seq_len, dim, threads, self.feats, self.masks,
+                                                            self.tasks[w], self.results, list(range(w, self.slots, workers))),
+                                  daemon=True) for w in range(workers)]
+        for p in self.procs:
+            p.start()
+        self.free = list(range(self.slots))
+        self.ticket = self.next_ticket = 0
+        self.done = {}
+
+    def can_submit(self):
+        return bool(self.free)
+
+    def submit(self, rows):
+        if not self.free:
+            raise RuntimeError("cpt_amd.io.DecodePool: every slot is in flight; release() one first")
+        # prefer a slot of the worker with the fewest batches in flight
+        busy = [0] * self.workers
+        for k in range(self.slots):
+            if k not in self.free:
+                busy[k % self.workers] += 1
+        slot = min(self.free, key=lambda k: (busy[k % self.workers], k))
+        self.free.remove(slot)
+        self.tasks[slot % self.workers].put((self.ticket, slot, list(rows)))
+        self.ticket += 1
+        return slot
+
+    def next(self, timeout=120.0):
+        """Result of the oldest unreturned batch: (slot, names, infos, seqs_per_row, regions_per_seq)."""
+        while self.next_ticket not in self.done:
+            t, slot, names, infos, spr, regions, err = self.results.get(timeout=timeout)
+            self.done[t] = (slot, names, infos, spr, regions, err)
+        slot, names, infos, spr, regions, err = self.done.pop(self.next_ticket)
+        self.next_ticket += 1
+        if err is not None:
+            self.free.append(slot)
+            raise RuntimeError("cpt_amd.io.DecodePool worker: " + err)
+        return slot, names, infos, spr, regions
+
+    def release(self, slot):
+        self.free.append(slot)
+
+    def close(self):
+        for q in self.tasks:
+            q.put(None)
+        for p in self.procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.terminate()
+        if self.pinned:
+            rt = torch.cuda.cudart()
+            for t in (self.feats, self.masks):
+                rt.cudaHostUnregister(t.data_ptr())
+            self.pinned = False
+        self.procs = []
+
+    def __del__(self):
+        try:
+            if self.procs:
+                self.close()
+        except Exception:
+            pass

@@ -115,3 +115,45 @@ def test_decode_rows_native_batch(golden_dir, threads):
         io.decode_rows(payloads, img_seq_len=6, max_seqs=4)
     with pytest.raises(RuntimeError, match="do not fit max_regions"):
         io.decode_rows(payloads, img_seq_len=4)
+
+
+def test_decode_pool_worker_processes_match_direct_decode(golden_dir):
+    """Section 8(f).2: worker processes decoding batches of rows into the shared ring give, slot by slot and in submission
+    order, exactly what the in-process decoder gives for the same rows."""
+    import json
+    tsv_path = os.path.join(golden_dir, "tiny_prompt_rows.tsv")
+    tsv = io.TSVFile(tsv_path)
+    n = tsv.num_rows()
+    pool = io.DecodePool(tsv_path, max_seqs=10, img_seq_len=50, workers=2, slots=3, threads=1, pin=False)
+    try:
+        batches = [[0, 1], [2], [1, 2, 0], [0], [2, 1]]
+        got = []
+        it = iter(batches)
+        pending = 0
+        for rows in it:
+            while not pool.can_submit():
+                slot, names, infos, spr, regions = pool.next()
+                S = sum(spr)
+                got.append((names, [json.loads(b) for b in infos], pool.feats[slot][:S].clone(), pool.masks[slot][:S].clone(), spr, regions))
+                pool.release(slot)
+                pending -= 1
+            pool.submit(rows)
+            pending += 1
+        while pending:
+            slot, names, infos, spr, regions = pool.next()
+            S = sum(spr)
+            got.append((names, [json.loads(b) for b in infos], pool.feats[slot][:S].clone(), pool.masks[slot][:S].clone(), spr, regions))
+            pool.release(slot)
+            pending -= 1
+        assert len(got) == len(batches)
+        for rows, (names, infos, f, m, spr, regions) in zip(batches, got):
+            cols = [tsv.seek_raw(i) for i in rows]
+            assert names == [c[0].decode().strip() for c in cols]
+            ref_infos, rf, rm, rspr, rreg = io.decode_rows([c[1].strip() for c in cols], 50, max_seqs=10)
+            assert spr == rspr and regions == rreg and infos == ref_infos
+            assert torch.equal(f, rf) and torch.equal(m, rm)
+        with pytest.raises(RuntimeError):
+            pool.submit([n + 5])
+            pool.next()
+    finally:
+        pool.close()
