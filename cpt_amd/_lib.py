@@ -96,6 +96,10 @@ _SIGS = {
     "cpt_gemm_ln_cons": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_gemm_ln_prod": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int,
                                    C.c_int, C.c_int, vp]),
+    "cpt_gemm_ln_prod3": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, vp]),
+    "cpt_resid3_split": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "cpt_resid3_merge": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_split3": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_select_regions": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
     "cpt_argmax_columns": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),

@@ -133,6 +133,53 @@ template <typename T> struct FragOf;
 template <> struct FragOf<bf16> { typedef bf16x8 type; };
 template <> struct FragOf<float> { typedef f32x4 type; };
 
+// ---- 3-byte residual stream (bf16 encoder, round 2) ---------------------------------------------------------------
+// The LayerNorm producers used to write every pre-LayerNorm sum twice (fp32 for the next residual add + bf16 for the
+// next GEMM's A operand: 6 B out, 4 B in per element) and their epilogues run at the memory system's limit, so only fewer
+// bytes help.  A value x is now kept as T = its fp32 pattern rounded to the top 24 bits (sign, exponent, 15 mantissa
+// bits; round half away, carry runs into the exponent like any IEEE rounding), split into
+//   hi = (T + 0x80) >> 8   the bf16 operand of the next GEMM (round-half-away of T: a plain bf16 tensor), and
+//   lo = T & 0xff          one signed byte, T - (hi << 8),
+// 3 B out + 3 B in per element; readers rebuild x' = ((hi << 8) + (int8)lo) << 8 with |x' - x| <= 2^-17 |x| (the bf16
+// operands beside it carry 2^-9).  Inf and NaN survive (the low byte of an infinity is 0).
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void r3_encode(const f32x4& v, u32x2_t& hi, unsigned& lo) {
+    unsigned t[4], x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ve = v[e];
+        const unsigned b = __float_as_uint(ve);
+        x[e] = b + 0x80u;            // byte 1 = lo
+        t[e] = b + 0x8080u;          // bytes 3:2 = hi
+    }
+    hi[0] = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u);
+    hi[1] = __builtin_amdgcn_perm(t[3], t[2], 0x07060302u);
+    const unsigned p01 = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0501u);
+    const unsigned p23 = __builtin_amdgcn_perm(x[3], x[2], 0x0c0c0501u);
+    lo = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+__device__ __forceinline__ f32x4 r3_decode(const u32x2_t& hi, unsigned lo) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned h = (e & 1) ? (hi[e >> 1] & 0xffff0000u) : (hi[e >> 1] << 16);
+        const int s = __builtin_amdgcn_sbfe((int)lo, 8 * e, 8);
+        r[e] = __uint_as_float((unsigned)(s << 8) + h);
+    }
+    return r;
+}
+__device__ __forceinline__ float r3_decode1(bf16 hi, signed char lo) {
+    unsigned short hb; __builtin_memcpy(&hb, &hi, 2);
+    const unsigned h = (unsigned)hb << 16;
+    return __uint_as_float(h + (unsigned)((int)lo << 8));
+}
+__device__ __forceinline__ void r3_encode1(float v, bf16& hi, signed char& lo) {
+    const unsigned b = __float_as_uint(v);
+    const unsigned short hb = (unsigned short)((b + 0x8080u) >> 16);
+    __builtin_memcpy(&hi, &hb, 2);
+    lo = (signed char)(((b + 0x80u) >> 8) & 0xffu);
+}
+
 // 32x32 accumulator element r of lane l sits at (row, col):
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }

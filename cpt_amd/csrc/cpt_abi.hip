@@ -136,6 +136,7 @@ int cpt_check_device(int dev) {
 static int g_fold_ln = 1;      // bf16 mode with cpt_model.fold: fold the encoder LayerNorms into the GEMMs (0 = run them as kernels)
 static int g_fuse_attn = 1;    // bf16, L <= 128: QKV projection + attention in one kernel (0 = two kernels; 2 = one workgroup per CU)
 static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
+static int g_resid3 = 1;       // fused bf16 encoder: residual stream in the 3-byte form (bf16 hi + int8 lo) instead of fp32 + bf16 copies
 
 int cpt_set_tuning(int key, int value) {
     if (key == 4) { g_lp_resid = value; return CPT_OK; }
@@ -146,6 +147,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 2) { cpt::set_attn_bwd_variant(value); return CPT_OK; }
     if (key == 3) { cpt::set_splitk_target(value); return CPT_OK; }
     if (key == 7) { cpt::set_gemm_skew(value); return CPT_OK; }
+    if (key == 9) { g_resid3 = value; return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
 }
@@ -223,6 +225,21 @@ int cpt_gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float
                      int M, int N, int K, void* stream) {
     return check_launch(cpt::gemm_ln_prod(A, lda, W, ldw, bias, resid, ldr, st_in, g_in, b_in, eps, hidden, out_f32, out_lp, st_out, ldo,
                                           M, N, K, (hipStream_t)stream), "cpt_gemm_ln_prod");
+}
+
+int cpt_gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
+                      const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi, void* out_lo,
+                      float* st_out, int ldo, int M, int N, int K, void* stream) {
+    return check_launch(cpt::gemm_ln_prod3(A, lda, W, ldw, bias, resid_hi, resid_lo, ldr, st_in, g_in, b_in, eps, hidden, out_hi, out_lo, st_out, ldo,
+                                           M, N, K, (hipStream_t)stream), "cpt_gemm_ln_prod3");
+}
+
+int cpt_resid3_split(const float* x, void* hi_bf16, void* lo_i8, size_t n, void* stream) {
+    return check_launch(cpt::r3_split(x, hi_bf16, lo_i8, n, (hipStream_t)stream), "cpt_resid3_split");
+}
+
+int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, void* stream) {
+    return check_launch(cpt::r3_merge(hi_bf16, lo_i8, pos, out, R, L, H, gather, (hipStream_t)stream), "cpt_resid3_merge");
 }
 
 int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,
@@ -329,9 +346,15 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const bool fold = lp && m->fold && g_fold_ln && !g_lp_resid;
     const bool fuse_attn = lp && g_fuse_attn && L <= 128 && H % 64 == 0;
     const bool pre_ln = fold && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS));   // x_f32 left un-normalised after the encoder
+    // 3-byte residual stream (common.h r3_encode): the pre-LayerNorm sums live as bf16 hi (x_lp / a_lp, the GEMM operands) +
+    // int8 lo (the head of the `pre` / a_f32 regions); the producers read and write 3 + 3 bytes per element instead of 4 + 6.
+    const bool r3 = fold && g_resid3;
+    void* x_lo = pre;
+    void* a_lo = a_f32;
     if (fold) {
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
         // producer GEMMs accumulate their row sums, the consumer GEMMs normalise in their epilogue.
+        if (r3) { Scope p(CPT_K_EMBED, s); TRY(cpt::r3_split(x_f32, x_lp, x_lo, (size_t)M * H, s), "resid3_split(embeddings)"); }
         float* stats = (float*)(ws + w.stats);         // [layers][2] tables of [M][slots][2] partial row sums (no zeroing needed)
         const size_t tbl = (size_t)cpt::ln_stat_slots(H) * M * 2;
         for (int l = 0; l < d.layers; ++l) {
@@ -355,11 +378,17 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
               TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s), "attention"); }
             }
             { Scope p(CPT_K_GEMM_AO, s);
+              if (r3) TRY(cpt::gemm_ln_prod3(ctx, H, y.w_ao, H, y.b_ao, x_lp, x_lo, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
+                                             a_lp, a_lo, st1, H, M, H, H, s), "gemm(attn out, LN producer, 3-byte residual)");
+              else
               TRY(cpt::gemm_ln_prod(ctx, H, y.w_ao, H, y.b_ao, x_f32, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
                                     a_f32, a_lp, st1, H, M, H, H, s), "gemm(attn out, LN producer)"); }
             { Scope p(CPT_K_GEMM_FFN1, s);
               TRY(cpt::gemm_ln_cons(a_lp, H, f.w_in_f, H, st1, f.c_in, f.d_in, d.ln_eps, H, 1, ffn, I, M, I, H, s), "gemm(ffn up, folded LN)"); }
             { Scope p(CPT_K_GEMM_FFN2, s);
+              if (r3) TRY(cpt::gemm_ln_prod3(ffn, I, y.w_out, I, y.b_out, a_lp, a_lo, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_lp, x_lo, st2, H, M, H, I, s),
+                          "gemm(ffn down, LN producer, 3-byte residual)");
+              else
               TRY(cpt::gemm_ln_prod(ffn, I, y.w_out, I, y.b_out, a_f32, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_f32, x_lp, st2, H, M, H, I, s),
                   "gemm(ffn down, LN producer)"); }
         }
@@ -367,6 +396,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         const cpt_layer& yl = m->layers[d.layers - 1];
         if (flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) {
             Scope p(CPT_K_LN, s);
+            if (r3) TRY(cpt::r3_merge(x_lp, x_lo, nullptr, x_f32, M, L, H, 0, s), "resid3_merge(all rows)");
             TRY(cpt::layernorm_rows(x_f32, yl.ln2_g, yl.ln2_b, d.ln_eps, x_f32, x_lp, dt, M, H, M, 0, 0, s), "layernorm(final)");
         }
     } else
@@ -410,7 +440,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         if (pre_ln) {
             const cpt_layer& yl = m->layers[d.layers - 1];
             float* rf = (float*)(ws + w.rows_f32);
-            TRY(cpt::gather_rows(x_f32, CPT_F32, nullptr, rf, B, L, H, s), "gather([CLS] pre-LN)");
+            if (r3) TRY(cpt::r3_merge(x_lp, x_lo, nullptr, rf, B, L, H, 1, s), "resid3_merge([CLS] pre-LN)");
+            else TRY(cpt::gather_rows(x_f32, CPT_F32, nullptr, rf, B, L, H, s), "gather([CLS] pre-LN)");
             TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, rows, dt, B, H, B, 0, 0, s), "layernorm([CLS] rows)");
         } else
         TRY(cpt::gather_rows(x_lp, dt, nullptr, rows, B, L, H, s), "gather([CLS])");
@@ -438,7 +469,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
             if (pre_ln) {
                 const cpt_layer& yl = m->layers[d.layers - 1];
                 float* rf = (float*)(ws + w.rows_f32);
-                TRY(cpt::gather_rows(x_f32, CPT_F32, b->mask_pos, rf, B, L, H, s), "gather([MASK] pre-LN)");
+                if (r3) TRY(cpt::r3_merge(x_lp, x_lo, b->mask_pos, rf, B, L, H, 1, s), "resid3_merge([MASK] pre-LN)");
+                else TRY(cpt::gather_rows(x_f32, CPT_F32, b->mask_pos, rf, B, L, H, s), "gather([MASK] pre-LN)");
                 TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, g, dt, B, H, B, 0, 0, s), "layernorm([MASK] rows)");
             } else {
                 TRY(cpt::gather_rows(x_lp, dt, b->mask_pos, g, B, L, H, s), "gather([MASK])");

@@ -141,6 +141,7 @@ constexpr int CPT_EPI_LNCONS = 7;      // internal: A operand is a pre-LayerNorm
 constexpr int CPT_EPI_LNCONS_GELU = 8; // internal: same + GELU
 constexpr int CPT_EPI_ATTN = 9;        // internal: fused QKV projection + self-attention of one (sequence, head) per workgroup
 constexpr int CPT_EPI_ATTN_LN = 10;    // internal: same, A operand is a pre-LayerNorm tensor (LayerNorm folded like LNCONS)
+constexpr int CPT_EPI_LNPROD3 = 11;    // internal: LNPROD with the residual stream in the 3-byte form (bf16 hi + int8 lo, see r3_encode): in and out
 
 // ---------------------------------------------------------------------------------------------
 // Pipelined kernel: STAGES-deep LDS ring fed by LDS-DMA with COUNTED vmcnt waits (tiles stay in
@@ -161,6 +162,8 @@ struct EpiX {
     float* st_out;         // LNPROD: partial row sums of this GEMM's output, slot = output column / 96
     int st_out_slots;      // slots per row of st_out (ln_stat_slots of this GEMM's N)
     void* out_lp;          // LNPROD: copy of the output in the compute dtype
+    const signed char* resid_lo;  // LNPROD3: low bytes of the residual (its bf16 hi part travels in `resid`)
+    signed char* out_lo;          // LNPROD3: low bytes of the output (hi part -> out_lp; no fp32 copy is written)
     const float* colc;     // LNCONS: c[n] = sum_k W'[n][k]  (W' = gain-folded weight as the MFMA sees it)
     const float* cold;     // LNCONS: d[n] = sum_k beta[k] W[n][k] + bias[n]
     float eps, inv_h;      // LayerNorm eps, 1 / hidden
@@ -683,11 +686,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     unsigned char* slab = smem + wave * (16 * CPW);
     unsigned char* side = smem + NW * (16 * CPW) + wave * SIDE;
     const int wrow0 = m0 + wm * (MI * 32), wcol0 = n0 + wn * WCOLS;
-    constexpr bool LNPROD = EPI == CPT_EPI_LNPROD;
+    constexpr bool R3 = EPI == CPT_EPI_LNPROD3;                  // residual stream in the 3-byte form (r3_encode), in and out
+    constexpr bool LNPROD = EPI == CPT_EPI_LNPROD || R3;
     constexpr bool LNCONS = EPI == CPT_EPI_LNCONS || EPI == CPT_EPI_LNCONS_GELU;
     constexpr bool HAS_RESID = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || LNPROD;
     constexpr bool DO_GELU = EPI == CPT_EPI_GELU || EPI == CPT_EPI_LNCONS_GELU;
-    const T* resid_lp = reinterpret_cast<const T*>(resid);      // EPI_RESID_LP: same rows, compute dtype
+    const T* resid_lp = reinterpret_cast<const T*>(resid);      // EPI_RESID_LP: same rows, compute dtype; LNPROD3: the hi part
     const bool fold_resid = LNPROD && ex.g_in != nullptr;       // residual = LayerNorm(resid; st_in, g_in, b_in)
     // fp32 outputs without residual (e.g. the vocabulary decoder, ldo = 30522): rows are only 8-byte aligned, but 16-byte
     // stores to dword-aligned addresses are legal (the HSA target runs in unaligned-access mode) -- no alignment demand.
@@ -719,7 +723,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col];
         if (EPI == CPT_EPI_RESID_LP) x += to_f32(resid_lp[(size_t)row * ldr + col]);
         if constexpr (LNPROD) {
-            float r = resid[(size_t)row * ldr + col];
+            float r;
+            if constexpr (R3) r = r3_decode1(reinterpret_cast<const bf16*>(resid)[(size_t)row * ldr + col], ex.resid_lo[(size_t)row * ldr + col]);
+            else r = resid[(size_t)row * ldr + col];
             if (fold_resid) {
                 float mu, rs;
                 stats_of(row, mu, rs);
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             }
         }
         // residual rows, loaded one slice ahead of their use
-        struct Aux { f32x4 r[HAS_RESID ? NIT : 1]; };
+        struct Aux { f32x4 r[(HAS_RESID && !R3) ? NIT : 1]; u32x2_t h[R3 ? NIT : 1]; unsigned l[R3 ? NIT : 1]; };
         auto load_aux = [&](int sl, Aux& a) {
             if (abl & 128) return;                    // ablation: no residual loads
 #pragma unroll
@@ -786,6 +792,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                 const int row = crow(wrow0 + sl * 16 + rr);
                 if constexpr (HAS_RESID) {
                     const size_t off = (size_t)row * ldr + ccol(wcol0 + ch * 4);
+                    if constexpr (R3) {                // raw loads only: decoding here would wait for them one slice early
+                        a.h[it] = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16*>(resid) + off);
+                        a.l[it] = *reinterpret_cast<const unsigned*>(ex.resid_lo + off);
+                    } else
                     if constexpr (EPI == CPT_EPI_RESID_LP && sizeof(T) == 2) {
                         const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(resid_lp + off);
                         a.r[it] = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
@@ -831,6 +841,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         t4 = *reinterpret_cast<const f32x4*>(side_t + ch * 4);
                     }
                     const float mu = ms.x, rs = ms.y;
+                    f32x4 rr4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (R3) rr4 = r3_decode(ax.h[it], ax.l[it]);
+                    else if constexpr (HAS_RESID) rr4 = ax.r[it];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if constexpr (LNCONS) v[e] = ln_fold(v[e], mu, rs, cv[it % P][e], bv[it % P][e]);
@@ -845,13 +858,19 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         float x = v[e];
                         if constexpr (DO_GELU && sizeof(T) != 2) x = gelu_for<T>(x);
                         if (EPI == CPT_EPI_TANH) x = tanhf(x);
-                        if constexpr (LNPROD) x += ln_apply(ax.r[it][e], mu, rs, g4[e], t4[e]);     // mu=0, rs=1, g=1, b=0 when not folded
-                        else if constexpr (HAS_RESID) x += ax.r[it][e];
+                        if constexpr (LNPROD) x += ln_apply(rr4[e], mu, rs, g4[e], t4[e]);     // mu=0, rs=1, g=1, b=0 when not folded
+                        else if constexpr (HAS_RESID) x += rr4[e];
                         v[e] = x;
                     }
                   }
                   const bool in_mat = !GUARD || (row < M && col < N);
                   if (abl & 64) { asm volatile("" :: "v"(v)); } else if (in_mat) {   // ablation 64: no global stores
+                    if constexpr (R3) {
+                        u32x2_t hq; unsigned lq;
+                        r3_encode(v, hq, lq);
+                        *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16*>(ex.out_lp) + (size_t)row * ldo + col) = hq;
+                        *reinterpret_cast<unsigned*>(ex.out_lo + (size_t)row * ldo + col) = lq;
+                    } else
                     if constexpr (sizeof(OT) == 2) {
                         bf16x4 pk;
 #pragma unroll
@@ -863,7 +882,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     } else {
                         *reinterpret_cast<f32x4_u*>(out + (size_t)row * ldo + col) = v;
                     }
-                    if constexpr (LNPROD) {
+                    if constexpr (LNPROD && !R3) {
                         T* olp = reinterpret_cast<T*>(ex.out_lp) + (size_t)row * ldo + col;
                         if constexpr (sizeof(T) == 2) {
                             bf16x4 pk;
@@ -886,9 +905,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         for (int e = 0; e < 4; ++e) {
                             if (col + e < N) {
                                 const float x = finish1(v[e], row, col + e);
+                                if constexpr (R3) {
+                                    bf16 hq; signed char lq;
+                                    r3_encode1(x, hq, lq);
+                                    reinterpret_cast<bf16*>(ex.out_lp)[(size_t)row * ldo + col + e] = hq;
+                                    ex.out_lo[(size_t)row * ldo + col + e] = lq;
+                                } else {
                                 if constexpr (EPI == CPT_EPI_ATOMIC && sizeof(OT) == 4) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, x);
                                 else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
                                 if constexpr (LNPROD) reinterpret_cast<T*>(ex.out_lp)[(size_t)row * ldo + col + e] = from_f32<T>(x);
+                                }
                                 fin[e] = x;
                             }
                         }
@@ -996,7 +1022,7 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         long best_cost = -1;
         // residual-type epilogues do not fit the 168 (12 waves) / 128 (two workgroups per CU) register caps without
         // scratch spills, and a spilling instance runs 3-5x slower: those shapes are not candidates for them
-        constexpr bool heavy_epi = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || EPI == CPT_EPI_LNPROD;
+        constexpr bool heavy_epi = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || EPI == CPT_EPI_LNPROD || EPI == CPT_EPI_LNPROD3;
         for (int i = 0; i < 9; ++i) {
             if (cand[i].bm == 0 || (heavy_epi && (i == 3 || i == 4))) continue;
             const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
@@ -1126,6 +1152,24 @@ int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bi
     ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
     launch_fast<bf16, CPT_EPI_LNPROD, float>(g_gemm_variant >= 3 ? g_gemm_variant : 3, (const bf16*)A, lda, (const bf16*)W, ldw, bias,
                                             resid, ldr, out_f32, ldo, M, N, K, s, &ex);
+    return CPT_OK;
+}
+
+// Same producer with the residual stream in the 3-byte form (r3_encode): residual = (resid_hi bf16, resid_lo int8) [M][ldr],
+// output = (out_hi bf16 = the next GEMM's A operand, out_lo int8) [M][ldo]; no fp32 tensor is read or written.
+int gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
+                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
+                  void* out_hi, void* out_lo, float* st_out, int ldo, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
+    if (!A || !W || !resid_hi || !resid_lo || !out_hi || !out_lo || !st_out) return CPT_ERR_NULL;
+    if (N % 8 || ldo % 8 || ldr % 8 || (((uintptr_t)out_hi | (uintptr_t)out_lo | (uintptr_t)resid_hi | (uintptr_t)resid_lo | (uintptr_t)bias | (uintptr_t)g_in | (uintptr_t)b_in) & 15))
+        return CPT_ERR_ALIGN;
+    EpiX ex = {};
+    ex.st_in = st_in; ex.st_in_parts = ln_stat_parts(hidden); ex.g_in = g_in; ex.b_in = b_in; ex.st_out = st_out; ex.st_out_slots = ln_stat_slots(N); ex.out_lp = out_hi;
+    ex.resid_lo = (const signed char*)resid_lo; ex.out_lo = (signed char*)out_lo;
+    ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
+    launch_fast<bf16, CPT_EPI_LNPROD3, float>(g_gemm_variant >= 3 ? g_gemm_variant : 3, (const bf16*)A, lda, (const bf16*)W, ldw, bias,
+                                             (const float*)resid_hi, ldr, (float*)nullptr, ldo, M, N, K, s, &ex);
     return CPT_OK;
 }
 

@@ -62,6 +62,12 @@ int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw,
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
                  float* out_f32, void* out_lp, float* st_out, int ldo, int M, int N, int K, hipStream_t s);
+// the same producer with the residual stream in the 3-byte form (common.h: r3_encode), in and out
+int gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
+                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
+                  void* out_hi, void* out_lo, float* st_out, int ldo, int M, int N, int K, hipStream_t s);
+int r3_split(const float* x, void* hi_bf16, void* lo_i8, size_t n, hipStream_t s);
+int r3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, hipStream_t s);
 int ln_stat_parts(int n_cols);      // 96-column blocks of a gemm_ln_prod of n_cols columns
 int ln_stat_slots(int n_cols);      // slots per row of the partial row-sum table [M][slots][2] it fills
 int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,

@@ -302,6 +302,44 @@ int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B
     return CPT_OK;
 }
 
+// ---- 3-byte residual stream (common.h: r3_encode) -----------------------------------------------
+// split: x fp32 [n] -> hi bf16 [n] + lo int8 [n] (the encoder input, once per forward);  merge: the inverse, either for
+// every row or for one gathered row per sequence (pos NULL: row 0) -- what the heads read after the last layer.
+__global__ __launch_bounds__(256) void r3_split_kernel(const f32x4* __restrict__ x, u32x2_t* __restrict__ hi, unsigned* __restrict__ lo, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        u32x2_t h; unsigned l;
+        r3_encode(x[i], h, l);
+        hi[i] = h; lo[i] = l;
+    }
+}
+int r3_split(const float* x, void* hi, void* lo, size_t n, hipStream_t s) {
+    if (!x || !hi || !lo) return CPT_ERR_NULL;
+    if (n % 4 || (((uintptr_t)x | (uintptr_t)hi | (uintptr_t)lo) & 15)) return CPT_ERR_ALIGN;
+    const size_t n4 = n / 4;
+    if (n4 == 0) return CPT_OK;
+    const int blocks = (int)min((n4 + 255) / 256, (size_t)4096);
+    r3_split_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const f32x4*)x, (u32x2_t*)hi, (unsigned*)lo, n4);
+    return CPT_OK;
+}
+__global__ __launch_bounds__(256) void r3_merge_kernel(const u32x2_t* __restrict__ hi, const unsigned* __restrict__ lo, const int64_t* __restrict__ pos,
+                                                       f32x4* __restrict__ out, int R, int L, int gather, int q) {
+    // one block per output row; gather: row r reads source row r * L + clamp(pos[r]) (pos NULL: 0), else source row r
+    const int r = blockIdx.x;
+    size_t src = r;
+    if (gather) {
+        long p = pos ? pos[r] : 0;
+        p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+        src = (size_t)r * L + p;
+    }
+    for (int c = threadIdx.x; c < q; c += 256) out[(size_t)r * q + c] = r3_decode(hi[src * q + c], lo[src * q + c]);
+}
+int r3_merge(const void* hi, const void* lo, const int64_t* pos, float* out, int R, int L, int H, int gather, hipStream_t s) {
+    if (!hi || !lo || !out) return CPT_ERR_NULL;
+    if (R <= 0 || H % 4 || (gather && L <= 0)) return CPT_ERR_SHAPE;
+    r3_merge_kernel<<<dim3(R), dim3(256), 0, s>>>((const u32x2_t*)hi, (const unsigned*)lo, pos, (f32x4*)out, R, L, gather, H / 4);
+    return CPT_OK;
+}
+
 // ---- cross entropy over rows (ignore_index = -1) ----------------------------------------------
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                       float* __restrict__ loss, float* __restrict__ dlogits, int R, int V) {

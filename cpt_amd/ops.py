@@ -125,6 +125,46 @@ def row_stats_table(x, hidden=None):
     return st
 
 
+def resid3_split(x):
+    """fp32 x -> (hi bf16, lo int8) of the 3-byte residual stream (include/cpt_hip.h cpt_resid3_split)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    hi = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    lo = torch.empty(x.shape, device=x.device, dtype=torch.int8)
+    L.check(L.lib().cpt_resid3_split(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), L.stream_ptr()), "cpt_resid3_split")
+    return hi, lo
+
+
+def resid3_merge(hi, lo, pos=None, L_rows=None):
+    """(hi, lo)[R*][H] -> fp32; with L_rows: one row per group of L_rows source rows, row pos[r] of group r (pos None: row 0)."""
+    _need_cuda(hi, lo)
+    H = hi.size(-1)
+    if L_rows is None:
+        R = hi.numel() // H
+        out = torch.empty((R, H), device=hi.device, dtype=torch.float32)
+        L.check(L.lib().cpt_resid3_merge(hi.data_ptr(), lo.data_ptr(), None, out.data_ptr(), R, 1, H, 0, L.stream_ptr()), "cpt_resid3_merge")
+        return out
+    R = hi.numel() // H // L_rows
+    out = torch.empty((R, H), device=hi.device, dtype=torch.float32)
+    L.check(L.lib().cpt_resid3_merge(hi.data_ptr(), lo.data_ptr(), L.ptr(pos), out.data_ptr(), R, L_rows, H, 1, L.stream_ptr()), "cpt_resid3_merge")
+    return out
+
+
+def gemm_ln_prod3(a, w, bias, resid_hi, resid_lo, st_in=None, g_in=None, b_in=None, eps=1e-12, hidden=None):
+    """gemm_ln_prod with the residual and the output in the 3-byte form: returns (out_hi bf16, out_lo int8, st_out)."""
+    _need_cuda(a, w, bias, resid_hi, resid_lo)
+    M, K = a.shape
+    N = w.size(0)
+    hidden = hidden or N
+    out_hi = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    out_lo = torch.empty((M, N), device=a.device, dtype=torch.int8)
+    st_out = torch.zeros((M, ln_stat_slots(N), 2), device=a.device, dtype=torch.float32)
+    L.check(L.lib().cpt_gemm_ln_prod3(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), L.ptr(bias), resid_hi.data_ptr(), resid_lo.data_ptr(),
+                                      resid_hi.stride(0), L.ptr(st_in), L.ptr(g_in), L.ptr(b_in), float(eps), hidden, out_hi.data_ptr(),
+                                      out_lo.data_ptr(), st_out.data_ptr(), out_hi.stride(0), M, N, K, L.stream_ptr()), "cpt_gemm_ln_prod3")
+    return out_hi, out_lo, st_out
+
+
 def gemm_ln_cons(a, wf, st_in, colc, cold, eps, hidden, gelu):
     """[gelu]( rstd * (a @ wf.T - mean * colc) + cold ): bf16 a[M,K], wf[N,K]; st_in from row_stats_table / gemm_ln_prod."""
     _need_cuda(a, wf, st_in, colc, cold)

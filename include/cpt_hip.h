@@ -314,6 +314,20 @@ int cpt_gemm_ln_prod(const void* A_bf16, int lda, const void* W_bf16, int ldw, c
                      const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, float* out_f32,
                      void* out_bf16, float* st_out, int ldo, int M, int N, int K, void* stream);
 
+/* The producer with the residual stream in the 3-byte form (round 2; cpt_model_fwd's default in bf16 mode, cpt_set_tuning(9, 0)
+ * restores the fp32 + bf16 pair): a pre-LayerNorm sum x travels as T = its fp32 pattern rounded to 24 bits (round half away),
+ * hi = (T + 0x80) >> 8 as a plain bf16 tensor (the next GEMM's A operand) and lo = the signed byte T - (hi << 8);
+ * x' = ((hi << 8) + lo) << 8, |x' - x| <= 2^-17 |x|.  3 + 3 bytes per element through the epilogue instead of 4 + 6.
+ *   cpt_gemm_ln_prod3: as cpt_gemm_ln_prod with resid = (resid_hi bf16, resid_lo int8) [M][ldr], out = (out_hi bf16, out_lo int8) [M][ldo]
+ *   cpt_resid3_split:  x fp32 [n] -> hi, lo (n % 4 == 0, 16-byte aligned)
+ *   cpt_resid3_merge:  the inverse into out fp32 [R][H]; gather = 0: source row r; gather = 1: source row r * L + pos[r]
+ *                      (pos NULL: r * L), the rows the heads read (modeling_rec.py:143, modeling_bert.py:275) */
+int cpt_gemm_ln_prod3(const void* A_bf16, int lda, const void* W_bf16, int ldw, const float* bias, const void* resid_hi, const void* resid_lo,
+                      int ldr, const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi, void* out_lo,
+                      float* st_out, int ldo, int M, int N, int K, void* stream);
+int cpt_resid3_split(const float* x, void* hi_bf16, void* lo_i8, size_t n, void* stream);
+int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, void* stream);
+
 /* Split-operand copy for CPT_BF16X3: x fp32 [R][K] (leading dimension ld) -> out bf16 [R][3K] holding, per row, the blocks
  * hi | hi | lo (weight_order 0: activations) or hi | lo | hi (weight_order 1: nn.Linear weights), hi = bf16(x),
  * lo = bf16(x - hi).  A bf16 GEMM of the two over K' = 3K is x.w to ~2^-16 relative. */
@@ -350,7 +364,8 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 4  1 = bf16 residual stream in the kernel-per-op bf16 encoder (default 0: fp32 residual)
  *   key 5  0 = run the encoder LayerNorms as kernels even when cpt_model.fold is given (default 1: folded)
  *   key 6  QKV projection + attention: 0 = two kernels, 1 (default) = fused, two workgroups per CU,
- *          2 = fused, one workgroup per CU (bf16, L <= 128 only; otherwise always two kernels) */
+ *          2 = fused, one workgroup per CU (bf16, L <= 128 only; otherwise always two kernels)
+ *   key 9  residual stream of the fused bf16 encoder: 1 (default) = 3-byte form (cpt_gemm_ln_prod3), 0 = fp32 + bf16 copies */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
  * start / after prologue issue / after K loop / after staging / end, and the XCC id). */

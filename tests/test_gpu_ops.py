@@ -305,6 +305,84 @@ def test_ln_consumer_kernels_are_bit_identical(dev):
         assert torch.equal(outs[3][:960], outs[(v, "small")]), "variant %d, 960-row problem" % v
 
 
+def _r3_encode_np(x):
+    """CPU restatement of the 3-byte residual code (csrc/common.h r3_encode): T = fp32 pattern rounded half away to 24 bits,
+    hi = (T + 0x80) >> 8 (a bf16 pattern), lo = int8(T - (hi << 8))."""
+    b = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    hi = (((b + 0x8080) >> 16) & 0xffff).astype(np.uint16)
+    lo = (((b + 0x80) >> 8) & 0xff).astype(np.uint8).view(np.int8)
+    return hi, lo
+
+
+def _r3_decode_np(hi, lo):
+    v = ((hi.astype(np.int64) << 16) + (lo.astype(np.int64) << 8)) & 0xffffffff
+    return v.astype(np.uint32).view(np.float32)
+
+
+def test_resid3_codec_matches_restatement(dev):
+    """3-byte residual stream: the device split / merge kernels equal the numpy restatement bit for bit (incl. zeros, denormals,
+    infinities, values that round up into the next exponent, lo = -128 / 127), hi is a legal bf16 within one bf16 ulp of RNE,
+    and decode(encode(x)) is within 2^-17 relative."""
+    from cpt_amd import ops
+    rng = _rng(31)
+    x = (rng.standard_normal(1 << 16) * np.exp(rng.uniform(-20, 20, 1 << 16))).astype(np.float32)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, 1e-40, -1e-40, 3.4028235e38, 1.0, -1.0], np.float32)
+    pats = np.array([0x3f807f80, 0x3f808080, 0x3f80807f, 0x3f7fff80, 0x3f7fffff, 0x7f7fff7f, 0x00000080, 0x3f800080, 0xbf80ff80], np.uint32).view(np.float32)
+    x[:special.size] = special
+    x[special.size:special.size + pats.size] = pats
+    hi_ref, lo_ref = _r3_encode_np(x)
+    xt = torch.from_numpy(x).to(dev).view(256, 256)
+    hi, lo = ops.resid3_split(xt)
+    assert np.array_equal(hi.view(torch.int16).cpu().numpy().view(np.uint16).ravel(), hi_ref)
+    assert np.array_equal(lo.cpu().numpy().ravel(), lo_ref)
+    back = ops.resid3_merge(hi, lo).cpu().numpy().ravel()
+    ref_back = _r3_decode_np(hi_ref, lo_ref)
+    assert np.array_equal(back.view(np.uint32), ref_back.view(np.uint32))
+    fin = np.isfinite(x) & (np.abs(x) > 1e-37) & (np.abs(x) < 1e38)
+    assert np.max(np.abs(back[fin] - x[fin]) / np.abs(x[fin])) <= 2.0 ** -16
+    assert np.array_equal(back[~np.isfinite(x)], x[~np.isfinite(x)])
+    rne = torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16).astype(np.int64)
+    ok = np.isfinite(x)
+    assert np.max(np.abs(hi_ref.astype(np.int64)[ok] - rne[ok])) <= 1
+    # gathered rows: row pos[r] of every group of L rows
+    pos = torch.tensor([3, 0, 7, 15] * 4, dtype=torch.int64, device=dev)
+    g = ops.resid3_merge(hi, lo, pos, 16).cpu().numpy()
+    want = back.reshape(16, 16, 256)[np.arange(16), pos.cpu().numpy()]
+    assert np.array_equal(g, want)
+
+
+@pytest.mark.parametrize("K", [768, 3072])
+def test_gemm_ln_prod3_matches_fp32_producer(dev, K):
+    """The 3-byte producer against the fp32 producer on the same operands: with the residual given as (hi, lo) and as the fp32
+    values those decode to, the outputs agree to the code's resolution (decode(out3) vs out_f32 within 2^-16 relative + the
+    residual's own 2^-17), out_hi is the code's hi of out_f32 up to that resolution, the row sums are equal to 1e-6 relative;
+    rows are batch invariant bit for bit (ragged M included)."""
+    from cpt_amd import ops
+    rng = _rng(K)
+    M, H = 1000, 768
+    x = (_t(rng, M, H, scale=1.2) + 0.3).to(dev)
+    hi, lo = ops.resid3_split(x)
+    xq = ops.resid3_merge(hi, lo)                      # what the (hi, lo) pair holds exactly
+    st = ops.row_stats_table(x)
+    a = _t(rng, M, K).to(torch.bfloat16).to(dev)
+    w = _t(rng, H, K, scale=0.03).to(torch.bfloat16).to(dev)
+    bias, g, bt = _t(rng, H, scale=0.1).to(dev), (1 + _t(rng, H, scale=0.1)).to(dev), _t(rng, H, scale=0.1).to(dev)
+    for fold in (True, False):
+        gi, bi, si = (g, bt, st) if fold else (None, None, None)
+        o_f32, o_bf16, st_f32 = ops.gemm_ln_prod(a, w, bias, xq, si, gi, bi, 1e-12, H)
+        o_hi, o_lo, st3 = ops.gemm_ln_prod3(a, w, bias, hi, lo, si, gi, bi, 1e-12, H)
+        dec = ops.resid3_merge(o_hi, o_lo)
+        err = ((dec - o_f32).abs() / o_f32.abs().clamp_min(1e-3)).max().item()
+        assert err <= 2.0 ** -16, err
+        assert torch.equal(st3, st_f32)                # row sums are taken from the unrounded values in both forms
+        dh = (o_hi.view(torch.int16).int() - o_bf16.view(torch.int16).int()).abs().max().item()
+        assert dh <= 1, dh
+        for Ms in (77, 120):
+            s_hi, s_lo, s_st = ops.gemm_ln_prod3(a[:Ms].contiguous(), w, bias, hi[:Ms].contiguous(), lo[:Ms].contiguous(),
+                                                 si[:Ms].contiguous() if fold else None, gi, bi, 1e-12, H)
+            assert torch.equal(s_hi, o_hi[:Ms]) and torch.equal(s_lo, o_lo[:Ms]) and torch.equal(s_st, st3[:Ms])
+
+
 @pytest.mark.parametrize("Mbig,Msmall", [(7680, 840), (7680, 120), (1000, 77)])
 def test_operators_are_batch_invariant(dev, Mbig, Msmall):
     """Rows [0, Msmall) of a big problem equal the same rows run as their own problem, bit for bit, for the four GEMM forms of

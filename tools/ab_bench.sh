@@ -6,6 +6,6 @@ for t in "$@"; do
 import sys, json
 d = json.loads(sys.stdin.read())
 k = d['kernel_ms_per_step']
-print('tune %-8s ms/step %.4f  qkv %.3f ao %.3f up %.3f down %.3f attn %.3f ln %.3f' % ('$t', d['ms_per_step'], k['gemm_qkv'], k['gemm_attn_out'], k['gemm_ffn_up'], k['gemm_ffn_down'], k['attention'], k['layernorm']))"
+print('tune %-8s ms/step %.4f  qkv %.3f ao %.3f up %.3f down %.3f attn %.3f ln %.3f' % ('$t', d['ms_per_step'], k['gemm_qkv'], k['gemm_attn_out'], k['gemm_ffn_up'], k['gemm_ffn_down'], k.get('attention', 0), k.get('layernorm', 0)))"
 done
 done
