@@ -4,6 +4,7 @@
 // The dense parts (dgrad / wgrad) reuse the MFMA GEMM of gemm.hip on transposed, zero-padded
 // operands produced here; everything in this file is HBM-bound row / element work in fp32.
 #include "common.h"
+#include "attn_core.h"
 #include "kernels.h"
 
 namespace cpt {
@@ -685,8 +686,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 // As in the forward kernel, probabilities sit in the A-operand layout of the next MFMA once the
 // contraction index of the B operand is permuted identically, so nothing round-trips through LDS.
 __device__ __forceinline__ int kq_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// TR = true (round 2, 128 < L <= 288: the GQA / VCR few-shot shapes L = 165 + 45 and 165 + 100): the transposed copies of
+// Q, K, dO (3 x 64 x (2 LP + 8) bytes) do not fit beside four 288-row tiles, so the B operands of the products that
+// contract over rows are read from the ROW tiles with the gfx950 LDS transpose read ds_read_b64_tr_b16 (as the forward
+// kernel reads V, attn_core.h).  The row swizzle of this variant rotates the 3-bit row-pair index ((p & 1) << 2 | p >> 1):
+// still a bijection over the 8 row pairs a 16-byte fragment read touches (conflict-free), and the four consecutive rows of
+// one transpose read land in four different 32-byte bank ranges.
+__device__ __forceinline__ int kq_off_tr(int row, int chunk) {
+    const int p = (row >> 1) & 7;
+    return row * 128 + ((chunk ^ (((p & 1) << 2) | (p >> 1))) << 4);
+}
 
-template <int NKB>
+template <int NKB, bool TR = false>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
                                                             const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int B, int L, int heads,
                                                             DropSpec dr) {
@@ -697,10 +708,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
     unsigned char* sK = sQ + LP * 128;
     unsigned char* sV = sK + LP * 128;
     unsigned char* sO = sV + LP * 128;                 // dO rows
-    unsigned char* tQ = sO + LP * 128;                 // [64][LP] transposed (+pad)
+    unsigned char* tQ = sO + LP * 128;                 // [64][LP] transposed (+pad); TR: the row tiles themselves
     unsigned char* tK = tQ + 64 * TROW;
     unsigned char* tO = tK + 64 * TROW;
     float* sMask = reinterpret_cast<float*>(tO + 64 * TROW);   // [LP]
+    if constexpr (TR) { tQ = sQ; tK = sK; tO = sO; sMask = reinterpret_cast<float*>(sO + LP * 128); }
+    auto roff = [](int row, int chunk) { return TR ? kq_off_tr(row, chunk) : kq_off(row, chunk); };
     float* sM = sMask + LP;                            // row max
     float* sLi = sM + LP;                              // 1 / row sum
     float* sD = sLi + LP;                              // rowsum(dP * P)
@@ -721,10 +734,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
             v4 = *reinterpret_cast<const uint4*>(base + (size_t)r * ldq + 2 * H + c * 8);
             o4 = *reinterpret_cast<const uint4*>(dctx + ((size_t)b * L + r) * H + h * 64 + c * 8);
         }
-        *reinterpret_cast<uint4*>(sQ + kq_off(r, c)) = q4;
-        *reinterpret_cast<uint4*>(sK + kq_off(r, c)) = k4;
-        *reinterpret_cast<uint4*>(sV + kq_off(r, c)) = v4;
-        *reinterpret_cast<uint4*>(sO + kq_off(r, c)) = o4;
+        *reinterpret_cast<uint4*>(sQ + roff(r, c)) = q4;
+        *reinterpret_cast<uint4*>(sK + roff(r, c)) = k4;
+        *reinterpret_cast<uint4*>(sV + roff(r, c)) = v4;
+        *reinterpret_cast<uint4*>(sO + roff(r, c)) = o4;
+        if constexpr (!TR) {
         const bf16* qe = reinterpret_cast<const bf16*>(&q4);
         const bf16* ke = reinterpret_cast<const bf16*>(&k4);
         const bf16* oe = reinterpret_cast<const bf16*>(&o4);
@@ -733,6 +747,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
             *reinterpret_cast<bf16*>(tQ + (c * 8 + j) * TROW + r * 2) = qe[j];
             *reinterpret_cast<bf16*>(tK + (c * 8 + j) * TROW + r * 2) = ke[j];
             *reinterpret_cast<bf16*>(tO + (c * 8 + j) * TROW + r * 2) = oe[j];
+        }
         }
     }
     for (int key = tid; key < LP; key += 256) {
@@ -744,7 +759,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
 
     const int fr = lane & 31, fh = lane >> 5;
     auto rowfrag = [&](const unsigned char* tile, int row, int ks) {
-        return *reinterpret_cast<const bf16x8*>(tile + kq_off(row, 2 * ks + fh));
+        return *reinterpret_cast<const bf16x8*>(tile + roff(row, 2 * ks + fh));
     };
     auto pack8 = [&](const f32x16& x, int s2) {
         bf16x8 o;
@@ -752,7 +767,22 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
         for (int j = 0; j < 8; ++j) o[j] = (bf16)x[8 * s2 + j];
         return o;
     };
-    auto ldT = [&](const unsigned char* tile, int row, int e0) {       // 4 elements at e0, 4 at e0 + 8
+    // B operand of a product contracting over tile rows: lane (lane & 31) = head-dim column `row`, slots = tile rows
+    // e0 + [0, 4) and e0 + 8 + [0, 4)  (e0 = 32 blk + 16 s2 + 4 fh: the row order the accumulator-derived A operand uses)
+    auto ldT = [&](const unsigned char* tile, int row, int e0) {
+        if constexpr (TR) {
+            // one transpose read = a [4 rows][16 columns] block per 16-lane group: lane s points at row e0 + ((s & 15) >> 2),
+            // columns 16 ((s >> 4) & 1) + 4 (s & 3) of this 32-column block, and receives its own column (lane & 31) of the
+            // four rows.  (`row` = db * 32 + fr: only the block index db enters the address.)
+            const int r0 = e0 + ((lane & 15) >> 2);
+            const int dcol = (row & ~31) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const bf16x4 lo = lds_read_tr16(tile + kq_off_tr(r0, dcol >> 3) + (dcol & 7) * 2);
+            const bf16x4 hi = lds_read_tr16(tile + kq_off_tr(r0 + 8, dcol >> 3) + (dcol & 7) * 2);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] = lo[j]; o[4 + j] = hi[j]; }
+            return o;
+        }
         const unsigned char* p = tile + row * TROW + e0 * 2;
         const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
         const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 16);
@@ -763,6 +793,94 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
     };
 
     // ================= phase A: query blocks (lane = query) =================
+    if constexpr (TR) {
+    // Long sequences: only the scores of all key blocks stay in registers (16 NKB); the dP blocks are computed twice --
+    // once for D = rowsum(dP . P), once for dS -- instead of being held (another 16 NKB registers: spills at NKB >= 7).
+    for (int qb = wave; qb < NKB; qb += 4) {
+        f32x16 st[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sK, kb * 32 + fr, ks), rowfrag(sQ, qb * 32 + fr, ks), st[kb], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = st[kb][r] * 0.125f + sMask[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+                st[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = expf(st[kb][r] - mx); st[kb][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        const int qd = min(qb * 32 + fr, L - 1);
+        bf16x8 fo[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fo[ks] = rowfrag(sO, qb * 32 + fr, ks);
+        auto dp_block = [&](int kb) {      // gradient of the (dropped) probabilities of key block kb, transposed like st
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sV, kb * 32 + fr, ks), fo[ks], d, 0, 0, 0);
+            if (dr.thresh != 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bool keep[4];
+                    drop_attn_row4(dr, (uint32_t)blockIdx.x, qd, kb * 8 + 2 * g + fh, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[4 * g + j] = keep[j] ? d[4 * g + j] * dr.scale : 0.f;
+                }
+            }
+            return d;
+        };
+        float dd = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f32x16 d = dp_block(kb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] *= inv; dd += st[kb][r] * d[r]; }
+        }
+        dd += __shfl_xor(dd, 32, 64);
+        if (fh == 0) { sM[qb * 32 + fr] = mx; sLi[qb * 32 + fr] = inv; sD[qb * 32 + fr] = dd; }
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 d = dp_block(kb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = st[kb][r] * (d[r] - dd);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pa = pack8(d, s2);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, ldT(tK, db * 32 + fr, kb * 32 + 16 * s2 + 4 * fh), o[db], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + acc_row(r, lane);
+                if (q < L) dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = (bf16)(o[db][r] * 0.125f);
+            }
+    }
+    } else {
     for (int qb = wave; qb < NKB; qb += 4) {
         f32x16 st[NKB], dp[NKB];
 #pragma unroll
@@ -837,6 +955,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
                 if (q < L) dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = (bf16)(o[db][r] * 0.125f);
             }
     }
+    }
     __syncthreads();
 
     // ================= phase B: key blocks (lane = key) =================
@@ -901,12 +1020,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
     }
 }
 
-template <int NKB>
+template <int NKB, bool TR = false>
 static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int heads, const DropSpec& dr,
                                 hipStream_t s) {
     constexpr int LP = NKB * 32;
-    const size_t lds = (size_t)4 * LP * 128 + (size_t)3 * 64 * (LP * 2 + 8) + (size_t)4 * LP * sizeof(float);
-    auto k = attn_bwd_mfma_kernel<NKB>;
+    const size_t lds = (size_t)4 * LP * 128 + (TR ? 0 : (size_t)3 * 64 * (LP * 2 + 8)) + (size_t)4 * LP * sizeof(float);
+    auto k = attn_bwd_mfma_kernel<NKB, TR>;
     static bool done = false;
     if (lds > 64 * 1024 && !done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -917,17 +1036,23 @@ static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void
     return CPT_OK;
 }
 
-int g_attn_bwd_variant = 1;      // 1: MFMA kernel for bf16 when L <= 128; 0: generic kernel always
+int g_attn_bwd_variant = 1;      // 1: MFMA kernels for bf16 (L <= 288); 0: generic kernel always; 2: transpose-read MFMA variant also for L <= 128 (tests)
 void set_attn_bwd_variant(int v) { g_attn_bwd_variant = v; }
 
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
                   const DropSpec* drop) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
     const DropSpec dr = drop ? *drop : DropSpec{};
+    if (dtype == CPT_BF16 && g_attn_bwd_variant == 2 && L <= 128) return attn_bwd_mfma_launch<4, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
     if (dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L <= 128) {
         if (L <= 32) return attn_bwd_mfma_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
         if (L <= 64) return attn_bwd_mfma_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
         return attn_bwd_mfma_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
+    }
+    if (dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 288) {      // GQA / VCR shapes: transpose-read variant
+        if (L <= 160) return attn_bwd_mfma_launch<5, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
+        if (L <= 224) return attn_bwd_mfma_launch<7, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
+        return attn_bwd_mfma_launch<9, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
     }
     const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + (dr.thresh ? 3 : 2) * AB_QB * (L + 1) + L) * sizeof(float);
     if (lds > 160 * 1024) return CPT_ERR_SHAPE;            // L <= ~176 in this round (RefCOCO L = 120)

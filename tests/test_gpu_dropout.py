@@ -86,10 +86,13 @@ def test_exported_masks_match_cpu_restatement_and_rate(dev):
     assert not torch.equal(a, _export(dev, p, 1, 2, False, 64, 128))
 
 
-@pytest.mark.parametrize("mode,Lt,Li", [("fp32", 20, 6), ("bf16", 20, 6), ("fp32", 60, 40), ("bf16", 60, 40)])
+# (165, 45) and (165, 100): the GQA and VCR few-shot sequence lengths (Oscar/cmds/gqa/_cpt_fsl_base.sh:19,27; BASELINE config 5):
+# bf16 runs the transpose-read MFMA attention backward (csrc/bwd.hip, 128 < L <= 288), fp32 at L = 145 the generic kernel
+@pytest.mark.parametrize("mode,Lt,Li", [("fp32", 20, 6), ("bf16", 20, 6), ("fp32", 60, 40), ("bf16", 60, 40),
+                                        ("fp32", 100, 45), ("bf16", 100, 45), ("bf16", 165, 45), ("bf16", 165, 100)])
 def test_loss_and_gradients_match_oracle_with_the_same_masks(dev, mode, Lt, Li):
     p = 0.1
-    cfg = cfgmod.tiny(max_position_embeddings=96)
+    cfg = cfgmod.tiny(max_position_embeddings=max(96, Lt))
     m = _model(cfg, dev, mode, p)
     B = 3
     b = synth.make_batch(B, cfg, seed=5, max_seq_len=Lt, img_seq_len=Li, vary_regions=True)
@@ -105,7 +108,7 @@ def test_loss_and_gradients_match_oracle_with_the_same_masks(dev, mode, Lt, Li):
     assert abs(loss.item() - float(ref_loss)) < ltol, (loss.item(), float(ref_loss))
     # and the loss differs from the dropout-free one (the masks really were applied)
     free, _ = O.train_step_grads(sd, cfg.to_dict(), b)
-    assert abs(float(free) - float(ref_loss)) > 1e-3
+    assert abs(float(free) - float(ref_loss)) > 2e-4
     worst = 0.0
     for name, prm in m.named_parameters():
         g = ref.get(name)
