@@ -233,7 +233,7 @@ def main():
         cfg = cfgmod.oscar_base()
         if args.workload == "gqa":
             Lt, Li = 165, 45
-            if args.batch == 64:
+            if args.batch == 64 and not train:
                 args.batch = 256
         model = REC_MLM_CPT(cfg)
         model.load_state_dict(synth.init_state_dict(cfg, seed, head="cpt", randomize_all=False))
@@ -316,7 +316,7 @@ def main():
                 "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": ("Oscar-base CPT few-shot training step (fwd+bwd+grad all-reduce+AdamW), batch %d/GPU, "
-                                        "50 regions, seq_len 120, %s, dropout %.2g" % (B, args.dtype, cfg.hidden_dropout_prob)) if train else
+                                        "%d regions, seq_len %d+%d, %s, dropout %.2g" % (B, Li, Lt, Li, args.dtype, cfg.hidden_dropout_prob)) if train else
                                        {"refcoco": "Oscar-base CPT RefCOCO inference, batch %d/GPU, 50 regions, seq_len 120, %s, [MASK]-row logits%s",
                                         "gqa": "Oscar-base CPT GQA inference (BASELINE configs[3] shape), batch %d/GPU, 45 regions, seq_len 165+45, %s, "
                                                "[MASK]-row logits%s",

@@ -221,9 +221,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         gsum[i] = f32x4{0, 0, 0, 0};
         bsum[i] = f32x4{0, 0, 0, 0};
         const int c = (lane + 64 * i) * 4;
-        gg[i] = (i < nv && c < H) ? *reinterpret_cast<const f32x4*>(g + c) : f32x4{0, 0, 0, 0};
+        gg[i] = (g && i < nv && c < H) ? *reinterpret_cast<const f32x4*>(g + c) : f32x4{0, 0, 0, 0};
     }
     const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    if (!g) {
+        // no LayerNorm on this path (use_img_layernorm = 0, modeling_bert.py:263-264): the backward is the row gather alone
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const size_t yrow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
+#pragma unroll
+            for (int i = 0; i < LNB_MAXV; ++i) {
+                const int c = (lane + 64 * i) * 4;
+                if (i < nv && c < H) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(dy + yrow * H + c);
+                    if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)r * H + c) = o;
+                    if (dx_lp) {
+                        if constexpr (sizeof(LP) == 2) {
+                            bf16x4 p;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) p[j] = (bf16)o[j];
+                            *reinterpret_cast<bf16x4*>(dx_lp + (size_t)r * H + c) = p;
+                        } else {
+                            *reinterpret_cast<f32x4*>(dx_lp + (size_t)r * H + c) = o;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int r = r0 + wave; r < r1; r += 4) {
         const size_t yrow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
         f32x4 xv[LNB_MAXV], dv[LNB_MAXV], uv[LNB_MAXV];
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s) {
     if (R <= 0 || H % 4 || H > 256 * LNB_MAXV || grp <= 0) return CPT_ERR_SHAPE;
-    if (!dy || !x || !g || !dg || !db) return CPT_ERR_NULL;
+    if (!dy || (g && (!x || !dg || !db))) return CPT_ERR_NULL;      // g == NULL: identity (row gather only)
     const int rpb = R >= 2048 ? 16 : 8;      // rows per block: fewer blocks = fewer dgamma/dbeta atomics (2*H per block)
     dim3 grid((R + rpb - 1) / rpb), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;

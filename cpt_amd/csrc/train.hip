@@ -87,7 +87,6 @@ int check_common(const cpt_model* m, const cpt_batch* b, void* ws, size_t ws_byt
     const bool nsp = !m->w_tr && !m->w_dec && m->w_pool && m->w_rel && d.n_rel > 0;
     if (!b->labels || (!nsp && !b->mask_pos)) return abi_fail(CPT_ERR_NULL, "%s: labels (and, for the MLM head, mask_pos) are required", who);
     if (b->Li > 0 && !b->img_feats) return abi_fail(CPT_ERR_NULL, "%s: img_feats is NULL", who);
-    if (b->Li > 0 && !(d.use_img_ln && m->img_ln_g)) return abi_fail(CPT_ERR_SHAPE, "%s: training without use_img_layernorm is not implemented", who);
     if (!nsp && (!m->w_tr || !m->w_dec)) return abi_fail(CPT_ERR_NULL, "%s: model has neither the MLM head nor the NSP head (pooler + seq_relationship)", who);
     if (nsp && d.n_rel > 64) return abi_fail(CPT_ERR_SHAPE, "%s: n_rel %d > 64", who, d.n_rel);
     if (ws_bytes < w.total) return abi_fail(CPT_ERR_WORKSPACE, "%s: workspace %zu < required %zu bytes", who, ws_bytes, w.total);
@@ -170,7 +169,9 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
         TRY(cpt::gemm(dt, CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, imgpre, CPT_F32, H,
                       B * Li, H, d.img_dim_pad, s), "gemm(img_embedding)");
-        TRY(cpt::layernorm_rows(imgpre, m->img_ln_g, m->img_ln_b, d.img_ln_eps, x_f32, LB(0, w.o_xin), dt, B * Li, H, Li, L, Lt, s), "layernorm(img)");
+        const bool iln = d.use_img_ln && m->img_ln_g;       // use_img_layernorm = 0 (modeling_bert.py:263): the projection is used as is
+        TRY(cpt::layernorm_rows(imgpre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, x_f32, LB(0, w.o_xin), dt, B * Li, H, Li, L, Lt, s),
+            "layernorm(img)");
     }
     if (ph)   // BertEmbeddings' dropout on the text rows and modeling_bert.py:266 on the region rows: one pass over all rows
         TRY(cpt::dropout_rows(x_f32, nullptr, x_f32, LB(0, w.o_xin), dt, M, H, drop_spec(drop, 0, false), s), "dropout(embeddings)");
@@ -379,8 +380,9 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         const int R = B * Li;
         float* dimg = (float*)(ws + w.dimg);
         void* dimg_lp = ws + w.dimg_lp;
-        TRY(cpt::ln_bwd(dx, (const float*)(ws + w.imgpre), m->img_ln_g, d.img_ln_eps, dimg, dt == CPT_BF16 ? dimg_lp : nullptr, dt,
-                        g->img_ln_g, g->img_ln_b, R, H, Li, L, Lt, 0, s), "ln_bwd(img)");
+        const bool iln = d.use_img_ln && m->img_ln_g;
+        TRY(cpt::ln_bwd(dx, (const float*)(ws + w.imgpre), iln ? m->img_ln_g : nullptr, d.img_ln_eps, dimg, dt == CPT_BF16 ? dimg_lp : nullptr, dt,
+                        iln ? g->img_ln_g : nullptr, iln ? g->img_ln_b : nullptr, R, H, Li, L, Lt, 0, s), "ln_bwd(img)");
         TRY(cpt::colsum(dimg, CPT_F32, H, g->b_img, R, H, s), "colsum(b_img)");
         float* gimg = (float*)(ws + w.gimg);
         e = hipMemsetAsync(gimg, 0, (size_t)H * Dp * 4, s);

@@ -161,6 +161,45 @@ def test_bf16_training_reduces_loss(dev):
     assert l2 < losses[-1] + 0.05
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_no_img_layernorm_forward_and_gradients(dev, mode):
+    """use_img_layernorm = 0 (modeling_bert.py:263-264: the region projection enters the encoder without LayerNorm): logits,
+    loss and every gradient against the oracle's forward / autograd; there is no bert.LayerNorm parameter at all."""
+    from oracle import cpt_oracle as O
+    cfg = cfgmod.tiny(use_img_layernorm=0)
+    m = _model(cfg, 77, dev, mode)
+    assert not any(n.startswith("bert.LayerNorm") for n, _ in m.named_parameters())
+    b = synth.make_batch(3, cfg, seed=11, max_seq_len=20, img_seq_len=6, vary_regions=True)
+    d = {k: v.to(dev) for k, v in b.items()}
+    loss, scores = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], masked_lm_labels=d["colors"],
+                     mask_token_pos=d["mask_token_pos"])
+    loss.backward()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    sd["cls.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    ref_loss, ref = O.train_step_grads(sd, cfg.to_dict(), b)
+    ltol, gtol = (2e-4, 2e-4) if mode == "fp32" else (4e-2, 8e-2)
+    assert abs(loss.item() - float(ref_loss)) < ltol, (loss.item(), float(ref_loss))
+    n = 0
+    for name, prm in m.named_parameters():
+        g = ref.get(name)
+        if g is None:
+            continue
+        rel, mx = _rel(prm.grad, g)
+        if float(g.abs().max()) < 1e-6 and mx < (1e-5 if mode == "fp32" else 1e-3):
+            continue          # key bias
+        assert rel < gtol, (name, rel, mx)
+        n += 1
+    assert n > 25
+    # inference path of the same model
+    m.eval()
+    with torch.no_grad():
+        got = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0]
+    want = O.rec_mlm_cpt_forward(sd, cfg.to_dict(), b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                                 mask_rows_only=b["mask_token_pos"])[0]
+    err = (got.float().cpu() - want).abs().max().item()
+    assert err < (1e-3 if mode == "fp32" else 4e-2), err
+
+
 def test_attention_backward_variants_agree(dev):
     """MFMA attention backward (bf16) against the generic fp32-math kernel on the same inputs."""
     from cpt_amd import _lib as L
