@@ -148,6 +148,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 3) { cpt::set_splitk_target(value); return CPT_OK; }
     if (key == 7) { cpt::set_gemm_skew(value); return CPT_OK; }
     if (key == 9) { g_resid3 = value; return CPT_OK; }
+    if (key == 10) { cpt::set_wgrad_tn(value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
 }
@@ -240,6 +241,13 @@ int cpt_resid3_split(const float* x, void* hi_bf16, void* lo_i8, size_t n, void*
 
 int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, void* stream) {
     return check_launch(cpt::r3_merge(hi_bf16, lo_i8, pos, out, R, L, H, gather, (hipStream_t)stream), "cpt_resid3_merge");
+}
+
+int cpt_gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
+                void* stream) {
+    if (!cpt::gemm_tn_eligible(M, N, K, lda, ldw, ldo))
+        return fail(CPT_ERR_SHAPE, "cpt_gemm_tn: needs M %% 128 == 0, N %% 128 == 0 (or 192), K %% 64 == 0, lda/ldw %% 8 == 0, ldo == N (got M=%d N=%d K=%d)", M, N, K);
+    return check_launch(cpt::gemm_tn(A, lda, W, ldw, out, ldo, M, N, K, partials, partial_bytes, (hipStream_t)stream), "cpt_gemm_tn");
 }
 
 int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,

@@ -14,6 +14,7 @@
 // written to the other LDS buffer afterwards: one barrier per K-tile).
 //   T = bf16 : v_mfma_f32_32x32x16_bf16, fp32 accumulate
 //   T = f32  : v_mfma_f32_32x32x2_f32 (exact fp32; parity mode)
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -206,7 +207,20 @@ __device__ __forceinline__ void sum_parts(const float* __restrict__ st, int part
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
-template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1>
+// TN = 1 (round 2, weight gradients): out[M][N] = sum_k A[k][m] . W[k][n] -- both operands are stored with the CONTRACTION index as
+// the slow dimension (A = dY [rows][M], W = X [rows][N], K = rows), which is how the backward pass holds them.  A K-tile is 64
+// rows of each operand (the same bytes per stage as the NT form: TBM * 128 + TBN * 128), staged by LDS-DMA as row-major
+// [64][TBM] / [64][TBN] tiles whose 16-byte chunks are XOR-swizzled inside aligned groups of 8 by 2 * (row & 3) on the SOURCE
+// side, and the MFMA fragments come out of them through ds_read_b64_tr_b16 (two transpose reads = 8 consecutive contraction
+// rows of one output row/column).  A half-wave's transpose read touches 4 rows x 64 bytes (two 16-lane groups, 32 B each per row):
+// tn_swz places the four rows in the four 64-byte quarters of the 256-byte bank row for both tile pitches.  Replaces the two
+// explicit transposes per weight gradient (11 % of the training step in round 1).  Requires M % TBM == 0, N % TBN == 0,
+// K % 64 == 0 (the caller falls back to the transposed-operand form otherwise).
+// chunk-index XOR of tile row `row` (chunks per row cpr = 16: pitch 256 B, rows alias -> quarter = row & 3; cpr = 24: pitch 384 B,
+// rows alternate between the two halves of the bank row -> one more bit from row >> 1); always inside an aligned group of 8 chunks
+__device__ __forceinline__ int tn_swz(int row, int cpr) { return (cpr % 16 == 0) ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
+
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1, int TN = 0>
 __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_pipe_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
@@ -294,12 +308,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     // stage costs two SALU ops + one buffer_load...lds per 1 KiB piece and no VALU.
     constexpr int GA = TBM / 8 / NW;                  // pieces i < GA come from A, the rest from W
     static_assert((TBM / 8) % NW == 0, "A pieces must split evenly over the waves");
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
+    static_assert(!TN || (sizeof(T) == 2 && EPI == CPT_EPI_NONE && TBM % 64 == 0 && TBN % 64 == 0), "TN form: bf16, plain epilogue");
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)(TN ? K : M) * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)(TN ? K : N) * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
+    constexpr int CPRA = TBM / 8, CPRB = TBN / 8;      // TN: 16-byte chunks per tile row
     // G <= 6: one VGPR per piece, computed once.  Bigger tiles (registers go to the accumulators): the offsets are rebuilt at
     // every issue from the piece's row (2 VALU per 1 KiB piece); with an even wave count the swizzle term is the same for
     // every piece of a lane.
     constexpr bool VOFF_ARRAY = G <= 6 || ATTN;
+    static_assert(!TN || VOFF_ARRAY, "TN form keeps its piece offsets in registers");
     static_assert(VOFF_ARRAY || NW % 2 == 0, "rebuilt offsets need an even wave count");
     const int rbase = wave * 8 + (lane >> 3);
     const unsigned c16 = (unsigned)(((lane & 7) ^ ((rbase >> 1) & 7)) * 16);
@@ -311,6 +328,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         const int g = i * NW + wave;
         const int r = g * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
+        if constexpr (TN) {
+            // piece g = 64 consecutive chunk positions of the row-major [64][CPR] tile; position (row, ch) holds source chunk ch ^ 2 (row & 3)
+            const int idx = (i < GA ? g : g - TBM / 8) * 64 + lane;
+            const int cpr = i < GA ? CPRA : CPRB;
+            const int row = idx / cpr, ch = idx - row * cpr;
+            const int sch = ch ^ tn_swz(row, cpr);
+            voff[i] = i < GA ? (unsigned)(((size_t)row * lda + m0 + sch * 8) * sizeof(T))
+                             : (unsigned)(((size_t)row * ldw + n0 + sch * 8) * sizeof(T));
+        } else
         if (i < GA) voff[i] = (unsigned)(((size_t)min(m0 + r, M - 1) * lda + c * CE) * sizeof(T));
         else if constexpr (ATTN) {
             const int rw = r - TBM;                   // 0..191 -> row of the fused [3H][K] weight: (q|k|v) block, this head, row in head
@@ -321,6 +347,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     auto stage = [&](int slot, int k0) {
         if (abl & 1) return;                          // ablation: no operand traffic
         const int soff = k0 * (int)sizeof(T);
+        const int soffA = TN ? k0 * lda * (int)sizeof(T) : soff, soffW = TN ? k0 * ldw * (int)sizeof(T) : soff;   // TN: k0 counts rows
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int g = i * NW + wave;
@@ -329,8 +356,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             if constexpr (VOFF_ARRAY) vo = voff[i];
             else if (i < GA) vo = (unsigned)min(m0 + rbase + i * NW * 8, M - 1) * (unsigned)(lda * (int)sizeof(T)) + c16;
             else vo = (unsigned)min(n0 + rbase + i * NW * 8 - TBM, N - 1) * (unsigned)(ldw * (int)sizeof(T)) + c16;
-            if (i < GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lds, 16, vo, soff, 0, 0);
-            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lds, 16, vo, soff, 0, 0);
+            if (i < GA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lds, 16, vo, soffA, 0, 0);
+            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lds, 16, vo, soffW, 0, 0);
         }
     };
 
@@ -365,6 +392,31 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         if (abl & 2) return;                          // ablation: no LDS fragment reads
         const unsigned char* sa = smem + slot * STAGE_BYTES;
         const unsigned char* sw = sa + TBM * ROWB;
+        if constexpr (TN) {
+            // contraction rows ks * 16 + 8 fh + [0, 8) of tile column (block start + lane & 31): two transpose reads, 4 rows apart
+            // (same row & 3, hence the same swizzle term and a constant second address)
+            const int row = ks * 16 + 8 * fh + ((lane & 15) >> 2);
+            const int cl = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            // The reads are INLINE ASM: through the builtin hipcc puts `s_waitcnt vmcnt(0)` in front of every transpose read while
+            // an LDS-DMA is in flight (it cannot tell the tile being read from the one being filled), which serialises the ring
+            // (measured: 2200 instead of 1450 cycles per K-tile).  The compiler therefore does not track these reads either:
+            // touch() waits for them with explicit counted lgkmcnt.
+            auto tr8 = [&](const unsigned char* tile, auto cpr_tag, int col) {
+                constexpr int cpr = decltype(cpr_tag)::value;
+                const unsigned q = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(tile + (row * cpr + ((col >> 3) ^ tn_swz(row, cpr))) * 16 + (col & 7) * 2);
+                u32x2_t lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(q));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(q), "n"(4 * cpr * 16));
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t o = {lo[0], lo[1], hi[0], hi[1]};
+                return __builtin_bit_cast(bf16x8, o);
+            };
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[pb][i] = tr8(sa, std::integral_constant<int, CPRA>{}, wm * (MI * 32) + i * 32 + cl);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[pb][j] = tr8(sw, std::integral_constant<int, CPRB>{}, wn * (NJ * 32) + j * 32 + cl);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
             fa[pb][i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * (MI * 32) + i * 32 + fr, ks * 2 + fh));
@@ -385,6 +437,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     // make the compiler place its lgkmcnt wait for buffer `pb` HERE (before younger ds_reads are
     // issued) instead of in front of the MFMAs that consume it
     auto touch = [&](int pb) {
+        if constexpr (TN) {
+            // asm transpose reads (see ldfrag): buffers are read in the order 0, 1, 2, 3, 0, ... and LDS reads return in order,
+            // so buffer pb has landed once at most the reads of the buffer issued after it are outstanding (none after buffer 3)
+            static_assert(!TN || FD == 4, "TN form: four fragment buffers");
+            if (pb < 3) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MI + NJ) * 2));
+            else asm volatile("s_waitcnt lgkmcnt(0)");
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(fa[pb][i]));
 #pragma unroll
@@ -495,6 +554,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     static_assert(DIRECT || (16 * CPW + SIDE) * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
     static_assert(DIRECT || (MI * 32 <= 64 && CH <= 64), "side area is filled by one wave pass");
     if (split != 0) bias = nullptr;                   // split-K: the bias is added once
+    if constexpr (TN) out += (size_t)split * M * ldo; // TN split-K: every split writes its own partial matrix (reduced in slot order afterwards)
     if constexpr (DIRECT) {
         // ---- direct epilogue: the accumulators are TRANSPOSED (operands swapped in mma): lane = output row
         // (wrow0 + 32 i + (lane & 31)), register quad g of block j = the four consecutive columns
@@ -968,11 +1028,11 @@ extern int g_gemm_abl;
 int g_gemm_skew = 0;
 void set_gemm_skew(int v) { g_gemm_skew = v; }
 
-template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1>
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1, int TN = 0>
 static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bias, const float* resid, int ldr,
                        OT* out, int ldo, int M, int N, int K, hipStream_t s, int splitk = 1, const EpiX* ex = nullptr) {
     constexpr int LDS = STAGES * (TBM + TBN) * ROWB;     // the epilogue's per-wave slabs reuse the ring
-    auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP, FD, OCC>;
+    auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP, FD, OCC, TN>;
     static bool attr_done = false;
     if (LDS > 64 * 1024 && !attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1131,6 +1191,50 @@ int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw,
     if (dtype == CPT_F32)
         return launch_pipe<float, CPT_EPI_ATOMIC, float, 128, 192, 4, 2, 3>((const float*)A, lda, (const float*)W, ldw, nullptr, nullptr, 0, out, ldo, M, N, K, s, splitk);
     return CPT_ERR_DTYPE;
+}
+
+// ---- TN form: out[M][N] (fp32) = sum over the K rows of A[k][m] . W[k][n]  (weight gradients: A = dY, W = X) ----------------
+// K is split over enough workgroups to fill the chip when the output has few tiles (768 x 768: 24); every split writes its
+// own partial matrix into `partials` and a second kernel adds them in split order (deterministic, no atomics, no zeroing).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ out, size_t n4, int S) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = part[i];
+        for (int k = 1; k < S; ++k) { const f32x4 b = part[(size_t)k * n4 + i]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+        out[i] = a;
+    }
+}
+
+int gemm_tn_eligible(int M, int N, int K, int lda, int ldw, int ldo) {
+    return M > 0 && N > 0 && K > 0 && M % 128 == 0 && (N % 192 == 0 || N % 128 == 0) && K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldo == N;
+}
+
+int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
+            hipStream_t s) {
+    if (!gemm_tn_eligible(M, N, K, lda, ldw, ldo)) return CPT_ERR_SHAPE;
+    if (!A || !W || !out) return CPT_ERR_NULL;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)partials) & 15)) return CPT_ERR_ALIGN;
+    if ((size_t)K * (size_t)std::max(lda, ldw) * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;      // 32-bit buffer offsets
+    const bool w192 = N % 192 == 0;
+    const int tiles = (M / 128) * (N / (w192 ? 192 : 128)), nt = K / 64;
+    int S = 256 / tiles;
+    if (S > 8) S = 8;
+    if (S > nt / 3) S = nt / 3;                        // at least three K-tiles (one ring) per split
+    const size_t mat = (size_t)M * N * 4;
+    if (!partials) S = 1;
+    while (S > 1 && (size_t)S * mat > partial_bytes) --S;
+    if (S < 1) S = 1;
+    float* dst = S > 1 ? (float*)partials : out;
+    const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
+    int rc;
+    if (w192) rc = launch_pipe<bf16, CPT_EPI_NONE, float, 128, 192, 4, 2, 3, 1, 4, 1, 1>(a, lda, w, ldw, nullptr, nullptr, 0, dst, ldo, M, N, K, s, S);
+    else      rc = launch_pipe<bf16, CPT_EPI_NONE, float, 128, 128, 4, 2, 3, 1, 4, 1, 1>(a, lda, w, ldw, nullptr, nullptr, 0, dst, ldo, M, N, K, s, S);
+    if (rc != CPT_OK) return rc;
+    if (S > 1) {
+        const size_t n4 = mat / 16;
+        const int blocks = (int)std::min<size_t>((n4 + 255) / 256, 2048);
+        reduce_partials_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S);
+    }
+    return CPT_OK;
 }
 
 // ---- LayerNorm folded into the GEMMs around it (bf16 throughput path) -------------------------------

@@ -58,6 +58,11 @@ int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s);
 
+// out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients
+// without operand transposes); needs gemm_tn_eligible; `partials` (optional) holds the split-K partial matrices
+int gemm_tn_eligible(int M, int N, int K, int lda, int ldw, int ldo);
+int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
+            hipStream_t s);
 int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s);
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
@@ -83,6 +88,7 @@ int argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids, in
 int fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* colc,
                     float* cold, int N, int K, hipStream_t s);
 void set_splitk_target(int v);
+void set_wgrad_tn(int v);    // 1 (default): bf16 weight gradients through the TN GEMM; 0: explicit operand transposes
 void set_attn_bwd_variant(int v);
 void set_gemm_variant(int v);
 void set_gemm_abl(int v);

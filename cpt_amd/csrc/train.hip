@@ -12,6 +12,9 @@ namespace cpt { int abi_fail(int code, const char* fmt, ...); int abi_check(int 
 using cpt::abi_check;
 using cpt::abi_fail;
 
+namespace cpt { int g_wgrad_tn = 1; void set_wgrad_tn(int v) { g_wgrad_tn = v; } }
+using cpt::g_wgrad_tn;
+
 namespace {
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -22,7 +25,7 @@ struct TrainLayout {
     size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2;     // offsets inside a layer block
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
     size_t dx, dpre, da, dpre_lp, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
-    size_t total;
+    size_t total, tA_bytes;
     int Mp, Bp, Vp, Rp;
 };
 
@@ -60,7 +63,8 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li) {
     w.dctx = take(M * H * es);
     w.dbig = take(M * std::max(3 * H, I) * es);
     const size_t cols = std::max<size_t>({(size_t)w.Mp, (size_t)w.Bp, (size_t)w.Rp});
-    w.tA = take(std::max<size_t>({3 * H, I, V}) * cols * es);
+    w.tA_bytes = std::max<size_t>({3 * H, I, V}) * cols * es;
+    w.tA = take(w.tA_bytes);
     w.tB = take(std::max<size_t>({I, Dp, H}) * cols * es);
     w.wT = take(std::max<size_t>({3 * H * H, I * H, H * (size_t)w.Vp}) * es);
     w.gimg = take(H * Dp * 4);
@@ -266,6 +270,12 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     // out[Nout][Kout] (fp32 gradient of a Linear weight) = dY^T . X over the M rows
     auto wgrad = [&](const void* dY, int dY_dt, int ldy, int Nout, const void* X, int ldx, int Kout, int rows, int rows_p,
                      float* out, int ldo, const char* what) -> int {
+        // bf16, tile-aligned shapes: the TN form of the GEMM reads dY and X as they are (transpose reads in LDS); tA serves as
+        // its split-K partial buffer.  Everything else (fp32 mode, head-sized problems) goes through explicit transposes.
+        if (g_wgrad_tn && dt == CPT_BF16 && dY_dt == CPT_BF16 && rows == rows_p && cpt::gemm_tn_eligible(Nout, Kout, rows, ldy, ldx, ldo)) {
+            TRY(cpt::gemm_tn(dY, ldy, X, ldx, out, ldo, Nout, Kout, rows, tA, w.tA_bytes, s), what);
+            return CPT_OK;
+        }
         TRY(cpt::transpose_cast(dY, dY_dt, ldy, tA, dt, rows_p, rows, Nout, s), what);
         TRY(cpt::transpose_cast(X, dt, ldx, tB, dt, rows_p, rows, Kout, s), what);
         // (split-K with fp32 atomics was measured slower at B=32: 11.7-16.6 ms/step vs 10.4 -- see DESIGN.md)

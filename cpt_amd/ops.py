@@ -125,6 +125,18 @@ def row_stats_table(x, hidden=None):
     return st
 
 
+def gemm_tn(a, w, split_scratch=True):
+    """out[M, N] fp32 = a.T @ w for bf16 a[K, M], w[K, N] (the weight-gradient form: contraction over rows, no transposed copies)."""
+    _need_cuda(a, w)
+    K, M = a.shape
+    N = w.size(1)
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    part = torch.empty((8 * M * N,), device=a.device, dtype=torch.float32) if split_scratch else None
+    L.check(L.lib().cpt_gemm_tn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), N, M, N, K,
+                                L.ptr(part), part.numel() * 4 if part is not None else 0, L.stream_ptr()), "cpt_gemm_tn")
+    return out
+
+
 def resid3_split(x):
     """fp32 x -> (hi bf16, lo int8) of the 3-byte residual stream (include/cpt_hip.h cpt_resid3_split)."""
     _need_cuda(x)

@@ -328,6 +328,14 @@ int cpt_gemm_ln_prod3(const void* A_bf16, int lda, const void* W_bf16, int ldw, 
 int cpt_resid3_split(const float* x, void* hi_bf16, void* lo_i8, size_t n, void* stream);
 int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, void* stream);
 
+/* Weight-gradient GEMM in the TN form (what cpt_train_bwd runs for dW = dY^T . X, fewshot/refcoco_cpt.py:248's autograd of
+ * every nn.Linear): out[M][N] fp32 = sum over k < K of A[k][m] * W[k][n], A bf16 [K][lda], W bf16 [K][ldw] -- both operands
+ * as the backward pass holds them (rows = tokens), no transposed copies.  M % 128 == 0, N % 128 == 0 or N % 192 == 0,
+ * K % 64 == 0, ldo == N.  partials (optional, partial_bytes): scratch for split-K partial matrices (up to 8 * M * N * 4
+ * bytes are used when the output has few tiles); they are added in split order, so the result is reproducible. */
+int cpt_gemm_tn(const void* A_bf16, int lda, const void* W_bf16, int ldw, float* out, int ldo, int M, int N, int K, void* partials,
+                size_t partial_bytes, void* stream);
+
 /* Split-operand copy for CPT_BF16X3: x fp32 [R][K] (leading dimension ld) -> out bf16 [R][3K] holding, per row, the blocks
  * hi | hi | lo (weight_order 0: activations) or hi | lo | hi (weight_order 1: nn.Linear weights), hi = bf16(x),
  * lo = bf16(x - hi).  A bf16 GEMM of the two over K' = 3K is x.w to ~2^-16 relative. */
@@ -365,7 +373,9 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 5  0 = run the encoder LayerNorms as kernels even when cpt_model.fold is given (default 1: folded)
  *   key 6  QKV projection + attention: 0 = two kernels, 1 (default) = fused, two workgroups per CU,
  *          2 = fused, one workgroup per CU (bf16, L <= 128 only; otherwise always two kernels)
- *   key 9  residual stream of the fused bf16 encoder: 1 (default) = 3-byte form (cpt_gemm_ln_prod3), 0 = fp32 + bf16 copies */
+ *   key 9  residual stream of the fused bf16 encoder: 1 (default) = 3-byte form (cpt_gemm_ln_prod3), 0 = fp32 + bf16 copies
+ *   key 10 bf16 weight gradients of cpt_train_bwd: 1 (default) = TN GEMM (operands read as stored, split-K partials reduced in
+ *          order), 0 = explicit operand transposes + NT GEMM */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
  * start / after prologue issue / after K loop / after staging / end, and the XCC id). */

@@ -305,6 +305,32 @@ def test_ln_consumer_kernels_are_bit_identical(dev):
         assert torch.equal(outs[3][:960], outs[(v, "small")]), "variant %d, 960-row problem" % v
 
 
+@pytest.mark.parametrize("K,M,N", [(3840, 768, 768), (3840, 2304, 768), (3840, 768, 3072), (1600, 768, 2112), (960, 1024, 1024),
+                                   (192, 128, 192), (64, 128, 128), (53760, 768, 768)])
+def test_gemm_tn_weight_gradient_form(dev, K, M, N):
+    """out = A^T W with both bf16 operands stored rows = contraction index (dY [tokens][out], X [tokens][in]): the TN GEMM reads
+    them through LDS transpose reads.  Against torch fp32 matmul of the same bf16 values; with and without split-K scratch the
+    result must agree to fp32 summation-order noise, and two runs are bit-equal (partials are added in split order)."""
+    from cpt_amd import ops
+    rng = _rng(K + M + N)
+    a = _t(rng, K, M).to(torch.bfloat16).to(dev)
+    w = _t(rng, K, N).to(torch.bfloat16).to(dev)
+    a[:, 5] = 0.0
+    a[7, 5] = 1.0                                  # output row 5 = row 7 of w exactly: catches any row / column permutation
+    ref = a.float().t() @ w.float()
+    got = ops.gemm_tn(a, w)
+    tol = 2e-5 * (K ** 0.5) + 1e-4
+    assert (got - ref).abs().max().item() < tol * 4, (got - ref).abs().max().item()
+    assert torch.equal(got[5], w[7].float())
+    assert torch.equal(got, ops.gemm_tn(a, w))
+    one = ops.gemm_tn(a, w, split_scratch=False)   # no scratch: one split
+    assert (one - ref).abs().max().item() < tol * 4
+    # strided operands (a column block of a wider tensor, as dqkv / the FFN activations are)
+    wide = _t(rng, K, N + 64).to(torch.bfloat16).to(dev)
+    got2 = ops.gemm_tn(a, wide[:, 64:])
+    assert (got2 - a.float().t() @ wide[:, 64:].float()).abs().max().item() < tol * 4
+
+
 def _r3_encode_np(x):
     """CPU restatement of the 3-byte residual code (csrc/common.h r3_encode): T = fp32 pattern rounded half away to 24 bits,
     hi = (T + 0x80) >> 8 (a bf16 pattern), lo = int8(T - (hi << 8))."""

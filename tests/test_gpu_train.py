@@ -200,6 +200,28 @@ def test_no_img_layernorm_forward_and_gradients(dev, mode):
     assert err < (1e-3 if mode == "fp32" else 4e-2), err
 
 
+def test_weight_gradients_tn_gemm_vs_transposed_operands(dev):
+    """bf16 weight gradients: the TN GEMM (operands read as stored) against the explicit-transpose + NT GEMM path on the same
+    batch (M = 8 x 120 = 960 rows = 15 K-tiles), every parameter; both accumulate in fp32 over the same bf16 products."""
+    from cpt_amd import _lib as L
+    cfg = cfgmod.oscar_base(num_hidden_layers=2)
+    b = {k: v.to(dev) for k, v in synth.make_batch(8, cfg, seed=21).items()}
+    grads = {}
+    for tn in (0, 1):
+        L.check(L.lib().cpt_set_tuning(10, tn))
+        try:
+            m = _model(cfg, 5, dev, "bf16")
+            loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                        masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+            loss.backward()
+            grads[tn] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            L.check(L.lib().cpt_set_tuning(10, 1))
+    for n in grads[0]:
+        rel, mx = _rel(grads[1][n], grads[0][n].cpu())
+        assert rel < 1e-4 or mx < 1e-7, (n, rel, mx)
+
+
 def test_attention_backward_variants_agree(dev):
     """MFMA attention backward (bf16) against the generic fp32-math kernel on the same inputs."""
     from cpt_amd import _lib as L
