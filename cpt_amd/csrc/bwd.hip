@@ -211,7 +211,8 @@ template <typename LP, bool GELU_IN>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ g, float eps, float* __restrict__ dx,
                                                      LP* __restrict__ dx_lp, float* __restrict__ dg, float* __restrict__ db,
-                                                     int R, int H, int grp, int grp_stride, int grp_off, int rows_per_block) {
+                                                     int R, int H, int grp, int grp_stride, int grp_off, int rows_per_block,
+                                                     float* __restrict__ part) {
     __shared__ float red[2][4][256 * LNB_MAXV];     // [dg|db][wave][column]  (32 KB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = (H + 255) / 256;
@@ -327,23 +328,53 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             red[1][wave][(lane + 64 * i) * 4 + j] = bsum[i][j];
         }
     __syncthreads();
+    if (part) {     // two-stage column sums: this block's partial row [2][H], added up by ln_bwd_reduce_kernel
+        for (int c = threadIdx.x; c < H; c += 256) {
+            part[((size_t)blockIdx.x * 2 + 0) * H + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+            part[((size_t)blockIdx.x * 2 + 1) * H + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < H; c += 256) {
         atomicAdd(&dg[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
         atomicAdd(&db[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
 }
 
+// second stage: column c of [nb][2][H] partials; blockIdx.y takes a slice of the nb blocks, one atomic per (slice, column)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dg, float* __restrict__ db,
+                                                            int nb, int H, int per) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * H) return;
+    const int b0 = blockIdx.y * per;
+    float v[16];                                        // per == 16: all loads in flight before the first add
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (b0 + k < nb) ? part[(size_t)(b0 + k) * 2 * H + c] : 0.f;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += v[k];
+    atomicAdd(c < H ? &dg[c] : &db[c - H], a);
+}
+
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
-           float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s) {
+           float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
+           float* part, size_t part_bytes) {
     if (R <= 0 || H % 4 || H > 256 * LNB_MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!dy || (g && (!x || !dg || !db))) return CPT_ERR_NULL;      // g == NULL: identity (row gather only)
-    const int rpb = R >= 2048 ? 16 : 8;      // rows per block: fewer blocks = fewer dgamma/dbeta atomics (2*H per block)
+    // rows per block: with atomics fewer blocks = fewer dgamma/dbeta atomics (2*H per block); with a partial-sum buffer (two-stage
+    // column sums) one row per wave keeps 4x the rows in flight: the kernel is latency-bound otherwise (22 -> ~10 us at 3840 rows)
+    int rpb = R >= 2048 ? 16 : 8;
+    if (g && part && R >= 1024 && (size_t)((R + 3) / 4) * 2 * H * 4 <= part_bytes) rpb = 4; else part = nullptr;
     dim3 grid((R + rpb - 1) / rpb), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
-#define LNB(LPT, GI) ln_bwd_kernel<LPT, GI><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb)
+#define LNB(LPT, GI) ln_bwd_kernel<LPT, GI><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part)
     if (lp16) { if (gelu_in) LNB(bf16, true); else LNB(bf16, false); }
     else      { if (gelu_in) LNB(float, true); else LNB(float, false); }
 #undef LNB
+    if (part) {
+        const int nb = (int)grid.x, per = 16;
+        ln_bwd_reduce_kernel<<<dim3((2 * H + 255) / 256, (nb + per - 1) / per), dim3(256), 0, s>>>(part, dg, db, nb, H, per);
+    }
     return CPT_OK;
 }
 
@@ -723,7 +754,7 @@ __device__ __forceinline__ int kq_off_tr(int row, int chunk) {
 }
 
 template <int NKB, bool TR = false>
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
+__global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
                                                             const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int B, int L, int heads,
                                                             DropSpec dr) {
     constexpr int LP = NKB * 32;
@@ -1061,15 +1092,17 @@ static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void
     return CPT_OK;
 }
 
-int g_attn_bwd_variant = 1;      // 1: MFMA kernels for bf16 (L <= 288); 0: generic kernel always; 2: transpose-read MFMA variant also for L <= 128 (tests)
+int g_attn_bwd_variant = 1;      // 1: transpose-read MFMA kernels for bf16 (L <= 288); 0: generic kernel always; 2: L <= 128 through the older MFMA kernel with transposed tile copies
 void set_attn_bwd_variant(int v) { g_attn_bwd_variant = v; }
 
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
                   const DropSpec* drop) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
     const DropSpec dr = drop ? *drop : DropSpec{};
-    if (dtype == CPT_BF16 && g_attn_bwd_variant == 2 && L <= 128) return attn_bwd_mfma_launch<4, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
-    if (dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L <= 128) {
+    // L <= 128: the transpose-read kernel needs 68 KB of LDS and 209 registers -> two workgroups per CU (B * heads = 384 workgroups
+    // in one round instead of two): 43.6 vs 51.2 us at B = 32 (rocprofv3)
+    if (dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L > 64 && L <= 128) return attn_bwd_mfma_launch<4, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
+    if (dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 128) {
         if (L <= 32) return attn_bwd_mfma_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
         if (L <= 64) return attn_bwd_mfma_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
         return attn_bwd_mfma_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);

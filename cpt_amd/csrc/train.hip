@@ -25,7 +25,7 @@ struct TrainLayout {
     size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2;     // offsets inside a layer block
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
     size_t dx, dpre, da, dpre_lp, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
-    size_t total, tA_bytes;
+    size_t total, tA_bytes, tB_bytes;
     int Mp, Bp, Vp, Rp;
 };
 
@@ -65,7 +65,8 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li) {
     const size_t cols = std::max<size_t>({(size_t)w.Mp, (size_t)w.Bp, (size_t)w.Rp});
     w.tA_bytes = std::max<size_t>({3 * H, I, V}) * cols * es;
     w.tA = take(w.tA_bytes);
-    w.tB = take(std::max<size_t>({I, Dp, H}) * cols * es);
+    w.tB_bytes = std::max<size_t>({I, Dp, H}) * cols * es;      // also the scratch of ln_bwd's two-stage column sums
+    w.tB = take(w.tB_bytes);
     w.wT = take(std::max<size_t>({3 * H * H, I * H, H * (size_t)w.Vp}) * es);
     w.gimg = take(H * Dp * 4);
     w.dl_lp = take((size_t)B * w.Vp * es);
@@ -351,7 +352,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         const cpt_layer_grads& gy = g->layers[l];
         // x_out = LN2(pre2); pre2 = h W_out^T + b_out + a
         TRY(cpt::ln_bwd(dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln2_g, gy.ln2_b,
-                        M, H, M, 0, 0, 0, s), "ln_bwd(ffn)");
+                        M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes), "ln_bwd(ffn)");
         if (ph) TRY(cpt::dropout_rows(dpre, nullptr, dmask, dt == CPT_BF16 ? dmask_lp : nullptr, dt, M, H, drop_spec(drop, 3 + 3 * l, false), s), "dropout_bwd(ffn down)");
         TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_out, M, H, s), "colsum(b_out)");
         rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_h), I, I, M, Mp, gy.w_out, I, "wgrad(ffn down)");
@@ -367,7 +368,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         if (rc) return rc;
         // a = LN1(pre1); pre1 = ctx W_ao^T + b_ao + x_in
         TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln1_g, gy.ln1_b,
-                        M, H, M, 0, 0, 0, s), "ln_bwd(attn)");
+                        M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes), "ln_bwd(attn)");
         if (ph) TRY(cpt::dropout_rows(dpre, nullptr, dmask, dt == CPT_BF16 ? dmask_lp : nullptr, dt, M, H, drop_spec(drop, 2 + 3 * l, false), s), "dropout_bwd(attn out)");
         TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_ao, M, H, s), "colsum(b_ao)");
         rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_ctx), H, H, M, Mp, gy.w_ao, H, "wgrad(attn out)");
