@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("CPT_LIB_PATH") or os.path.join(HERE, "libcpt_hip.so")
 CPT_F32, CPT_BF16, CPT_BF16X3 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID = 0, 1, 2, 3
 OUT_SEQ, OUT_POOLED, OUT_MASK_LOGITS, OUT_ALL_LOGITS, OUT_LOSS, OUT_REL = 1, 2, 4, 8, 16, 32
+ATTN_MASK_3D = 256        # input flag: attention mask is (B, L, L)
 K_NAMES = ["gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up", "gemm_ffn_down",
            "embed_ln", "img_proj", "head", "op"]
 

@@ -35,7 +35,9 @@ __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >>
 template <typename T, int NKB>
 __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
-    T* __restrict__ probs, int B, int L, int heads, DropSpec dr) {
+    T* __restrict__ probs, int B, int L, int heads, DropSpec dr, int mask3) {
+    // mask3: attn_mask is [B][L][L] (one row per query, modeling_bert.py:215-216) instead of [B][L]: the per-key LDS vector
+    // then only marks the padding keys and every lane adds its own query's row from global memory
     typedef typename FragOf<T>::type frag_t;
     constexpr int CE = Chunk<T>::N;
     constexpr int NC = HD / CE;                       // chunks per K row
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     }
     for (int key = tid; key < LP; key += ATT_THREADS) {
         float mv = -INFINITY;                          // padding keys beyond L: excluded outright
-        if (key < L) mv = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
+        if (key < L) mv = (attn_mask && !mask3) ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
         sMask[key] = LPT ? mv * LOG2E : mv;            // bf16 path: softmax in base 2 (one v_exp_f32 per score)
     }
     // K rows XOR-swizzled; V row-major (bf16, transpose-read later) or transposed element-wise (f32)
@@ -104,10 +106,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     }
     __syncthreads();
     if (q0 >= L) return;   // whole wave has no query rows (uniform per wave)
+    const int64_t* mrow = (mask3 && attn_mask) ? attn_mask + ((size_t)b * L + min(q, L - 1)) * L : nullptr;
     if constexpr (LPT) {     // bf16: the shared core (attn_core.h); everything below is the fp32 parity path
         T* crow = ctx + ((size_t)b * L + min(q, L - 1)) * H + h * HD;
         T* prow = probs ? probs + (((size_t)b * heads + h) * L + min(q, L - 1)) * L : nullptr;
-        attn_core_bf16<NKB>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)blockIdx.x, min(q, L - 1));
+        attn_core_bf16<NKB>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)blockIdx.x, min(q, L - 1), mrow);
         return;
     }
 
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float s = st[kb][r] * 0.125f + sMask[kb * 32 + key_of(r, fh)];
+            float s = st[kb][r] * 0.125f + sMask[kb * 32 + key_of(r, fh)];
+            if (mrow) { const int key = kb * 32 + key_of(r, fh); if (key < L) s += (1.0f - (float)mrow[key]) * -10000.0f; }
             st[kb][r] = s;
             mx = fmaxf(mx, s);
         }
@@ -216,7 +220,7 @@ static size_t att_lds_bytes() {
 }
 
 template <typename T, int NKB>
-static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s) {
+static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3) {
     const size_t lds = att_lds_bytes<T, NKB>();
     auto kern = attention_kernel<T, NKB>;
     if (lds > 64 * 1024) {
@@ -224,26 +228,26 @@ static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* pro
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
     }
     dim3 grid(B * heads, (L + 127) / 128), block(ATT_THREADS);
-    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads, dr);
+    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads, dr, mask3);
     return CPT_OK;
 }
 
 template <typename T>
-static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s) {
-    if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, dr, s);
-    if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, dr, s);
-    if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, dr, s);
-    if (L <= 288) return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, dr, s);
+static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3) {
+    if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3);
+    if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3);
+    if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3);
+    if (L <= 288) return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3);
     return CPT_ERR_SHAPE;
 }
 
 int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s,
-              const DropSpec* drop) {
+              const DropSpec* drop, int mask_3d) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
     if (!qkv || !ctx) return CPT_ERR_NULL;
     const DropSpec dr = drop ? *drop : DropSpec{};
-    if (dtype == CPT_BF16) return att_dispatch<bf16>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s);
-    if (dtype == CPT_F32) return att_dispatch<float>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s);
+    if (dtype == CPT_BF16) return att_dispatch<bf16>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d);
+    if (dtype == CPT_F32) return att_dispatch<float>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d);
     return CPT_ERR_DTYPE;
 }
 

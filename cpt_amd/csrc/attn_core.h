@@ -37,7 +37,8 @@ __device__ __forceinline__ int att_key_of(int r, int h) { return (r & 3) + 8 * (
 template <int NKB>
 __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsigned char* sK, const unsigned char* sV,
                                                const float* sMask, int lane, bool valid, bf16* ctx_row,
-                                               bf16* probs_row, int L, const DropSpec& dr = DropSpec{}, uint32_t bh = 0, int q = 0) {
+                                               bf16* probs_row, int L, const DropSpec& dr = DropSpec{}, uint32_t bh = 0, int q = 0,
+                                               const int64_t* mrow = nullptr) {   // mrow: this lane's row of a 3-D attention mask (modeling_bert.py:215-216)
     const int fr = lane & 31, fh = lane >> 5;
     // S^T = K . Q^T : accumulator rows = keys, column (lane&31) = query
     f32x16 st[NKB];
@@ -57,7 +58,8 @@ __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsi
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float s = st[kb][r] * (0.125f * ATT_LOG2E) + sMask[kb * 32 + att_key_of(r, fh)];
+            float s = st[kb][r] * (0.125f * ATT_LOG2E) + sMask[kb * 32 + att_key_of(r, fh)];
+            if (mrow) { const int key = kb * 32 + att_key_of(r, fh); if (key < L) s += (1.0f - (float)mrow[key]) * (-10000.0f * ATT_LOG2E); }
             st[kb][r] = s;
             mx = fmaxf(mx, s);
         }

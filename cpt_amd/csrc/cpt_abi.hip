@@ -352,7 +352,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     }
     // (a5-a9) encoder
     const bool fold = lp && m->fold && g_fold_ln && !g_lp_resid;
-    const bool fuse_attn = lp && g_fuse_attn && L <= 128 && H % 64 == 0;
+    const int mask3 = (flags & CPT_ATTN_MASK_3D) ? 1 : 0;
+    const bool fuse_attn = lp && g_fuse_attn && L <= 128 && H % 64 == 0 && !mask3;
     const bool pre_ln = fold && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS));   // x_f32 left un-normalised after the encoder
     // 3-byte residual stream (common.h r3_encode): the pre-LayerNorm sums live as bf16 hi (x_lp / a_lp, the GEMM operands) +
     // int8 lo (the head of the `pre` / a_f32 regions); the producers read and write 3 + 3 bytes per element instead of 4 + 6.
@@ -383,7 +384,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
               if (l == 0) TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
               else TRY(cpt::gemm_ln_cons(x_lp, H, f.w_qkv_f, H, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, 0, qkv, 3 * H, M, 3 * H, H, s), "gemm(qkv, folded LN)"); }
             { Scope p(CPT_K_ATTN, s);
-              TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s), "attention"); }
+              TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s, nullptr, mask3), "attention"); }
             }
             { Scope p(CPT_K_GEMM_AO, s);
               if (r3) TRY(cpt::gemm_ln_prod3(ctx, H, y.w_ao, H, y.b_ao, x_lp, x_lo, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
@@ -418,7 +419,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         { Scope p(CPT_K_GEMM_QKV, s);
           TRY(gm(CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H), "gemm(qkv)"); }
         { Scope p(CPT_K_ATTN, s);
-          TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s), "attention"); }
+          TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s, nullptr, mask3), "attention"); }
         }
         const bool lpr = lp && g_lp_resid;                       // residual operand read as bf16, fp32 copy not written
         const bool last = l + 1 == d.layers;

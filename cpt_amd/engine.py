@@ -428,9 +428,9 @@ class PackedModel(object):
         input_ids = prep(input_ids, torch.int64, "input_ids")
         token_type_ids = prep(token_type_ids, torch.int64, "token_type_ids")
         position_ids = prep(position_ids, torch.int64, "position_ids")
-        if attention_mask is not None and attention_mask.dim() != 2:
-            # reference accepts a 3-D mask too (modeling_bert.py:215-216); no CPT driver uses it
-            raise NotImplementedError("cpt_amd: only 2-D attention_mask is supported by the HIP path")
+        mask3 = attention_mask is not None and attention_mask.dim() == 3
+        if attention_mask is not None and attention_mask.dim() not in (2, 3):
+            raise NotImplementedError("cpt_amd: attention_mask must be 2-D or 3-D (modeling_bert.py:213-218)")
         attention_mask = prep(attention_mask, torch.int64, "attention_mask")
         img_feats = prep(img_feats, torch.float32, "img_feats")
         mask_pos = prep(mask_pos, torch.int64, "mask_token_pos")
@@ -441,8 +441,10 @@ class PackedModel(object):
         if img_feats is not None and img_feats.size(2) != self.cfg.img_feature_dim:
             raise RuntimeError("cpt_amd: img_feats last dim %d != config.img_feature_dim %d"
                                % (img_feats.size(2), self.cfg.img_feature_dim))
-        if attention_mask is not None and tuple(attention_mask.shape) != (B, Lseq):
-            raise RuntimeError("cpt_amd: attention_mask shape %s != (%d, %d)" % (tuple(attention_mask.shape), B, Lseq))
+        want = (B, Lseq, Lseq) if mask3 else (B, Lseq)
+        if attention_mask is not None and tuple(attention_mask.shape) != want:
+            raise RuntimeError("cpt_amd: attention_mask shape %s != %s" % (tuple(attention_mask.shape), want))
+        call_flags = flags | (L.ATTN_MASK_3D if mask3 else 0)      # (B, L, L): one mask row per query (modeling_bert.py:215-216)
         m, _ = self.descriptor()
         H, V = self.cfg.hidden_size, self.cfg.vocab_size
         out = {}
@@ -469,7 +471,7 @@ class PackedModel(object):
                      position_ids=L.ptr(position_ids), attn_mask=L.ptr(attention_mask), img_feats=L.ptr(img_feats),
                      mask_pos=L.ptr(mask_pos), labels=L.ptr(labels))
         ws = self.workspace(B, Lt, Li, flags)
-        L.check(L.lib().cpt_model_fwd(C.byref(m), C.byref(bt), C.byref(o), flags, ws.data_ptr(), ws.numel(),
+        L.check(L.lib().cpt_model_fwd(C.byref(m), C.byref(bt), C.byref(o), call_flags, ws.data_ptr(), ws.numel(),
                                       L.stream_ptr()), "cpt_model_fwd")
         if flags & L.OUT_LOSS:
             acc = out["loss_acc"]

@@ -146,7 +146,9 @@ enum {
     CPT_OUT_MASK_LOGITS = 4,/* prediction scores of the [MASK] rows only [B][V] fp32 */
     CPT_OUT_ALL_LOGITS = 8, /* prediction scores of every position [B][L][V] (modeling_rec.py:143) */
     CPT_OUT_LOSS = 16,      /* CrossEntropy(ignore_index=-1) (modeling_rec.py:147-150) */
-    CPT_OUT_REL = 32        /* cls.seq_relationship(pooled) [B][n_rel] (modeling_vcr.py NSPCPT) */
+    CPT_OUT_REL = 32,       /* cls.seq_relationship(pooled) [B][n_rel] (modeling_vcr.py NSPCPT) */
+    CPT_ATTN_MASK_3D = 256  /* input flag: cpt_batch.attn_mask is [B][L][L], one mask row per query (modeling_bert.py:215-216);
+                               inference only, attention runs as its own kernel (no QKV fusion) */
 };  /* (training keeps its activations through cpt_train_fwd / cpt_train_bwd below, not through a flag here) */
 
 typedef struct {

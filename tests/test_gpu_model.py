@@ -76,6 +76,38 @@ def test_tiny_all_stages_fp32(dev, golden_dir):
     assert abs(loss_rows.item() - float(g["loss"])) < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_three_dimensional_attention_mask(dev, mode):
+    """attention_mask of shape (B, L, L) -- one mask row per query, modeling_bert.py:215-216 (no CPT driver sends one, the
+    reference model accepts it): a broadcast 2-D mask gives the bits of the 2-D call, a per-query mask matches the oracle."""
+    from oracle import cpt_oracle as O
+    cfg = cfgmod.tiny()
+    m, _ = _model(cfg, 1234, dev, mode)
+    b = synth.make_batch(3, cfg, seed=4, max_seq_len=20, img_seq_len=6, vary_regions=True)
+    d = {k: v.to(dev) for k, v in b.items()}
+    Lq = b["attention_mask"].size(1)
+    m3 = b["attention_mask"][:, None, :].expand(-1, Lq, -1).contiguous()
+    with torch.no_grad():
+        two = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0]
+        three = m(d["input_ids"], d["segment_ids"], m3.to(dev), img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0]
+    if mode == "fp32":
+        assert torch.equal(two, three)
+    else:   # the 2-D call runs the fused QKV + attention kernel and the folded encoder; same arithmetic per element
+        assert (two - three).abs().max().item() < 1e-5
+    rng = np.random.Generator(np.random.PCG64(9))
+    per_q = torch.from_numpy((rng.random((3, Lq, Lq)) < 0.7).astype(np.int64)) * m3
+    per_q[:, torch.arange(Lq), torch.arange(Lq)] = 1            # every query keeps itself
+    with torch.no_grad():
+        got = m(d["input_ids"], d["segment_ids"], per_q.to(dev), img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0]
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    sd["cls.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    want = O.rec_mlm_cpt_forward(sd, cfg.to_dict(), b["input_ids"], b["segment_ids"], per_q, img_feats=b["img_feats"],
+                                 mask_rows_only=b["mask_token_pos"])[0]
+    err = (got.float().cpu() - want).abs().max().item()
+    assert err < (1e-3 if mode == "fp32" else BF16_TOL), err
+    assert (got.float().cpu() - two.float().cpu()).abs().max().item() > 1e-3     # the mask rows really were applied
+
+
 def test_tiny_checkpoint_surface(dev, golden_dir):
     """from_pretrained on the legacy-named (gamma/beta) fixture checkpoint == reference's output."""
     from cpt_amd.modeling_bert import BertImgForPreTraining
