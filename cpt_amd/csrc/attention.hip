@@ -33,7 +33,7 @@ template <> __device__ __forceinline__ int k_off<float>(int row, int chunk) { re
 __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 template <typename T, int NKB>
-__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
     T* __restrict__ probs, int B, int L, int heads, DropSpec dr, int mask3) {
     // mask3: attn_mask is [B][L][L] (one row per query, modeling_bert.py:215-216) instead of [B][L]: the per-key LDS vector
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     constexpr int VPAD = 16;                          // f32: bytes, makes V^T column reads conflict-free
     constexpr int VROW = LP * (int)sizeof(T) + VPAD;  // f32: bytes per V^T row
     constexpr int KS = NC / 2;                        // MFMA chunk steps over head dim
-    constexpr int V_BYTES = LPT ? LP * VP16 : HD * VROW;
+    constexpr bool VSWZ = LPT && NKB > 7;             // L > 224: swizzled 128-byte V rows (73.7 + 1.2 KB: two workgroups per CU) instead of the padded pitch
+    constexpr int V_BYTES = LPT ? LP * (VSWZ ? 128 : VP16) : HD * VROW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sK = smem;                              // LP rows
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
         if (idx < LP * NC) {
             *reinterpret_cast<uint4*>(sK + k_off<T>(key, c)) = kreg[i];
             if constexpr (LPT) {
-                *reinterpret_cast<uint4*>(sV + key * VP16 + c * 16) = vreg[i];
+                if constexpr (VSWZ) *reinterpret_cast<uint4*>(sV + att_voff_swz(key, c)) = vreg[i];
+                else *reinterpret_cast<uint4*>(sV + key * VP16 + c * 16) = vreg[i];
             } else {
                 const T* ve = reinterpret_cast<const T*>(&vreg[i]);
 #pragma unroll
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
     if constexpr (LPT) {     // bf16: the shared core (attn_core.h); everything below is the fp32 parity path
         T* crow = ctx + ((size_t)b * L + min(q, L - 1)) * H + h * HD;
         T* prow = probs ? probs + (((size_t)b * heads + h) * L + min(q, L - 1)) * L : nullptr;
-        attn_core_bf16<NKB>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)blockIdx.x, min(q, L - 1), mrow);
+        attn_core_bf16<NKB, VSWZ>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)blockIdx.x, min(q, L - 1), mrow);
         return;
     }
 
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(
 template <typename T, int NKB>
 static size_t att_lds_bytes() {
     constexpr int LP = NKB * 32;
-    const size_t v_bytes = sizeof(T) == 2 ? (size_t)LP * VP16 : (size_t)HD * (LP * sizeof(T) + 16);
+    const size_t v_bytes = sizeof(T) == 2 ? (size_t)LP * (NKB > 7 ? 128 : VP16) : (size_t)HD * (LP * sizeof(T) + 16);
     return (size_t)LP * HD * sizeof(T) + v_bytes + (size_t)LP * sizeof(float);
 }
 

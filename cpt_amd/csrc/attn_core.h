@@ -16,6 +16,14 @@ constexpr float ATT_LOG2E = 1.44269504088896340736f;
 // K / Q tile rows are 64 bf16 = 128 B = 8 chunks of 16 B, XOR-swizzled so that fragment reads are conflict-free
 __device__ __forceinline__ int att_koff16(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// V tile, swizzled form (VSWZ, used where the padded pitch does not leave room for two workgroups per CU: L > 224): 128-byte rows
+// whose 16-byte chunks are XOR-ed with the row-pair index rotated by one bit -- rows r, r+1 sit in the two halves of a 256-byte
+// bank row, rows r+2, r+3 in the other 64-byte half of each, so the four rows of a transpose read use four different quarters.
+__device__ __forceinline__ int att_voff_swz(int row, int chunk) {
+    const int p = (row >> 1) & 7;
+    return row * 128 + ((chunk ^ (((p & 1) << 2) | (p >> 1))) << 4);
+}
+
 // ds_read_b64_tr_b16 (gfx950 LDS transpose read; lane mapping measured with tools/tr_probe.hip): within a 16-lane
 // group lane i, slot j receives element (i & 3) of the 8 bytes addressed by lane 4*j + (i >> 2).  With lane s
 // pointing at V[key0 + (s >> 2)][d0 + 4*(s & 3) ...] the group reads a row-major [4 keys][16 d] block and lane i
@@ -34,7 +42,7 @@ __device__ __forceinline__ int att_key_of(int r, int h) { return (r & 3) + 8 * (
 //   sV   [NKB*32] rows of ATT_VP16 bytes, row-major
 //   sMask[NKB*32] additive mask already multiplied by log2(e); -inf for padding keys
 // Writes ctx_row[0..63] (this lane's query, head slice) if `valid`; optionally the probabilities (training).
-template <int NKB>
+template <int NKB, bool VSWZ = false>
 __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsigned char* sK, const unsigned char* sV,
                                                const float* sMask, int lane, bool valid, bf16* ctx_row,
                                                bf16* probs_row, int L, const DropSpec& dr = DropSpec{}, uint32_t bh = 0, int q = 0,
@@ -119,10 +127,11 @@ __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsi
             for (int j = 0; j < 8; ++j) pa[j] = (bf16)st[kb][8 * s2 + j];
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const unsigned char* vr = sV + (kb * 32 + 16 * s2 + 4 * fh + ((lane & 15) >> 2)) * ATT_VP16 +
-                                          (db * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+                const int vrow = kb * 32 + 16 * s2 + 4 * fh + ((lane & 15) >> 2), vcol = db * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                const unsigned char* vr = VSWZ ? sV + att_voff_swz(vrow, vcol >> 3) + (vcol & 7) * 2 : sV + vrow * ATT_VP16 + vcol * 2;
+                const unsigned char* vr8 = VSWZ ? sV + att_voff_swz(vrow + 8, vcol >> 3) + (vcol & 7) * 2 : vr + 8 * ATT_VP16;
                 const bf16x4 lo = lds_read_tr16(vr);
-                const bf16x4 hi = lds_read_tr16(vr + 8 * ATT_VP16);
+                const bf16x4 hi = lds_read_tr16(vr8);
                 bf16x8 vb;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { vb[j] = lo[j]; vb[4 + j] = hi[j]; }

@@ -308,14 +308,19 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     // stage costs two SALU ops + one buffer_load...lds per 1 KiB piece and no VALU.
     constexpr int GA = TBM / 8 / NW;                  // pieces i < GA come from A, the rest from W
     static_assert((TBM / 8) % NW == 0, "A pieces must split evenly over the waves");
-    static_assert(!TN || (sizeof(T) == 2 && EPI == CPT_EPI_NONE && TBM % 64 == 0 && TBN % 64 == 0), "TN form: bf16, plain epilogue");
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)(TN ? K : M) * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
+    // TN = 2 (data gradients: out[M][N] = sum_k A[m][k] . W[k][n], W = the nn.Linear weight [out_features = k][in_features = n] as
+    // stored): A is staged and read as in the NT form, W as in the TN form -- no transposed weight copies.
+    constexpr bool TA = TN == 1, TW = TN != 0;        // which operands have the contraction index as their slow dimension
+    static_assert(!TN || (sizeof(T) == 2 && TBM % 64 == 0 && TBN % 64 == 0), "TN / NN forms: bf16");
+    static_assert(TN != 1 || EPI == CPT_EPI_NONE, "TN form: plain epilogue");
+    static_assert(TN != 2 || EPI == CPT_EPI_NONE || EPI == CPT_EPI_RESID, "NN form: plain or residual epilogue");
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)(TA ? K : M) * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)(TN ? K : N) * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
     constexpr int CPRA = TBM / 8, CPRB = TBN / 8;      // TN: 16-byte chunks per tile row
     // G <= 6: one VGPR per piece, computed once.  Bigger tiles (registers go to the accumulators): the offsets are rebuilt at
     // every issue from the piece's row (2 VALU per 1 KiB piece); with an even wave count the swizzle term is the same for
     // every piece of a lane.
-    constexpr bool VOFF_ARRAY = G <= 6 || ATTN;
+    constexpr bool VOFF_ARRAY = G <= 6 || ATTN || TN != 0;
     static_assert(!TN || VOFF_ARRAY, "TN form keeps its piece offsets in registers");
     static_assert(VOFF_ARRAY || NW % 2 == 0, "rebuilt offsets need an even wave count");
     const int rbase = wave * 8 + (lane >> 3);
@@ -328,8 +333,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         const int g = i * NW + wave;
         const int r = g * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        if constexpr (TN) {
-            // piece g = 64 consecutive chunk positions of the row-major [64][CPR] tile; position (row, ch) holds source chunk ch ^ 2 (row & 3)
+        if ((i < GA && TA) || (i >= GA && TW)) {
+            // piece g = 64 consecutive chunk positions of the row-major [64][CPR] tile; position (row, ch) holds source chunk ch ^ tn_swz(row)
             const int idx = (i < GA ? g : g - TBM / 8) * 64 + lane;
             const int cpr = i < GA ? CPRA : CPRB;
             const int row = idx / cpr, ch = idx - row * cpr;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     auto stage = [&](int slot, int k0) {
         if (abl & 1) return;                          // ablation: no operand traffic
         const int soff = k0 * (int)sizeof(T);
-        const int soffA = TN ? k0 * lda * (int)sizeof(T) : soff, soffW = TN ? k0 * ldw * (int)sizeof(T) : soff;   // TN: k0 counts rows
+        const int soffA = TA ? k0 * lda * (int)sizeof(T) : soff, soffW = TW ? k0 * ldw * (int)sizeof(T) : soff;   // transposed operand: k0 counts rows
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int g = i * NW + wave;
@@ -412,7 +417,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                 return __builtin_bit_cast(bf16x8, o);
             };
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[pb][i] = tr8(sa, std::integral_constant<int, CPRA>{}, wm * (MI * 32) + i * 32 + cl);
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (TA) fa[pb][i] = tr8(sa, std::integral_constant<int, CPRA>{}, wm * (MI * 32) + i * 32 + cl);
+                else {      // NN form: the A fragment as in the NT form, but asm too (every LDS read of the loop must be counted by touch())
+                    const unsigned q = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(sa + lds_off(wm * (MI * 32) + i * 32 + fr, ks * 2 + fh));
+                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                    u32x4_t v;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(q));
+                    fa[pb][i] = __builtin_bit_cast(bf16x8, v);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fb[pb][j] = tr8(sw, std::integral_constant<int, CPRB>{}, wn * (NJ * 32) + j * 32 + cl);
             return;
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             // asm transpose reads (see ldfrag): buffers are read in the order 0, 1, 2, 3, 0, ... and LDS reads return in order,
             // so buffer pb has landed once at most the reads of the buffer issued after it are outstanding (none after buffer 3)
             static_assert(!TN || FD == 4, "TN form: four fragment buffers");
-            if (pb < 3) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MI + NJ) * 2));
+            if (pb < 3) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((TA ? 2 : 1) * MI + 2 * NJ));
             else asm volatile("s_waitcnt lgkmcnt(0)");
         }
 #pragma unroll
@@ -554,7 +568,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     static_assert(DIRECT || (16 * CPW + SIDE) * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
     static_assert(DIRECT || (MI * 32 <= 64 && CH <= 64), "side area is filled by one wave pass");
     if (split != 0) bias = nullptr;                   // split-K: the bias is added once
-    if constexpr (TN) out += (size_t)split * M * ldo; // TN split-K: every split writes its own partial matrix (reduced in slot order afterwards)
+    if constexpr (TN == 1) out += (size_t)split * M * ldo; // TN split-K: every split writes its own partial matrix (reduced in slot order afterwards)
     if constexpr (DIRECT) {
         // ---- direct epilogue: the accumulators are TRANSPOSED (operands swapped in mma): lane = output row
         // (wrow0 + 32 i + (lane & 31)), register quad g of block j = the four consecutive columns
@@ -1235,6 +1249,32 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
         reduce_partials_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S);
     }
     return CPT_OK;
+}
+
+// ---- NN form: out[M][N] = A[M][K] . W[K][N] (+ resid), W = an nn.Linear weight [out_features = K][in_features = N] as stored:
+// the data gradients dX = dY . W of the backward pass without a transposed weight copy --------------------------------------
+int gemm_nn_eligible(int M, int N, int K, int lda, int ldw) {
+    return M > 0 && N > 0 && K > 0 && N % 192 == 0 && K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0 && (size_t)K * ldw * 2 <= (size_t)0x7fffffff;
+}
+
+int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
+            hipStream_t s) {
+    if (!gemm_nn_eligible(M, N, K, lda, ldw)) return CPT_ERR_SHAPE;
+    if (!A || !W || !out) return CPT_ERR_NULL;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)resid) & 15)) return CPT_ERR_ALIGN;
+    const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
+    // 64-row tiles when 128-row tiles would leave half the chip idle (M = 3840, N = 768: 120 vs 240 workgroups)
+    const long wg128 = (long)((M + 127) / 128) * (N / 192);
+    const bool small = wg128 < 200;
+#define CPT_NN(EPI, OT, CFG_TBM, CFG_WM) launch_pipe<bf16, EPI, OT, CFG_TBM, 192, CFG_WM, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (OT*)out, ldo, M, N, K, s, 1)
+    if (out_dtype == CPT_BF16) {
+        if (resid) return CPT_ERR_DTYPE;
+        return small ? CPT_NN(CPT_EPI_NONE, bf16, 64, 2) : CPT_NN(CPT_EPI_NONE, bf16, 128, 4);
+    }
+    if (out_dtype != CPT_F32) return CPT_ERR_DTYPE;
+    if (resid) return small ? CPT_NN(CPT_EPI_RESID, float, 64, 2) : CPT_NN(CPT_EPI_RESID, float, 128, 4);
+    return small ? CPT_NN(CPT_EPI_NONE, float, 64, 2) : CPT_NN(CPT_EPI_NONE, float, 128, 4);
+#undef CPT_NN
 }
 
 // ---- LayerNorm folded into the GEMMs around it (bf16 throughput path) -------------------------------

@@ -64,6 +64,11 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
 int gemm_tn_eligible(int M, int N, int K, int lda, int ldw, int ldo);
 int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
             hipStream_t s);
+// out[M][N] = A[M][K] . W[K][N] (+ resid): W stored with the contraction index as its slow dimension (data gradients against an
+// nn.Linear weight as stored); bf16 operands, out fp32 (optionally + fp32 resid) or bf16
+int gemm_nn_eligible(int M, int N, int K, int lda, int ldw);
+int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
+            hipStream_t s);
 int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s);
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,

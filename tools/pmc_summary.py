@@ -11,14 +11,14 @@ def family(name, prev):
     if "ffn_up_2pass_kernel" in name:
         return "gemm_ffn_up(+gelu)"                     # gemm_ffn.hip: the two-pass 384 x 256 FFN-up kernel
     if "gemm_pipe_kernel" in name:
-        # template arguments: <T, EPI, OT, ...>; EPI 0 none, 1 gelu, 3 resid, 6 LN producer, 7/8 LN consumer (+gelu), 9/10 fused QKV + attention
+        # template arguments: <T, EPI, OT, ...>; EPI 0 none, 1 gelu, 3 resid, 6 / 11 LN producer, 7/8 LN consumer (+gelu), 9/10 fused QKV + attention
         if "Li9EDF16b" in name or "Li10EDF16b" in name:
             return "gemm_qkv_attn"                      # fused QKV projection + attention
         if "Li8EDF16b" in name or "Li1EDF16b" in name:
             return "gemm_ffn_up(+gelu)"
         if "Li7EDF16b" in name or "Li0EDF16b" in name:
             return "gemm_qkv"
-        if "Li6Ef" in name or "Li3Ef" in name:
+        if "Li11Ef" in name or "Li6Ef" in name or "Li3Ef" in name:        # 11: LN producer with the 3-byte residual stream
             return "gemm_attn_out" if prev in ("attention", "gemm_qkv_attn") else "gemm_ffn_down"
         return "gemm_other"
     if "layernorm_rows" in name:
