@@ -33,7 +33,7 @@ template <> __device__ __forceinline__ int k_off<float>(int row, int chunk) { re
 __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 template <typename T, int NKB>
-__global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
+__global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kernel(
     const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
     T* __restrict__ probs, int B, int L, int heads, DropSpec dr, int mask3) {
     // mask3: attn_mask is [B][L][L] (one row per query, modeling_bert.py:215-216) instead of [B][L]: the per-key LDS vector

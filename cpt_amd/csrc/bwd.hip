@@ -388,9 +388,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = (H + 255) / 256;
     const int R = B * Lt;
-    f32x4 gsum[LNB_MAXV], bsum[LNB_MAXV], gg[LNB_MAXV];
+    const bool two_types = type_vocab <= 2;
+    f32x4 gsum[LNB_MAXV], bsum[LNB_MAXV], gg[LNB_MAXV], t0[LNB_MAXV], t1[LNB_MAXV];
 #pragma unroll
     for (int i = 0; i < LNB_MAXV; ++i) {
+        t0[i] = f32x4{0, 0, 0, 0};
+        t1[i] = f32x4{0, 0, 0, 0};
         gsum[i] = f32x4{0, 0, 0, 0};
         bsum[i] = f32x4{0, 0, 0, 0};
         const int c = (lane + 64 * i) * 4;
@@ -454,7 +457,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
                     // nn.Embedding(padding_idx=0): the lookup contributes no gradient to row 0
                     if (wid != 0) atomicAdd(&dword[(size_t)wid * H + c + j], d);
                     atomicAdd(&dposw[(size_t)pid * H + c + j], d);
-                    atomicAdd(&dtypew[(size_t)tid * H + c + j], d);
+                    // token_type table: two rows shared by every token -- per-element atomics were 1100-way contended (226 us);
+                    // the block keeps one partial row per type and adds it once
+                    if (two_types) { if (tid == 0) t0[i][j] += d; else t1[i][j] += d; }
+                    else atomicAdd(&dtypew[(size_t)tid * H + c + j], d);
                 }
             }
         }
@@ -470,6 +476,21 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     for (int c = threadIdx.x; c < H; c += 256) {
         atomicAdd(&dg[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
         atomicAdd(&db[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+    if (two_types) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[0][wave][(lane + 64 * i) * 4 + j] = t0[i][j];
+                red[1][wave][(lane + 64 * i) * 4 + j] = t1[i][j];
+            }
+        __syncthreads();
+        for (int c = threadIdx.x; c < H; c += 256) {
+            atomicAdd(&dtypew[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            if (type_vocab > 1) atomicAdd(&dtypew[H + c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
     }
 }
 
