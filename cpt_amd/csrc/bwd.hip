@@ -212,13 +212,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ g, float eps, float* __restrict__ dx,
                                                      LP* __restrict__ dx_lp, float* __restrict__ dg, float* __restrict__ db,
                                                      int R, int H, int grp, int grp_stride, int grp_off, int rows_per_block,
-                                                     float* __restrict__ part) {
-    __shared__ float red[2][4][256 * LNB_MAXV];     // [dg|db][wave][column]  (32 KB)
+                                                     float* __restrict__ part, DropSpec dr, float* __restrict__ dbias) {
+    // dr / dbias (training backward of LN(dropout(dense) + residual), round 2): dx_lp receives the gradient that enters the dense
+    // layer -- dx through the dropout mask of the forward (regenerated, dropout.h; thresh 0: identity) -- and dbias its column
+    // sums = the gradient of the dense bias; dx itself stays unmasked (it feeds the residual path).  Replaces a dropout_rows and
+    // a colsum launch per LayerNorm.
+    __shared__ float red[3][4][256 * LNB_MAXV];     // [dg|db|dbias][wave][column]  (48 KB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = (H + 255) / 256;
-    f32x4 gsum[LNB_MAXV], bsum[LNB_MAXV], gg[LNB_MAXV];
+    f32x4 gsum[LNB_MAXV], bsum[LNB_MAXV], gg[LNB_MAXV], xsum[LNB_MAXV];
 #pragma unroll
     for (int i = 0; i < LNB_MAXV; ++i) {
+        xsum[i] = f32x4{0, 0, 0, 0};
         gsum[i] = f32x4{0, 0, 0, 0};
         bsum[i] = f32x4{0, 0, 0, 0};
         const int c = (lane + 64 * i) * 4;
@@ -306,6 +311,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     o[j] = d;
                 }
                 if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)r * H + c) = o;
+                if (dr.thresh != 0) {
+                    bool keep[4];
+                    drop_hidden4(dr, ((uint64_t)r * H + c) >> 2, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = keep[j] ? o[j] * dr.scale : 0.f;
+                }
+                if (dbias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xsum[i][j] += o[j];
+                }
                 if (dx_lp) {
                     if constexpr (sizeof(LP) == 2) {
                         bf16x4 p;
@@ -326,54 +341,60 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         for (int j = 0; j < 4; ++j) {
             red[0][wave][(lane + 64 * i) * 4 + j] = gsum[i][j];
             red[1][wave][(lane + 64 * i) * 4 + j] = bsum[i][j];
+            red[2][wave][(lane + 64 * i) * 4 + j] = xsum[i][j];
         }
     __syncthreads();
-    if (part) {     // two-stage column sums: this block's partial row [2][H], added up by ln_bwd_reduce_kernel
-        for (int c = threadIdx.x; c < H; c += 256) {
-            part[((size_t)blockIdx.x * 2 + 0) * H + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-            part[((size_t)blockIdx.x * 2 + 1) * H + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        }
+    const int nsum = dbias ? 3 : 2;
+    if (part) {     // two-stage column sums: this block's partial rows [nsum][H], added up by ln_bwd_reduce_kernel
+        for (int c = threadIdx.x; c < H; c += 256)
+            for (int k = 0; k < nsum; ++k)
+                part[((size_t)blockIdx.x * nsum + k) * H + c] = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
         return;
     }
     for (int c = threadIdx.x; c < H; c += 256) {
         atomicAdd(&dg[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
         atomicAdd(&db[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        if (dbias) atomicAdd(&dbias[c], red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
     }
 }
 
-// second stage: column c of [nb][2][H] partials; blockIdx.y takes a slice of the nb blocks, one atomic per (slice, column)
+// second stage: column c of [nb][nsum][H] partials; blockIdx.y takes a slice of the nb blocks, one atomic per (slice, column)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dg, float* __restrict__ db,
-                                                            int nb, int H, int per) {
+                                                            float* __restrict__ dbias, int nb, int H, int per) {
+    const int nsum = dbias ? 3 : 2;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= 2 * H) return;
+    if (c >= nsum * H) return;
     const int b0 = blockIdx.y * per;
     float v[16];                                        // per == 16: all loads in flight before the first add
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = (b0 + k < nb) ? part[(size_t)(b0 + k) * 2 * H + c] : 0.f;
+    for (int k = 0; k < 16; ++k) v[k] = (b0 + k < nb) ? part[(size_t)(b0 + k) * nsum * H + c] : 0.f;
     float a = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) a += v[k];
-    atomicAdd(c < H ? &dg[c] : &db[c - H], a);
+    atomicAdd(c < H ? &dg[c] : (c < 2 * H ? &db[c - H] : &dbias[c - 2 * H]), a);
 }
 
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
-           float* part, size_t part_bytes) {
+           float* part, size_t part_bytes, const DropSpec* drop, float* dbias) {
+    const DropSpec dr = drop ? *drop : DropSpec{};
+    if ((dr.thresh != 0 || dbias) && (!g || grp != R)) return CPT_ERR_SHAPE;      // mask / bias sums: compact rows only
+    const int nsum = dbias ? 3 : 2;
     if (R <= 0 || H % 4 || H > 256 * LNB_MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!dy || (g && (!x || !dg || !db))) return CPT_ERR_NULL;      // g == NULL: identity (row gather only)
     // rows per block: with atomics fewer blocks = fewer dgamma/dbeta atomics (2*H per block); with a partial-sum buffer (two-stage
     // column sums) one row per wave keeps 4x the rows in flight: the kernel is latency-bound otherwise (22 -> ~10 us at 3840 rows)
     int rpb = R >= 2048 ? 16 : 8;
-    if (g && part && R >= 1024 && (size_t)((R + 3) / 4) * 2 * H * 4 <= part_bytes) rpb = 4; else part = nullptr;
+    if (g && part && R >= 1024 && (size_t)((R + 3) / 4) * nsum * H * 4 <= part_bytes) rpb = 4; else part = nullptr;
     dim3 grid((R + rpb - 1) / rpb), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
-#define LNB(LPT, GI) ln_bwd_kernel<LPT, GI><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part)
+#define LNB(LPT, GI) ln_bwd_kernel<LPT, GI><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias)
     if (lp16) { if (gelu_in) LNB(bf16, true); else LNB(bf16, false); }
     else      { if (gelu_in) LNB(float, true); else LNB(float, false); }
 #undef LNB
     if (part) {
         const int nb = (int)grid.x, per = 16;
-        ln_bwd_reduce_kernel<<<dim3((2 * H + 255) / 256, (nb + per - 1) / per), dim3(256), 0, s>>>(part, dg, db, nb, H, per);
+        ln_bwd_reduce_kernel<<<dim3((nsum * H + 255) / 256, (nb + per - 1) / per), dim3(256), 0, s>>>(part, dg, db, dbias, nb, H, per);
     }
     return CPT_OK;
 }

@@ -37,7 +37,8 @@ int gelu_fwd(const void* u, void* h, int dtype, size_t n, hipStream_t s);
 int gelu_bwd(const void* dh, const void* u, void* du, int dtype, size_t n, hipStream_t s);
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
-           float* part = nullptr, size_t part_bytes = 0);      // part: scratch for two-stage dgamma / dbeta sums ((R / 4) * 2 * H floats)
+           float* part = nullptr, size_t part_bytes = 0,       // part: scratch for two-stage column sums ((R / 4) * 3 * H floats)
+           const DropSpec* drop = nullptr, float* dbias = nullptr);   // drop: dx_lp = dx through that hidden-site mask; dbias += column sums of it
 int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
               const float* posw, const float* typew, const float* g, float eps, float* dword, float* dposw,
               float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,

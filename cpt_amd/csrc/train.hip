@@ -356,10 +356,19 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         const cpt_layer& y = m->layers[l];
         const cpt_layer_grads& gy = g->layers[l];
         // x_out = LN2(pre2); pre2 = h W_out^T + b_out + a
+        // bf16: the LayerNorm backward also applies the dense output's dropout mask to the gradient that goes on into the dense
+        // layer (written as bf16 only) and sums its columns for the bias gradient: no dropout_rows / colsum launches
+        const bool fuse_db = dt == CPT_BF16;
+        if (fuse_db) {
+            const cpt::DropSpec sp2 = drop_spec(drop, 3 + 3 * l, false);
+            TRY(cpt::ln_bwd(dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, ph ? dmask_lp : dpre_lp, dt, gy.ln2_g, gy.ln2_b,
+                            M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes, ph ? &sp2 : nullptr, gy.b_out), "ln_bwd(ffn)+dropout+bias");
+        } else {
         TRY(cpt::ln_bwd(dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln2_g, gy.ln2_b,
                         M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes), "ln_bwd(ffn)");
         if (ph) TRY(cpt::dropout_rows(dpre, nullptr, dmask, dt == CPT_BF16 ? dmask_lp : nullptr, dt, M, H, drop_spec(drop, 3 + 3 * l, false), s), "dropout_bwd(ffn down)");
         TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_out, M, H, s), "colsum(b_out)");
+        }
         rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_h), I, I, M, Mp, gy.w_out, I, "wgrad(ffn down)");
         if (rc) return rc;
         rc = dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)");
@@ -372,10 +381,16 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         rc = dgrad(dbig, I, I, y.w_in, H, I, H, M, dpre, da, CPT_F32, "dgrad(ffn up)+residual");
         if (rc) return rc;
         // a = LN1(pre1); pre1 = ctx W_ao^T + b_ao + x_in
+        if (fuse_db) {
+            const cpt::DropSpec sp1 = drop_spec(drop, 2 + 3 * l, false);
+            TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, ph ? dmask_lp : dpre_lp, dt, gy.ln1_g, gy.ln1_b,
+                            M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes, ph ? &sp1 : nullptr, gy.b_ao), "ln_bwd(attn)+dropout+bias");
+        } else {
         TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln1_g, gy.ln1_b,
                         M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes), "ln_bwd(attn)");
         if (ph) TRY(cpt::dropout_rows(dpre, nullptr, dmask, dt == CPT_BF16 ? dmask_lp : nullptr, dt, M, H, drop_spec(drop, 2 + 3 * l, false), s), "dropout_bwd(attn out)");
         TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_ao, M, H, s), "colsum(b_ao)");
+        }
         rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_ctx), H, H, M, Mp, gy.w_ao, H, "wgrad(attn out)");
         if (rc) return rc;
         rc = dgrad(dpre_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");

@@ -337,6 +337,11 @@ int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos,
  * bytes are used when the output has few tiles); they are added in split order, so the result is reproducible. */
 int cpt_gemm_tn(const void* A_bf16, int lda, const void* W_bf16, int ldw, float* out, int ldo, int M, int N, int K, void* partials,
                 size_t partial_bytes, void* stream);
+/* Data-gradient GEMM in the NN form (dX = dY . W against an nn.Linear weight as stored): out[M][N] = A[M][K] . W[K][N] (+ resid),
+ * A bf16 [M][lda], W bf16 [K][ldw] (row = contraction index = out_features), out fp32 (optionally + fp32 resid [M][ldr]) or bf16.
+ * N % 192 == 0, K % 64 == 0. */
+int cpt_gemm_nn(const void* A_bf16, int lda, const void* W_bf16, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo,
+                int M, int N, int K, void* stream);
 
 /* Split-operand copy for CPT_BF16X3: x fp32 [R][K] (leading dimension ld) -> out bf16 [R][3K] holding, per row, the blocks
  * hi | hi | lo (weight_order 0: activations) or hi | lo | hi (weight_order 1: nn.Linear weights), hi = bf16(x),

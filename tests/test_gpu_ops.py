@@ -331,6 +331,29 @@ def test_gemm_tn_weight_gradient_form(dev, K, M, N):
     assert (got2 - a.float().t() @ wide[:, 64:].float()).abs().max().item() < tol * 4
 
 
+@pytest.mark.parametrize("M,N,K,resid,odt", [(3840, 768, 3072, True, torch.float32), (3840, 3072, 768, False, torch.bfloat16),
+                                             (3840, 768, 768, False, torch.bfloat16), (3840, 768, 2304, True, torch.float32),
+                                             (1000, 768, 768, False, torch.float32), (77, 192, 64, True, torch.float32),
+                                             (53760, 768, 768, False, torch.bfloat16)])
+def test_gemm_nn_data_gradient_form(dev, M, N, K, resid, odt):
+    """out = A W (+ resid) with W stored [K][N] (an nn.Linear weight, rows = the contraction index): A staged as in the NT form, W read
+    through LDS transpose reads; 64-row and 128-row tile instantiations, ragged M, every epilogue the backward pass uses."""
+    from cpt_amd import ops
+    rng = _rng(M + N + K)
+    a = _t(rng, M, K).to(torch.bfloat16).to(dev)
+    w = _t(rng, K, N, scale=0.05).to(torch.bfloat16).to(dev)
+    w[:, 3] = 0.0
+    w[11, 3] = 1.0                                  # output column 3 = column 11 of a exactly
+    r = _t(rng, M, N).to(dev) if resid else None
+    ref = a.float() @ w.float() + (r if resid else 0.0)
+    got = ops.gemm_nn(a, w, r, odt)
+    tol = (2e-5 * (K ** 0.5) + 1e-4) * 4 if odt == torch.float32 else 0.02 * (K ** 0.5) * 0.05 + 0.02
+    assert (got.float() - ref).abs().max().item() < tol, (got.float() - ref).abs().max().item()
+    if not resid:
+        assert torch.equal(got[:, 3].float(), a[:, 11].float())
+    assert torch.equal(got, ops.gemm_nn(a, w, r, odt))
+
+
 def _r3_encode_np(x):
     """CPU restatement of the 3-byte residual code (csrc/common.h r3_encode): T = fp32 pattern rounded half away to 24 bits,
     hi = (T + 0x80) >> 8 (a bf16 pattern), lo = int8(T - (hi << 8))."""

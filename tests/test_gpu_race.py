@@ -60,6 +60,25 @@ def test_gemm_ring_race_screen(dev, variant, M, N, K, epi):
     assert bad == 0, "%d of the launches differed from the first one" % bad
 
 
+@pytest.mark.parametrize("form,M,N,K", [("tn", 768, 768, 3840), ("tn", 3072, 768, 3840), ("tn", 1024, 1024, 960), ("nn", 3840, 768, 3072),
+                                        ("nn", 3840, 3072, 768), ("nn", 1000, 768, 768)])
+def test_gradient_gemm_forms_race_screen(dev, form, M, N, K):
+    """TN (weight gradients, split-K partials added in order) and NN (data gradients) forms: operand tiles read by inline-asm
+    transpose reads behind explicit counted lgkmcnt waits -- exactly the kind of synchronisation a timing change would break."""
+    from cpt_amd import ops
+    torch.manual_seed(M + K)
+    if form == "tn":
+        a = torch.randn(K, M, device=dev).to(torch.bfloat16)
+        w = torch.randn(K, N, device=dev).to(torch.bfloat16)
+        bad = _screen(dev, lambda s: (ops.gemm_tn(a, w),), n=300)
+    else:
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        w = (torch.randn(K, N, device=dev) * 0.05).to(torch.bfloat16)
+        r = torch.randn(M, N, device=dev)
+        bad = _screen(dev, lambda s: (ops.gemm_nn(a, w, r, torch.float32),), n=300)
+    assert bad == 0, "%d of the launches differed from the first one" % bad
+
+
 @pytest.mark.parametrize("variant,M,N,K", [(3, 7680, 3072, 768), (20, 2000, 4096, 1024), (15, 7680, 3072, 768), (19, 7680, 3072, 768), (14, 7680, 2304, 768)])
 def test_ln_consumer_race_screen(dev, variant, M, N, K):
     """Two-pass FFN-up kernel (variant 3, K = 768 and 1024 incl. a ragged last row tile) and the direct-epilogue tile shapes."""
@@ -93,6 +112,10 @@ def test_ln_producer_race_screen(dev, K):
     g, bt = 1.0 + 0.1 * torch.randn(N, device=dev), 0.1 * torch.randn(N, device=dev)
     bad = _screen(dev, lambda s: ops.gemm_ln_prod(a, w, bias, resid, st_in, g, bt, 1e-12, N), n=LAUNCHES if K < 3000 else 300)
     assert bad == 0, "%d of the launches differed from the first one" % bad
+    # the same producer with the 3-byte residual stream (what the fused encoder runs)
+    hi, lo = ops.resid3_split(resid)
+    bad = _screen(dev, lambda s: ops.gemm_ln_prod3(a, w, bias, hi, lo, st_in, g, bt, 1e-12, N), n=300)
+    assert bad == 0, "3-byte producer: %d of the launches differed from the first one" % bad
 
 
 def test_fused_qkv_attention_race_screen(dev):
