@@ -170,6 +170,7 @@ struct EpiX {
     float eps, inv_h;      // LayerNorm eps, 1 / hidden
     const int64_t* mask;   // ATTN: [B][L] attention mask (1 keep / 0 drop) or NULL
     int seq_len, heads;    // ATTN: tokens per sequence (<= 128), attention heads
+    int w_rows;            // NN form: rows of W that exist (0: K); rows beyond read as zero (K rounded up to a K-tile multiple)
     int skew;              // two-workgroups-per-CU shapes: start delay of every second workgroup (see skew_start)
 };
 
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     static_assert(TN != 1 || EPI == CPT_EPI_NONE, "TN form: plain epilogue");
     static_assert(TN != 2 || EPI == CPT_EPI_NONE || EPI == CPT_EPI_RESID, "NN form: plain or residual epilogue");
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)(TA ? K : M) * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)(TN ? K : N) * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)(TN ? ((TN == 2 && ex.w_rows > 0) ? ex.w_rows : K) : N) * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
     constexpr int CPRA = TBM / 8, CPRB = TBN / 8;      // TN: 16-byte chunks per tile row
     // G <= 6: one VGPR per piece, computed once.  Bigger tiles (registers go to the accumulators): the offsets are rebuilt at
     // every issue from the piece's row (2 VALU per 1 KiB piece); with an even wave count the swizzle term is the same for
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     static_assert(DIRECT || (16 * CPW + SIDE) * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
     static_assert(DIRECT || (MI * 32 <= 64 && CH <= 64), "side area is filled by one wave pass");
     if (split != 0) bias = nullptr;                   // split-K: the bias is added once
-    if constexpr (TN == 1) out += (size_t)split * M * ldo; // TN split-K: every split writes its own partial matrix (reduced in slot order afterwards)
+    if constexpr (TN != 0) out += (size_t)split * M * ldo; // TN / NN split-K: every split writes its own partial matrix (reduced in slot order afterwards)
     if constexpr (DIRECT) {
         // ---- direct epilogue: the accumulators are TRANSPOSED (operands swapped in mma): lane = output row
         // (wrow0 + 32 i + (lane & 31)), register quad g of block j = the four consecutive columns
@@ -1258,15 +1259,36 @@ int gemm_nn_eligible(int M, int N, int K, int lda, int ldw) {
 }
 
 int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
-            hipStream_t s) {
+            hipStream_t s, int w_rows, void* partials, size_t partial_bytes) {
     if (!gemm_nn_eligible(M, N, K, lda, ldw)) return CPT_ERR_SHAPE;
     if (!A || !W || !out) return CPT_ERR_NULL;
-    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)resid) & 15)) return CPT_ERR_ALIGN;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)resid | (uintptr_t)partials) & 15)) return CPT_ERR_ALIGN;
+    if (w_rows < 0 || w_rows > K) return CPT_ERR_SHAPE;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
     // 64-row tiles when 128-row tiles would leave half the chip idle (M = 3840, N = 768: 120 vs 240 workgroups)
     const long wg128 = (long)((M + 127) / 128) * (N / 192);
     const bool small = wg128 < 200;
-#define CPT_NN(EPI, OT, CFG_TBM, CFG_WM) launch_pipe<bf16, EPI, OT, CFG_TBM, 192, CFG_WM, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (OT*)out, ldo, M, N, K, s, 1)
+    EpiX ex = {};
+    ex.w_rows = w_rows;
+    // few output tiles and a long contraction (the decoder's data gradient: 32 x 768 outputs over K = 30528 ran on 4 CUs for 220 us):
+    // split K over up to 64 workgroups per tile, partial matrices added in split order
+    if (out_dtype == CPT_F32 && !resid && partials && ldo == N) {
+        const long tiles = (long)((M + 63) / 64) * (N / 192);
+        const int nt = K / 64;
+        int S = (int)(256 / tiles);
+        if (S > 64) S = 64;
+        if (S > nt / 3) S = nt / 3;
+        const size_t mat = (size_t)M * N * 4;
+        while (S > 1 && (size_t)S * mat > partial_bytes) --S;
+        if (S >= 4) {
+            int rc = launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, nullptr, 0, (float*)partials, ldo, M, N, K, s, S, &ex);
+            if (rc != CPT_OK) return rc;
+            const size_t n4 = mat / 16;
+            reduce_partials_kernel<<<dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S);
+            return CPT_OK;
+        }
+    }
+#define CPT_NN(EPI, OT, CFG_TBM, CFG_WM) launch_pipe<bf16, EPI, OT, CFG_TBM, 192, CFG_WM, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (OT*)out, ldo, M, N, K, s, 1, &ex)
     if (out_dtype == CPT_BF16) {
         if (resid) return CPT_ERR_DTYPE;
         return small ? CPT_NN(CPT_EPI_NONE, bf16, 64, 2) : CPT_NN(CPT_EPI_NONE, bf16, 128, 4);

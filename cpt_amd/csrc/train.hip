@@ -287,8 +287,9 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     auto dgrad = [&](const void* dY, int ldy, int Nout_p, const void* Wt, int ldw, int Nout, int Kout, int rows,
                      const float* resid, void* out, int out_dt, const char* what) -> int {
         // bf16, tile-aligned: the NN form reads the weight as stored (transpose reads in LDS)
-        if (g_wgrad_tn && dt == CPT_BF16 && Nout == Nout_p && cpt::gemm_nn_eligible(rows, Kout, Nout, ldy, ldw)) {
-            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout, s), what);
+        // (Nout < Nout_p: the K-tile padding columns of dY are zero and the weight rows beyond Nout read as zero)
+        if (g_wgrad_tn && dt == CPT_BF16 && cpt::gemm_nn_eligible(rows, Kout, Nout_p, ldy, ldw)) {
+            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes), what);
             return CPT_OK;
         }
         TRY(cpt::transpose_cast(Wt, dt, ldw, wT, dt, Nout_p, Nout, Kout, s), what);

@@ -125,14 +125,17 @@ def row_stats_table(x, hidden=None):
     return st
 
 
-def gemm_nn(a, w, resid=None, out_dtype=torch.float32):
-    """out[M, N] = a @ w (+ resid) for bf16 a[M, K], w[K, N] (w = an nn.Linear weight as stored: the data-gradient form)."""
+def gemm_nn(a, w, resid=None, out_dtype=torch.float32, split_scratch=False):
+    """out[M, N] = a @ w (+ resid) for bf16 a[M, K], w[Kw, N] (w = an nn.Linear weight as stored: the data-gradient form).
+    Kw <= K: K is a's column count rounded up to a multiple of 64 with zero columns; w rows beyond Kw count as zero."""
     _need_cuda(a, w, resid)
     M, K = a.shape
     N = w.size(1)
     out = torch.empty((M, N), device=a.device, dtype=out_dtype)
+    part = torch.empty((64 * M * N,), device=a.device, dtype=torch.float32) if split_scratch else None
     L.check(L.lib().cpt_gemm_nn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), L.ptr(resid), resid.stride(0) if resid is not None else 0,
-                                out.data_ptr(), L.CPT_BF16 if out_dtype == torch.bfloat16 else L.CPT_F32, N, M, N, K, L.stream_ptr()), "cpt_gemm_nn")
+                                out.data_ptr(), L.CPT_BF16 if out_dtype == torch.bfloat16 else L.CPT_F32, N, M, N, K, w.size(0),
+                                L.ptr(part), part.numel() * 4 if part is not None else 0, L.stream_ptr()), "cpt_gemm_nn")
     return out
 
 

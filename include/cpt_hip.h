@@ -339,9 +339,11 @@ int cpt_gemm_tn(const void* A_bf16, int lda, const void* W_bf16, int ldw, float*
                 size_t partial_bytes, void* stream);
 /* Data-gradient GEMM in the NN form (dX = dY . W against an nn.Linear weight as stored): out[M][N] = A[M][K] . W[K][N] (+ resid),
  * A bf16 [M][lda], W bf16 [K][ldw] (row = contraction index = out_features), out fp32 (optionally + fp32 resid [M][ldr]) or bf16.
- * N % 192 == 0, K % 64 == 0. */
+ * N % 192 == 0, K % 64 == 0.  w_rows (0: K): rows of W that exist when K was rounded up to a multiple of 64 -- rows beyond read as
+ * zero, A's extra columns must hold zeros (the vocabulary-sized decoder, 30522 rows).  partials (optional): scratch for split-K when the
+ * output has few tiles and K is long (fp32 output without residual; up to 64 * M * N * 4 bytes used, added in split order). */
 int cpt_gemm_nn(const void* A_bf16, int lda, const void* W_bf16, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo,
-                int M, int N, int K, void* stream);
+                int M, int N, int K, int w_rows, void* partials, size_t partial_bytes, void* stream);
 
 /* Split-operand copy for CPT_BF16X3: x fp32 [R][K] (leading dimension ld) -> out bf16 [R][3K] holding, per row, the blocks
  * hi | hi | lo (weight_order 0: activations) or hi | lo | hi (weight_order 1: nn.Linear weights), hi = bf16(x),

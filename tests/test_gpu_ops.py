@@ -354,6 +354,26 @@ def test_gemm_nn_data_gradient_form(dev, M, N, K, resid, odt):
     assert torch.equal(got, ops.gemm_nn(a, w, r, odt))
 
 
+def test_gemm_nn_split_k_and_row_bound(dev):
+    """The decoder's data gradient: 32 x 768 outputs over the vocabulary (K = 30522 rounded up to 30528 with zero columns in A; the
+    weight has 30522 rows and is followed by other live memory): split-K partials added in order, rows beyond the bound read as
+    zero -- also when what follows the weight in memory is NaN."""
+    from cpt_amd import ops
+    rng = _rng(30522)
+    V, Vp, H, B = 30522, 30528, 768, 32
+    a = torch.zeros(B, Vp, dtype=torch.bfloat16, device=dev)
+    a[:, :V] = (_t(rng, B, V, scale=0.01)).to(torch.bfloat16).to(dev)
+    buf = torch.full((Vp + 8, H), float("nan"), dtype=torch.bfloat16, device=dev)       # the weight's rows, then NaN
+    buf[:V] = _t(rng, V, H, scale=0.05).to(torch.bfloat16).to(dev)
+    w = buf[:V]
+    ref = a[:, :V].float() @ w.float()
+    for scratch in (True, False):
+        got = ops.gemm_nn(a, w, None, torch.float32, split_scratch=scratch)
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() < 2e-3, (scratch, (got - ref).abs().max().item())
+    assert torch.equal(ops.gemm_nn(a, w, None, torch.float32, split_scratch=True), ops.gemm_nn(a, w, None, torch.float32, split_scratch=True))
+
+
 def _r3_encode_np(x):
     """CPU restatement of the 3-byte residual code (csrc/common.h r3_encode): T = fp32 pattern rounded half away to 24 bits,
     hi = (T + 0x80) >> 8 (a bf16 pattern), lo = int8(T - (hi << 8))."""
