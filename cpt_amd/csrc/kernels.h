@@ -58,7 +58,9 @@ int dropout_mask(int kind, unsigned char* out, int n0, int n1, int n2, const Dro
 int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16, size_t n,
                float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s);
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
-                      int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s);
+                      int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
+                      const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr);
+// resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients
 // without operand transposes); needs gemm_tn_eligible; `partials` (optional) holds the split-K partial matrices

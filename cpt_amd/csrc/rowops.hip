@@ -60,7 +60,11 @@ __device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lan
 template <typename LP, bool GELU_IN>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
-    float* __restrict__ out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off) {
+    float* __restrict__ out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
+    const float* __restrict__ resid, DropSpec dr, float* __restrict__ pre_out) {
+    // resid / dr / pre_out (training forward of LN(dropout(dense) + residual), modeling_bert.py:85-86,145 with the third-party
+    // BertSelfOutput / BertOutput): the row that is normalised is dropout(x) + resid, written to pre_out for the backward pass --
+    // the same arithmetic, in the same order, as the dropout_rows pass this replaces
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -76,6 +80,18 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[i][j] = gelu_erf(v[i][j]);
             }
+            if (dr.thresh != 0) {
+                bool keep[4];
+                drop_hidden4(dr, ((uint64_t)r * H + c) >> 2, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = keep[j] ? v[i][j] * dr.scale : 0.f;
+            }
+            if (resid) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(resid + (size_t)r * H + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] += rr[j];
+            }
+            if (pre_out) *reinterpret_cast<f32x4*>(pre_out + (size_t)r * H + c) = v[i];
         }
     }
     float mean = 0.f, rstd = 1.f;
@@ -87,13 +103,14 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
 
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
-                      int gelu_in, hipStream_t s) {
+                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out) {
     if (R <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
+    const DropSpec dr = drop ? *drop : DropSpec{};
     if (grp_stride == 0 && grp != R) grp_stride = grp;
     dim3 grid((R + 3) / 4), block(ROW_THREADS);
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
-#define LNK(LPT, GI) layernorm_rows_kernel<LPT, GI><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off)
+#define LNK(LPT, GI) layernorm_rows_kernel<LPT, GI><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
     else      { if (gelu_in) LNK(float, true); else LNK(float, false); }
 #undef LNK

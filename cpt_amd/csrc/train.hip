@@ -190,20 +190,25 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention");
         if (ph) {   // LN(dropout(dense(ctx)) + x): the residual add moves from the GEMM epilogue into the dropout pass
             TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, nullptr, 0, LB(l, w.o_pre1), CPT_F32, H, M, H, H, s), "gemm(attn out)");
-            TRY(cpt::dropout_rows((const float*)LB(l, w.o_pre1), x_f32, (float*)LB(l, w.o_pre1), nullptr, dt, M, H, drop_spec(drop, 2 + 3 * l, false), s),
-                "dropout(attn out)+residual");
-        } else
+            // dropout + residual + LayerNorm in one row pass (pre1 = dropout(dense) + x is stored for the backward pass)
+            const cpt::DropSpec sp = drop_spec(drop, 2 + 3 * l, false);
+            TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
+                                       x_f32, &sp, (float*)LB(l, w.o_pre1)), "dropout(attn out)+residual+layernorm");
+        } else {
         TRY(cpt::gemm(dt, CPT_EPI_RESID, LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, x_f32, H, LB(l, w.o_pre1), CPT_F32, H, M, H, H, s), "gemm(attn out)");
         TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, s), "layernorm(attn)");
+        }
         TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_a), H, y.w_in, H, y.b_in, nullptr, 0, LB(l, w.o_u), dt, I, M, I, H, s), "gemm(ffn up)");
         TRY(cpt::gelu_fwd(LB(l, w.o_u), LB(l, w.o_h), dt, (size_t)M * I, s), "gelu");
         if (ph) {
             TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, 0, LB(l, w.o_pre2), CPT_F32, H, M, H, I, s), "gemm(ffn down)");
-            TRY(cpt::dropout_rows((const float*)LB(l, w.o_pre2), a_f32, (float*)LB(l, w.o_pre2), nullptr, dt, M, H, drop_spec(drop, 3 + 3 * l, false), s),
-                "dropout(ffn down)+residual");
-        } else
+            const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
+            TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
+                                       a_f32, &sp, (float*)LB(l, w.o_pre2)), "dropout(ffn down)+residual+layernorm");
+        } else {
         TRY(cpt::gemm(dt, CPT_EPI_RESID, LB(l, w.o_h), I, y.w_out, I, y.b_out, a_f32, H, LB(l, w.o_pre2), CPT_F32, H, M, H, I, s), "gemm(ffn down)");
         TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, s), "layernorm(ffn)");
+        }
     }
     // head on the [MASK] rows
     void* rows = ws + w.rows;
