@@ -142,6 +142,7 @@ constexpr int CPT_EPI_LNCONS = 7;      // internal: A operand is a pre-LayerNorm
 constexpr int CPT_EPI_LNCONS_GELU = 8; // internal: same + GELU
 constexpr int CPT_EPI_ATTN = 9;        // internal: fused QKV projection + self-attention of one (sequence, head) per workgroup
 constexpr int CPT_EPI_ATTN_LN = 10;    // internal: same, A operand is a pre-LayerNorm tensor (LayerNorm folded like LNCONS)
+constexpr int CPT_EPI_GELU2 = 12;      // internal (training forward): writes u = A.W^T + bias (bf16, to EpiX.out_lp) AND gelu(u) (to out): BertIntermediate
 constexpr int CPT_EPI_LNPROD3 = 11;    // internal: LNPROD with the residual stream in the 3-byte form (bf16 hi + int8 lo, see r3_encode): in and out
 
 // ---------------------------------------------------------------------------------------------
@@ -765,7 +766,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     constexpr bool LNPROD = EPI == CPT_EPI_LNPROD || R3;
     constexpr bool LNCONS = EPI == CPT_EPI_LNCONS || EPI == CPT_EPI_LNCONS_GELU;
     constexpr bool HAS_RESID = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || LNPROD;
-    constexpr bool DO_GELU = EPI == CPT_EPI_GELU || EPI == CPT_EPI_LNCONS_GELU;
+    constexpr bool GELU2 = EPI == CPT_EPI_GELU2;      // pre-activation stored too; the GELU is taken of the STORED (bf16-rounded) value, as the two-kernel form did
+    static_assert(!GELU2 || (sizeof(T) == 2 && sizeof(OT) == 2), "GELU2: bf16 in, bf16 out");
+    constexpr bool DO_GELU = EPI == CPT_EPI_GELU || EPI == CPT_EPI_LNCONS_GELU || GELU2;
     const T* resid_lp = reinterpret_cast<const T*>(resid);      // EPI_RESID_LP: same rows, compute dtype; LNPROD3: the hi part
     const bool fold_resid = LNPROD && ex.g_in != nullptr;       // residual = LayerNorm(resid; st_in, g_in, b_in)
     // fp32 outputs without residual (e.g. the vocabulary decoder, ldo = 30522): rows are only 8-byte aligned, but 16-byte
@@ -792,6 +795,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
             x = ln_fold(a, mu, rs, ex.colc[col], ex.cold[col]);
         } else {
             x = a + (bias ? bias[col] : 0.f);
+        }
+        if constexpr (GELU2) {
+            const T ub = from_f32<T>(x);
+            reinterpret_cast<T*>(ex.out_lp)[(size_t)row * ldo + col] = ub;
+            x = to_f32(ub);
         }
         if (DO_GELU) x = gelu_for<T>(x);
         if (EPI == CPT_EPI_TANH) x = tanhf(x);
@@ -923,6 +931,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     for (int e = 0; e < 4; ++e) {
                         if constexpr (LNCONS) v[e] = ln_fold(v[e], mu, rs, cv[it % P][e], bv[it % P][e]);
                         else v[e] = v[e] + bv[it % P][e];
+                    }
+                    if constexpr (GELU2) {
+                        bf16x4 ub;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { ub[e] = (bf16)v[e]; v[e] = (float)ub[e]; }
+                        if (!GUARD || (row < M && col < N)) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(ex.out_lp) + (size_t)row * ldo + col) = ub;
                     }
                     if constexpr (DO_GELU && sizeof(T) == 2) {        // bf16 path: packed-fp32 fast GELU on pairs
                         const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
@@ -1249,6 +1263,19 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
         const int blocks = (int)std::min<size_t>((n4 + 255) / 256, 2048);
         reduce_partials_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S);
     }
+    return CPT_OK;
+}
+
+// Training forward of BertIntermediate (modeling_bert.py:144): u = A.W^T + bias (bf16, kept for the backward pass) and h = gelu(u)
+// from one GEMM (the GELU used to be its own pass over the M x I tensor)
+int gemm_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias, void* u_out, void* h_out, int ldo, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8 || ldo % 8 || N % 8) return CPT_ERR_SHAPE;
+    if (!A || !W || !u_out || !h_out) return CPT_ERR_NULL;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)u_out | (uintptr_t)h_out | (uintptr_t)bias) & 15)) return CPT_ERR_ALIGN;
+    EpiX ex = {};
+    ex.out_lp = u_out;
+    launch_fast<bf16, CPT_EPI_GELU2, bf16>(g_gemm_variant >= 3 ? g_gemm_variant : 3, (const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0,
+                                          (bf16*)h_out, ldo, M, N, K, s, &ex);
     return CPT_OK;
 }
 

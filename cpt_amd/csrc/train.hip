@@ -198,8 +198,12 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         TRY(cpt::gemm(dt, CPT_EPI_RESID, LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, x_f32, H, LB(l, w.o_pre1), CPT_F32, H, M, H, H, s), "gemm(attn out)");
         TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, s), "layernorm(attn)");
         }
+        if (dt == CPT_BF16 && H % 64 == 0 && I % 8 == 0) {
+            TRY(cpt::gemm_gelu2(LB(l, w.o_a), H, y.w_in, H, y.b_in, LB(l, w.o_u), LB(l, w.o_h), I, M, I, H, s), "gemm(ffn up)+gelu");
+        } else {
         TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_a), H, y.w_in, H, y.b_in, nullptr, 0, LB(l, w.o_u), dt, I, M, I, H, s), "gemm(ffn up)");
         TRY(cpt::gelu_fwd(LB(l, w.o_u), LB(l, w.o_h), dt, (size_t)M * I, s), "gelu");
+        }
         if (ph) {
             TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, 0, LB(l, w.o_pre2), CPT_F32, H, M, H, I, s), "gemm(ffn down)");
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
