@@ -143,6 +143,7 @@ constexpr int CPT_EPI_LNCONS_GELU = 8; // internal: same + GELU
 constexpr int CPT_EPI_ATTN = 9;        // internal: fused QKV projection + self-attention of one (sequence, head) per workgroup
 constexpr int CPT_EPI_ATTN_LN = 10;    // internal: same, A operand is a pre-LayerNorm tensor (LayerNorm folded like LNCONS)
 constexpr int CPT_EPI_GELU2 = 12;      // internal (training forward): writes u = A.W^T + bias (bf16, to EpiX.out_lp) AND gelu(u) (to out): BertIntermediate
+constexpr int CPT_EPI_GELUGRAD = 13;   // internal (training backward): out = (A.W) * gelu'(u), u (compute dtype) passed in the residual slot: dgrad of BertOutput.dense + gelu backward
 constexpr int CPT_EPI_LNPROD3 = 11;    // internal: LNPROD with the residual stream in the 3-byte form (bf16 hi + int8 lo, see r3_encode): in and out
 
 // ---------------------------------------------------------------------------------------------
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     constexpr bool TA = TN == 1, TW = TN != 0;        // which operands have the contraction index as their slow dimension
     static_assert(!TN || (sizeof(T) == 2 && TBM % 64 == 0 && TBN % 64 == 0), "TN / NN forms: bf16");
     static_assert(TN != 1 || EPI == CPT_EPI_NONE, "TN form: plain epilogue");
-    static_assert(TN != 2 || EPI == CPT_EPI_NONE || EPI == CPT_EPI_RESID, "NN form: plain or residual epilogue");
+    static_assert(TN != 2 || EPI == CPT_EPI_NONE || EPI == CPT_EPI_RESID || EPI == CPT_EPI_GELUGRAD, "NN form: plain, residual or GELU-gradient epilogue");
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)(TA ? K : M) * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)(TN ? ((TN == 2 && ex.w_rows > 0) ? ex.w_rows : K) : N) * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
     constexpr int CPRA = TBM / 8, CPRB = TBN / 8;      // TN: 16-byte chunks per tile row
@@ -765,7 +766,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     constexpr bool R3 = EPI == CPT_EPI_LNPROD3;                  // residual stream in the 3-byte form (r3_encode), in and out
     constexpr bool LNPROD = EPI == CPT_EPI_LNPROD || R3;
     constexpr bool LNCONS = EPI == CPT_EPI_LNCONS || EPI == CPT_EPI_LNCONS_GELU;
-    constexpr bool HAS_RESID = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || LNPROD;
+    constexpr bool GG = EPI == CPT_EPI_GELUGRAD;       // the "residual" operand is u (compute dtype): the result is multiplied by gelu'(u)
+    constexpr bool HAS_RESID = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || LNPROD || GG;
     constexpr bool GELU2 = EPI == CPT_EPI_GELU2;      // pre-activation stored too; the GELU is taken of the STORED (bf16-rounded) value, as the two-kernel form did
     static_assert(!GELU2 || (sizeof(T) == 2 && sizeof(OT) == 2), "GELU2: bf16 in, bf16 out");
     constexpr bool DO_GELU = EPI == CPT_EPI_GELU || EPI == CPT_EPI_LNCONS_GELU || GELU2;
@@ -805,6 +807,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         if (EPI == CPT_EPI_TANH) x = tanhf(x);
         if (EPI == CPT_EPI_RESID) x += resid[(size_t)row * ldr + col];
         if (EPI == CPT_EPI_RESID_LP) x += to_f32(resid_lp[(size_t)row * ldr + col]);
+        if constexpr (GG) x *= gelu_grad_for<T>(to_f32(resid_lp[(size_t)row * ldr + col]));
         if constexpr (LNPROD) {
             float r;
             if constexpr (R3) r = r3_decode1(reinterpret_cast<const bf16*>(resid)[(size_t)row * ldr + col], ex.resid_lo[(size_t)row * ldr + col]);
@@ -879,10 +882,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         a.h[it] = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16*>(resid) + off);
                         a.l[it] = *reinterpret_cast<const unsigned*>(ex.resid_lo + off);
                     } else
-                    if constexpr (EPI == CPT_EPI_RESID_LP && sizeof(T) == 2) {
+                    if constexpr ((EPI == CPT_EPI_RESID_LP || GG) && sizeof(T) == 2) {
                         const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(resid_lp + off);
                         a.r[it] = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
-                    } else if constexpr (EPI == CPT_EPI_RESID_LP) {
+                    } else if constexpr (EPI == CPT_EPI_RESID_LP || GG) {
                         a.r[it] = *reinterpret_cast<const f32x4*>(resid_lp + off);
                     } else {
                         a.r[it] = *reinterpret_cast<const f32x4*>(resid + off);
@@ -948,6 +951,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         if constexpr (DO_GELU && sizeof(T) != 2) x = gelu_for<T>(x);
                         if (EPI == CPT_EPI_TANH) x = tanhf(x);
                         if constexpr (LNPROD) x += ln_apply(rr4[e], mu, rs, g4[e], t4[e]);     // mu=0, rs=1, g=1, b=0 when not folded
+                        else if constexpr (GG) x *= gelu_grad_for<T>(rr4[e]);
                         else if constexpr (HAS_RESID) x += rr4[e];
                         v[e] = x;
                     }
@@ -1286,7 +1290,7 @@ int gemm_nn_eligible(int M, int N, int K, int lda, int ldw) {
 }
 
 int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
-            hipStream_t s, int w_rows, void* partials, size_t partial_bytes) {
+            hipStream_t s, int w_rows, void* partials, size_t partial_bytes, const void* gelu_u, int ldu) {
     if (!gemm_nn_eligible(M, N, K, lda, ldw)) return CPT_ERR_SHAPE;
     if (!A || !W || !out) return CPT_ERR_NULL;
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)resid | (uintptr_t)partials) & 15)) return CPT_ERR_ALIGN;
@@ -1318,8 +1322,14 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
 #define CPT_NN(EPI, OT, CFG_TBM, CFG_WM) launch_pipe<bf16, EPI, OT, CFG_TBM, 192, CFG_WM, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (OT*)out, ldo, M, N, K, s, 1, &ex)
     if (out_dtype == CPT_BF16) {
         if (resid) return CPT_ERR_DTYPE;
+        if (gelu_u) {       // out = (A.W) * gelu'(u): the GELU backward rides in the epilogue (u bf16 [M][ldu])
+            if (ldu % 8 || ((uintptr_t)gelu_u & 15)) return CPT_ERR_ALIGN;
+            resid = (const float*)gelu_u; ldr = ldu;
+            return small ? CPT_NN(CPT_EPI_GELUGRAD, bf16, 64, 2) : CPT_NN(CPT_EPI_GELUGRAD, bf16, 128, 4);
+        }
         return small ? CPT_NN(CPT_EPI_NONE, bf16, 64, 2) : CPT_NN(CPT_EPI_NONE, bf16, 128, 4);
     }
+    if (gelu_u) return CPT_ERR_DTYPE;
     if (out_dtype != CPT_F32) return CPT_ERR_DTYPE;
     if (resid) return small ? CPT_NN(CPT_EPI_RESID, float, 64, 2) : CPT_NN(CPT_EPI_RESID, float, 128, 4);
     return small ? CPT_NN(CPT_EPI_NONE, float, 64, 2) : CPT_NN(CPT_EPI_NONE, float, 128, 4);

@@ -71,7 +71,8 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
 // nn.Linear weight as stored); bf16 operands, out fp32 (optionally + fp32 resid) or bf16
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw);
 int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
-            hipStream_t s, int w_rows = 0, void* partials = nullptr, size_t partial_bytes = 0);
+            hipStream_t s, int w_rows = 0, void* partials = nullptr, size_t partial_bytes = 0, const void* gelu_u = nullptr, int ldu = 0);
+// gelu_u (bf16 out only): out = (A.W) * gelu'(u) with u bf16 [M][ldu] -- the GELU backward fused into the data-gradient GEMM
 // w_rows: rows of W that exist when K was rounded up to a multiple of 64 (A's extra columns must be zero); partials: split-K scratch
 // u = A.W^T + bias (bf16) and h = gelu(u) (bf16) from one bf16 GEMM (training forward of BertIntermediate)
 int gemm_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias, void* u_out, void* h_out, int ldo, int M, int N, int K, hipStream_t s);

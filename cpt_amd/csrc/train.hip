@@ -294,13 +294,14 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     };
     // out[rows][Kout] = dY[rows][Nout] . Wt[Nout][Kout]  (+ resid), Wt given as the Linear weight [Nout][Kout]
     auto dgrad = [&](const void* dY, int ldy, int Nout_p, const void* Wt, int ldw, int Nout, int Kout, int rows,
-                     const float* resid, void* out, int out_dt, const char* what) -> int {
+                     const float* resid, void* out, int out_dt, const char* what, const void* gelu_u = nullptr) -> int {
         // bf16, tile-aligned: the NN form reads the weight as stored (transpose reads in LDS)
         // (Nout < Nout_p: the K-tile padding columns of dY are zero and the weight rows beyond Nout read as zero)
         if (g_wgrad_tn && dt == CPT_BF16 && cpt::gemm_nn_eligible(rows, Kout, Nout_p, ldy, ldw)) {
-            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes), what);
+            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes, gelu_u, Kout), what);
             return CPT_OK;
         }
+        if (gelu_u) return -12345;      // caller runs the unfused pair
         TRY(cpt::transpose_cast(Wt, dt, ldw, wT, dt, Nout_p, Nout, Kout, s), what);
         TRY(cpt::gemm(dt, resid ? CPT_EPI_RESID : CPT_EPI_NONE, dY, ldy, wT, Nout_p, nullptr, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s), what);
         return CPT_OK;
@@ -381,10 +382,13 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         }
         rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_h), I, I, M, Mp, gy.w_out, I, "wgrad(ffn down)");
         if (rc) return rc;
-        rc = dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)");
-        if (rc) return rc;
-        // h = gelu(u); u = a W_in^T + b_in
-        TRY(cpt::gelu_bwd(dbig, LB(l, w.o_u), dbig, dt, (size_t)M * I, s), "gelu_bwd");
+        // h = gelu(u); u = a W_in^T + b_in: bf16 runs the GELU backward in the epilogue of the data-gradient GEMM
+        rc = dt == CPT_BF16 ? dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)+gelu_bwd", LB(l, w.o_u)) : -12345;
+        if (rc == -12345) {
+            rc = dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)");
+            if (rc) return rc;
+            TRY(cpt::gelu_bwd(dbig, LB(l, w.o_u), dbig, dt, (size_t)M * I, s), "gelu_bwd");
+        } else if (rc) return rc;
         TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
         rc = wgrad(dbig, dt, I, I, LB(l, w.o_a), H, H, M, Mp, gy.w_in, H, "wgrad(ffn up)");
         if (rc) return rc;
