@@ -153,8 +153,8 @@ def lib():
             fn = getattr(l, name)        # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if l.cpt_version() != 1:
-            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 1" % l.cpt_version())
+        if l.cpt_version() != 2:
+            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 2" % l.cpt_version())
         _lib = l
     return _lib
 

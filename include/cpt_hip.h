@@ -12,7 +12,10 @@
  *     (PyTorch's caching allocator in practice) unless marked host.  The library never
  *     allocates device memory and keeps no pointer after a call returns.
  *   - every call is asynchronous on the hipStream_t passed as `stream` (void* here so the
- *     header needs no HIP include); no internal threads; re-entrant.
+ *     header needs no HIP include); no internal threads; the compute entry points keep no state between calls and are
+ *     re-entrant.  Exceptions, all process-global and meant for A/B measurements and diagnostics only: cpt_set_tuning,
+ *     cpt_prof_enable / cpt_prof_read, cpt_debug_gemm_trace.  One process drives one GPU (as torch.distributed launches the
+ *     reference): kernel attributes (dynamic LDS sizes) are set once per process.
  *   - return value: CPT_OK (0) or a negative status; cpt_last_error() gives a host string for
  *     the calling thread.  No C++ exception crosses the boundary.
  *   - dtype: CPT_F32 runs every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32; parity mode, matches
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CPT_ABI_VERSION 1
+#define CPT_ABI_VERSION 2     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2) */
 
 enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2 };
 enum { CPT_EPI_NONE = 0, CPT_EPI_GELU = 1, CPT_EPI_TANH = 2, CPT_EPI_RESID = 3 };
