@@ -340,12 +340,19 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     void* a_lp = ws + w.a_lp;
     void* ffn = ws + w.ffn;
 
+    // 3-byte residual stream (common.h r3_encode): the pre-LayerNorm sums live as bf16 hi (x_lp / a_lp, the GEMM operands) +
+    // int8 lo (the head of the x_f32 / a_f32 regions, which hold no fp32 tensor in this mode); the producers read and write
+    // 3 + 3 bytes per element instead of 4 + 6, and the embedding kernels write their rows in that form directly.
+    const bool fold = lp && m->fold && g_fold_ln && !g_lp_resid;
+    const bool r3 = fold && g_resid3;
+    void* x_lo = x_f32;
+    void* a_lo = a_f32;
     // (a2) text embeddings -> rows b*L + t
     {
         Scope p(CPT_K_EMBED, s);
         TRY(cpt::embed_ln(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb,
-                          m->emb_ln_g, m->emb_ln_b, d.ln_eps, x_f32, lp ? x_lp : nullptr, dt, B, Lt, L, H,
-                          d.vocab, d.max_pos, d.type_vocab, s), "embed_ln");
+                          m->emb_ln_g, m->emb_ln_b, d.ln_eps, r3 ? nullptr : x_f32, lp ? x_lp : nullptr, dt, B, Lt, L, H,
+                          d.vocab, d.max_pos, d.type_vocab, s, r3 ? x_lo : nullptr), "embed_ln");
     }
     // (a3,a4) region projection -> rows b*L + Lt + i
     if (Li > 0) {
@@ -354,23 +361,16 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
         TRY(gm(CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, pre, CPT_F32, H, B * Li, H), "gemm(img_embedding)");
         const bool iln = d.use_img_ln && m->img_ln_g;
-        TRY(cpt::layernorm_rows(pre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, x_f32,
-                                lp ? x_lp : nullptr, dt, B * Li, H, Li, L, Lt, s), "layernorm(img)");
+        TRY(cpt::layernorm_rows_ex(pre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, r3 ? nullptr : x_f32,
+                                   lp ? x_lp : nullptr, dt, B * Li, H, Li, L, Lt, 0, s, nullptr, nullptr, nullptr, r3 ? x_lo : nullptr), "layernorm(img)");
     }
     // (a5-a9) encoder
-    const bool fold = lp && m->fold && g_fold_ln && !g_lp_resid;
     const int mask3 = (flags & CPT_ATTN_MASK_3D) ? 1 : 0;
     const bool fuse_attn = lp && g_fuse_attn && L <= 128 && H % 64 == 0 && !mask3;
     const bool pre_ln = fold && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS));   // x_f32 left un-normalised after the encoder
-    // 3-byte residual stream (common.h r3_encode): the pre-LayerNorm sums live as bf16 hi (x_lp / a_lp, the GEMM operands) +
-    // int8 lo (the head of the `pre` / a_f32 regions); the producers read and write 3 + 3 bytes per element instead of 4 + 6.
-    const bool r3 = fold && g_resid3;
-    void* x_lo = pre;
-    void* a_lo = a_f32;
     if (fold) {
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
         // producer GEMMs accumulate their row sums, the consumer GEMMs normalise in their epilogue.
-        if (r3) { Scope p(CPT_K_EMBED, s); TRY(cpt::r3_split(x_f32, x_lp, x_lo, (size_t)M * H, s), "resid3_split(embeddings)"); }
         float* stats = (float*)(ws + w.stats);         // [layers][2] tables of [M][slots][2] partial row sums (no zeroing needed)
         const size_t tbl = (size_t)cpt::ln_stat_slots(H) * M * 2;
         for (int l = 0; l < d.layers; ++l) {
@@ -412,8 +412,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         const cpt_layer& yl = m->layers[d.layers - 1];
         if (flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) {
             Scope p(CPT_K_LN, s);
-            if (r3) TRY(cpt::r3_merge(x_lp, x_lo, nullptr, x_f32, M, L, H, 0, s), "resid3_merge(all rows)");
-            TRY(cpt::layernorm_rows(x_f32, yl.ln2_g, yl.ln2_b, d.ln_eps, x_f32, x_lp, dt, M, H, M, 0, 0, s), "layernorm(final)");
+            if (r3) TRY(cpt::r3_merge(x_lp, x_lo, nullptr, pre, M, L, H, 0, s), "resid3_merge(all rows)");   // (x_lo lives in the x_f32 region)
+            TRY(cpt::layernorm_rows(r3 ? pre : x_f32, yl.ln2_g, yl.ln2_b, d.ln_eps, x_f32, x_lp, dt, M, H, M, 0, 0, s), "layernorm(final)");
         }
     } else
     for (int l = 0; l < d.layers; ++l) {

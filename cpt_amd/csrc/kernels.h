@@ -13,7 +13,7 @@ int gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, con
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
              float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
-             int max_pos, int type_vocab, hipStream_t s);
+             int max_pos, int type_vocab, hipStream_t s, void* out_lo = nullptr);   // out_lo: rows leave in the 3-byte residual form (hi -> out_lp)
 
 int layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                    void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
@@ -59,7 +59,7 @@ int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char
                float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s);
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
-                      const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr);
+                      const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr);
 // resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients

@@ -28,7 +28,8 @@ __device__ __forceinline__ void ln_stats(const f32x4 (&v)[MAXV], int nv, int lan
 
 template <typename LP>
 __device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lane, int H, float mean, float rstd,
-                                         const float* g, const float* b, float* of, LP* ol) {
+                                         const float* g, const float* b, float* of, LP* ol, signed char* olo = nullptr) {
+    // olo != NULL (bf16 LP only): the row leaves in the 3-byte residual form (common.h r3_encode): hi -> ol, lo -> olo
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = (lane + 64 * i) * 4;
@@ -43,6 +44,15 @@ __device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lan
                 y = v[i];
             }
             if (of) *reinterpret_cast<f32x4*>(of + c) = y;
+            if constexpr (sizeof(LP) == 2) {
+                if (olo) {
+                    u32x2_t hq; unsigned lq;
+                    r3_encode(y, hq, lq);
+                    *reinterpret_cast<u32x2_t*>(ol + c) = hq;
+                    *reinterpret_cast<unsigned*>(olo + c) = lq;
+                    continue;
+                }
+            }
             if (ol) {
                 if constexpr (sizeof(LP) == 2) {
                     bf16x4 p;
@@ -61,7 +71,7 @@ template <typename LP, bool GELU_IN>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* __restrict__ out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
-    const float* __restrict__ resid, DropSpec dr, float* __restrict__ pre_out) {
+    const float* __restrict__ resid, DropSpec dr, float* __restrict__ pre_out, signed char* __restrict__ out_lo) {
     // resid / dr / pre_out (training forward of LN(dropout(dense) + residual), modeling_bert.py:85-86,145 with the third-party
     // BertSelfOutput / BertOutput): the row that is normalised is dropout(x) + resid, written to pre_out for the backward pass --
     // the same arithmetic, in the same order, as the dropout_rows pass this replaces
@@ -98,19 +108,20 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     if (g) ln_stats(v, nv, lane, H, mean, rstd, eps);
     const size_t orow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
     ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
-                 out_lp ? out_lp + orow * H : nullptr);
+                 out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
 }
 
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
-                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out) {
+                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo) {
+    if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
     if (R <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
     const DropSpec dr = drop ? *drop : DropSpec{};
     if (grp_stride == 0 && grp != R) grp_stride = grp;
     dim3 grid((R + 3) / 4), block(ROW_THREADS);
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
-#define LNK(LPT, GI) layernorm_rows_kernel<LPT, GI><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out)
+#define LNK(LPT, GI) layernorm_rows_kernel<LPT, GI><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
     else      { if (gelu_in) LNK(float, true); else LNK(float, false); }
 #undef LNK
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(
     const int64_t* __restrict__ ids, const int64_t* __restrict__ tt, const int64_t* __restrict__ pos,
     const float* __restrict__ word, const float* __restrict__ posw, const float* __restrict__ typew,
     const float* __restrict__ g, const float* __restrict__ bta, float eps, float* __restrict__ out_f32,
-    LP* __restrict__ out_lp, int B, int Lt, int L, int H, int vocab, int max_pos, int type_vocab) {
+    LP* __restrict__ out_lp, int B, int Lt, int L, int H, int vocab, int max_pos, int type_vocab, signed char* __restrict__ out_lo) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
     if (r >= B * Lt) return;
@@ -158,21 +169,22 @@ __global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(
     ln_stats(v, nv, lane, H, mean, rstd, eps);
     const size_t orow = (size_t)b * L + t;
     ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
-                 out_lp ? out_lp + orow * H : nullptr);
+                 out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
 }
 
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
              float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
-             int max_pos, int type_vocab, hipStream_t s) {
+             int max_pos, int type_vocab, hipStream_t s, void* out_lo) {
     if (B <= 0 || Lt <= 0 || L < Lt || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
+    if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
     if (!ids || !word || !posw || !typew || !g || !bta) return CPT_ERR_NULL;
     if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
     dim3 grid((B * Lt + 3) / 4), block(ROW_THREADS);
     if (out_lp && lp_dtype == CPT_BF16)
-        embed_ln_kernel<bf16><<<grid, block, 0, s>>>(ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, (bf16*)out_lp, B, Lt, L, H, vocab, max_pos, type_vocab);
+        embed_ln_kernel<bf16><<<grid, block, 0, s>>>(ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, (bf16*)out_lp, B, Lt, L, H, vocab, max_pos, type_vocab, (signed char*)out_lo);
     else
-        embed_ln_kernel<float><<<grid, block, 0, s>>>(ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, (float*)out_lp, B, Lt, L, H, vocab, max_pos, type_vocab);
+        embed_ln_kernel<float><<<grid, block, 0, s>>>(ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, (float*)out_lp, B, Lt, L, H, vocab, max_pos, type_vocab, nullptr);
     return CPT_OK;
 }
 
