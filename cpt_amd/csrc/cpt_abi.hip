@@ -246,7 +246,7 @@ int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos,
 int cpt_gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
                 int w_rows, void* partials, size_t partial_bytes, void* stream) {
     if (!cpt::gemm_nn_eligible(M, N, K, lda, ldw))
-        return fail(CPT_ERR_SHAPE, "cpt_gemm_nn: needs N %% 192 == 0, K %% 64 == 0, lda/ldw %% 8 == 0 (got M=%d N=%d K=%d)", M, N, K);
+        return fail(CPT_ERR_SHAPE, "cpt_gemm_nn: needs N %% 192 == 0 or N %% 128 == 0, K %% 64 == 0, lda/ldw %% 8 == 0 (got M=%d N=%d K=%d)", M, N, K);
     return check_launch(cpt::gemm_nn(A, lda, W, ldw, resid, ldr, out, out_dtype, ldo, M, N, K, (hipStream_t)stream, w_rows, partials, partial_bytes), "cpt_gemm_nn");
 }
 

@@ -1286,7 +1286,7 @@ int gemm_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias
 // ---- NN form: out[M][N] = A[M][K] . W[K][N] (+ resid), W = an nn.Linear weight [out_features = K][in_features = N] as stored:
 // the data gradients dX = dY . W of the backward pass without a transposed weight copy --------------------------------------
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw) {
-    return M > 0 && N > 0 && K > 0 && N % 192 == 0 && K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0 && (size_t)K * ldw * 2 <= (size_t)0x7fffffff;
+    return M > 0 && N > 0 && K > 0 && (N % 192 == 0 || N % 128 == 0) && K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0 && (size_t)K * ldw * 2 <= (size_t)0x7fffffff;
 }
 
 int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
@@ -1297,13 +1297,14 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
     if (w_rows < 0 || w_rows > K) return CPT_ERR_SHAPE;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
     // 64-row tiles when 128-row tiles would leave half the chip idle (M = 3840, N = 768: 120 vs 240 workgroups)
-    const long wg128 = (long)((M + 127) / 128) * (N / 192);
-    const bool small = wg128 < 200;
+    const bool n192 = N % 192 == 0;                   // hidden 768 / 3072; otherwise 128-column tiles (Oscar-large: 1024 / 4096)
+    const long wg128 = (long)((M + 127) / 128) * (N / (n192 ? 192 : 128));
+    const bool small = wg128 < 200 && n192;
     EpiX ex = {};
     ex.w_rows = w_rows;
     // few output tiles and a long contraction (the decoder's data gradient: 32 x 768 outputs over K = 30528 ran on 4 CUs for 220 us):
     // split K over up to 64 workgroups per tile, partial matrices added in split order
-    if (out_dtype == CPT_F32 && !resid && partials && ldo == N) {
+    if (out_dtype == CPT_F32 && !resid && partials && ldo == N && n192) {
         const long tiles = (long)((M + 63) / 64) * (N / 192);
         const int nt = K / 64;
         int S = (int)(256 / tiles);
@@ -1320,6 +1321,20 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
         }
     }
 #define CPT_NN(EPI, OT, CFG_TBM, CFG_WM) launch_pipe<bf16, EPI, OT, CFG_TBM, 192, CFG_WM, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (OT*)out, ldo, M, N, K, s, 1, &ex)
+#define CPT_NN128(EPI, OT) launch_pipe<bf16, EPI, OT, 128, 128, 4, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (OT*)out, ldo, M, N, K, s, 1, &ex)
+    if (!n192) {
+        if (out_dtype == CPT_BF16) {
+            if (resid) return CPT_ERR_DTYPE;
+            if (gelu_u) {
+                if (ldu % 8 || ((uintptr_t)gelu_u & 15)) return CPT_ERR_ALIGN;
+                resid = (const float*)gelu_u; ldr = ldu;
+                return CPT_NN128(CPT_EPI_GELUGRAD, bf16);
+            }
+            return CPT_NN128(CPT_EPI_NONE, bf16);
+        }
+        if (out_dtype != CPT_F32 || gelu_u) return CPT_ERR_DTYPE;
+        return resid ? CPT_NN128(CPT_EPI_RESID, float) : CPT_NN128(CPT_EPI_NONE, float);
+    }
     if (out_dtype == CPT_BF16) {
         if (resid) return CPT_ERR_DTYPE;
         if (gelu_u) {       // out = (A.W) * gelu'(u): the GELU backward rides in the epilogue (u bf16 [M][ldu])
@@ -1334,6 +1349,7 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
     if (resid) return small ? CPT_NN(CPT_EPI_RESID, float, 64, 2) : CPT_NN(CPT_EPI_RESID, float, 128, 4);
     return small ? CPT_NN(CPT_EPI_NONE, float, 64, 2) : CPT_NN(CPT_EPI_NONE, float, 128, 4);
 #undef CPT_NN
+#undef CPT_NN128
 }
 
 // ---- LayerNorm folded into the GEMMs around it (bf16 throughput path) -------------------------------

@@ -342,7 +342,7 @@ int cpt_gemm_tn(const void* A_bf16, int lda, const void* W_bf16, int ldw, float*
                 size_t partial_bytes, void* stream);
 /* Data-gradient GEMM in the NN form (dX = dY . W against an nn.Linear weight as stored): out[M][N] = A[M][K] . W[K][N] (+ resid),
  * A bf16 [M][lda], W bf16 [K][ldw] (row = contraction index = out_features), out fp32 (optionally + fp32 resid [M][ldr]) or bf16.
- * N % 192 == 0, K % 64 == 0.  w_rows (0: K): rows of W that exist when K was rounded up to a multiple of 64 -- rows beyond read as
+ * N % 192 == 0 or N % 128 == 0, K % 64 == 0.  w_rows (0: K): rows of W that exist when K was rounded up to a multiple of 64 -- rows beyond read as
  * zero, A's extra columns must hold zeros (the vocabulary-sized decoder, 30522 rows).  partials (optional): scratch for split-K when the
  * output has few tiles and K is long (fp32 output without residual; up to 64 * M * N * 4 bytes used, added in split order). */
 int cpt_gemm_nn(const void* A_bf16, int lda, const void* W_bf16, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo,

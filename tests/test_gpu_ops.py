@@ -334,6 +334,7 @@ def test_gemm_tn_weight_gradient_form(dev, K, M, N):
 @pytest.mark.parametrize("M,N,K,resid,odt", [(3840, 768, 3072, True, torch.float32), (3840, 3072, 768, False, torch.bfloat16),
                                              (3840, 768, 768, False, torch.bfloat16), (3840, 768, 2304, True, torch.float32),
                                              (1000, 768, 768, False, torch.float32), (77, 192, 64, True, torch.float32),
+                                             (2120, 1024, 4096, True, torch.float32), (2120, 4096, 1024, False, torch.bfloat16),
                                              (53760, 768, 768, False, torch.bfloat16)])
 def test_gemm_nn_data_gradient_form(dev, M, N, K, resid, odt):
     """out = A W (+ resid) with W stored [K][N] (an nn.Linear weight, rows = the contraction index): A staged as in the NT form, W read

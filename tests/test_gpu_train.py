@@ -200,11 +200,13 @@ def test_no_img_layernorm_forward_and_gradients(dev, mode):
     assert err < (1e-3 if mode == "fp32" else 4e-2), err
 
 
-def test_weight_gradients_tn_gemm_vs_transposed_operands(dev):
-    """bf16 weight gradients: the TN GEMM (operands read as stored) against the explicit-transpose + NT GEMM path on the same
-    batch (M = 8 x 120 = 960 rows = 15 K-tiles), every parameter; both accumulate in fp32 over the same bf16 products."""
+@pytest.mark.parametrize("size", ["base", "large"])
+def test_weight_gradients_tn_gemm_vs_transposed_operands(dev, size):
+    """bf16 weight / data gradients: the TN / NN GEMM forms (operands read as stored) against the explicit-transpose + NT GEMM path
+    on the same batch (M = 8 x 120 = 960 rows = 15 K-tiles), every parameter; both accumulate in fp32 over the same bf16 products.
+    large: hidden 1024 / 4096 (Oscar-large, the VCR few-shot model) takes the 128-column tile instantiations."""
     from cpt_amd import _lib as L
-    cfg = cfgmod.oscar_base(num_hidden_layers=2)
+    cfg = cfgmod.oscar_base(num_hidden_layers=2) if size == "base" else cfgmod.oscar_large(num_hidden_layers=2)
     b = {k: v.to(dev) for k, v in synth.make_batch(8, cfg, seed=21).items()}
     grads = {}
     for tn in (0, 1):
