@@ -227,8 +227,10 @@ def main():
         model.copy_from_pretraining_model(pre)
         if args.batch == 64:
             args.batch = 32
-        if train or args.all_rows:
-            raise SystemExit("--workload vcr is an inference workload (NSP-CPT scoring head)")
+        if args.all_rows:
+            raise SystemExit("--workload vcr has no all-row head (NSP-CPT relation head)")
+        if train and args.batch == 32:
+            args.batch = 8          # configs[4] few-shot step: 4 choices x 2 questions per GPU
     else:
         cfg = cfgmod.oscar_base()
         if args.workload == "gqa":
@@ -250,8 +252,15 @@ def main():
         opt = FusedAdamW(model, lr=3e-5, betas=(0.9, 0.98), weight_decay=0.01,       # fewshot/refcoco_cpt.py:509-513
                          grad_wire=args.grad_wire)
     mpos = None if args.all_rows else b["mask_token_pos"]
+    nsp_labels = (torch.arange(B, device=dev) % 3).to(torch.int64)       # VCR: relation label per (question, choice) sequence
 
     def step():
+        if train and args.workload == "vcr":     # fewshot/vcr_nsp_cpt.py:425-470: relation-label cross entropy through the NSP-CPT head
+            opt.zero_grad()
+            loss, logits = model(b["input_ids"], b["segment_ids"], b["attention_mask"], nsp_labels, img_feats=b["img_feats"])
+            loss.backward()
+            opt.step()
+            return logits
         if train:
             opt.zero_grad()
             loss, logits = model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
@@ -315,8 +324,9 @@ def main():
                 "unit": "pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                "config": {"workload": ("Oscar-base CPT few-shot training step (fwd+bwd+grad all-reduce+AdamW), batch %d/GPU, "
-                                        "%d regions, seq_len %d+%d, %s, dropout %.2g" % (B, Li, Lt, Li, args.dtype, cfg.hidden_dropout_prob)) if train else
+                "config": {"workload": ("%s few-shot training step (fwd+bwd+grad all-reduce+AdamW), batch %d/GPU, "
+                                        "%d regions, seq_len %d+%d, %s, dropout %.2g" % ("Oscar-large (24 layers) VCR NSP-CPT" if args.workload == "vcr" else
+                                                                                         "Oscar-base CPT", B, Li, Lt, Li, args.dtype, cfg.hidden_dropout_prob)) if train else
                                        {"refcoco": "Oscar-base CPT RefCOCO inference, batch %d/GPU, 50 regions, seq_len 120, %s, [MASK]-row logits%s",
                                         "gqa": "Oscar-base CPT GQA inference (BASELINE configs[3] shape), batch %d/GPU, 45 regions, seq_len 165+45, %s, "
                                                "[MASK]-row logits%s",

@@ -102,7 +102,7 @@ _SIGS = {
     "cpt_resid3_split": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "cpt_resid3_merge": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_gemm_nn": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
-    "cpt_gemm_tn": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "cpt_gemm_tn": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "cpt_split3": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_select_regions": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
     "cpt_argmax_columns": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),

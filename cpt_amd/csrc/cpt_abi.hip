@@ -250,11 +250,11 @@ int cpt_gemm_nn(const void* A, int lda, const void* W, int ldw, const float* res
     return check_launch(cpt::gemm_nn(A, lda, W, ldw, resid, ldr, out, out_dtype, ldo, M, N, K, (hipStream_t)stream, w_rows, partials, partial_bytes), "cpt_gemm_nn");
 }
 
-int cpt_gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
-                void* stream) {
+int cpt_gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, int k_rows, void* partials,
+                size_t partial_bytes, void* stream) {
     if (!cpt::gemm_tn_eligible(M, N, K, lda, ldw, ldo))
         return fail(CPT_ERR_SHAPE, "cpt_gemm_tn: needs M %% 128 == 0, N %% 128 == 0 (or 192), K %% 64 == 0, lda/ldw %% 8 == 0, ldo == N (got M=%d N=%d K=%d)", M, N, K);
-    return check_launch(cpt::gemm_tn(A, lda, W, ldw, out, ldo, M, N, K, partials, partial_bytes, (hipStream_t)stream), "cpt_gemm_tn");
+    return check_launch(cpt::gemm_tn(A, lda, W, ldw, out, ldo, M, N, K, partials, partial_bytes, (hipStream_t)stream, k_rows), "cpt_gemm_tn");
 }
 
 int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,

@@ -317,8 +317,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     static_assert(!TN || (sizeof(T) == 2 && TBM % 64 == 0 && TBN % 64 == 0), "TN / NN forms: bf16");
     static_assert(TN != 1 || EPI == CPT_EPI_NONE, "TN form: plain epilogue");
     static_assert(TN != 2 || EPI == CPT_EPI_NONE || EPI == CPT_EPI_RESID || EPI == CPT_EPI_GELUGRAD, "NN form: plain, residual or GELU-gradient epilogue");
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)(TA ? K : M) * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)(TN ? ((TN == 2 && ex.w_rows > 0) ? ex.w_rows : K) : N) * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
+    const int k_rows = (TN && ex.w_rows > 0) ? ex.w_rows : K;     // rows of a transposed-read operand that exist (K rounded up to a K-tile multiple: the rest reads as zero)
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)(TA ? k_rows : M) * lda * sizeof(T), (size_t)0x7fffffff), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)(TN ? k_rows : N) * ldw * sizeof(T), (size_t)0x7fffffff), 0x00020000);
     constexpr int CPRA = TBM / 8, CPRB = TBN / 8;      // TN: 16-byte chunks per tile row
     // G <= 6: one VGPR per piece, computed once.  Bigger tiles (registers go to the accumulators): the offsets are rebuilt at
     // every issue from the piece's row (2 VALU per 1 KiB piece); with an even wave count the swizzle term is the same for
@@ -1242,8 +1243,11 @@ int gemm_tn_eligible(int M, int N, int K, int lda, int ldw, int ldo) {
 }
 
 int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
-            hipStream_t s) {
+            hipStream_t s, int k_rows) {
     if (!gemm_tn_eligible(M, N, K, lda, ldw, ldo)) return CPT_ERR_SHAPE;
+    if (k_rows < 0 || k_rows > K) return CPT_ERR_SHAPE;
+    EpiX ex = {};
+    ex.w_rows = k_rows;        // rows of A / W that exist (0: K); K - k_rows < 64 rows of padding read as zero through the buffer bounds
     if (!A || !W || !out) return CPT_ERR_NULL;
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)partials) & 15)) return CPT_ERR_ALIGN;
     if ((size_t)K * (size_t)std::max(lda, ldw) * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;      // 32-bit buffer offsets
@@ -1259,8 +1263,8 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
     float* dst = S > 1 ? (float*)partials : out;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
     int rc;
-    if (w192) rc = launch_pipe<bf16, CPT_EPI_NONE, float, 128, 192, 4, 2, 3, 1, 4, 1, 1>(a, lda, w, ldw, nullptr, nullptr, 0, dst, ldo, M, N, K, s, S);
-    else      rc = launch_pipe<bf16, CPT_EPI_NONE, float, 128, 128, 4, 2, 3, 1, 4, 1, 1>(a, lda, w, ldw, nullptr, nullptr, 0, dst, ldo, M, N, K, s, S);
+    if (w192) rc = launch_pipe<bf16, CPT_EPI_NONE, float, 128, 192, 4, 2, 3, 1, 4, 1, 1>(a, lda, w, ldw, nullptr, nullptr, 0, dst, ldo, M, N, K, s, S, &ex);
+    else      rc = launch_pipe<bf16, CPT_EPI_NONE, float, 128, 128, 4, 2, 3, 1, 4, 1, 1>(a, lda, w, ldw, nullptr, nullptr, 0, dst, ldo, M, N, K, s, S, &ex);
     if (rc != CPT_OK) return rc;
     if (S > 1) {
         const size_t n4 = mat / 16;

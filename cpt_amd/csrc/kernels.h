@@ -66,7 +66,7 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
 // without operand transposes); needs gemm_tn_eligible; `partials` (optional) holds the split-K partial matrices
 int gemm_tn_eligible(int M, int N, int K, int lda, int ldw, int ldo);
 int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
-            hipStream_t s);
+            hipStream_t s, int k_rows = 0);     // k_rows: rows of A / W that exist when K was rounded up to a multiple of 64
 // out[M][N] = A[M][K] . W[K][N] (+ resid): W stored with the contraction index as its slow dimension (data gradients against an
 // nn.Linear weight as stored); bf16 operands, out fp32 (optionally + fp32 resid) or bf16
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw);

@@ -282,8 +282,9 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
                      float* out, int ldo, const char* what) -> int {
         // bf16, tile-aligned shapes: the TN form of the GEMM reads dY and X as they are (transpose reads in LDS); tA serves as
         // its split-K partial buffer.  Everything else (fp32 mode, head-sized problems) goes through explicit transposes.
-        if (g_wgrad_tn && dt == CPT_BF16 && dY_dt == CPT_BF16 && rows == rows_p && cpt::gemm_tn_eligible(Nout, Kout, rows, ldy, ldx, ldo)) {
-            TRY(cpt::gemm_tn(dY, ldy, X, ldx, out, ldo, Nout, Kout, rows, tA, w.tA_bytes, s), what);
+        // (rows_p = rows rounded up to a K-tile: the missing rows read as zero through the buffer bounds)
+        if (g_wgrad_tn && dt == CPT_BF16 && dY_dt == CPT_BF16 && cpt::gemm_tn_eligible(Nout, Kout, rows_p, ldy, ldx, ldo)) {
+            TRY(cpt::gemm_tn(dY, ldy, X, ldx, out, ldo, Nout, Kout, rows_p, tA, w.tA_bytes, s, rows), what);
             return CPT_OK;
         }
         TRY(cpt::transpose_cast(dY, dY_dt, ldy, tA, dt, rows_p, rows, Nout, s), what);

@@ -144,9 +144,10 @@ def gemm_tn(a, w, split_scratch=True):
     _need_cuda(a, w)
     K, M = a.shape
     N = w.size(1)
+    Kp = (K + 63) // 64 * 64            # rows beyond K read as zero (buffer bounds)
     out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     part = torch.empty((8 * M * N,), device=a.device, dtype=torch.float32) if split_scratch else None
-    L.check(L.lib().cpt_gemm_tn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), N, M, N, K,
+    L.check(L.lib().cpt_gemm_tn(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), N, M, N, Kp, K,
                                 L.ptr(part), part.numel() * 4 if part is not None else 0, L.stream_ptr()), "cpt_gemm_tn")
     return out
 

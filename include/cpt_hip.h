@@ -336,10 +336,11 @@ int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos,
 /* Weight-gradient GEMM in the TN form (what cpt_train_bwd runs for dW = dY^T . X, fewshot/refcoco_cpt.py:248's autograd of
  * every nn.Linear): out[M][N] fp32 = sum over k < K of A[k][m] * W[k][n], A bf16 [K][lda], W bf16 [K][ldw] -- both operands
  * as the backward pass holds them (rows = tokens), no transposed copies.  M % 128 == 0, N % 128 == 0 or N % 192 == 0,
- * K % 64 == 0, ldo == N.  partials (optional, partial_bytes): scratch for split-K partial matrices (up to 8 * M * N * 4
+ * K % 64 == 0, ldo == N.  k_rows (0: K): token rows that exist when K was rounded up to a multiple of 64 (the rest read as zero).
+ * partials (optional, partial_bytes): scratch for split-K partial matrices (up to 8 * M * N * 4
  * bytes are used when the output has few tiles); they are added in split order, so the result is reproducible. */
-int cpt_gemm_tn(const void* A_bf16, int lda, const void* W_bf16, int ldw, float* out, int ldo, int M, int N, int K, void* partials,
-                size_t partial_bytes, void* stream);
+int cpt_gemm_tn(const void* A_bf16, int lda, const void* W_bf16, int ldw, float* out, int ldo, int M, int N, int K, int k_rows,
+                void* partials, size_t partial_bytes, void* stream);
 /* Data-gradient GEMM in the NN form (dX = dY . W against an nn.Linear weight as stored): out[M][N] = A[M][K] . W[K][N] (+ resid),
  * A bf16 [M][lda], W bf16 [K][ldw] (row = contraction index = out_features), out fp32 (optionally + fp32 resid [M][ldr]) or bf16.
  * N % 192 == 0 or N % 128 == 0, K % 64 == 0.  w_rows (0: K): rows of W that exist when K was rounded up to a multiple of 64 -- rows beyond read as

@@ -306,15 +306,20 @@ def test_ln_consumer_kernels_are_bit_identical(dev):
 
 
 @pytest.mark.parametrize("K,M,N", [(3840, 768, 768), (3840, 2304, 768), (3840, 768, 3072), (1600, 768, 2112), (960, 1024, 1024),
-                                   (192, 128, 192), (64, 128, 128), (53760, 768, 768)])
+                                   (192, 128, 192), (64, 128, 128), (53760, 768, 768), (2120, 1024, 4096), (100, 128, 128)])
 def test_gemm_tn_weight_gradient_form(dev, K, M, N):
     """out = A^T W with both bf16 operands stored rows = contraction index (dY [tokens][out], X [tokens][in]): the TN GEMM reads
     them through LDS transpose reads.  Against torch fp32 matmul of the same bf16 values; with and without split-K scratch the
     result must agree to fp32 summation-order noise, and two runs are bit-equal (partials are added in split order)."""
     from cpt_amd import ops
     rng = _rng(K + M + N)
-    a = _t(rng, K, M).to(torch.bfloat16).to(dev)
-    w = _t(rng, K, N).to(torch.bfloat16).to(dev)
+    # the operands are the first K rows of buffers whose tails hold NaN: token counts that are not a multiple of the 64-row K-tile
+    # (2120 = 8 x 265, 100) must read the missing rows as zero through the buffer bounds, not whatever follows in memory
+    abuf = torch.full((K + 64, M), float("nan"), dtype=torch.bfloat16, device=dev)
+    wbuf = torch.full((K + 64, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    abuf[:K] = _t(rng, K, M).to(torch.bfloat16).to(dev)
+    wbuf[:K] = _t(rng, K, N).to(torch.bfloat16).to(dev)
+    a, w = abuf[:K], wbuf[:K]
     a[:, 5] = 0.0
     a[7, 5] = 1.0                                  # output row 5 = row 7 of w exactly: catches any row / column permutation
     ref = a.float().t() @ w.float()

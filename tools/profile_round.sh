@@ -11,7 +11,8 @@ python bench.py --steps 10 --warmup 3 --dtype bf16x3 --no-cpu > $O/${T}_bench_b6
 python bench.py --steps 10 --warmup 3 --workload gqa > $O/${T}_bench_gqa_b256_bf16.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --workload vcr > $O/${T}_bench_vcr_large_b32_bf16.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --mode train > $O/${T}_bench_train_b32_bf16.json 2>/dev/null
-python bench.py --steps 5 --warmup 2 --mode train --workload gqa --batch 64 > $O/${T}_bench_train_gqa_b64_bf16.json 2>/dev/null
+python bench.py --steps 5 --warmup 2 --mode train --workload gqa > $O/${T}_bench_train_gqa_b32_bf16.json 2>/dev/null
+python bench.py --steps 5 --warmup 2 --mode train --workload vcr > $O/${T}_bench_train_vcr_large_b8_bf16.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --all-rows --no-cpu > $O/${T}_bench_b64_bf16_allrows.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/${T}_prof; rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu --no-roofline > $O/${T}_bench_under_rocprof.json 2> $O/${T}_prof.log
