@@ -1230,10 +1230,12 @@ int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw,
 // ---- TN form: out[M][N] (fp32) = sum over the K rows of A[k][m] . W[k][n]  (weight gradients: A = dY, W = X) ----------------
 // K is split over enough workgroups to fill the chip when the output has few tiles (768 x 768: 24); every split writes its
 // own partial matrix into `partials` and a second kernel adds them in split order (deterministic, no atomics, no zeroing).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ out, size_t n4, int S) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ out, size_t n4, int S,
+                                                              const f32x4* __restrict__ resid = nullptr) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         f32x4 a = part[i];
         for (int k = 1; k < S; ++k) { const f32x4 b = part[(size_t)k * n4 + i]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+        if (resid) { const f32x4 r = resid[i]; a[0] += r[0]; a[1] += r[1]; a[2] += r[2]; a[3] += r[3]; }     // same order as the epilogue: sum, then + residual
         out[i] = a;
     }
 }
@@ -1308,7 +1310,7 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
     ex.w_rows = w_rows;
     // few output tiles and a long contraction (the decoder's data gradient: 32 x 768 outputs over K = 30528 ran on 4 CUs for 220 us):
     // split K over up to 64 workgroups per tile, partial matrices added in split order
-    if (out_dtype == CPT_F32 && !resid && partials && ldo == N && n192) {
+    if (out_dtype == CPT_F32 && (!resid || ldr == N) && partials && ldo == N && n192) {
         const long tiles = (long)((M + 63) / 64) * (N / 192);
         const int nt = K / 64;
         int S = (int)(256 / tiles);
@@ -1320,7 +1322,8 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
             int rc = launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, nullptr, 0, (float*)partials, ldo, M, N, K, s, S, &ex);
             if (rc != CPT_OK) return rc;
             const size_t n4 = mat / 16;
-            reduce_partials_kernel<<<dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S);
+            reduce_partials_kernel<<<dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S,
+                                                                                                                  (const f32x4*)resid);
             return CPT_OK;
         }
     }
