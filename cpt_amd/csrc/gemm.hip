@@ -572,7 +572,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     static_assert(DIRECT || (16 * CPW + SIDE) * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
     static_assert(DIRECT || (MI * 32 <= 64 && CH <= 64), "side area is filled by one wave pass");
     if (split != 0) bias = nullptr;                   // split-K: the bias is added once
-    if constexpr (TN != 0) out += (size_t)split * M * ldo; // TN / NN split-K: every split writes its own partial matrix (reduced in slot order afterwards)
+    if constexpr (TN != 0 || EPI == CPT_EPI_NONE) out += (size_t)split * M * ldo; // split-K (TN / NN forms, gemm_nt_split): every split writes its own partial matrix; split = 0 when K is not split: every split writes its own partial matrix (reduced in slot order afterwards)
     if constexpr (DIRECT) {
         // ---- direct epilogue: the accumulators are TRANSPOSED (operands swapped in mma): lane = output row
         // (wrow0 + 32 i + (lane & 31)), register quad g of block j = the four consecutive columns
@@ -1286,6 +1286,28 @@ int gemm_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias
     ex.out_lp = u_out;
     launch_fast<bf16, CPT_EPI_GELU2, bf16>(g_gemm_variant >= 3 ? g_gemm_variant : 3, (const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0,
                                           (bf16*)h_out, ldo, M, N, K, s, &ex);
+    return CPT_OK;
+}
+
+// NT GEMM with fp32 output for SMALL row counts (the few-shot step at 4 sequences per GPU: 480 rows = 32 tiles of 64 x 192 on 256 CUs,
+// 48 K-tiles in sequence for the FFN-down): K split over workgroups, partial matrices added in split order, then + resid.
+// Returns CPT_ERR_SHAPE when the problem does not call for it (the caller runs the plain GEMM).
+int gemm_nt_split(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr, float* out, int ldo, int M, int N, int K,
+                  void* partials, size_t partial_bytes, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8 || N % 4 || ldo != N || (resid && ldr != N) || !partials) return CPT_ERR_SHAPE;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)resid | (uintptr_t)partials | (uintptr_t)bias) & 15)) return CPT_ERR_ALIGN;
+    const long tiles = (long)((M + 63) / 64) * ((N + 191) / 192);
+    const int nt = K / 64;
+    int S = (int)(256 / tiles);
+    if (S > 16) S = 16;
+    if (S > nt / 3) S = nt / 3;
+    const size_t mat = (size_t)M * N * 4;
+    while (S > 1 && (size_t)S * mat > partial_bytes) --S;
+    if (S < 3) return CPT_ERR_SHAPE;
+    int rc = launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, (float*)partials, ldo, M, N, K, s, S);
+    if (rc != CPT_OK) return rc;
+    const size_t n4 = mat / 16;
+    reduce_partials_kernel<<<dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S, (const f32x4*)resid);
     return CPT_OK;
 }
 

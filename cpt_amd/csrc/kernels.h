@@ -76,6 +76,9 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
 // w_rows: rows of W that exist when K was rounded up to a multiple of 64 (A's extra columns must be zero); partials: split-K scratch
 // u = A.W^T + bias (bf16) and h = gelu(u) (bf16) from one bf16 GEMM (training forward of BertIntermediate)
 int gemm_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias, void* u_out, void* h_out, int ldo, int M, int N, int K, hipStream_t s);
+// bf16 NT GEMM, fp32 out (+ bias, + resid), K split for small row counts; CPT_ERR_SHAPE = not worth it / not applicable (caller: plain gemm)
+int gemm_nt_split(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr, float* out, int ldo, int M, int N, int K,
+                  void* partials, size_t partial_bytes, hipStream_t s);
 int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s);
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,

@@ -180,6 +180,15 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     }
     if (ph)   // BertEmbeddings' dropout on the text rows and modeling_bert.py:266 on the region rows: one pass over all rows
         TRY(cpt::dropout_rows(x_f32, nullptr, x_f32, LB(0, w.o_xin), dt, M, H, drop_spec(drop, 0, false), s), "dropout(embeddings)");
+    // dense layers with fp32 output (attn-out, FFN-down): at small row counts K is split over workgroups (gemm_nt_split)
+    auto dense_f32 = [&](const void* A, int lda, const void* W, int K, const float* bias, const float* resid, void* out, int N, const char* what) -> int {
+        if (dt == CPT_BF16 && g_wgrad_tn) {
+            const int rs = cpt::gemm_nt_split(A, lda, W, K, bias, resid, N, (float*)out, N, M, N, K, ws + w.tA, w.tA_bytes, s);
+            if (rs == CPT_OK) return abi_check(CPT_OK, what);
+            if (rs != CPT_ERR_SHAPE) return abi_check(rs, what);
+        }
+        return abi_check(cpt::gemm(dt, resid ? CPT_EPI_RESID : CPT_EPI_NONE, A, lda, W, K, bias, resid, N, out, CPT_F32, N, M, N, K, s), what);
+    };
     for (int l = 0; l < d.layers; ++l) {
         const cpt_layer& y = m->layers[l];
         need(1 + l);
@@ -189,13 +198,13 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
         TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention");
         if (ph) {   // LN(dropout(dense(ctx)) + x): the residual add moves from the GEMM epilogue into the dropout pass
-            TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, nullptr, 0, LB(l, w.o_pre1), CPT_F32, H, M, H, H, s), "gemm(attn out)");
+            if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, nullptr, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
             // dropout + residual + LayerNorm in one row pass (pre1 = dropout(dense) + x is stored for the backward pass)
             const cpt::DropSpec sp = drop_spec(drop, 2 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
                                        x_f32, &sp, (float*)LB(l, w.o_pre1)), "dropout(attn out)+residual+layernorm");
         } else {
-        TRY(cpt::gemm(dt, CPT_EPI_RESID, LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, x_f32, H, LB(l, w.o_pre1), CPT_F32, H, M, H, H, s), "gemm(attn out)");
+        if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, x_f32, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
         TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, s), "layernorm(attn)");
         }
         if (dt == CPT_BF16 && H % 64 == 0 && I % 8 == 0) {
@@ -205,12 +214,12 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         TRY(cpt::gelu_fwd(LB(l, w.o_u), LB(l, w.o_h), dt, (size_t)M * I, s), "gelu");
         }
         if (ph) {
-            TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, 0, LB(l, w.o_pre2), CPT_F32, H, M, H, I, s), "gemm(ffn down)");
+            if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
                                        a_f32, &sp, (float*)LB(l, w.o_pre2)), "dropout(ffn down)+residual+layernorm");
         } else {
-        TRY(cpt::gemm(dt, CPT_EPI_RESID, LB(l, w.o_h), I, y.w_out, I, y.b_out, a_f32, H, LB(l, w.o_pre2), CPT_F32, H, M, H, I, s), "gemm(ffn down)");
+        if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, a_f32, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
         TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, s), "layernorm(ffn)");
         }
     }
