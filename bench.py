@@ -315,7 +315,9 @@ def main():
                 "frac": round(ach / peak, 4),
                 "traffic": pmc_traffic_bytes(dom) if (B == 64 and args.dtype == "bf16" and args.workload == "refcoco") else None,
                 "avg_launch_ms": round(avg_ms, 5),
-                "flop_per_launch": gemm_flops(dom, M, H, I)}
+                "flop_per_launch": gemm_flops(dom, M, H, I),
+                # every encoder GEMM against the same peak (gemm_qkv: projection flops only; its launches also run the attention)
+                "all_kernels_frac": {k: round(gemm_flops(k, M, H, I) / (gem[k][0] / gem[k][1] * 1e-3) / 1e12 / peak, 4) for k in gem}}
     if world > 1:
         dist.barrier()
 
