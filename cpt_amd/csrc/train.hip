@@ -303,6 +303,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         return CPT_OK;
     };
     // out[rows][Kout] = dY[rows][Nout] . Wt[Nout][Kout]  (+ resid), Wt given as the Linear weight [Nout][Kout]
+    constexpr int NOT_FUSED = 1 << 20;       // dgrad(..., gelu_u): the shape has no fused GELU-gradient epilogue
     auto dgrad = [&](const void* dY, int ldy, int Nout_p, const void* Wt, int ldw, int Nout, int Kout, int rows,
                      const float* resid, void* out, int out_dt, const char* what, const void* gelu_u = nullptr) -> int {
         // bf16, tile-aligned: the NN form reads the weight as stored (transpose reads in LDS)
@@ -311,7 +312,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes, gelu_u, Kout), what);
             return CPT_OK;
         }
-        if (gelu_u) return -12345;      // caller runs the unfused pair
+        if (gelu_u) return NOT_FUSED;   // caller runs the unfused pair (dgrad, then gelu_bwd)
         TRY(cpt::transpose_cast(Wt, dt, ldw, wT, dt, Nout_p, Nout, Kout, s), what);
         TRY(cpt::gemm(dt, resid ? CPT_EPI_RESID : CPT_EPI_NONE, dY, ldy, wT, Nout_p, nullptr, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s), what);
         return CPT_OK;
@@ -393,8 +394,8 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_h), I, I, M, Mp, gy.w_out, I, "wgrad(ffn down)");
         if (rc) return rc;
         // h = gelu(u); u = a W_in^T + b_in: bf16 runs the GELU backward in the epilogue of the data-gradient GEMM
-        rc = dt == CPT_BF16 ? dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)+gelu_bwd", LB(l, w.o_u)) : -12345;
-        if (rc == -12345) {
+        rc = dt == CPT_BF16 ? dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)+gelu_bwd", LB(l, w.o_u)) : NOT_FUSED;
+        if (rc == NOT_FUSED) {
             rc = dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)");
             if (rc) return rc;
             TRY(cpt::gelu_bwd(dbig, LB(l, w.o_u), dbig, dt, (size_t)M * I, s), "gelu_bwd");
