@@ -18,52 +18,91 @@ import torch
 from . import _lib as L
 
 
+def _line_starts(path, chunk_bytes=64 << 20):
+    """Byte offset of the start of every line of `path` (numpy int64), found by scanning the file for newlines in
+    bounded chunks; a final line without a newline still counts, an empty tail after the last newline does not."""
+    size = os.path.getsize(path)
+    pieces = [np.zeros(1, dtype=np.int64)] if size else []
+    with open(path, "rb") as f:
+        done = 0
+        while done < size:
+            blk = np.frombuffer(f.read(chunk_bytes), dtype=np.uint8)
+            nl = np.flatnonzero(blk == 10).astype(np.int64)
+            pieces.append(nl + (done + 1))
+            done += blk.size
+    starts = np.concatenate(pieces) if pieces else np.zeros(0, dtype=np.int64)
+    return starts[starts < size]
+
+
 def generate_lineidx_file(filein, idxout):
-    """tsv_file.py:8-18: byte offset of every line."""
-    tmp = idxout + ".tmp"
-    with open(filein, "rb") as tsvin, open(tmp, "w") as out:
-        fsize = os.fstat(tsvin.fileno()).st_size
-        fpos = 0
-        while fpos != fsize:
-            out.write(str(fpos) + "\n")
-            tsvin.readline()
-            fpos = tsvin.tell()
-    os.rename(tmp, idxout)
+    """Writes the `.lineidx` companion the reference reads and writes (Oscar/oscar/utils/tsv_file.py:8-18): one decimal
+    byte offset per line of `filein`.  Written to a temporary name first so that a concurrent reader never sees half a file."""
+    starts = _line_starts(filein)
+    tmp = "%s.%d.tmp" % (idxout, os.getpid())
+    with open(tmp, "w") as out:
+        out.write("".join("%d\n" % o for o in starts.tolist()))
+    os.replace(tmp, idxout)
 
 
 class TSVFile(object):
-    """tsv_file.py:21-85.  Rows are returned as ``bytes`` columns by ``seek_raw`` (what the decoder wants) and as
-    stripped ``str`` columns by ``seek`` / ``[]`` exactly like the reference."""
+    """Random access to the rows of a TSV file through its `.lineidx` companion: the public surface of the reference's
+    reader (Oscar/oscar/utils/tsv_file.py:20-85: ``TSVFile(path, generate_lineidx)``, ``num_rows`` / ``len``, ``seek`` / ``[]``,
+    ``seek_first_column``) on top of a read-only memory map and a numpy offset table, which is also what the native decoder
+    wants: ``row_span(i)`` gives the byte range of a row inside ``buffer()`` so that 4 MB rows are decoded in place out of the
+    page cache and never become Python ``bytes`` (``DecodePool``).  ``seek_raw`` returns the columns as ``bytes``."""
 
     def __init__(self, tsv_file, generate_lineidx=False):
         self.tsv_file = tsv_file
         self.lineidx = os.path.splitext(tsv_file)[0] + ".lineidx"
-        self._fp = None
-        self._lineidx = None
-        self.pid = None
-        if not os.path.isfile(self.lineidx) and generate_lineidx:
+        self._offsets = None        # int64 [rows + 1]: row starts, then the file size
+        self._map = None
+        self._map_owner = None      # the process that created the map (a forked child maps again)
+        if generate_lineidx and not os.path.isfile(self.lineidx):
             generate_lineidx_file(self.tsv_file, self.lineidx)
 
-    def __del__(self):
-        if self._fp:
-            self._fp.close()
-
-    def __str__(self):
+    def __repr__(self):
         return "TSVFile(tsv_file='{}')".format(self.tsv_file)
 
-    __repr__ = __str__
+    # ---- offsets / map -------------------------------------------------------------------------------------------
+    def offsets(self):
+        """int64 array of the row start offsets followed by the file size (len = num_rows + 1)."""
+        if self._offsets is None:
+            with open(self.lineidx, "rb") as f:
+                txt = f.read().split()
+            table = np.empty(len(txt) + 1, dtype=np.int64)
+            if txt:
+                table[:-1] = np.array(txt, dtype=np.int64)
+            table[-1] = os.path.getsize(self.tsv_file)
+            self._offsets = table
+        return self._offsets
 
+    def buffer(self):
+        """The whole file as a read-only memory map (shared page cache; re-mapped in a forked worker)."""
+        if self._map is None or self._map_owner != os.getpid():
+            import mmap
+            with open(self.tsv_file, "rb") as f:
+                self._map = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if os.fstat(f.fileno()).st_size else b""
+            self._map_owner = os.getpid()
+        return self._map
+
+    def row_span(self, idx):
+        """(first byte, one past the last byte) of row `idx` in ``buffer()``, line terminator included."""
+        offs = self.offsets()
+        n = len(offs) - 1
+        if not -n <= idx < n:
+            raise IndexError("row %d of a %d-row TSV file" % (idx, n))
+        idx %= n
+        return int(offs[idx]), int(offs[idx + 1])
+
+    # ---- the reference's surface ---------------------------------------------------------------------------------
     def num_rows(self):
-        self._ensure_lineidx_loaded()
-        return len(self._lineidx)
+        return len(self.offsets()) - 1
 
     __len__ = num_rows
 
     def seek_raw(self, idx):
-        self._ensure_tsv_opened()
-        self._ensure_lineidx_loaded()
-        self._fp.seek(self._lineidx[idx])
-        return self._fp.readline().split(b"\t")
+        lo, hi = self.row_span(idx)
+        return self.buffer()[lo:hi].split(b"\t")
 
     def seek(self, idx):
         return [c.decode("utf-8").strip() for c in self.seek_raw(idx)]
@@ -71,17 +110,10 @@ class TSVFile(object):
     __getitem__ = seek
 
     def seek_first_column(self, idx):
-        return self.seek_raw(idx)[0].decode("utf-8")
-
-    def _ensure_lineidx_loaded(self):
-        if self._lineidx is None:
-            with open(self.lineidx, "r") as fp:
-                self._lineidx = [int(i.strip()) for i in fp.readlines()]
-
-    def _ensure_tsv_opened(self):
-        if self._fp is None or self.pid != os.getpid():     # re-open after fork (DataLoader workers), as the reference
-            self._fp = open(self.tsv_file, "rb")
-            self.pid = os.getpid()
+        lo, hi = self.row_span(idx)
+        buf = self.buffer()
+        tab = buf.find(b"\t", lo, hi)
+        return buf[lo:(tab if tab >= 0 else hi)].decode("utf-8")
 
 
 def b64_to_f32(s, dim=2054):
@@ -296,18 +328,12 @@ class RegionStager(object):
 # H2D copy of a finished slot and the forward.
 
 def _pool_worker(tsv_path, img_seq_len, dim, threads, feats, masks, tasks, results, my_slots):
-    import mmap
     for k in my_slots:                  # map this worker's slots now: first-touch page faults stay out of the steady state
         feats[k].zero_()
         masks[k].zero_()
     tsv = TSVFile(tsv_path)
-    tsv._ensure_lineidx_loaded()
-    offs = tsv._lineidx
-    fp = open(tsv_path, "rb")
-    size = os.fstat(fp.fileno()).st_size
-    mm = mmap.mmap(fp.fileno(), 0, access=mmap.ACCESS_READ)      # rows are decoded in place out of the page cache
+    mm = tsv.buffer()                                             # rows are decoded in place out of the page cache
     base = np.frombuffer(mm, dtype=np.uint8).ctypes.data
-    ws = b" \t\r\n"
     while True:
         job = tasks.get()
         if job is None:
@@ -319,8 +345,7 @@ def _pool_worker(tsv_path, img_seq_len, dim, threads, feats, masks, tasks, resul
             lens = np.zeros(max(n, 1), dtype=np.uint64)
             names = []
             for j, i in enumerate(rows):
-                lo = offs[i]                                      # (IndexError for a row that does not exist: reported below)
-                hi = offs[i + 1] if i + 1 < len(offs) else size
+                lo, hi = tsv.row_span(i)                          # (IndexError for a row that does not exist: reported below)
                 tab = mm.find(b"\t", lo, hi)
                 if tab < 0:
                     raise ValueError("row %d has no tab-separated payload" % i)

@@ -53,67 +53,79 @@ class PreTrainedModel(nn.Module):
         sd = {k: v.detach().to("cpu").clone() for k, v in model_to_save.state_dict().items()}
         torch.save(sd, os.path.join(save_directory, WEIGHTS_NAME))
 
+    # ---- checkpoint loading ---------------------------------------------------------------------------------------
+    # One pass over a name -> tensor table instead of nn.Module's recursive loader: the tensors this model owns (parameters and
+    # buffers under their state-dict names; tied weights appear under every name they have, all aliasing one storage, which in
+    # a packed model is a slice of the flat buffer) are looked up in the checkpoint after its keys have been normalised, and
+    # copied in place.  Observable behaviour follows the reference loader (Oscar/oscar/modeling/modeling_utils.py:689-875).
+    _TOLERATED_MISMATCH = "cls.seq_relationship."     # a 2-class checkpoint head under a 3-class config (or the reverse) is re-initialised, :858-860
+
+    @classmethod
+    def _checkpoint_table(cls, raw, model):
+        """Checkpoint keys -> this model's names: legacy LayerNorm names (``gamma`` / ``beta``, :811-823) become ``weight`` /
+        ``bias``; a checkpoint of the bare encoder loads into ``model.bert`` and a prefixed checkpoint into a bare encoder
+        (:843-851).  Returns (table, names of the model this checkpoint is expected to fill)."""
+        table = {}
+        for key, tensor in raw.items():
+            table[key.replace("gamma", "weight").replace("beta", "bias")] = tensor
+        prefix = cls.base_model_prefix + "."
+        prefixed = any(k.startswith(cls.base_model_prefix) for k in table)
+        own = list(model.state_dict(keep_vars=True))
+        if hasattr(model, cls.base_model_prefix) and not prefixed:
+            table = {prefix + k: t for k, t in table.items()}
+            own = [n for n in own if n.startswith(prefix)]
+        elif not hasattr(model, cls.base_model_prefix) and prefixed:
+            table = {(k[len(prefix):] if k.startswith(prefix) else "\0" + k): t for k, t in table.items()}   # head keys cannot match
+        return table, own
+
+    def adopt_state_dict(self, raw):
+        """Copies a checkpoint's tensors into this model in place; returns {missing_keys, unexpected_keys, error_msgs}."""
+        table, own = self._checkpoint_table(raw, self)
+        mine = self.state_dict(keep_vars=True)
+        missing, errors = [], []
+        with torch.no_grad():
+            for name in own:
+                src = table.get(name)
+                if src is None:
+                    missing.append(name)
+                elif tuple(src.shape) != tuple(mine[name].shape):
+                    errors.append("size mismatch for {}: copying a param with shape {} from checkpoint, the shape in current model is {}."
+                                  .format(name, tuple(src.shape), tuple(mine[name].shape)))
+                else:
+                    mine[name].copy_(src)
+        wanted = set(own)
+        unexpected = [k.lstrip("\0") for k in table if k not in wanted]
+        return {"missing_keys": missing, "unexpected_keys": unexpected, "error_msgs": errors}
+
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *model_args, **kwargs):
         config = kwargs.pop("config", None)
         state_dict = kwargs.pop("state_dict", None)
         kwargs.pop("cache_dir", None)
+        want_info = kwargs.pop("output_loading_info", False)
         if kwargs.pop("from_tf", False):
             raise NotImplementedError("TensorFlow checkpoints are not supported")
-        output_loading_info = kwargs.pop("output_loading_info", False)
         if config is None:
-            config, model_kwargs = cls.config_class.from_pretrained(
-                pretrained_model_name_or_path, return_unused_kwargs=True, **kwargs)
-        else:
-            model_kwargs = kwargs
-        if os.path.isdir(pretrained_model_name_or_path):
-            archive_file = os.path.join(pretrained_model_name_or_path, WEIGHTS_NAME)
-        else:
-            archive_file = pretrained_model_name_or_path
-        model = cls(config, *model_args, **model_kwargs)
+            config, kwargs = cls.config_class.from_pretrained(pretrained_model_name_or_path, return_unused_kwargs=True, **kwargs)
+        model = cls(config, *model_args, **kwargs)
         if state_dict is None:
-            state_dict = torch.load(archive_file, map_location="cpu")
-        state_dict = dict(state_dict)
-        for key in list(state_dict.keys()):
-            new_key = None
-            if "gamma" in key:
-                new_key = key.replace("gamma", "weight")
-            if "beta" in key:
-                new_key = key.replace("beta", "bias")
-            if new_key:
-                state_dict[new_key] = state_dict.pop(key)
-
-        missing_keys, unexpected_keys, error_msgs = [], [], []
-
-        def load(module, prefix=""):
-            module._load_from_state_dict(state_dict, prefix, {}, True, missing_keys, unexpected_keys, error_msgs)
-            for name, child in module._modules.items():
-                if child is not None:
-                    load(child, prefix + name + ".")
-
-        start_prefix = ""
-        model_to_load = model
-        has_prefix = any(s.startswith(cls.base_model_prefix) for s in state_dict.keys())
-        if not hasattr(model, cls.base_model_prefix) and has_prefix:
-            start_prefix = cls.base_model_prefix + "."
-        if hasattr(model, cls.base_model_prefix) and not has_prefix:
-            model_to_load = getattr(model, cls.base_model_prefix)
-        load(model_to_load, prefix=start_prefix)
-        if missing_keys:
-            logger.info("Weights of %s not initialized from pretrained model: %s", model.__class__.__name__, missing_keys)
-        if unexpected_keys:
-            logger.info("Weights from pretrained model not used in %s: %s", model.__class__.__name__, unexpected_keys)
-        if len(error_msgs) == 2 and "size mismatch for cls.seq_relationship.weight" in error_msgs[0]:
-            logger.info("Error(s) in loading state_dict for %s:\n\t%s", model.__class__.__name__, "\n\t".join(error_msgs))
-        elif error_msgs:
-            raise RuntimeError("Error(s) in loading state_dict for {}:\n\t{}".format(
-                model.__class__.__name__, "\n\t".join(error_msgs)))
-        if hasattr(model, "tie_weights"):
-            model.tie_weights()
+            path = pretrained_model_name_or_path
+            state_dict = torch.load(os.path.join(path, WEIGHTS_NAME) if os.path.isdir(path) else path, map_location="cpu")
+        info = model.adopt_state_dict(state_dict)
+        who = model.__class__.__name__
+        if info["missing_keys"]:
+            logger.info("Weights of %s not initialized from pretrained model: %s", who, info["missing_keys"])
+        if info["unexpected_keys"]:
+            logger.info("Weights from pretrained model not used in %s: %s", who, info["unexpected_keys"])
+        if info["error_msgs"]:
+            text = "Error(s) in loading state_dict for {}:\n\t{}".format(who, "\n\t".join(info["error_msgs"]))
+            if all(m.startswith("size mismatch for " + cls._TOLERATED_MISMATCH) for m in info["error_msgs"]):
+                logger.info(text)
+            else:
+                raise RuntimeError(text)
+        model.tie_weights()
         model.eval()
-        if output_loading_info:
-            return model, {"missing_keys": missing_keys, "unexpected_keys": unexpected_keys, "error_msgs": error_msgs}
-        return model
+        return (model, info) if want_info else model
 
 
 ImgPreTrainedModel = PreTrainedModel

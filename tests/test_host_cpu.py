@@ -90,6 +90,35 @@ def test_state_dict_keys_and_checkpoint_roundtrip(golden_dir):
         BertImgForPreTraining.from_pretrained(ck, config=cfg3)
 
 
+def test_checkpoint_prefix_forms(golden_dir):
+    """modeling_utils.py:843-851: a bare-encoder checkpoint fills ``model.bert`` of a head model, a head-model checkpoint fills a
+    bare encoder (its head keys are reported unused); legacy gamma / beta names are accepted in both."""
+    from cpt_amd.modeling_bert import BertImgForPreTraining, BertImgModel
+    ck = os.path.join(golden_dir, "tiny_ckpt")
+    cfg = cfgmod.BertConfig.from_pretrained(ck)
+    full = BertImgForPreTraining.from_pretrained(ck, config=cfg)
+    sd = full.state_dict()
+    bare = {k[len("bert."):].replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta"): v
+            for k, v in sd.items() if k.startswith("bert.")}
+    torch.manual_seed(5)
+    m, info = BertImgForPreTraining.from_pretrained(None, config=cfg, state_dict=bare, output_loading_info=True)
+    assert not info["missing_keys"] and not info["unexpected_keys"] and not info["error_msgs"]
+    for k, v in sd.items():
+        if k.startswith("bert."):
+            assert torch.equal(m.state_dict()[k], v), k
+    enc, info = BertImgModel.from_pretrained(None, config=cfg, state_dict=sd, output_loading_info=True)
+    assert not info["missing_keys"] and not info["error_msgs"]
+    assert sorted(info["unexpected_keys"]) == sorted(k for k in sd if not k.startswith("bert."))
+    for k, v in enc.state_dict().items():
+        assert torch.equal(v, sd["bert." + k]), k
+    # a key the model does not have is reported, a missing one too
+    part = dict(sd)
+    part.pop("bert.pooler.dense.bias")
+    part["bert.not_a_parameter"] = torch.zeros(1)
+    _, info = BertImgForPreTraining.from_pretrained(None, config=cfg, state_dict=part, output_loading_info=True)
+    assert info["missing_keys"] == ["bert.pooler.dense.bias"] and info["unexpected_keys"] == ["bert.not_a_parameter"]
+
+
 def test_unsupported_surface_raises():
     from cpt_amd.modeling_rec import REC_MLM_CPT
     m = REC_MLM_CPT(cfgmod.tiny())

@@ -1,0 +1,148 @@
+// Ceiling yardstick for the bench shapes ("bf16 peak ... measured by a hipBLASLt / own-kernel peak probe on the
+// box ... re-measure, do not trust").  TOOLS ONLY: never linked into libcpt_hip.so, never on the product path.
+//   1. hipBLASLt on the four encoder GEMMs of BASELINE configs[1] (M = 64 x 120 = 7680; N x K = 2304 x 768, 768 x 768,
+//      3072 x 768, 768 x 3072), bf16 in / bf16 out / fp32 accumulate, operands in the layouts the path holds them
+//      (A [M][K] row-major, W [N][K] row-major = nn.Linear), every algorithm the heuristic returns timed, best reported.
+//      Random [-1, 1) operands (the guide's rule 25: zero-filled operands clock higher).  Plain GEMM: no bias / GELU / residual /
+//      LayerNorm / attention, so this is a ceiling for the MATRIX part of each launch, not for the fused launch.
+//   2. HBM streaming: float4 copy and read-only sum over buffers far beyond the 256 MB Infinity Cache (1 GiB each), plus the
+//      same kernels on a 48 MB working set (what the step's row kernels actually see: MALL-resident).
+// Build + run (GPU box):  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/yardstick.hip -lhipblaslt -o tools/yardstick.bin
+//                         tools/yardstick.bin > gpurun_out/r03_yardstick.json
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+#define CB(x) do { hipblasStatus_t s_ = (x); if (s_ != HIPBLAS_STATUS_SUCCESS) { fprintf(stderr, "hipBLASLt error %d at %s:%d\n", (int)s_, __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        const float f = (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f;          // uniform [-1, 1)
+        p[i] = (unsigned short)(__float_as_uint(f) >> 16);
+    }
+}
+__global__ void fill_f32(float* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (float)(i & 1023) * 0.001f;
+}
+__global__ __launch_bounds__(256) void copy_f4(const float4* __restrict__ a, float4* __restrict__ b, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void read_f4(const float4* __restrict__ a, float* __restrict__ out, size_t n4) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { const float4 v = a[i]; s += v.x + v.y + v.z + v.w; }
+    if (s == 12345.678f) out[0] = s;      // keeps the loads alive
+}
+
+template <typename F> static double time_us(F&& fn, int warm, int iters) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < warm; ++i) fn();
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) fn();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return (double)ms * 1e3 / iters;
+}
+
+struct Shape { const char* name; int M, N, K; };
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("{\"device\": \"%s\", \"cus\": %d, \"note\": \"tools-only ceiling probe; random [-1,1) bf16 operands; HIP-event time over back-to-back launches\",\n",
+           prop.gcnArchName, prop.multiProcessorCount);
+
+    // ---- 1. hipBLASLt ----------------------------------------------------------------------------------------------
+    hipblasLtHandle_t h;
+    CB(hipblasLtCreate(&h));
+    const size_t ws_bytes = 256u << 20;
+    void* ws;
+    CK(hipMalloc(&ws, ws_bytes));
+    const Shape shapes[4] = {{"gemm_qkv (7680 x 2304 x 768)", 7680, 2304, 768}, {"gemm_attn_out (7680 x 768 x 768)", 7680, 768, 768},
+                             {"gemm_ffn_up (7680 x 3072 x 768)", 7680, 3072, 768}, {"gemm_ffn_down (7680 x 768 x 3072)", 7680, 768, 3072}};
+    printf(" \"hipblaslt_bf16\": {\n");
+    for (int si = 0; si < 4; ++si) {
+        const Shape& s = shapes[si];
+        unsigned short *A, *W, *C;
+        CK(hipMalloc(&A, (size_t)s.M * s.K * 2)); CK(hipMalloc(&W, (size_t)s.N * s.K * 2)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2));
+        fill_bf16<<<1024, 256>>>(A, (size_t)s.M * s.K, 1u);
+        fill_bf16<<<1024, 256>>>(W, (size_t)s.N * s.K, 2u);
+        // row-major out[M][N] = A[M][K] . W[N][K]^T   ==   column-major C(N x M) = op_T(W as K x N, ld K) . (A as K x M, ld K)
+        hipblasLtMatmulDesc_t desc;
+        CB(hipblasLtMatmulDescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+        hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+        CB(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)));
+        CB(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)));
+        hipblasLtMatrixLayout_t la, lb, lc;
+        CB(hipblasLtMatrixLayoutCreate(&la, HIP_R_16BF, s.K, s.N, s.K));
+        CB(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16BF, s.K, s.M, s.K));
+        CB(hipblasLtMatrixLayoutCreate(&lc, HIP_R_16BF, s.N, s.M, s.N));
+        hipblasLtMatmulPreference_t pref;
+        CB(hipblasLtMatmulPreferenceCreate(&pref));
+        CB(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes, sizeof(ws_bytes)));
+        const int want = 32;
+        std::vector<hipblasLtMatmulHeuristicResult_t> res(want);
+        int got = 0;
+        CB(hipblasLtMatmulAlgoGetHeuristic(h, desc, la, lb, lc, lc, pref, want, res.data(), &got));
+        const float alpha = 1.f, beta = 0.f;
+        double best = 1e30, first = -1;
+        int best_i = -1;
+        for (int i = 0; i < got; ++i) {
+            if (res[i].state != HIPBLAS_STATUS_SUCCESS) continue;
+            auto run = [&]() { CB(hipblasLtMatmul(h, desc, &alpha, W, la, A, lb, &beta, C, lc, C, lc, &res[i].algo, ws, ws_bytes, 0)); };
+            const double us = time_us(run, 3, 20);
+            if (first < 0) first = us;
+            if (us < best) { best = us; best_i = i; }
+        }
+        // best algorithm again with more iterations
+        if (best_i >= 0) {
+            auto run = [&]() { CB(hipblasLtMatmul(h, desc, &alpha, W, la, A, lb, &beta, C, lc, C, lc, &res[best_i].algo, ws, ws_bytes, 0)); };
+            best = std::min(best, time_us(run, 5, 100));
+        }
+        const double flop = 2.0 * s.M * s.N * s.K;
+        printf("  \"%s\": {\"algos_tried\": %d, \"heuristic_first_us\": %.2f, \"best_us\": %.2f, \"best_TFLOPs\": %.1f, \"frac_of_2.5PF\": %.4f}%s\n",
+               s.name, got, first, best, flop / best * 1e-6, flop / best * 1e-6 / 2500.0, si < 3 ? "," : "");
+        CB(hipblasLtMatmulPreferenceDestroy(pref));
+        CB(hipblasLtMatrixLayoutDestroy(la)); CB(hipblasLtMatrixLayoutDestroy(lb)); CB(hipblasLtMatrixLayoutDestroy(lc));
+        CB(hipblasLtMatmulDescDestroy(desc));
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C));
+    }
+    printf(" },\n");
+    CK(hipFree(ws));
+    CB(hipblasLtDestroy(h));
+
+    // ---- 2. HBM streaming ------------------------------------------------------------------------------------------
+    printf(" \"hbm_stream\": {\n");
+    const size_t sizes[2] = {(size_t)1 << 30, (size_t)24 << 20};       // 1 GiB per buffer (>> 256 MB MALL); 24 MB per buffer (MALL-resident)
+    const char* tags[2] = {"1GiB_per_buffer", "24MiB_per_buffer_MALL_resident"};
+    for (int k = 0; k < 2; ++k) {
+        float *a, *b, *o;
+        CK(hipMalloc(&a, sizes[k])); CK(hipMalloc(&b, sizes[k])); CK(hipMalloc(&o, 256));
+        fill_f32<<<2048, 256>>>(a, sizes[k] / 4);
+        const size_t n4 = sizes[k] / 16;
+        double best_c = 1e30, best_r = 1e30;
+        int gc = 0, gr = 0;
+        const int grids[4] = {1024, 2048, 4096, 8192};
+        for (int g : grids) {
+            const double c = time_us([&]() { copy_f4<<<g, 256>>>((const float4*)a, (float4*)b, n4); }, 2, k ? 50 : 10);
+            const double r = time_us([&]() { read_f4<<<g, 256>>>((const float4*)a, o, n4); }, 2, k ? 50 : 10);
+            if (c < best_c) { best_c = c; gc = g; }
+            if (r < best_r) { best_r = r; gr = g; }
+        }
+        printf("  \"%s\": {\"copy_us\": %.1f, \"copy_GBs_read_plus_write\": %.0f, \"copy_grid\": %d, \"read_us\": %.1f, \"read_GBs\": %.0f, \"read_grid\": %d}%s\n",
+               tags[k], best_c, 2.0 * sizes[k] / best_c * 1e-3, gc, best_r, (double)sizes[k] / best_r * 1e-3, gr, k == 0 ? "," : "");
+        CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(o));
+    }
+    printf(" }\n}\n");
+    return 0;
+}
