@@ -595,7 +595,7 @@ int scale_cast(const float* x, const float* loss_acc, float scale, const float* 
 // Forward of the reference's hidden dropouts (BertEmbeddings / modeling_bert.py:266 / BertSelfOutput / BertOutput) and,
 // with resid = NULL, their backward.  4 elements per thread = one Philox call (dropout.h).
 template <typename TL>
-__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ x, const float* __restrict__ resid, float* __restrict__ y,
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* x, const float* resid, float* y,      // x == y in the in-place calls of the training step: no __restrict__
                                                            TL* __restrict__ y_lp, size_t n4, DropSpec d) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
@@ -1136,6 +1136,16 @@ static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void
 
 int g_attn_bwd_variant = 1;      // 1: transpose-read MFMA kernels for bf16 (L <= 288); 0: generic kernel always; 2: L <= 128 through the older MFMA kernel with transposed tile copies
 void set_attn_bwd_variant(int v) { g_attn_bwd_variant = v; }
+
+// Whether attention_bwd has a kernel for (dtype, L, dropout on the probabilities): asked by cpt_train_fwd so that an unsupported
+// combination is rejected BEFORE the forward runs, not after it
+int attention_bwd_supported(int dtype, int L, int has_drop) {
+    if (L <= 0) return 0;
+    if (dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 288) return 1;
+    if (dtype != CPT_BF16 && dtype != CPT_F32) return 0;
+    const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + (has_drop ? 3 : 2) * AB_QB * (L + 1) + L) * sizeof(float);
+    return lds <= 160 * 1024;
+}
 
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
                   const DropSpec* drop) {

@@ -52,6 +52,7 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
                   const DropSpec* drop = nullptr);
 // y = dropout(x) (+ resid): x, y fp32 [R][H] (in place allowed), y_lp optional copy in lp_dtype; element index of the mask =
 // row * H + col.  Forward of the hidden dropouts and, with resid = NULL, their backward (the mask applied to a gradient).
+int attention_bwd_supported(int dtype, int L, int has_drop);
 int dropout_rows(const float* x, const float* resid, float* y, void* y_lp, int lp_dtype, int R, int H, const DropSpec& d, hipStream_t s);
 // keep-mask export (tests): kind 0 hidden [R][H]; kind 1 attention [BH][L][L]; out = 1 keep / 0 drop
 int dropout_mask(int kind, unsigned char* out, int n0, int n1, int n2, const DropSpec& d, hipStream_t s);

@@ -69,9 +69,9 @@ __device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lan
 
 template <typename LP, bool GELU_IN>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
-    const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
-    float* __restrict__ out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
-    const float* __restrict__ resid, DropSpec dr, float* __restrict__ pre_out, signed char* __restrict__ out_lo) {
+    const float* x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
+    float* out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
+    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo) {      // x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
     // resid / dr / pre_out (training forward of LN(dropout(dense) + residual), modeling_bert.py:85-86,145 with the third-party
     // BertSelfOutput / BertOutput): the row that is normalised is dropout(x) + resid, written to pre_out for the backward pass --
     // the same arithmetic, in the same order, as the dropout_rows pass this replaces

@@ -157,6 +157,13 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     hipStream_t s = (hipStream_t)stream;
     const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, dt = d.dtype;
     if (L > 288) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: sequence length %d > 288", L);
+    if (!cpt::attention_bwd_supported(dt, L, pa ? 1 : 0))       // reject here, not after the forward has run (the backward's attention kernel sets the limit)
+    {
+        int lmax = L;
+        while (lmax > 0 && !cpt::attention_bwd_supported(dt, lmax, pa ? 1 : 0)) --lmax;
+        return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: no attention backward for dtype %d at sequence length %d%s (longest supported: %d)", dt, L,
+                        pa ? " with attention dropout" : "", lmax);
+    }
     unsigned char* ws = (unsigned char*)workspace;
     float* x_f32 = (float*)(ws + w.x_f32);
     float* a_f32 = (float*)(ws + w.a_f32);

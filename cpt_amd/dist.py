@@ -102,9 +102,15 @@ class ShardedGradSync(object):
     (half the bytes; the sum is then a bf16 sum).
     """
 
-    def __init__(self, buckets, device, wire=None, group=None):
+    def __init__(self, buckets, device, wire=None, group=None, force_collectives=False):
         self.rank, self.world = rank_world()
         self.group = group
+        # world size 1 normally short-circuits every collective (a copy); force_collectives sends them through
+        # torch.distributed anyway (needs an initialised process group), so that the stream / event choreography of the
+        # RCCL path can be exercised on ONE GPU (tests/test_gpu_dp.py::test_rccl_path_on_one_gpu)
+        self.collectives = self.world > 1 or bool(force_collectives)
+        if self.collectives and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("cpt_amd.dist: force_collectives needs torch.distributed.init_process_group first")
         self.buckets = dict(buckets)
         self.order = sorted(self.buckets)
         self.device = torch.device(device)
@@ -142,10 +148,13 @@ class ShardedGradSync(object):
 
     # -- backward: reduce-scatter -------------------------------------------------------------------------------
     def begin_backward(self):
-        if self._rs and self.cuda:       # a previous backward's reduce-scatters were never consumed by a step()
-            for _w, done in self._rs.values():
-                if done is not None:
-                    torch.cuda.current_stream(self.device).wait_event(done)
+        """Call BEFORE the gradient buffer is touched: reduce-scatters of an earlier backward that no step() consumed may still
+        be reading it (device: the compute stream waits for their events; host-driven backends: the works are waited for)."""
+        for work, done in self._rs.values():
+            if work is not None:
+                work.wait()
+            if done is not None:
+                torch.cuda.current_stream(self.device).wait_event(done)
         self.reduced = set()
         self._rs = {}
 
@@ -156,7 +165,7 @@ class ShardedGradSync(object):
         self.reduced.add(k)
         lo, hi = self.buckets[k]
         out = self.shard_view(self.gshard, k)
-        if self.world == 1:
+        if not self.collectives:
             out.copy_(grad[lo:hi])
             return
         if self.cuda:
@@ -209,7 +218,7 @@ class ShardedGradSync(object):
         """Queue the all-gather of every bucket of `flat` (this rank's shard already updated in place), buckets in
         forward order.  after_update(k) runs on the current stream before bucket k is sent (unused by default)."""
         self._ag = {}
-        if self.world == 1:
+        if not self.collectives:
             return
         for k in self.order:
             lo, hi = self.buckets[k]
@@ -252,7 +261,7 @@ class ShardedGradSync(object):
         for k in self.order:
             lo, hi = self.buckets[k]
             sv = self.shard_view(shard_buf, k).contiguous()
-            if self.world == 1:
+            if not self.collectives:
                 full[lo:hi].copy_(sv)
             else:
                 dist.all_gather_into_tensor(full[lo:hi], sv, group=self.group)

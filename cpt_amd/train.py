@@ -55,6 +55,8 @@ class _TrainState(object):
         self.drop_seed = None   # Philox key of the dropout masks (default: torch.initial_seed() mixed with the rank)
         self.drop_step = 0      # counter word: one fresh mask set per training forward
         self.sync = None        # dist.ShardedGradSync when an optimizer runs this engine data-parallel
+        self.defer = False      # data parallel: backward leaves the reduce-scatter to optimizer.step() (FusedAdamW.no_sync / defer_reduce)
+        self.sent_version = None   # version counter of `grad` when its reduce-scatter started: a later in-place edit cannot reach the update
 
     def ensure(self):
         eng = self.eng
@@ -202,11 +204,15 @@ class _MLMLoss(torch.autograd.Function):
         m, _ = eng.descriptor()
         views = _named_grad_views(eng, st)
         accumulate = any(p.grad is not None for p, v in views if v is not None)
+        if st.sync is not None:
+            st.sync.begin_backward()      # reduce-scatters of an unconsumed earlier backward may still read st.grad: wait BEFORE touching it
         if accumulate:
             keep = st.grad.clone()
         st.grad.zero_()
         g, _ = st.gdesc
-        sync = st.sync if not accumulate else None
+        # the early reduce-scatter only when this backward completes the gradient: not while accumulating, not under no_sync()
+        sync = st.sync if not (accumulate or st.defer) else None
+        st.sent_version = None
         errs = []
 
         def grads_ready(_user, k):
@@ -214,13 +220,7 @@ class _MLMLoss(torch.autograd.Function):
                 sync.grads_ready(st.grad, k)
             except Exception as e:
                 errs.append(e)
-        if sync is not None:
-            sync.begin_backward()
-            cb = L.BUCKET_CB(grads_ready)
-        else:
-            cb = L.NULL_CB
-            if st.sync is not None:
-                st.sync.begin_backward()          # accumulation step: buckets are reduced in optimizer.step()
+        cb = L.BUCKET_CB(grads_ready) if sync is not None else L.NULL_CB     # (None: buckets are reduced in optimizer.step())
         gl = grad_loss.to(torch.float32).contiguous()          # device scalar: no host synchronisation between fwd and bwd
         L.check(L.lib().cpt_train_bwd_ex(C.byref(m), C.byref(bt), C.byref(g), 1.0, gl.data_ptr(), st.ws.data_ptr(), st.ws.numel(),
                                          L.stream_ptr(), cb, None, C.byref(drop) if drop is not None else None), "cpt_train_bwd")
@@ -230,6 +230,11 @@ class _MLMLoss(torch.autograd.Function):
             st.grad.add_(keep)
         for p, v in views:
             p.grad = v
+        if sync is not None:
+            # The p.grad views alias the buffer whose reduce-scatter is already in flight: an in-place edit now (e.g.
+            # torch.nn.utils.clip_grad_norm_, fewshot/vcr_nsp_cpt.py:461) would race with it and could never reach the update.
+            # Views share their base's version counter, so step() can tell and refuse (FusedAdamW.step).
+            st.sent_version = st.grad._version
         st.saved = None
         return None, None, None, None
 
@@ -308,12 +313,21 @@ class FusedAdamW(object):
         under the rest of backward (dist.ShardedGradSync);
       * step() runs AdamW on this rank's 1/N shard of every bucket (moments are sharded: 1/N of the state per GPU)
         and queues the parameter all-gather, which the next forward waits for bucket by bucket.
-      ``p.grad`` views hold this rank's LOCAL gradients (the averaged ones exist only as shards); use
-      ``clip_grad_norm_`` below instead of torch.nn.utils.clip_grad_norm_.
-    grad_wire: None (fp32 on the wire) or "bf16" (gradients cast to bf16 for the reduce-scatter: half the bytes)."""
+      ``p.grad`` views hold this rank's LOCAL gradients (the averaged ones exist only as shards) and are READ-ONLY once
+      backward has returned: their reduce-scatter is already in flight, so step() raises if they were edited in place.  Use
+      ``clip_grad_norm_`` below instead of torch.nn.utils.clip_grad_norm_ (fewshot/vcr_nsp_cpt.py:461), or
+      ``defer_reduce=True`` (the reduce-scatter runs inside step(), local gradients stay editable, no overlap with backward);
+      wrap the leading micro-steps of a gradient-accumulation window in ``no_sync()``.
+      ``state_dict()`` / ``load_state_dict()`` / ``train.save_checkpoint`` are COLLECTIVE in this mode (the sharded moments are
+      gathered): every rank must call them, unlike the model's own ``state_dict()``.
+    grad_wire: None (fp32 on the wire) or "bf16" (gradients cast to bf16 for the reduce-scatter: half the bytes).
+    force_collectives: run the collectives even at world size 1 (exercises the RCCL stream choreography on one GPU)."""
 
-    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_wire=None):
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_wire=None, defer_reduce=False,
+                 force_collectives=False):
         self.model = model
+        self.defer_reduce = bool(defer_reduce)
+        self.force_collectives = bool(force_collectives)
         self.eng = model._engine()
         self.betas = betas
         self.eps = eps
@@ -329,19 +343,38 @@ class FusedAdamW(object):
         self._stale_shadow = set()
         import torch.distributed as dist
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        if self.world > 1 and next(model.parameters()).is_cuda:
+        self.dp = self.world > 1 or self.force_collectives
+        if self.dp and next(model.parameters()).is_cuda:
             self._ensure()
+
+    def no_sync(self):
+        """Context manager (DistributedDataParallel.no_sync): backward passes inside it do not start the gradient
+        reduce-scatter -- for the leading micro-steps of a gradient-accumulation window, whose partial sums would be sent for
+        nothing.  The buckets are reduced by the backward that follows outside the context, or by step()."""
+        opt = self
+
+        class _NoSync(object):
+            def __enter__(self_inner):
+                st = _state(opt.eng)
+                self_inner.prev = st.defer
+                st.defer = True
+
+            def __exit__(self_inner, *exc):
+                _state(opt.eng).defer = self_inner.prev or opt.defer_reduce
+                return False
+        return _NoSync()
 
     def _ensure(self):
         eng = self.eng
         eng.ensure_packed()
         dev = eng.flat.device
-        if self.world > 1 and (self.sync is None or self.sync.device != dev):
+        if self.dp and (self.sync is None or self.sync.device != dev):
             from . import dist as cdist
-            self.sync = cdist.ShardedGradSync(eng.buckets, dev, wire=self.grad_wire)
+            self.sync = cdist.ShardedGradSync(eng.buckets, dev, wire=self.grad_wire, force_collectives=self.force_collectives)
             cdist.broadcast_(eng.flat, 0)             # replicas start from rank 0's parameters
             eng.weights_updated()
             _state(eng).sync = self.sync
+            _state(eng).defer = self.defer_reduce
             self.m = None
         n_state = self.sync.shard_elems if self.sync is not None else eng.flat.numel()
         if self.m is None or self.m.numel() != n_state or self.m.device != dev:
@@ -410,6 +443,12 @@ class FusedAdamW(object):
         sync = self.sync
         if eng.pending is not None:
             eng.complete_pending()
+        if st.sent_version is not None and st.grad._version != st.sent_version:
+            raise RuntimeError(
+                "cpt_amd: a parameter's .grad was modified in place after backward() had already started the data-parallel "
+                "reduce-scatter of the gradients (the edit cannot reach the update and races with the transfer).  For global-norm "
+                "clipping call optimizer.clip_grad_norm_(max_norm) instead of torch.nn.utils.clip_grad_norm_; to edit local "
+                "gradients build the optimizer with defer_reduce=True (the reduce-scatter then runs inside step()).")
         sync.finish_reduce(st.grad)
         for k in sync.order:
             slo, shi = sync.shard_range(k)
@@ -487,10 +526,18 @@ def save_checkpoint(save_dir, model, optimizer=None, global_step=0, extra=None):
     optimizer.pt and training_state.json, so that a few-shot run resumes where it stopped."""
     import json
     import os
+    import torch.distributed as dist
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    # Data parallel: COLLECTIVE -- every rank calls this and rank 0 writes, which is how the reference's save_model is called
+    # too (fewshot/refcoco_cpt.py:548 on every rank, the rank test inside utils/save_model.py:6); the optimizer's sharded
+    # moments are gathered by optimizer.state_dict(), so guarding THIS call with `if rank == 0` would hang the other ranks.
+    opt_sd = optimizer.state_dict() if optimizer is not None else None
+    if rank != 0:
+        return
     os.makedirs(save_dir, exist_ok=True)
     model.save_pretrained(save_dir)
-    if optimizer is not None:
-        torch.save(optimizer.state_dict(), os.path.join(save_dir, "optimizer.pt"))
+    if opt_sd is not None:
+        torch.save(opt_sd, os.path.join(save_dir, "optimizer.pt"))
     with open(os.path.join(save_dir, "training_state.json"), "w") as f:
         json.dump({"global_step": int(global_step), "extra": extra or {}}, f)
 

@@ -114,6 +114,194 @@ def test_product_dp_step_world2_matches_single_process(mode, wire):
     assert r[0]["opt"]["step_count"] == STEPS
 
 
+# ---- the RCCL branch itself ("nccl" backend: communication stream, events, work.wait() as a stream dependency) -----------------
+# World size 2 needs two devices (RCCL refuses two ranks on one GPU) and the GPU test box has one, so the branch is driven
+# at world size 1 with force_collectives: every bucket goes through reduce_scatter_tensor / all_gather_into_tensor on the
+# communication stream exactly as on eight GPUs; the sum over one rank is the identity, so the run must reproduce the plain
+# single-process step BIT FOR BIT.  (replaces DistributedDataParallel at fewshot/refcoco_cpt.py:516-522.)
+
+def _nccl1_worker(rank, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import torch.distributed as dist
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    from cpt_amd.train import FusedAdamW
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = {}
+    try:
+        cfg = cfgmod.tiny()
+        b = {k: v.to(dev) for k, v in synth.make_batch(4, cfg, seed=5, max_seq_len=20, img_seq_len=6).items()}
+
+        def make(mode, **kw):
+            c = cfgmod.tiny()
+            c.hidden_dropout_prob = c.attention_probs_dropout_prob = 0.0
+            m = REC_MLM_CPT(c)
+            m.load_state_dict(synth.init_state_dict(c, 1234, head="cpt"))
+            m.tie_weights()
+            m.to(dev).train()
+            m.set_compute_dtype(mode)
+            return m, FusedAdamW(m, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.01, force_collectives=True, **kw)
+
+        for mode, wire in (("fp32", None), ("bf16", None), ("fp32", "bf16")):
+            m, opt = make(mode, grad_wire=wire)
+            assert opt.sync is not None and opt.sync.collectives and opt.sync.comm is not None
+            losses = _run(m, opt, b, slice(0, 4))
+            sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+            out[(mode, wire)] = {"losses": losses, "sd": sd}
+        # stress: 50 steps back to back while a second stream thrashes HBM / MALL (tests/test_gpu_race.py's pressure)
+        m, opt = make("bf16")
+        side = torch.cuda.Stream(device=dev)
+        ja = torch.empty(128 * 1024 * 1024 // 4, device=dev)
+        jb = torch.empty_like(ja)
+        with torch.cuda.stream(side):
+            for _ in range(200):
+                jb.copy_(ja)
+                ja.copy_(jb)
+        losses = _run(m, opt, b, slice(0, 4), steps=50)
+        torch.cuda.synchronize()
+        out["stress"] = {"losses": losses, "sd": {k: v.detach().cpu() for k, v in m.state_dict().items()}}
+        # an in-place edit of p.grad after backward cannot reach the update once the reduce-scatter is in flight: step() refuses
+        m, opt = make("fp32")
+        d = b
+        opt.zero_grad()
+        loss, _ = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], masked_lm_labels=d["colors"],
+                    mask_token_pos=d["mask_token_pos"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1e-3)       # the reference's VCR loop does this (fewshot/vcr_nsp_cpt.py:461)
+        try:
+            opt.step()
+            out["edit_raises"] = False
+        except RuntimeError as e:
+            out["edit_raises"] = "clip_grad_norm_" in str(e)
+        # defer_reduce=True: local gradients stay editable, the reduce-scatter runs inside step()
+        m, opt = make("fp32", defer_reduce=True)
+        opt.zero_grad()
+        loss, _ = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], masked_lm_labels=d["colors"],
+                    mask_token_pos=d["mask_token_pos"])
+        loss.backward()
+        for p_ in m.parameters():
+            if p_.grad is not None:
+                p_.grad.mul_(0.5)
+        opt.step()
+        m.eval()
+        out["deferred"] = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        # no_sync(): the first micro-step of an accumulation window sends nothing; the sum is reduced once
+        m, opt = make("fp32")
+        opt.zero_grad()
+        for i, rows in enumerate((slice(0, 2), slice(2, 4))):
+            dd = {k: v[rows] for k, v in b.items()}
+            ctx = opt.no_sync() if i == 0 else None
+            if ctx is not None:
+                ctx.__enter__()
+            loss, _ = m(dd["input_ids"], dd["segment_ids"], dd["attention_mask"], img_feats=dd["img_feats"], masked_lm_labels=dd["colors"],
+                        mask_token_pos=dd["mask_token_pos"])
+            loss.backward()
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+                assert not opt.sync.reduced                       # nothing was sent by the first micro-step
+        opt.step()
+        m.eval()
+        out["accum"] = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        torch.save(out, os.path.join(tmp, "nccl1.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_path_on_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_nccl1_worker, args=(_free_port(), tmp), nprocs=1, join=True)
+        r = torch.load(os.path.join(tmp, "nccl1.pt"))
+    dev = torch.device("cuda:0")
+    b = {k: v.to(dev) for k, v in synth.make_batch(4, cfgmod.tiny(), seed=5, max_seq_len=20, img_seq_len=6).items()}
+    for mode, wire in (("fp32", None), ("bf16", None), ("fp32", "bf16")):
+        m, opt = _make(cfgmod.tiny(), 1234, dev, mode)
+        assert opt.sync is None
+        losses = _run(m, opt, b, slice(0, 4))
+        got = r[(mode, wire)]
+        if wire is None:      # the collectives of one rank are the identity: same bits as the plain step
+            assert got["losses"] == losses, (mode, got["losses"], losses)
+            for k, v in m.state_dict().items():
+                assert torch.equal(got["sd"][k], v.cpu()), (mode, k)
+        else:                 # gradients rounded to bf16 on the wire
+            for k, v in m.state_dict().items():
+                if not k.endswith(".key.bias"):
+                    assert (got["sd"][k] - v.cpu()).abs().max().item() < 4e-3, k
+    m, opt = _make(cfgmod.tiny(), 1234, dev, "bf16")
+    losses = _run(m, opt, b, slice(0, 4), steps=50)
+    assert r["stress"]["losses"] == losses
+    for k, v in m.state_dict().items():
+        assert torch.equal(r["stress"]["sd"][k], v.cpu()), k
+    assert r["edit_raises"] is True
+    # defer_reduce: the halved local gradients reached the update -> equal to the plain step with the same edit
+    m, opt = _make(cfgmod.tiny(), 1234, dev, "fp32")
+    opt.zero_grad()
+    loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
+                mask_token_pos=b["mask_token_pos"])
+    loss.backward()
+    for p_ in m.parameters():
+        if p_.grad is not None:
+            p_.grad.mul_(0.5)
+    opt.step()
+    for k, v in m.state_dict().items():
+        assert torch.equal(r["deferred"][k], v.cpu()), k
+    # accumulation over two micro-batches
+    m, opt = _make(cfgmod.tiny(), 1234, dev, "fp32")
+    opt.zero_grad()
+    for rows in (slice(0, 2), slice(2, 4)):
+        dd = {k: v[rows] for k, v in b.items()}
+        loss, _ = m(dd["input_ids"], dd["segment_ids"], dd["attention_mask"], img_feats=dd["img_feats"], masked_lm_labels=dd["colors"],
+                    mask_token_pos=dd["mask_token_pos"])
+        loss.backward()
+    opt.step()
+    for k, v in m.state_dict().items():
+        assert torch.equal(r["accum"][k], v.cpu()), k
+
+
+def _nccl2_worker(rank, world, port, tmp, mode, wire):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import torch.distributed as dist
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        cfg = cfgmod.tiny()
+        m, opt = _make(cfg, 1234 + 17 * rank, dev, mode, wire)
+        b = {k: v.to(dev) for k, v in synth.make_batch(4, cfg, seed=5, max_seq_len=20, img_seq_len=6).items()}
+        per = 4 // world
+        losses = _run(m, opt, b, slice(rank * per, (rank + 1) * per))
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        torch.save({"sd": sd, "losses": losses}, os.path.join(tmp, "r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,wire", [("fp32", None), ("fp32", "bf16")])
+def test_product_dp_step_two_gpus_rccl(mode, wire):
+    """the same comparison over RCCL with one rank per device; skipped on boxes with fewer than two GPUs."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_nccl2_worker, args=(world, _free_port(), tmp, mode, wire), nprocs=world, join=True)
+        r = [torch.load(os.path.join(tmp, "r%d.pt" % i)) for i in range(world)]
+    dev = torch.device("cuda:0")
+    m, opt = _make(cfgmod.tiny(), 1234, dev, mode)
+    b = {k: v.to(dev) for k, v in synth.make_batch(4, cfgmod.tiny(), seed=5, max_seq_len=20, img_seq_len=6).items()}
+    losses = _run(m, opt, b, slice(0, 4))
+    ptol, ltol = (2e-6, 1e-5) if wire is None else (4e-3, 5e-2)
+    for k, v in m.state_dict().items():
+        assert torch.equal(r[0]["sd"][k], r[1]["sd"][k]), k
+        if not k.endswith(".key.bias"):
+            assert (r[0]["sd"][k] - v.cpu()).abs().max().item() < ptol, k
+    for s_ in range(STEPS):
+        assert abs(0.5 * (r[0]["losses"][s_] + r[1]["losses"][s_]) - losses[s_]) < ltol
+
+
 def test_stale_training_forward_raises():
     """loss_a = model(a); loss_b = model(b); loss_a.backward() must not consume b's activations."""
     if not torch.cuda.is_available():
