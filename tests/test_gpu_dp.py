@@ -147,9 +147,15 @@ def _nccl1_worker(rank, port, tmp):
         for mode, wire in (("fp32", None), ("bf16", None), ("fp32", "bf16")):
             m, opt = make(mode, grad_wire=wire)
             assert opt.sync is not None and opt.sync.collectives and opt.sync.comm is not None
-            losses = _run(m, opt, b, slice(0, 4))
+            l1 = _run(m, opt, b, slice(0, 4), steps=1)
+            m.eval()
+            with torch.no_grad():      # (waits for the pending parameter all-gather bucket by bucket)
+                m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"])
+            m.train()
+            sd1 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+            losses = l1 + _run(m, opt, b, slice(0, 4), steps=STEPS - 1)
             sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-            out[(mode, wire)] = {"losses": losses, "sd": sd}
+            out[(mode, wire)] = {"losses": losses, "sd": sd, "sd1": sd1}
         # stress: 50 steps back to back while a second stream thrashes HBM / MALL (tests/test_gpu_race.py's pressure)
         m, opt = make("bf16")
         side = torch.cuda.Stream(device=dev)
@@ -160,8 +166,11 @@ def _nccl1_worker(rank, port, tmp):
                 jb.copy_(ja)
                 ja.copy_(jb)
         losses = _run(m, opt, b, slice(0, 4), steps=50)
+        m.eval()
+        with torch.no_grad():          # the last step's all-gather is still pending here: the forward must wait for it per bucket
+            logits = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"])[0]
         torch.cuda.synchronize()
-        out["stress"] = {"losses": losses, "sd": {k: v.detach().cpu() for k, v in m.state_dict().items()}}
+        out["stress"] = {"losses": losses, "sd": {k: v.detach().cpu() for k, v in m.state_dict().items()}, "logits": logits.cpu()}
         # an in-place edit of p.grad after backward cannot reach the update once the reduce-scatter is in flight: step() refuses
         m, opt = make("fp32")
         d = b
@@ -217,24 +226,45 @@ def test_rccl_path_on_one_gpu():
         r = torch.load(os.path.join(tmp, "nccl1.pt"))
     dev = torch.device("cuda:0")
     b = {k: v.to(dev) for k, v in synth.make_batch(4, cfgmod.tiny(), seed=5, max_seq_len=20, img_seq_len=6).items()}
+    # The embedding scatter-add and the bias / LayerNorm column sums of the backward pass use fp32 atomics (order-dependent last
+    # bits), so two runs of the SAME step agree bit for bit only on gradients that do not pass through them: after ONE step
+    # every encoder weight matrix must be identical to the plain step (the collectives of one rank are the identity), the
+    # rest to rounding; later steps to the tolerances of the world-2 test.
     for mode, wire in (("fp32", None), ("bf16", None), ("fp32", "bf16")):
         m, opt = _make(cfgmod.tiny(), 1234, dev, mode)
         assert opt.sync is None
-        losses = _run(m, opt, b, slice(0, 4))
+        l1 = _run(m, opt, b, slice(0, 4), steps=1)
         got = r[(mode, wire)]
-        if wire is None:      # the collectives of one rank are the identity: same bits as the plain step
-            assert got["losses"] == losses, (mode, got["losses"], losses)
+        ptol, ltol = (2e-6, 1e-5) if (mode == "fp32" and wire is None) else (4e-3, 5e-2)
+        if wire is None:
+            assert got["losses"][0] == l1[0], (mode, got["losses"], l1)
             for k, v in m.state_dict().items():
-                assert torch.equal(got["sd"][k], v.cpu()), (mode, k)
-        else:                 # gradients rounded to bf16 on the wire
-            for k, v in m.state_dict().items():
-                if not k.endswith(".key.bias"):
-                    assert (got["sd"][k] - v.cpu()).abs().max().item() < 4e-3, k
+                if k.startswith("bert.encoder.") and k.endswith("weight") and v.dim() == 2:      # GEMM-produced gradients: no atomics on their path
+                    assert torch.equal(got["sd1"][k], v.cpu()), (mode, k)
+                else:
+                    assert (got["sd1"][k] - v.cpu()).abs().max().item() < ptol, (mode, k)
+        losses = l1 + _run(m, opt, b, slice(0, 4), steps=STEPS - 1)
+        for a_, b_ in zip(got["losses"], losses):
+            assert abs(a_ - b_) < ltol, (mode, wire, got["losses"], losses)
+        for k, v in m.state_dict().items():
+            if not k.endswith(".key.bias"):
+                assert (got["sd"][k] - v.cpu()).abs().max().item() < ptol, (mode, wire, k)
+    # stress run: finite, tracks the plain run, and the eval forward right behind the last step saw exactly the final
+    # parameters (its logits are reproduced bit for bit by a fresh model loaded with the final state dict: no stale shadow
+    # copy, no parameter read ahead of its all-gather)
     m, opt = _make(cfgmod.tiny(), 1234, dev, "bf16")
     losses = _run(m, opt, b, slice(0, 4), steps=50)
-    assert r["stress"]["losses"] == losses
-    for k, v in m.state_dict().items():
-        assert torch.equal(r["stress"]["sd"][k], v.cpu()), k
+    assert all(l == l and abs(l) < 1e4 for l in r["stress"]["losses"])
+    assert max(abs(a_ - b_) for a_, b_ in zip(r["stress"]["losses"], losses)) < 0.15, (r["stress"]["losses"][-3:], losses[-3:])
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    c = cfgmod.tiny()
+    fresh = REC_MLM_CPT(c)
+    fresh.load_state_dict(r["stress"]["sd"])
+    fresh.tie_weights()
+    fresh.to(dev).eval().set_compute_dtype("bf16")
+    with torch.no_grad():
+        again = fresh(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"])[0].cpu()
+    assert torch.equal(again, r["stress"]["logits"])
     assert r["edit_raises"] is True
     # defer_reduce: the halved local gradients reached the update -> equal to the plain step with the same edit
     m, opt = _make(cfgmod.tiny(), 1234, dev, "fp32")
@@ -247,7 +277,7 @@ def test_rccl_path_on_one_gpu():
             p_.grad.mul_(0.5)
     opt.step()
     for k, v in m.state_dict().items():
-        assert torch.equal(r["deferred"][k], v.cpu()), k
+        assert (r["deferred"][k] - v.cpu()).abs().max().item() < 2e-6, k
     # accumulation over two micro-batches
     m, opt = _make(cfgmod.tiny(), 1234, dev, "fp32")
     opt.zero_grad()
@@ -258,7 +288,7 @@ def test_rccl_path_on_one_gpu():
         loss.backward()
     opt.step()
     for k, v in m.state_dict().items():
-        assert torch.equal(r["accum"][k], v.cpu()), k
+        assert (r["accum"][k] - v.cpu()).abs().max().item() < 2e-6, k
 
 
 def _nccl2_worker(rank, world, port, tmp, mode, wire):
