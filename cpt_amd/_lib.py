@@ -33,7 +33,7 @@ class Layer(C.Structure):
 
 
 class LayerFold(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w_qkv_f", "c_qkv", "d_qkv", "w_in_f", "c_in", "d_in")]
+    _fields_ = [(n, C.c_void_p) for n in ("w_qkv_f", "c_qkv", "d_qkv", "w_in_f", "c_in", "d_in", "w_qkv_t")]
 
 
 class Model(C.Structure):
@@ -108,6 +108,7 @@ _SIGS = {
     "cpt_argmax_columns": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     "cpt_gather_rows": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_ce_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "cpt_retile_k32": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "cpt_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "cpt_debug_gemm_trace": (C.c_int, [vp]),
     "cpt_prof_enable": (C.c_int, [C.c_int]),
@@ -153,8 +154,8 @@ def lib():
             fn = getattr(l, name)        # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if l.cpt_version() != 2:
-            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 2" % l.cpt_version())
+        if l.cpt_version() != 3:
+            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 3" % l.cpt_version())
         _lib = l
     return _lib
 

@@ -180,6 +180,38 @@ __device__ __forceinline__ void r3_encode1(float v, bf16& hi, signed char& lo) {
     lo = (signed char)(((b + 0x80u) >> 8) & 0xffu);
 }
 
+// ---- partial row sums of the folded LayerNorm (gemm.hip "EpiX") ---------------------------------------------
+// Sum of the partial row sums of `row` in slot order.  Table layout [M][slots][2] with `slots` = parts rounded up to
+// an even number (ln_stat_slots): the partial sums of one row are contiguous (64 bytes for hidden = 768), so a reader
+// fetches them as 16-byte pairs of slots in one unrolled, branch-free batch.  Slots past `parts` hold garbage and
+// are skipped by a select.
+template <int MAXQ>   // MAXQ 16-byte loads = 2*MAXQ slots
+__device__ __forceinline__ void sum_parts_n(const float* __restrict__ st, int parts, int slots, int row, float& sum, float& sq) {
+    const f32x4* base = reinterpret_cast<const f32x4*>(st + (size_t)row * slots * 2);
+    const int nq = slots >> 1;
+    f32x4 v[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) v[q] = base[min(q, nq - 1)];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const bool u0 = 2 * q < parts, u1 = 2 * q + 1 < parts;      // (select, not multiply: an unused slot may hold NaN)
+        sum += u0 ? v[q][0] : 0.f; sq += u0 ? v[q][1] : 0.f;
+        sum += u1 ? v[q][2] : 0.f; sq += u1 ? v[q][3] : 0.f;
+    }
+}
+__device__ __forceinline__ void sum_parts(const float* __restrict__ st, int parts, int row, float& sum, float& sq) {
+    const int slots = (parts + 1) & ~1;
+    sum = 0.f; sq = 0.f;
+    if (parts <= 8) sum_parts_n<4>(st, parts, slots, row, sum, sq);
+    else if (parts <= 12) sum_parts_n<6>(st, parts, slots, row, sum, sq);
+    else {
+        for (int p = 0; p < parts; ++p) {
+            const float2 v = *reinterpret_cast<const float2*>(st + ((size_t)row * slots + p) * 2);
+            sum += v.x; sq += v.y;
+        }
+    }
+}
+
 // 32x32 accumulator element r of lane l sits at (row, col):
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }

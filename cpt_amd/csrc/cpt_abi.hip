@@ -119,6 +119,21 @@ FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
 
 }  // namespace
 
+// fused QKV projection + attention: form chosen by cpt_set_tuning(6, .)
+static int g_qkv_tiled = 1;    // form 3: read the K-tile-major weight copy (cpt_layer_fold.w_qkv_t) when the model carries one
+static int qkv_attn(int config, const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
+                    const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads, int K,
+                    hipStream_t s, const void* W_tiled) {
+    if (config == 3) {
+        if (cpt::qkv_attn3_eligible(L, heads, K)) {
+            const bool tl = W_tiled && g_qkv_tiled;
+            return cpt::gemm_qkv_attn3(A, lda, tl ? W_tiled : W, ldw, bias, st_in, colc, cold, eps, hidden, mask, ctx, ldo, B, L, heads, K, s, tl ? 1 : 0);
+        }
+        config = 1;
+    }
+    return cpt::gemm_qkv_attn(A, lda, W, ldw, bias, st_in, colc, cold, eps, hidden, mask, ctx, ldo, B, L, heads, K, config, s);
+}
+
 extern "C" {
 
 int cpt_version(void) { return CPT_ABI_VERSION; }
@@ -134,20 +149,27 @@ int cpt_check_device(int dev) {
 }
 
 static int g_fold_ln = 1;      // bf16 mode with cpt_model.fold: fold the encoder LayerNorms into the GEMMs (0 = run them as kernels)
-static int g_fuse_attn = 1;    // bf16, L <= 128: QKV projection + attention in one kernel (0 = two kernels; 2 = one workgroup per CU)
+static int g_fuse_attn = 3;    // bf16, L <= 128: QKV projection + attention in one kernel (0 = two kernels; 1 = one workgroup per (sequence, head), two per CU; 2 = same, one per CU; 3 = one workgroup per (sequence, three heads) where heads % 3 == 0, else 1)
 static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
 static int g_resid3 = 1;       // fused bf16 encoder: residual stream in the 3-byte form (bf16 hi + int8 lo) instead of fp32 + bf16 copies
 
 int cpt_set_tuning(int key, int value) {
+    if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
+        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_qkv_tiled = 1;
+        cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
+        cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_gemm_trace_filter(255, 0);
+        return CPT_OK;
+    }
     if (key == 4) { g_lp_resid = value; return CPT_OK; }
     if (key == 5) { g_fold_ln = value; return CPT_OK; }
     if (key == 6) { g_fuse_attn = value; return CPT_OK; }
     if (key == 0) { cpt::set_gemm_variant(value); return CPT_OK; }
-    if (key == 1) { cpt::set_gemm_abl(value); return CPT_OK; }
+    if (key == 1) { cpt::set_gemm_abl(value); cpt::set_q3_abl(value); return CPT_OK; }
     if (key == 2) { cpt::set_attn_bwd_variant(value); return CPT_OK; }
     if (key == 3) { cpt::set_splitk_target(value); return CPT_OK; }
     if (key == 7) { cpt::set_gemm_skew(value); return CPT_OK; }
     if (key == 9) { g_resid3 = value; return CPT_OK; }
+    if (key == 11) { g_qkv_tiled = value; return CPT_OK; }
     if (key == 10) { cpt::set_wgrad_tn(value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
@@ -155,6 +177,7 @@ int cpt_set_tuning(int key, int value) {
 
 int cpt_debug_gemm_trace(void* buf) {
     cpt::set_gemm_trace(buf);
+    cpt::set_q3_trace(buf);
     return CPT_OK;
 }
 
@@ -260,6 +283,10 @@ int cpt_gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int 
 int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,
                         float* colc, float* cold, int N, int K, void* stream) {
     return check_launch(cpt::fold_ln_weights(W, gamma, beta, bias, Wf_bf16, colc, cold, N, K, (hipStream_t)stream), "cpt_fold_ln_weights");
+}
+
+int cpt_retile_k32(const void* src_bf16, void* dst_bf16, int N, int K, void* stream) {
+    return check_launch(cpt::retile_k32(src_bf16, dst_bf16, N, K, (hipStream_t)stream), "cpt_retile_k32");
 }
 
 int cpt_select_regions(const float* mask_logits, int V, const int64_t* color_ids, int C, const int32_t* query_first, int Q,
@@ -382,10 +409,10 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
             const cpt_layer* yp = l > 0 ? &m->layers[l - 1] : nullptr;
             if (fuse_attn) {
               Scope p(CPT_K_GEMM_QKV, s);      // QKV projection + attention, one kernel; q/k/v never reach HBM
-              if (l == 0) TRY(cpt::gemm_qkv_attn(x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, nullptr, nullptr, d.ln_eps, H, b->attn_mask, ctx, H,
-                                                 B, L, d.heads, H, g_fuse_attn, s), "gemm(qkv)+attention");
-              else TRY(cpt::gemm_qkv_attn(x_lp, H, f.w_qkv_f, H, nullptr, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, b->attn_mask, ctx, H,
-                                          B, L, d.heads, H, g_fuse_attn, s), "gemm(qkv, folded LN)+attention");
+              if (l == 0) TRY(qkv_attn(g_fuse_attn, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, nullptr, nullptr, d.ln_eps, H, b->attn_mask, ctx, H,
+                                                 B, L, d.heads, H, s, f.w_qkv_t), "gemm(qkv)+attention");
+              else TRY(qkv_attn(g_fuse_attn, x_lp, H, f.w_qkv_f, H, nullptr, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, b->attn_mask, ctx, H,
+                                          B, L, d.heads, H, s, f.w_qkv_t), "gemm(qkv, folded LN)+attention");
             } else {
             { Scope p(CPT_K_GEMM_QKV, s);
               if (l == 0) TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
@@ -420,8 +447,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         const cpt_layer& y = m->layers[l];
         if (fuse_attn) {
           Scope p(CPT_K_GEMM_QKV, s);
-          TRY(cpt::gemm_qkv_attn(x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, nullptr, nullptr, d.ln_eps, H, b->attn_mask, ctx, H,
-                                 B, L, d.heads, H, g_fuse_attn, s), "gemm(qkv)+attention");
+          TRY(qkv_attn(g_fuse_attn, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, nullptr, nullptr, d.ln_eps, H, b->attn_mask, ctx, H,
+                                 B, L, d.heads, H, s, nullptr), "gemm(qkv)+attention");
         } else {
         { Scope p(CPT_K_GEMM_QKV, s);
           TRY(gm(CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H), "gemm(qkv)"); }

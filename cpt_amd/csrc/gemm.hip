@@ -177,37 +177,6 @@ struct EpiX {
 };
 
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
-// Sum of the partial row sums of `row` in slot order.  Table layout [M][slots][2] with `slots` = parts rounded up to
-// an even number (ln_stat_slots): the partial sums of one row are contiguous (64 bytes for hidden = 768), so a reader
-// fetches them as 16-byte pairs of slots in one unrolled, branch-free batch.  Slots past `parts` hold garbage and
-// are skipped by a select.
-template <int MAXQ>   // MAXQ 16-byte loads = 2*MAXQ slots
-__device__ __forceinline__ void sum_parts_n(const float* __restrict__ st, int parts, int slots, int row, float& sum, float& sq) {
-    const f32x4* base = reinterpret_cast<const f32x4*>(st + (size_t)row * slots * 2);
-    const int nq = slots >> 1;
-    f32x4 v[MAXQ];
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) v[q] = base[min(q, nq - 1)];
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-        const bool u0 = 2 * q < parts, u1 = 2 * q + 1 < parts;      // (select, not multiply: an unused slot may hold NaN)
-        sum += u0 ? v[q][0] : 0.f; sq += u0 ? v[q][1] : 0.f;
-        sum += u1 ? v[q][2] : 0.f; sq += u1 ? v[q][3] : 0.f;
-    }
-}
-__device__ __forceinline__ void sum_parts(const float* __restrict__ st, int parts, int row, float& sum, float& sq) {
-    const int slots = (parts + 1) & ~1;
-    sum = 0.f; sq = 0.f;
-    if (parts <= 8) sum_parts_n<4>(st, parts, slots, row, sum, sq);
-    else if (parts <= 12) sum_parts_n<6>(st, parts, slots, row, sum, sq);
-    else {
-        for (int p = 0; p < parts; ++p) {
-            const float2 v = *reinterpret_cast<const float2*>(st + ((size_t)row * slots + p) * 2);
-            sum += v.x; sq += v.y;
-        }
-    }
-}
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 // TN = 1 (round 2, weight gradients): out[M][N] = sum_k A[k][m] . W[k][n] -- both operands are stored with the CONTRACTION index as

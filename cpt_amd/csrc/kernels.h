@@ -99,6 +99,15 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
 int gemm_qkv_attn(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
                   const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads,
                   int K, int config, hipStream_t s);
+// round 3: the same fused launch with one workgroup per (sequence, three heads) (qkv_attn3.hip); needs qkv_attn3_eligible
+int qkv_attn3_eligible(int L, int heads, int K);
+void set_q3_trace(void* p);  // cpt_debug_gemm_trace: per-workgroup phase stamps of the kernel
+void set_q3_abl(int v);     // diagnostic builds (-DCPT_ABLATION): ablation bits of the kernel, see qkv_attn3.hip
+int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
+                   const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads,
+                   int K, hipStream_t s, int w_tiled = 0);     // w_tiled: W is the K-tile-major copy made by retile_k32
+// dst[K / 32][N][32] = src[N][K] (bf16): every K-tile of 32 of all rows contiguous (64 bytes per row, rows adjacent)
+int retile_k32(const void* src, void* dst, int N, int K, hipStream_t s);
 int select_regions(const float* logits, int V, const int64_t* color_ids, int C, const int* query_first, int Q,
                    int64_t none_id, int divide_by_none, int64_t* out_idx, float* out_score, hipStream_t s);
 int argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids, int R, int64_t* out_idx, float* out_val, hipStream_t s);

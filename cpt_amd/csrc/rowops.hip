@@ -1,6 +1,8 @@
 // HBM-bound row kernels of the CPT hot path: embedding gather + LayerNorm, (residual) LayerNorm,
 // pad/cast of region features, row gather, cross-entropy over [MASK] rows.
 // One 64-lane wavefront per row, 16-byte loads, statistics by wave shuffles; fp32 math.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -311,6 +313,27 @@ int fold_ln_weights(const float* W, const float* gamma, const float* beta, const
     if (N <= 0 || K <= 0 || K % 4) return CPT_ERR_SHAPE;
     if (!W || !gamma || !beta || !Wf_bf16 || !colc || !cold) return CPT_ERR_NULL;
     fold_ln_weights_kernel<<<dim3((N + 3) / 4), dim3(256), 0, s>>>(W, gamma, beta, bias, (bf16*)Wf_bf16, colc, cold, N, K);
+    return CPT_OK;
+}
+
+// ---- K-tile-major copy of a bf16 weight: dst[K / 32][N][32] = src[N][K] -------------------------------------------------------
+// The fused QKV + attention kernel of qkv_attn3.hip stages K-tiles of 32 (64 bytes per row): out of the row-major weight every
+// LDS-DMA request is half a cache line; in this layout a piece's 16 rows are one contiguous KiB.
+__global__ __launch_bounds__(256) void retile_k32_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int N, int K) {
+    const int cpr = K / 8;                                     // 16-byte chunks per source row
+    const size_t total = (size_t)N * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i / cpr), c = (int)(i - (size_t)n * cpr);
+        const int t = c >> 2, cc = c & 3;                      // K-tile, chunk inside it
+        dst[((size_t)t * N + n) * 4 + cc] = src[i];
+    }
+}
+int retile_k32(const void* src, void* dst, int N, int K, hipStream_t s) {
+    if (N <= 0 || K <= 0 || K % 32) return CPT_ERR_SHAPE;
+    if (!src || !dst) return CPT_ERR_NULL;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return CPT_ERR_ALIGN;
+    const size_t total = (size_t)N * (K / 8);
+    retile_k32_kernel<<<dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s>>>((const uint4*)src, (uint4*)dst, N, K);
     return CPT_OK;
 }
 

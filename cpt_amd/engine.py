@@ -281,6 +281,8 @@ class PackedModel(object):
         if self._fold is None or self._fold["w"].device != dev:
             self._fold = {"w": torch.empty(nl * (3 * H * H + I * H), device=dev, dtype=torch.bfloat16),
                           "v": torch.empty(nl * 2 * (3 * H + I), device=dev, dtype=torch.float32),
+                          # K-tile-major copies of the QKV weights for the (sequence, three heads) fused launch (cpt_retile_k32)
+                          "t": torch.empty(nl * 3 * H * H, device=dev, dtype=torch.bfloat16) if H % 32 == 0 else None,
                           "arr": (L.LayerFold * nl)()}
             self._desc = {}
         wbuf, vbuf, arr = self._fold["w"], self._fold["v"], self._fold["arr"]
@@ -309,6 +311,11 @@ class PackedModel(object):
                 L.check(L.lib().cpt_fold_ln_weights(fp(p + "attention.self.query.weight"), fp(q + "output.LayerNorm.weight"),
                                                     fp(q + "output.LayerNorm.bias"), fp(p + "attention.self.query.bias"),
                                                     f.w_qkv_f, f.c_qkv, f.d_qkv, 3 * H, H, st), "cpt_fold_ln_weights(qkv)")
+            if self._fold["t"] is not None:
+                # (layer 0 reads the plain weight: its K-tile-major copy comes from the bf16 shadow)
+                src = f.w_qkv_f if i > 0 else self.flat_lp.data_ptr() + self.offsets[p + "attention.self.query.weight"][0] * 2
+                f.w_qkv_t = self._fold["t"].data_ptr() + i * 3 * H * H * 2
+                L.check(L.lib().cpt_retile_k32(src, f.w_qkv_t, 3 * H, H, st), "cpt_retile_k32(qkv)")
             wo += 3 * H * H
             vo += 2 * 3 * H
         self._fold_stale = False

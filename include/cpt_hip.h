@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CPT_ABI_VERSION 2     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2) */
+#define CPT_ABI_VERSION 3     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32 (round 3) */
 
 enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2 };
 enum { CPT_EPI_NONE = 0, CPT_EPI_GELU = 1, CPT_EPI_TANH = 2, CPT_EPI_RESID = 3 };
@@ -102,6 +102,8 @@ typedef struct {           /* optional LayerNorm-folded operands of layer i (CPT
     const void* w_in_f;    /* [I][H] bf16 = attention.output.LayerNorm.weight of layer i * w_in */
     const float* c_in;     /* [I] */
     const float* d_in;     /* [I] */
+    const void* w_qkv_t;   /* ABI 3, optional (NULL: not used): K-tile-major copy [H / 32][3H][32] bf16 (cpt_retile_k32) of the QKV weight this
+                            * layer's fused QKV + attention launch reads -- w_qkv_f, or the plain w_qkv for layer 0 */
 } cpt_layer_fold;
 
 typedef struct {
@@ -306,6 +308,10 @@ int cpt_argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids
 int cpt_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16,
                         float* colc, float* cold, int N, int K, void* stream);
 
+/* K-tile-major copy of a bf16 weight: dst[K / 32][N][32] = src[N][K] (K % 32 == 0): the layout cpt_layer_fold.w_qkv_t holds.  The
+ * fused QKV + attention launch stages K-tiles of 32; out of this copy every 16-row LDS-DMA piece is one contiguous KiB. */
+int cpt_retile_k32(const void* src_bf16, void* dst_bf16, int N, int K, void* stream);
+
 /* The two GEMM forms of the fused bf16 encoder, as stand-alone operators (bf16 operands, fp32 accumulate).
  * Row statistics travel as partial sums: st[M][slots][2] (sum, sum of squares), one slot per 96-column block of the
  * `hidden`-wide producer, slots = number of blocks rounded up to even; readers add the slots in index order.
@@ -384,11 +390,14 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 3  split-K target for the generic path
  *   key 4  1 = bf16 residual stream in the kernel-per-op bf16 encoder (default 0: fp32 residual)
  *   key 5  0 = run the encoder LayerNorms as kernels even when cpt_model.fold is given (default 1: folded)
- *   key 6  QKV projection + attention: 0 = two kernels, 1 (default) = fused, two workgroups per CU,
- *          2 = fused, one workgroup per CU (bf16, L <= 128 only; otherwise always two kernels)
+ *   key 6  QKV projection + attention: 0 = two kernels, 1 = fused, one workgroup per (sequence, head), two per CU,
+ *          2 = the same, one per CU, 3 (default) = fused, one workgroup per (sequence, three heads) where heads % 3 == 0,
+ *          else 1 (bf16, L <= 128 only; otherwise always two kernels)
  *   key 9  residual stream of the fused bf16 encoder: 1 (default) = 3-byte form (cpt_gemm_ln_prod3), 0 = fp32 + bf16 copies
  *   key 10 bf16 weight gradients of cpt_train_bwd: 1 (default) = TN GEMM (operands read as stored, split-K partials reduced in
- *          order), 0 = explicit operand transposes + NT GEMM */
+ *          order), 0 = explicit operand transposes + NT GEMM
+ *   key 11 fused QKV + attention, form 3: 1 (default) = read cpt_layer_fold.w_qkv_t when given, 0 = always the row-major weight
+ *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
  * start / after prologue issue / after K loop / after staging / end, and the XCC id). */

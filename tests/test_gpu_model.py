@@ -211,7 +211,7 @@ def test_bf16_folded_layernorm_and_fused_attention(dev):
     m.bert.set_compute_dtype("bf16")
     res = {}
     try:
-        for fold, fuse in ((False, 0), (True, 0), (True, 1), (True, 2), (False, 1)):
+        for fold, fuse in ((False, 0), (True, 0), (True, 1), (True, 2), (False, 1), (True, 3), (False, 3)):
             for eng in (m._engine(), m.bert._engine()):
                 eng.fold_ln = fold
             L.check(L.lib().cpt_set_tuning(6, fuse), "cpt_set_tuning")
@@ -224,8 +224,15 @@ def test_bf16_folded_layernorm_and_fused_attention(dev):
             err = _stats("fold=%s fuse=%d [MASK] logits vs oracle" % (fold, fuse), rows, ref)
             assert err < BF16_TOL
     finally:
-        L.lib().cpt_set_tuning(6, 1)
+        L.lib().cpt_set_tuning(-1, 0)
     pos = b["mask_token_pos"]
+    # the three fused forms and the two-kernel form run the same arithmetic in the same order: identical bits
+    for fold in (True, False):
+        for fuse in ((1, 2, 3) if fold else (1, 3)):
+            for i in range(4):
+                assert torch.equal(res[(fold, fuse)][i], res[(fold, 0)][i]) if (fold, 0) in res else True, (fold, fuse, i)
+    for i in range(4):
+        assert torch.equal(res[(False, 3)][i], res[(False, 1)][i]), i
     base = res[(False, 0)]
     for key, r in res.items():
         if key == (False, 0):

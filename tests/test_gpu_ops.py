@@ -484,3 +484,17 @@ def test_operators_are_batch_invariant(dev, Mbig, Msmall):
         o2 = ops.gemm_ln_prod(ak[:Msmall].contiguous(), w, bias, x[:Msmall].contiguous(), st[:Msmall].contiguous(), g, bt, 1e-12, H)
         for nm, p, q in zip(("fp32", "bf16", "row sums"), o1, o2):
             assert torch.equal(p[:Msmall], q), "producer K=%d: %s" % (K, nm)
+
+
+def test_retile_k32_matches_reshape(dev):
+    """cpt_retile_k32: dst[K / 32][N][32] = src[N][K] (the K-tile-major weight copy the (sequence, three heads) QKV + attention launch reads)."""
+    from cpt_amd import _lib as L
+    torch.manual_seed(3)
+    for N, K in ((2304, 768), (96, 64), (7, 32)):
+        src = torch.randn(N, K, device=dev).to(torch.bfloat16)
+        dst = torch.empty(K // 32, N, 32, device=dev, dtype=torch.bfloat16)
+        L.check(L.lib().cpt_retile_k32(src.data_ptr(), dst.data_ptr(), N, K, L.stream_ptr()), "cpt_retile_k32")
+        want = src.view(N, K // 32, 32).permute(1, 0, 2).contiguous()
+        assert torch.equal(dst.view(torch.int16), want.view(torch.int16))
+    with pytest.raises(RuntimeError):
+        L.check(L.lib().cpt_retile_k32(src.data_ptr(), dst.data_ptr(), 7, 40, L.stream_ptr()), "cpt_retile_k32")
