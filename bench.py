@@ -25,6 +25,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}      # MI355X_MICROARCH.md: dense MFMA peaks
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r03_pmc_bench_summary.json"), os.path.join(ROOT, "profiles", "r02_pmc_bench_summary.json"))
+                 if os.path.exists(f)), os.path.join(ROOT, "profiles", "r03_pmc_bench_summary.json"))
+YARDSTICK_FILE = os.path.join(ROOT, "profiles", "r03_yardstick.json")
+
+
+def yardstick_us():
+    """Best hipBLASLt time (us) of the plain bf16 GEMM of each encoder projection at the bench shape, from the committed
+    tools/yardstick.hip run (profiles/r03_yardstick.json); {} when absent."""
+    try:
+        d = json.load(open(YARDSTICK_FILE))["hipblaslt_bf16"]
+        return {k.split(" ")[0]: v["best_us"] for k, v in d.items()}
+    except Exception:
+        return {}
+
+
+def fwd_gflop_per_seq(cfg, Lt, Li, mlm_head=True):
+    """Algorithmic forward GFLOP per sequence as SURVEY.md 8(d) counts it (2 m n k; padding not discounted; head on one row)."""
+    H, I, L, nl = cfg.hidden_size, cfg.intermediate_size, Lt + Li, cfg.num_hidden_layers
+    layer = 2.0 * L * (4 * H * H + 2 * H * I) + 4.0 * L * L * H
+    img = 2.0 * Li * cfg.img_feature_dim * H
+    head = 2.0 * (H * H + H * cfg.vocab_size) if mlm_head else 2.0 * (H * H + H * 3)
+    return (nl * layer + img + head + 2.0 * H * H) / 1e9
 
 
 def pmc_traffic_bytes(kernel):
@@ -32,7 +54,7 @@ def pmc_traffic_bytes(kernel):
     (profiles/r02_pmc_bench_summary.json, produced by tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in
     separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams on gfx950).
     None when the summary is absent or the batch differs from the profiled one."""
-    fn = os.path.join(ROOT, "profiles", "r02_pmc_bench_summary.json")
+    fn = PMC_FILE
     try:
         d = json.load(open(fn))
         fam = {"gemm_ffn_up": "gemm_ffn_up(+gelu)", "gemm_qkv": "gemm_qkv_attn", "gemm_attn_out": "gemm_attn_out",
@@ -124,23 +146,32 @@ def hbm_kernels(cfg, B, dev, iters=20):
     def entry(name, nbytes, sec):
         out[name] = {"bytes": int(nbytes), "us": round(sec * 1e6, 2), "GB/s": round(nbytes / sec / 1e9, 1),
                      "frac_of_8TB/s": round(nbytes / sec / 8e12, 3)}
-    x = torch.randn(M, H, device=dev)
     g = torch.randn(H, device=dev)
     bt = torch.randn(H, device=dev)
-    o32 = torch.empty_like(x)
-    o16 = torch.empty(M, H, device=dev, dtype=torch.bfloat16)
-    entry("layernorm_rows (fp32 in, fp32 + bf16 out)", M * H * (4 + 4 + 2),
-          timeit(lambda: ops.layernorm_rows(x, g, bt, 1e-12, out=o32, out_lp=o16)))
-    entry("layernorm_rows (fp32 in, bf16 out)", M * H * (4 + 2),
-          timeit(lambda: L.check(L.lib().cpt_layernorm_rows(x.data_ptr(), g.data_ptr(), bt.data_ptr(), 1e-12, None, o16.data_ptr(),
-                                                             L.CPT_BF16, M, H, M, 0, 0, L.stream_ptr()))))
-    ids = torch.randint(1000, 30000, (B, 70), device=dev)
-    tt = torch.zeros(B, 70, dtype=torch.long, device=dev)
     word = torch.randn(cfg.vocab_size, H, device=dev)
     posw = torch.randn(512, H, device=dev)
     typw = torch.randn(2, H, device=dev)
-    entry("embed_ln (3 gathers, fp32 + bf16 out)", B * 70 * H * (3 * 4 + 4 + 2),
-          timeit(lambda: ops.embed_ln(ids, tt, None, word, posw, typw, g, bt, 1e-12, 120, lp_dtype=torch.bfloat16)))
+    # Two working sets per row kernel: the bench shape (M = 7680 rows: 35-59 MB, resident in the 256 MB Infinity Cache and short
+    # enough that launch latency is a third of the time) and 8x the rows (> 256 MB in + out: what HBM itself sustains).
+    for scale, tag in ((1, "bench shape, Infinity-Cache resident"), (8, "8x rows, > 256 MB working set")):
+        Ms, Bs = M * scale, B * scale
+        x = torch.randn(Ms, H, device=dev)
+        o32 = torch.empty_like(x)
+        o16 = torch.empty(Ms, H, device=dev, dtype=torch.bfloat16)
+        entry("layernorm_rows (fp32 in, fp32 + bf16 out) [%s]" % tag, Ms * H * (4 + 4 + 2),
+              timeit(lambda: ops.layernorm_rows(x, g, bt, 1e-12, out=o32, out_lp=o16)))
+        entry("layernorm_rows (fp32 in, bf16 out) [%s]" % tag, Ms * H * (4 + 2),
+              timeit(lambda: L.check(L.lib().cpt_layernorm_rows(x.data_ptr(), g.data_ptr(), bt.data_ptr(), 1e-12, None, o16.data_ptr(),
+                                                                 L.CPT_BF16, Ms, H, Ms, 0, 0, L.stream_ptr()))))
+        ids = torch.randint(1000, 30000, (Bs, 70), device=dev)
+        tt = torch.zeros(Bs, 70, dtype=torch.long, device=dev)
+        e32 = torch.empty(Bs, 120, H, device=dev)             # (preallocated: ops.embed_ln would add two fill kernels per call)
+        e16 = torch.empty(Bs, 120, H, device=dev, dtype=torch.bfloat16)
+        entry("embed_ln (3 gathers, fp32 + bf16 out) [%s]" % tag, Bs * 70 * H * (3 * 4 + 4 + 2),
+              timeit(lambda: L.check(L.lib().cpt_embed_ln(ids.data_ptr(), tt.data_ptr(), None, word.data_ptr(), posw.data_ptr(), typw.data_ptr(),
+                                                           g.data_ptr(), bt.data_ptr(), 1e-12, e32.data_ptr(), e16.data_ptr(), L.CPT_BF16, Bs, 70, 120, H,
+                                                           cfg.vocab_size, 512, 2, L.stream_ptr()))))
+        del x, o32, o16, e32, e16
     n = 111_680_000 // 64 * 64
     p, gr, m, v = (torch.randn(n, device=dev) for _ in range(4))
     v.abs_()
@@ -152,6 +183,86 @@ def hbm_kernels(cfg, B, dev, iters=20):
         L.check(L.lib().cpt_adamw(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), code.data_ptr(), None, n, 3e-5, 0.9, 0.98,
                                   1e-8, 0.01, step[0], 1.0, L.stream_ptr()))
     entry("adamw (111.68 M params, 28 B/param)", n * 28, timeit(adam))
+    return out
+
+
+def extra_configs(dev, model, cfg, seed):
+    """The other BASELINE configurations at their stated per-GPU size, a few steps each (not the headline metric; the driver's
+    one bench line then carries a measured number for every configuration): configs[2] few-shot training step at 32 and at
+    4 sequences per GPU (its share at DP = 8), configs[3] GQA-shape inference B = 256, configs[4] Oscar-large VCR B = 32."""
+    from cpt_amd import config as cfgmod, synth, _lib, engine
+    from cpt_amd.train import FusedAdamW
+    out = {}
+
+    def timed(fn, warm, steps):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def gemm_fracs(fn, steps, M, H, I):
+        _lib.lib().cpt_prof_enable(1)
+        for _ in range(steps):
+            fn()
+        prof = engine.profile_read()
+        _lib.lib().cpt_prof_enable(0)
+        gem = {k: prof[k] for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn_up", "gemm_ffn_down") if prof[k][1]}
+        fr = {k: round(gemm_flops(k, M, H, I) / (gem[k][0] / gem[k][1] * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"], 4) for k in gem}
+        return fr, (max(gem, key=lambda k: gem[k][0]) if gem else None)
+
+    def infer_entry(m, c, B, Lt, Li, call, mlm_head):
+        b = {k: v.to(dev) for k, v in synth.make_batch(B, c, seed=seed, max_seq_len=Lt, img_seq_len=Li).items()}
+
+        def fn():
+            with torch.no_grad():
+                return call(m, b)
+        dt = timed(fn, 2, 5)
+        gf = fwd_gflop_per_seq(c, Lt, Li, mlm_head)
+        fr, dom = gemm_fracs(fn, 3, B * (Lt + Li), c.hidden_size, c.intermediate_size)
+        return {"pairs/s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": B, "seq_len": "%d+%d" % (Lt, Li), "steps": 5,
+                "fwd_GFLOP_per_seq": round(gf, 2), "frac_of_bf16_peak_end_to_end": round(B * gf / dt / 1e3 / PEAK_TFLOPS["bf16"], 4),
+                "dominant_kernel": dom, "dominant_kernel_frac": fr.get(dom), "gemm_fracs": fr}
+
+    # configs[3]: GQA shape on the Oscar-base model of the headline run
+    out["config3_gqa_infer_b256"] = infer_entry(
+        model, cfg, 256, 165, 45, lambda m, b: m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                                                 mask_token_pos=b["mask_token_pos"])[0], True)
+    # configs[4]: Oscar-large (24 layers, hidden 1024), NSP-CPT head, 100 regions; weights initialised on the device
+    from cpt_amd.modeling_bert import BertImgForPreTraining
+    from cpt_amd.modeling_vcr import NSPCPT
+    lc = cfgmod.oscar_large()
+    with torch.device(dev):
+        pre = BertImgForPreTraining(lc)
+        big = NSPCPT(lc)
+    big.copy_from_pretraining_model(pre)
+    big.to(dev).eval().set_compute_dtype("bf16")
+    out["config4_vcr_large_infer_b32"] = infer_entry(
+        big, lc, 32, 165, 100, lambda m, b: m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"])[0], False)
+    del big, pre
+    torch.cuda.empty_cache()
+    # configs[2]: few-shot training step (forward + backward + AdamW, dropout 0.1) on the Oscar-base model
+    model.train()
+    opt = FusedAdamW(model, lr=3e-5, betas=(0.9, 0.98), weight_decay=0.01)
+    gf3 = 3.0 * fwd_gflop_per_seq(cfg, 70, 50, True)
+    for B in (32, 4):
+        b = {k: v.to(dev) for k, v in synth.make_batch(B, cfg, seed=seed, max_seq_len=70, img_seq_len=50).items()}
+
+        def fn():
+            opt.zero_grad()
+            loss, _ = model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                            masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+            loss.backward()
+            opt.step()
+        dt = timed(fn, 2, 5)
+        out["config2_train_step_%dseq_per_gpu" % B] = {
+            "pairs/s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": B, "steps": 5,
+            "fwd_bwd_GFLOP_per_seq": round(gf3, 2), "frac_of_bf16_peak_end_to_end": round(B * gf3 / dt / 1e3 / PEAK_TFLOPS["bf16"], 4),
+            "note": "forward + backward + AdamW on one GPU, dropout 0.1" + ("; configs[2]'s per-GPU share at DP = 8" if B == 4 else "")}
+    model.eval()
     return out
 
 
@@ -168,6 +279,7 @@ def main():
                          "(configs[2]: forward+backward+grad all-reduce+AdamW, 32 sequences per GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (the `extra` object of the line)")
     ap.add_argument("--tune", default="", help="debug: comma list of key=value passed to cpt_set_tuning")
     ap.add_argument("--no-check", action="store_true", help="debug: skip the finite-output check (ablation runs)")
     ap.add_argument("--workload", default="refcoco", choices=["refcoco", "gqa", "vcr"],
@@ -314,10 +426,21 @@ def main():
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4),
                 "traffic": pmc_traffic_bytes(dom) if (B == 64 and args.dtype == "bf16" and args.workload == "refcoco") else None,
+                "traffic_source": "profiles/%s: rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled, see MI355X_MICROARCH.md), committed "
+                                  "with the round's artefacts -- NOT measured inside this run" % os.path.basename(PMC_FILE),
                 "avg_launch_ms": round(avg_ms, 5),
                 "flop_per_launch": gemm_flops(dom, M, H, I),
                 # every encoder GEMM against the same peak (gemm_qkv: projection flops only; its launches also run the attention)
                 "all_kernels_frac": {k: round(gemm_flops(k, M, H, I) / (gem[k][0] / gem[k][1] * 1e-3) / 1e12 / peak, 4) for k in gem}}
+        ys = yardstick_us() if (B == 64 and args.dtype == "bf16" and args.workload == "refcoco") else {}
+        if ys:
+            # the same launches against hipBLASLt's best PLAIN bf16 GEMM of the shape on this chip (tools/yardstick.hip; the fused
+            # launches also do bias / GELU / LayerNorm / residual / attention, so 1.0 is not the bar, the trend is)
+            roof["yardstick"] = {"source": "profiles/r03_yardstick.json (hipBLASLt, plain GEMM, stand-alone back-to-back launches)",
+                                 "hipblaslt_us": {k: ys[k] for k in gem if k in ys},
+                                 "hipblaslt_frac_of_peak": {k: round(gemm_flops(k, M, H, I) / (ys[k] * 1e-6) / 1e12 / peak, 4) for k in gem if k in ys},
+                                 "ours_us": {k: round(gem[k][0] / gem[k][1] * 1e3, 2) for k in gem},
+                                 "time_ratio_hipblaslt_over_ours": {k: round(ys[k] / (gem[k][0] / gem[k][1] * 1e3), 3) for k in gem if k in ys}}
     if world > 1:
         dist.barrier()
 
@@ -346,6 +469,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, seed, min(usable_cores(), 64))
         else:
             line["cpu_baseline"] = None
+        if n_gpus == 1 and not args.no_extra and not train and args.workload == "refcoco" and args.dtype == "bf16" and not args.tune:
+            line["extra"] = extra_configs(dev, model, cfg, seed)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

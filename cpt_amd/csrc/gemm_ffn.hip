@@ -40,7 +40,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT>       // K-tiles per pass: K = 64 NT
+template <int NT, bool LATE = true>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
 __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                                                               bf16* __restrict__ out, int ldo, int M, int N,
                                                               const float* __restrict__ st_in, int st_parts, const float* __restrict__ colc,
@@ -275,11 +275,18 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
         CPT_STAG();
         CPT_SB();
         if (trace) tc = clock64();
-        stage_a(sa, kt + 2);                       // (kt + 3 < 2 NT always holds in pass 0: NT >= 3)
-        stage_w(sw, kt + 3);
-        CPT_SB();
+        if (!LATE) {
+            stage_a(sa, kt + 2);                   // (kt + 3 < 2 NT always holds in pass 0: NT >= 3)
+            stage_w(sw, kt + 3);
+            CPT_SB();
+        }
         if (trace) { const long long td = clock64(); s_wait += tb - ta; s_bar += tc - tb; s_dma += td - tc; }
         CPT_KSTEP(acc0, 1, sa ^ 1, sw1, 0, true);
+        if (LATE) {                                // refill behind this wave's MFMAs: the eight waves' DMA issue does not sit between
+            stage_a(sa, kt + 2);                   // the barrier release and the first MFMA (same issue order: A(kt+2), then W(kt+3))
+            stage_w(sw, kt + 3);
+            CPT_SB();
+        }
         sa ^= 1; sw = sw1;
     }
     if (trace) trp = clock64();
@@ -312,12 +319,19 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
             CPT_STAG();
             CPT_SB();
             if (trace) tc = clock64();
-            if (kt + 2 < NT) stage_a(a_s, it + 2);
-            if (kt + 3 < NT) stage_w(w_s, it + 3);
-            CPT_SB();
+            if (!LATE) {
+                if (kt + 2 < NT) stage_a(a_s, it + 2);
+                if (kt + 3 < NT) stage_w(w_s, it + 3);
+                CPT_SB();
+            }
             if (trace) { const long long td = clock64(); s_wait += tb - ta; s_bar += tc - tb; s_dma += td - tc; }
         }
         CPT_KSTEP(acc1, 1, a_s ^ 1, w_s1, 0, more);
+        if (LATE && more) {
+            if (kt + 2 < NT) stage_a(a_s, it + 2);
+            if (kt + 3 < NT) stage_w(w_s, it + 3);
+            CPT_SB();
+        }
     }
     if (trace) tr2 = clock64();
     // pairs of pass 0 that did not fit under pass 1 (NT < 12), then pass 1's own epilogue (exposed)
@@ -344,10 +358,10 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
 #endif
 }
 
-template <int NT>
+template <int NT, bool LATE = true>
 int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int ldo, int M, int N, const float* st_in, int st_parts,
                  const float* colc, const float* cold, float eps, float inv_h, long long* trace, int abl, hipStream_t s) {
-    auto kern = ffn_up_2pass_kernel<NT>;
+    auto kern = ffn_up_2pass_kernel<NT, LATE>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -360,6 +374,9 @@ int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int 
 }
 
 }  // namespace
+
+int g_ffn_dma_late = 1;      // A/B switch (cpt_set_tuning key 12): 0 = refill DMA issued right behind the barrier (round 2)
+void set_ffn_dma_late(int v) { g_ffn_dma_late = v; }
 
 // shapes the two-pass kernel can run / shapes it is the better choice for
 int ffn_up_2pass_legal(int M, int N, int K) { return (K == 768 || K == 1024) && N % TN == 0 && M >= TM; }
@@ -375,6 +392,7 @@ int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const flo
     if (!ffn_up_2pass_legal(M, N, K)) return CPT_ERR_SHAPE;
     if (lda % 8 || ldw % 8 || ldo % 8 || (((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)out | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
     const float inv_h = 1.0f / (float)hidden;
+    if (K == 768 && !g_ffn_dma_late) return launch_2pass<12, false>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);
     if (K == 768) return launch_2pass<12>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);
     return launch_2pass<16>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);
 }

@@ -124,6 +124,7 @@ int ffn_up_2pass_legal(int M, int N, int K);
 int ffn_up_2pass_preferred(int M, int N, int K);
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
                       float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s);
+void set_ffn_dma_late(int v);
 void set_gemm_trace(void* p);
 void set_gemm_trace_filter(int epi, int k);
 

@@ -93,35 +93,70 @@ def test_config5_oscar_large_24_layers_b32(dev):
 
 
 def test_bf16_colour_argmax_flip_count_1024_sequences(dev):
-    """north_star: RefCOCO colour argmax identical to the reference.  bf16 throughput mode over 1024 RefCOCO-shaped
-    sequences (16 batches of 64) against the fp32 CPU oracle: error bound, and every colour-argmax flip must sit
-    inside the error band (margin of the fp32 top two colours below twice that sequence's own logit error)."""
+    """north_star: RefCOCO colour argmax identical to the reference.  1024 RefCOCO-shaped sequences (16 batches of 64) against
+    the fp32 CPU oracle, in the bf16 throughput mode and the bf16x3 parity mode, under BOTH selection rules of the reference:
+    zero-shot = argmax of the raw colour logits (zeroshot/refcoco_cpt.py:242), few-shot = argmax of colour logit / "none" logit
+    (fewshot/refcoco_cpt.py:291, the ratio SURVEY section 7 flags as the error amplifier).  Every flip must sit inside that
+    sequence's own error band; the observed counts go to gpurun_out/r03_argmax_flips.json (committed under profiles/)."""
+    import json
+    import os
     from cpt_amd.modeling_rec import REC_MLM_CPT
     cfg = cfgmod.oscar_base()
     sd = synth.init_state_dict(cfg, 88, head="cpt")
     m = REC_MLM_CPT(cfg)
     m.load_state_dict(sd)
     m.tie_weights()
-    m.to(dev).eval().set_compute_dtype("bf16")
+    m.to(dev).eval()
     cols = torch.tensor(list(synth.COLOR_IDS))
-    n_seq, flips, outside, worst = 0, 0, 0, 0.0
+    modes = ("bf16", "bf16x3")
+    st = {md: {"sequences": 0, "max_abs_logit_error": 0.0, "zero_shot_flips": 0, "zero_shot_flips_outside_error_band": 0,
+               "few_shot_ratio_flips": 0, "few_shot_ratio_flips_outside_error_band": 0} for md in modes}
     for it in range(16):
         b = synth.make_batch(64, cfg, seed=1000 + it, vary_regions=True)
         d = _dev(b, dev)
         with torch.no_grad():
-            got = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0].cpu()
             ref = O.rec_mlm_cpt_forward(sd, cfg.to_dict(), b["input_ids"], b["segment_ids"], b["attention_mask"],
                                         img_feats=b["img_feats"], mask_rows_only=b["mask_token_pos"])[0]
-        err_seq = (got - ref).abs().max(1).values
-        worst = max(worst, float(err_seq.max()))
-        gc, rc = got[:, cols], ref[:, cols]
-        flip = gc.argmax(1) != rc.argmax(1)
+        rc, rn = ref[:, cols], ref[:, synth.NONE_ID]
         top2 = rc.topk(2, 1).values
         margin = top2[:, 0] - top2[:, 1]
-        flips += int(flip.sum())
-        outside += int((flip & (margin >= 2 * err_seq)).sum())
-        n_seq += 64
-    print("bf16 vs fp32 oracle over %d sequences: max |d logit| %.3e, colour-argmax flips %d (%.2f %%), flips outside the error band %d"
-          % (n_seq, worst, flips, 100.0 * flips / n_seq, outside))
-    assert n_seq >= 1000 and worst < BF16_TOL and outside == 0
-    assert flips <= n_seq // 50          # random-init logits have small margins; observed well under 2 %
+        rr = rc / rn[:, None]                                    # few-shot score: colour / none
+        rtop2 = rr.topk(2, 1).values
+        rmargin = rtop2[:, 0] - rtop2[:, 1]
+        for md in modes:
+            m.set_compute_dtype(md)
+            with torch.no_grad():
+                got = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0].cpu()
+            err_seq = (got - ref).abs().max(1).values
+            gc, gn = got[:, cols], got[:, synth.NONE_ID]
+            flip = gc.argmax(1) != rc.argmax(1)
+            gr = gc / gn[:, None]
+            rflip = gr.argmax(1) != rr.argmax(1)
+            # error of a ratio a / n under |da|, |dn| <= e:  <= e (1 + |a / n|) / (|n| - e)   (first order; infinite when |n| <= e)
+            den = (rn.abs() - err_seq).clamp_min(1e-30)
+            rerr = torch.where(rn.abs() > err_seq, err_seq * (1.0 + rr.abs().max(1).values) / den, torch.full_like(err_seq, float("inf")))
+            s_ = st[md]
+            s_["sequences"] += 64
+            s_["max_abs_logit_error"] = max(s_["max_abs_logit_error"], float(err_seq.max()))
+            s_["zero_shot_flips"] += int(flip.sum())
+            s_["zero_shot_flips_outside_error_band"] += int((flip & (margin >= 2 * err_seq)).sum())
+            s_["few_shot_ratio_flips"] += int(rflip.sum())
+            s_["few_shot_ratio_flips_outside_error_band"] += int((rflip & (rmargin >= 2 * rerr)).sum())
+    rec = {"workload": "Oscar-base, random-init N(0, 0.02) weights (seed 88), 16 batches of 64 RefCOCO-shaped sequences (seeds 1000..1015), "
+                       "5 colour ids %s, none id %d; reference = fp32 CPU oracle" % (list(synth.COLOR_IDS), synth.NONE_ID),
+           "note": "random-init logits have small colour margins (no trained preference), so flips inside the error band are expected in bf16 mode; "
+                   "the parity mode is bf16x3", "modes": st}
+    print(json.dumps(rec))
+    try:
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_argmax_flips.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+    except OSError:
+        pass
+    for md in modes:
+        s_ = st[md]
+        assert s_["sequences"] >= 1000
+        assert s_["zero_shot_flips_outside_error_band"] == 0, (md, s_)
+    assert st["bf16x3"]["few_shot_ratio_flips_outside_error_band"] == 0, st["bf16x3"]      # (bf16 mode: recorded, not asserted)
+    assert st["bf16"]["max_abs_logit_error"] < BF16_TOL and st["bf16"]["zero_shot_flips"] <= 1024 // 50
+    assert st["bf16x3"]["max_abs_logit_error"] < 1e-3 and st["bf16x3"]["zero_shot_flips"] == 0       # the parity bar of north_star

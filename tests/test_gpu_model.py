@@ -160,7 +160,8 @@ def test_base_golden_mask_logits(dev, golden_dir, name, mode):
         top2 = ref_col.topk(2, -1).values
         margin = top2[:, 0] - top2[:, 1]
         same = got_col.argmax(-1) == ref_col.argmax(-1)
-        assert (same | (margin < 2 * err)).all()
+        err_row = (got - torch.from_numpy(g["mask_logits_sub"])).abs().max(1).values      # each sequence's OWN error, not the batch maximum
+        assert (same | (margin < 2 * err_row)).all()
         assert abs(loss.item() - float(g["loss"])) < 0.05
 
 
