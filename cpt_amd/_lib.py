@@ -99,6 +99,9 @@ _SIGS = {
                                    C.c_int, C.c_int, vp]),
     "cpt_gemm_ln_prod3": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int,
                                     C.c_int, C.c_int, vp]),
+    "cpt_panel_pack": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_gemm_ln_prod3_panel": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, vp]),
     "cpt_resid3_split": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "cpt_resid3_merge": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_gemm_nn": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
@@ -154,8 +157,8 @@ def lib():
             fn = getattr(l, name)        # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if l.cpt_version() != 3:
-            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 3" % l.cpt_version())
+        if l.cpt_version() != 4:
+            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 4" % l.cpt_version())
         _lib = l
     return _lib
 

@@ -42,11 +42,15 @@ __device__ __forceinline__ int att_key_of(int r, int h) { return (r & 3) + 8 * (
 //   sV   [NKB*32] rows of ATT_VP16 bytes, row-major
 //   sMask[NKB*32] additive mask already multiplied by log2(e); -inf for padding keys
 // Writes ctx_row[0..63] (this lane's query, head slice) if `valid`; optionally the probabilities (training).
-template <int NKB, bool VSWZ = false>
+// PANEL (round 3): the context goes out in the fragment-major panel layout of the attn-out GEMM's A operand (common.h panel_unit,
+// gemm_prod.hip) as 16-byte write-through stores: ctx_row is ignored, the destination is (pbase / pbytes = the whole ctx
+// buffer, prow = global row of this lane's query, pc8 = first 8-column chunk of the head's slice, pk16 = hidden / 16).
+template <int NKB, bool VSWZ = false, bool PANEL = false>
 __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsigned char* sK, const unsigned char* sV,
                                                const float* sMask, int lane, bool valid, bf16* ctx_row,
                                                bf16* probs_row, int L, const DropSpec& dr = DropSpec{}, uint32_t bh = 0, int q = 0,
-                                               const int64_t* mrow = nullptr) {   // mrow: this lane's row of a 3-D attention mask (modeling_bert.py:215-216)
+                                               const int64_t* mrow = nullptr,   // mrow: this lane's row of a 3-D attention mask (modeling_bert.py:215-216)
+                                               void* pbase = nullptr, int pbytes = 0, int prow = 0, int pc8 = 0, int pk16 = 0) {
     const int fr = lane & 31, fh = lane >> 5;
     // S^T = K . Q^T : accumulator rows = keys, column (lane&31) = query
     f32x16 st[NKB];
@@ -141,6 +145,29 @@ __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsi
     }
     // O^T accumulators: register r <-> head-dim column db*32 + 8*(r>>2) + 4*fh + (r&3), lane&31 <-> query:
     // four consecutive columns per register quad -> one 8-byte store
+    if constexpr (PANEL) {
+        // quads 2 gp and 2 gp + 1 of the two half-waves paired by v_permlane32_swap: lanes 0-31 hold columns [16 gp, 16 gp + 8) of
+        // block db, lanes 32-63 the next 8 (gemm.hip "direct epilogue"); both halves of a lane pair are the same query
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const auto prs = __builtin_amdgcn_make_buffer_rsrc(pbase, 0, pbytes, 0x00020000);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                u32x2 pk[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bf16x4 p4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p4[e] = (bf16)o[db][4 * (2 * gp + h) + e];
+                    pk[h] = __builtin_bit_cast(u32x2, p4);
+                }
+                const u32x2 s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                const u32x4_t w = {s0[0], s1[0], s0[1], s1[1]};
+                if (valid) __builtin_amdgcn_raw_buffer_store_b128(w, prs, panel_unit(prow, pc8 + db * 4 + 2 * gp + fh, pk16) * 16u, 0, CPT_ST_AUX);
+            }
+    } else
     if (valid) {
 #pragma unroll
         for (int db = 0; db < 2; ++db)

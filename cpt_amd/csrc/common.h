@@ -212,6 +212,41 @@ __device__ __forceinline__ void sum_parts(const float* __restrict__ st, int part
     }
 }
 
+// ---- round 3: fragment-major "panel" layout of a GEMM A operand + write-through output stores ------------------------------
+// panel[M / 32][K / 16][64][8] bf16 (gemm_prod.hip): the 16-byte unit holding columns [8 c8, 8 c8 + 8) of `row`; k16 = K / 16
+__device__ __forceinline__ unsigned panel_unit(int row, int c8, int k16) {
+    return (unsigned)(((row >> 5) * k16 + (c8 >> 1)) * 64 + (c8 & 1) * 32 + (row & 31));
+}
+// The big kernels of the encoder store their outputs WRITE-THROUGH (sc1): a plain store leaves the line dirty in the XCD's L2 and
+// the end-of-kernel release writes all of them back before the next kernel may start -- measured on the LayerNorm producers
+// (tools/panel_bench.py): 3.7 us between a launch's last workgroup and the next launch's first with plain stores, 1.9 us with
+// write-through stores or with no stores at all.  -DCPT_WT=0 restores plain stores (A/B builds).
+#ifndef CPT_WT
+#define CPT_WT 1
+#endif
+constexpr int CPT_ST_AUX = CPT_WT ? 16 : 0;          // aux field of the buffer-store builtins: sc1
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// Prefetch workgroups (round 3).  Every step streams the 170 MB of bf16 weights once, so each launch finds its weight matrix in HBM,
+// and a K loop that keeps ~150 KB per CU in flight runs at (bytes in flight) / (HBM latency): measured on the LayerNorm producers,
+// 1076 ticks per K-tile with Infinity-Cache-resident operands, 1560-1830 with either operand in HBM, 1464 in the model
+// (tools/panel_bench.py).  A launch whose tiles leave CUs idle (240 tiles on 256 CUs) therefore carries up to 16 extra workgroups
+// that do nothing but read the NEXT launch's weight matrix (part `part` of `parts`), which pulls it into the memory-side
+// Infinity Cache ~20-50 us before it is needed.  Results are discarded; correctness cannot depend on them.
+// The loads are LDS-DMA into a scratch KiB of the (otherwise unused) LDS of the prefetch workgroup: no VGPR destination, so nothing
+// the compiler may reuse while a load is in flight (an asm load into a "dead" register returned late and overwrote the next address).
+__device__ __forceinline__ void prefetch_region(const void* p, size_t bytes, int part, int parts, int tid, int nthreads, void* lds_scratch) {
+    const size_t n16 = bytes >> 4;
+    const size_t per = (n16 + parts - 1) / parts;
+    const size_t lo = (size_t)part * per;
+    const size_t hi = lo + per < n16 ? lo + per : n16;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    auto lds = (__attribute__((address_space(3))) void*)((unsigned char*)lds_scratch + (tid >> 6) * 1024);
+    for (size_t i = lo + tid; i < hi; i += nthreads)
+        __builtin_amdgcn_global_load_lds(q + i, lds, 16, 0, 0);
+}
+constexpr int CPT_PREFETCH_WGS = 16;
+
 // 32x32 accumulator element r of lane l sits at (row, col):
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }

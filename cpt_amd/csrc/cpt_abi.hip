@@ -123,14 +123,15 @@ FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
 static int g_qkv_tiled = 1;    // form 3: read the K-tile-major weight copy (cpt_layer_fold.w_qkv_t) when the model carries one
 static int qkv_attn(int config, const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
                     const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads, int K,
-                    hipStream_t s, const void* W_tiled) {
+                    hipStream_t s, const void* W_tiled, int ctx_panel = 0) {
     if (config == 3) {
         if (cpt::qkv_attn3_eligible(L, heads, K)) {
             const bool tl = W_tiled && g_qkv_tiled;
-            return cpt::gemm_qkv_attn3(A, lda, tl ? W_tiled : W, ldw, bias, st_in, colc, cold, eps, hidden, mask, ctx, ldo, B, L, heads, K, s, tl ? 1 : 0);
+            return cpt::gemm_qkv_attn3(A, lda, tl ? W_tiled : W, ldw, bias, st_in, colc, cold, eps, hidden, mask, ctx, ldo, B, L, heads, K, s, tl ? 1 : 0, ctx_panel);
         }
         config = 1;
     }
+    if (ctx_panel) return CPT_ERR_SHAPE;
     return cpt::gemm_qkv_attn(A, lda, W, ldw, bias, st_in, colc, cold, eps, hidden, mask, ctx, ldo, B, L, heads, K, config, s);
 }
 
@@ -151,13 +152,15 @@ int cpt_check_device(int dev) {
 static int g_fold_ln = 1;      // bf16 mode with cpt_model.fold: fold the encoder LayerNorms into the GEMMs (0 = run them as kernels)
 static int g_fuse_attn = 3;    // bf16, L <= 128: QKV projection + attention in one kernel (0 = two kernels; 1 = one workgroup per (sequence, head), two per CU; 2 = same, one per CU; 3 = one workgroup per (sequence, three heads) where heads % 3 == 0, else 1)
 static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
+static int g_panel = 1;        // fused bf16 encoder: ctx and the FFN activation travel in the fragment-major panel layout and the LayerNorm producers read them straight into registers (gemm_prod.hip) where the shapes allow
+static int g_prefetch = 1;     // panel mode: the 240-tile launches carry 16 workgroups that read the next launch's weights into the Infinity Cache (common.h prefetch_region)
 static int g_resid3 = 1;       // fused bf16 encoder: residual stream in the 3-byte form (bf16 hi + int8 lo) instead of fp32 + bf16 copies
 
 int cpt_set_tuning(int key, int value) {
     if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
-        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_qkv_tiled = 1;
+        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1;
         cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
-        cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_gemm_trace_filter(255, 0);
+        cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0);
         return CPT_OK;
     }
     if (key == 4) { g_lp_resid = value; return CPT_OK; }
@@ -171,6 +174,9 @@ int cpt_set_tuning(int key, int value) {
     if (key == 9) { g_resid3 = value; return CPT_OK; }
     if (key == 11) { g_qkv_tiled = value; return CPT_OK; }
     if (key == 12) { cpt::set_ffn_dma_late(value); return CPT_OK; }
+    if (key == 13) { cpt::set_prod_abl(value); return CPT_OK; }
+    if (key == 14) { g_panel = value; return CPT_OK; }
+    if (key == 15) { g_prefetch = value; return CPT_OK; }
     if (key == 10) { cpt::set_wgrad_tn(value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
@@ -257,6 +263,19 @@ int cpt_gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const floa
                       float* st_out, int ldo, int M, int N, int K, void* stream) {
     return check_launch(cpt::gemm_ln_prod3(A, lda, W, ldw, bias, resid_hi, resid_lo, ldr, st_in, g_in, b_in, eps, hidden, out_hi, out_lo, st_out, ldo,
                                            M, N, K, (hipStream_t)stream), "cpt_gemm_ln_prod3");
+}
+
+int cpt_panel_pack(const void* src_bf16, int ld, void* dst_bf16, int M, int K, int to_panel, void* stream) {
+    return check_launch(cpt::panel_pack(src_bf16, ld, dst_bf16, M, K, to_panel, (hipStream_t)stream), "cpt_panel_pack");
+}
+
+int cpt_gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
+                            const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi, void* out_lo,
+                            float* st_out, int ldo, int M, int N, int K, void* stream) {
+    if (!cpt::panel_eligible(M, N, K))
+        return fail(CPT_ERR_SHAPE, "cpt_gemm_ln_prod3_panel: needs M %% 128 == 0, N %% 192 == 0, K %% 256 == 0, K >= 512 (got M=%d N=%d K=%d)", M, N, K);
+    return check_launch(cpt::gemm_ln_prod3_panel(A_panel, W, ldw, bias, resid_hi, resid_lo, ldr, st_in, g_in, b_in, eps, hidden, out_hi, out_lo, st_out, ldo,
+                                                 M, N, K, (hipStream_t)stream), "cpt_gemm_ln_prod3_panel");
 }
 
 int cpt_resid3_split(const float* x, void* hi_bf16, void* lo_i8, size_t n, void* stream) {
@@ -396,6 +415,12 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const int mask3 = (flags & CPT_ATTN_MASK_3D) ? 1 : 0;
     const bool fuse_attn = lp && g_fuse_attn && L <= 128 && H % 64 == 0 && !mask3;
     const bool pre_ln = fold && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS));   // x_f32 left un-normalised after the encoder
+    // Panel mode (round 3): the attention kernel writes ctx and the FFN-up epilogue writes h as MFMA A fragments (gemm_prod.hip), the two
+    // LayerNorm producers read them straight into registers; same bits as the row-major kernels.  Needs the (sequence, three heads)
+    // attention form, the two-pass FFN-up kernel and tile-aligned shapes; everything else keeps the row-major tensors.
+    const bool panel = r3 && fuse_attn && g_fuse_attn == 3 && g_panel && cpt::qkv_attn3_eligible(L, d.heads, H) && cpt::ffn_up_2pass_preferred(M, I, H) &&
+                       cpt::panel_eligible(M, H, H) && cpt::panel_eligible(M, H, I);
+    const bool pfw = panel && g_prefetch;           // spare workgroups prefetch the next launch's weights (common.h prefetch_region)
     if (fold) {
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
         // producer GEMMs accumulate their row sums, the consumer GEMMs normalise in their epilogue.
@@ -411,9 +436,9 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
             if (fuse_attn) {
               Scope p(CPT_K_GEMM_QKV, s);      // QKV projection + attention, one kernel; q/k/v never reach HBM
               if (l == 0) TRY(qkv_attn(g_fuse_attn, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, nullptr, nullptr, d.ln_eps, H, b->attn_mask, ctx, H,
-                                                 B, L, d.heads, H, s, f.w_qkv_t), "gemm(qkv)+attention");
+                                                 B, L, d.heads, H, s, f.w_qkv_t, panel), "gemm(qkv)+attention");
               else TRY(qkv_attn(g_fuse_attn, x_lp, H, f.w_qkv_f, H, nullptr, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, b->attn_mask, ctx, H,
-                                          B, L, d.heads, H, s, f.w_qkv_t), "gemm(qkv, folded LN)+attention");
+                                          B, L, d.heads, H, s, f.w_qkv_t, panel), "gemm(qkv, folded LN)+attention");
             } else {
             { Scope p(CPT_K_GEMM_QKV, s);
               if (l == 0) TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
@@ -422,14 +447,28 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
               TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s, nullptr, mask3), "attention"); }
             }
             { Scope p(CPT_K_GEMM_AO, s);
+              if (panel) TRY(cpt::gemm_ln_prod3_panel(ctx, y.w_ao, H, y.b_ao, x_lp, x_lo, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
+                                                      a_lp, a_lo, st1, H, M, H, H, s, pfw ? f.w_in_f : nullptr, (size_t)I * H * 2), "gemm(attn out, LN producer, panel A)");
+              else
               if (r3) TRY(cpt::gemm_ln_prod3(ctx, H, y.w_ao, H, y.b_ao, x_lp, x_lo, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
                                              a_lp, a_lo, st1, H, M, H, H, s), "gemm(attn out, LN producer, 3-byte residual)");
               else
               TRY(cpt::gemm_ln_prod(ctx, H, y.w_ao, H, y.b_ao, x_f32, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
                                     a_f32, a_lp, st1, H, M, H, H, s), "gemm(attn out, LN producer)"); }
             { Scope p(CPT_K_GEMM_FFN1, s);
-              TRY(cpt::gemm_ln_cons(a_lp, H, f.w_in_f, H, st1, f.c_in, f.d_in, d.ln_eps, H, 1, ffn, I, M, I, H, s), "gemm(ffn up, folded LN)"); }
+              TRY(cpt::gemm_ln_cons(a_lp, H, f.w_in_f, H, st1, f.c_in, f.d_in, d.ln_eps, H, 1, ffn, I, M, I, H, s, panel, pfw ? y.w_out : nullptr, (size_t)H * I * 2), "gemm(ffn up, folded LN)"); }
             { Scope p(CPT_K_GEMM_FFN2, s);
+              if (panel) {
+                  // next layer's QKV weight (the copy its launch will read) and attention-output weight
+                  const void* nq = nullptr; const void* na = nullptr;
+                  if (pfw && l + 1 < d.layers) {
+                      const cpt_layer_fold& fn = m->fold[l + 1];
+                      nq = (fn.w_qkv_t && g_qkv_tiled) ? fn.w_qkv_t : fn.w_qkv_f;
+                      na = m->layers[l + 1].w_ao;
+                  }
+                  TRY(cpt::gemm_ln_prod3_panel(ffn, y.w_out, I, y.b_out, a_lp, a_lo, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_lp, x_lo, st2, H, M, H, I, s,
+                                               nq, (size_t)3 * H * H * 2, na, (size_t)H * H * 2), "gemm(ffn down, LN producer, panel A)");
+              } else
               if (r3) TRY(cpt::gemm_ln_prod3(ffn, I, y.w_out, I, y.b_out, a_lp, a_lo, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_lp, x_lo, st2, H, M, H, I, s),
                           "gemm(ffn down, LN producer, 3-byte residual)");
               else

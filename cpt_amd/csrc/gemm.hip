@@ -1393,13 +1393,18 @@ int gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const float* b
 // Consumer: A is the bf16 copy of a pre-LayerNorm tensor, Wf the gain-folded weight;
 // out = [gelu]( rstd[m] * (A.Wf^T - mean[m] * colc[n]) + cold[n] )  ==  [gelu]( LayerNorm(A) . W^T + bias )
 int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
-                 float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s) {
+                 float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s, int out_panel, const void* pf, size_t pf_bytes) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
     if (!A || !Wf || !st_in || !colc || !cold || !out_lp) return CPT_ERR_NULL;
     if (N % 8 || ldo % 8 || (((uintptr_t)out_lp | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
     EpiX ex = {};
     ex.st_in = st_in; ex.st_in_parts = ln_stat_parts(hidden); ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
     const int v = g_gemm_variant >= 3 ? g_gemm_variant : 3;
+    if (out_panel) {      // output in the panel layout of the FFN-down producer (gemm_prod.hip): the two-pass kernel only
+        if (!gelu || !ffn_up_2pass_legal(M, N, K)) return CPT_ERR_SHAPE;
+        void* tr = ((g_trace_epi < 0 || g_trace_epi == CPT_EPI_LNCONS_GELU) && (g_trace_k == 0 || g_trace_k == K)) ? (void*)g_gemm_trace : nullptr;
+        return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, tr, g_gemm_abl, s, 1, pf, pf_bytes);
+    }
     if (gelu && ((v == 3 && ffn_up_2pass_preferred(M, N, K)) || (v == 20 && ffn_up_2pass_legal(M, N, K)))) {     // variant 20: forced (tests)
         void* tr = ((g_trace_epi < 0 || g_trace_epi == CPT_EPI_LNCONS_GELU) && (g_trace_k == 0 || g_trace_k == K)) ? (void*)g_gemm_trace : nullptr;
         return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, tr, g_gemm_abl, s);

@@ -17,6 +17,8 @@
 // different depth: A half-tiles (24 KB) 2 deep, W tiles (32 KB) 3 deep -- the W tile of K-tile t+3 is requested two
 // iterations ahead, only the 24 KB A half-tile of t+2 has to arrive within one.  Plus the tile's 256-column c/d vectors
 // and its 384 rows' (mean, rstd): 149 KB.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -40,13 +42,23 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT, bool LATE = true>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
+// PANEL: out is the fragment-major panel copy [M / 32][N / 16][64][8] the FFN-down producer reads (gemm_prod.hip), rows padded to a
+// multiple of 32 by the caller; every 16-byte store of a half-wave then lands in one contiguous 512 bytes.
+template <int NT, bool LATE = true, bool PANEL = false>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
 __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                                                               bf16* __restrict__ out, int ldo, int M, int N,
                                                               const float* __restrict__ st_in, int st_parts, const float* __restrict__ colc,
                                                               const float* __restrict__ cold, float eps, float inv_h,
-                                                              long long* __restrict__ trace_arg, int abl_arg) {
+                                                              long long* __restrict__ trace_arg, int abl_arg,
+                                                              const void* __restrict__ pf, size_t pf_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // the first gridDim.x - tiles workgroups prefetch the next launch's weights into the Infinity Cache (common.h prefetch_region; gemm_prod.hip)
+    const int npf = gridDim.x - ((M + TM - 1) / TM) * (N / TN);
+    if ((int)blockIdx.x < npf) {
+        if (pf) prefetch_region(pf, pf_bytes, blockIdx.x, npf, threadIdx.x, 512, smem);
+        return;
+    }
 #ifdef CPT_ABLATION
     long long* __restrict__ trace = trace_arg;
     const int abl = abl_arg;          // diagnostic build: 1 no operand DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue under pass 1
@@ -57,7 +69,6 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
 #endif
     long long tr0 = 0, tr1 = 0, tr2 = 0, trp = 0, s_wait = 0, s_bar = 0, s_dma = 0, ta = 0, tb = 0, tc = 0;
     if (trace) tr0 = clock64();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
     int m0, n0;
     {
         const int tm = (M + TM - 1) / TM, tn = N / TN;
-        const int nwg = tm * tn, bid = blockIdx.x;
+        const int nwg = tm * tn, bid = blockIdx.x - npf;      // (prefetch workgroups come first)
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         const int gm = 4, per_group = gm * tn;
@@ -80,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)min((size_t)((M + 31) & ~31) * (PANEL ? N : ldo) * 2, (size_t)0x7fffffff), 0x00020000);
     const int rbase = wave * 8 + (lane >> 3);
     const unsigned c16 = (unsigned)(((lane & 7) ^ ((rbase >> 1) & 7)) * 16);
     // K-tile `it` of the 2 NT-tile stream (pass = it / NT): A half-tile into A slot `sa`, W tile into W slot `sw`
@@ -243,7 +255,10 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
         const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
         const int row = m0 + pass * HM + wm * 96 + i * 32 + fr;
         const int col = n0 + wn * 64 + j * 32 + 16 * gp + 8 * fh;
-        if (row < M) *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + col) = w;
+        if (row < M) {      // write-through (common.h CPT_ST_AUX): nothing of the 47 MB is left dirty in L2 for the end-of-kernel release
+            if constexpr (PANEL) __builtin_amdgcn_raw_buffer_store_b128(w, rsO, panel_unit(row, col >> 3, N >> 4) * 16u, 0, CPT_ST_AUX);
+            else *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + col) = w;      // row-major: 32 rows x 32 B per instruction -- write-through of partial lines measured SLOWER (51.2 vs 48 us)
+        }
     };
 
     // issued so far per wave: A0 W0 A1 W1 W2 = 3 4 3 4 4 pieces; tile 0 is complete when at most 11 are outstanding
@@ -351,25 +366,28 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
 #undef CPT_RETIRE
     if (trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long* t = trace + (size_t)blockIdx.x * 8;
+        long long* t = trace + (size_t)(blockIdx.x - npf) * 8;
         t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = trp; t[4] = clock64();
         t[5] = s_wait; t[6] = s_bar; t[7] = s_dma;         // wave 0: sums over the K-tiles (fragment retire + vmcnt wait, barrier, DMA issue)
     }
 #endif
 }
 
-template <int NT, bool LATE = true>
+template <int NT, bool LATE = true, bool PANEL = false>
 int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int ldo, int M, int N, const float* st_in, int st_parts,
-                 const float* colc, const float* cold, float eps, float inv_h, long long* trace, int abl, hipStream_t s) {
-    auto kern = ffn_up_2pass_kernel<NT, LATE>;
+                 const float* colc, const float* cold, float eps, float inv_h, long long* trace, int abl, hipStream_t s,
+                 const void* pf = nullptr, size_t pf_bytes = 0) {
+    auto kern = ffn_up_2pass_kernel<NT, LATE, PANEL>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         attr_done = true;
     }
-    const int nwg = ((M + TM - 1) / TM) * (N / TN);
-    kern<<<dim3(nwg), dim3(512), LDS_BYTES, s>>>(A, lda, W, ldw, out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, trace, abl);
+    const int ntile = ((M + TM - 1) / TM) * (N / TN);
+    const int npf = (pf && pf_bytes) ? (std::max(0, std::min(CPT_PREFETCH_WGS, 256 - ntile)) & ~7) : 0;
+    if (!npf) pf = nullptr;
+    kern<<<dim3(ntile + npf), dim3(512), LDS_BYTES, s>>>(A, lda, W, ldw, out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, trace, abl, pf, pf_bytes);
     return CPT_OK;
 }
 
@@ -388,8 +406,16 @@ int ffn_up_2pass_preferred(int M, int N, int K) {
 }
 
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
-                      float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s) {
+                      float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s, int out_panel,
+                      const void* pf, size_t pf_bytes) {
     if (!ffn_up_2pass_legal(M, N, K)) return CPT_ERR_SHAPE;
+    if ((size_t)((M + 31) & ~31) * (out_panel ? N : ldo) * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;      // 32-bit store offsets
+    if (out_panel) {
+        if (N % 16) return CPT_ERR_SHAPE;
+        if ((uintptr_t)pf & 15) return CPT_ERR_ALIGN;
+        if (K == 768) return launch_2pass<12, true, true>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s, pf, pf_bytes);
+        return launch_2pass<16, true, true>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s, pf, pf_bytes);
+    }
     if (lda % 8 || ldw % 8 || ldo % 8 || (((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)out | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
     const float inv_h = 1.0f / (float)hidden;
     if (K == 768 && !g_ffn_dma_late) return launch_2pass<12, false>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);

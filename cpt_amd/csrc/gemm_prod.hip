@@ -1,0 +1,417 @@
+// LayerNorm-PRODUCER GEMMs of the fused bf16 encoder (BertSelfOutput.dense / BertOutput.dense + residual,
+// /root/reference/Oscar/oscar/modeling/modeling_bert.py:85-86, :145 -> third-party BertSelfOutput / BertOutput) with the A operand
+// read STRAIGHT INTO REGISTERS from a fragment-major ("panel") copy of the activation (round 3):
+//   out = A . W^T + bias + LayerNorm_on_the_fly(resid)      in the 3-byte residual form, + partial row sums     (gemm.hip CPT_EPI_LNPROD3)
+//
+// Why: at M = 7680, N = 768 only 128 x 192 tiles fill the 256 CUs, and such a tile moves 40 KB of operands through the CU's
+// LDS-DMA path per 768 MFMA cycles -- the K loop ran at the DMA rate (1460-1530 cycles per K-tile measured in the model,
+// DESIGN.md 5h).  Each wave's A rows are private to a row of waves, so they need no LDS at all: the producer of A (the attention
+// kernel for ctx, the FFN-up epilogue for h) writes it as MFMA fragments,
+//   panel[M / 32][K / 16][64 lanes][8]:   element (row, k) at (((row / 32) (K / 16) + k / 16) 64 + ((k % 16) / 8) 32 + row % 32) 8 + k % 8
+// i.e. the 1 KiB that lane l = 32 (k % 16 / 8) + row % 32 of one v_mfma_f32_32x32x16_bf16 A operand reads is contiguous, and a
+// K-tile of 64 of a 32-row block is one contiguous 4 KiB.  A wave fetches its fragments with four buffer_load_dwordx4 per K-tile
+// (inline asm: hipcc would drain the LDS-DMA queue in front of a plain load's first use), three K-tiles ahead, into a rotating
+// set of four register buffers; only W (24 KB per K-tile) rides the LDS ring, four stages deep.  LDS-DMA per K-tile 40 -> 24 KB.
+// Same MFMA order over K as the row-major kernel: results are bit-identical to cpt_gemm_ln_prod3 (tested).
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace cpt {
+namespace {
+
+constexpr int TM = 128, TN = 192, NWV = 8, RB = 128;
+constexpr int ST = 4;                          // W ring depth = A register buffers
+constexpr int W_SLOT = TN * RB;                // 24 KB
+constexpr int GW = TN / 8 / NWV;               // LDS-DMA pieces per wave per K-tile (3)
+constexpr int GA = 4;                          // A fragment loads per wave per K-tile (one per k-step)
+constexpr int NJ = 3;                          // wave tile 32 x 96
+constexpr int LDS_BYTES = ST * W_SLOT;         // 96 KB; the epilogue's slabs reuse it
+constexpr int GROUP_M = 4;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int ldsoff(int row, int chunk) { return row * RB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <int IMM>
+__device__ __forceinline__ void a_load(u32x4& d, unsigned voff, const i32x4& rs, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(d) : "v"(voff), "s"(rs), "s"(soff), "n"(IMM));
+}
+
+// ABL (timing experiments only, cpt_set_tuning key 13; results are garbage for 1-3): 1 = the wn = 1 waves skip their A loads (half the
+// A load instructions), 2 = no A loads, 3 = no W LDS-DMA, 4 = refill issued right behind the barrier (correct results)
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
+    const bf16* __restrict__ Ap, const bf16* __restrict__ W, int ldw, const float* __restrict__ bias,
+    const bf16* __restrict__ resid_hi, const signed char* __restrict__ resid_lo, int ldr,
+    const float* __restrict__ st_in, int st_in_parts, const float* __restrict__ g_in, const float* __restrict__ b_in, float eps, float inv_h,
+    bf16* __restrict__ out_hi, signed char* __restrict__ out_lo, int ldo, float* __restrict__ st_out, int st_out_slots,
+    int M, int N, int K, long long* __restrict__ trace,
+    const void* __restrict__ pf0, size_t pf0_bytes, const void* __restrict__ pf1, size_t pf1_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // The FIRST gridDim.x - tiles workgroups prefetch the next launches' weights into the Infinity Cache (common.h prefetch_region):
+    // dispatched ahead of the tiles they start at once on CUs of their own (behind the tiles they queued for a busy CU and ran
+    // as a tail: attn-out 22.3 -> 23.0 us); their count is a multiple of 8, so block id -> XCD is the same for the tiles.
+    const int npf = gridDim.x - (M / TM) * (N / TN);
+    if ((int)blockIdx.x < npf) {
+        if (pf0) prefetch_region(pf0, pf0_bytes, blockIdx.x, npf, threadIdx.x, 512, smem);
+        if (pf1) prefetch_region(pf1, pf1_bytes, blockIdx.x, npf, threadIdx.x, 512, smem);
+        return;
+    }
+    long long tr0 = 0, tr1 = 0, tr2 = 0, tw0 = 0;
+    if (trace) { tr0 = clock64(); tw0 = wall_clock64(); }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // XCD-first, then GROUP_M row tiles per group (as gemm.hip)
+    int m0, n0;
+    {
+        const int tm = M / TM, tn = N / TN;
+        const int nwg = tm * tn, bid = blockIdx.x - npf;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int per_group = GROUP_M * tn;
+        const int g = lid / per_group, first_m = g * GROUP_M;
+        const int gsz = min(tm - first_m, GROUP_M);
+        const int in_g = lid - g * per_group;
+        m0 = (first_m + in_g % gsz) * TM;
+        n0 = (in_g / gsz) * TN;
+    }
+    const int nt = K / 64;
+
+    // W: LDS-DMA through a buffer descriptor, source-side XOR swizzle (gemm.hip)
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
+    unsigned voffw[GW];
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+        const int r = (i * NWV + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        voffw[i] = (unsigned)(((size_t)(n0 + r) * ldw + c * 8) * 2);
+    }
+    auto stage_w = [&](int slot, int t) {
+        if (ABL == 3) return;
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            auto lds = (__attribute__((address_space(3))) void*)(smem + slot * W_SLOT + (i * NWV + wave) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lds, 16, voffw[i], t * 128, 0, 0);
+        }
+    };
+    // A: this wave's 32-row block of the panel copy; K-tile t = 4 KiB at a_base + 4096 t, k-step ks at + 1024 ks, lane l at + 16 l
+    i32x4 rsA;
+    {
+        const unsigned long long pa = (unsigned long long)(uintptr_t)Ap;
+        rsA[0] = (int)(unsigned)(pa & 0xffffffffull);
+        rsA[1] = (int)(unsigned)((pa >> 32) & 0xffffull);
+        rsA[2] = (int)min((size_t)M * K * 2, (size_t)0x7fffffff);
+        rsA[3] = 0x00020000;
+    }
+    const unsigned voffa = (unsigned)lane * 16u;
+    const int a_base = __builtin_amdgcn_readfirstlane(((m0 >> 5) + wm) * (K >> 4) * 1024);
+    u32x4 afr[ST][GA];
+#define CPT_A_LOAD(BUF, T)                                                       \
+    do {                                                                         \
+        if (ABL == 2 || (ABL == 1 && wn == 1)) break;                             \
+        const int so_ = a_base + (T) * 4096;                                      \
+        a_load<0>(afr[BUF][0], voffa, rsA, so_);                                  \
+        a_load<1024>(afr[BUF][1], voffa, rsA, so_);                               \
+        a_load<2048>(afr[BUF][2], voffa, rsA, so_);                               \
+        a_load<3072>(afr[BUF][3], voffa, rsA, so_);                               \
+    } while (0)
+#define CPT_A_TOUCH(BUF) asm volatile("" : "+v"(afr[BUF][0]), "+v"(afr[BUF][1]), "+v"(afr[BUF][2]), "+v"(afr[BUF][3]))
+#define CPT_SB() __builtin_amdgcn_sched_barrier(0)
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // Issue order (per wave), the one every counted wait below assumes:
+    //   A(0) A(1) A(2) W(0) W(1) W(2) W(3) | iteration t: A(t+3) W(t+4) ...
+    // (prologue: the register loads first -- interleaved with the W pieces the first tile took 5.0 k instead of 3.1 k ticks to land)
+    // Loads complete in issue order, so "tile t+1 has landed" (its A fragments, older: its W pieces) = at most the ops issued
+    // after A(t+1) outstanding: W(t+2), A(t+2), W(t+3) = 2 GW + GA -- except in iteration 0, where W(1) is the younger one of
+    // tile 1's two parts and only W(2) W(3) may stay in flight.
+    CPT_A_LOAD(0, 0); CPT_A_LOAD(1, 1); CPT_A_LOAD(2, 2); CPT_SB();
+    stage_w(0, 0); stage_w(1, 1); stage_w(2, 2); stage_w(3, 3); CPT_SB();
+
+    bf16x8 fb[4][NJ];
+    auto ldfrag = [&](int slot, int ks, int pb) {
+        const unsigned char* sw = smem + slot * W_SLOT;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            fb[pb][j] = *reinterpret_cast<const bf16x8*>(sw + ldsoff(wn * 96 + j * 32 + fr, ks * 2 + fh));
+    };
+    auto touch = [&](int pb) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[pb][j]));
+    };
+#define CPT_MMA(BUF, KS)                                                                                           \
+    do {                                                                                                           \
+        const bf16x8 a_ = __builtin_bit_cast(bf16x8, afr[BUF][KS]);                                                 \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][0], acc[0], 0, 0, 0);                           \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][1], acc[1], 0, 0, 0);                           \
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][2], acc[2], 0, 0, 0);                           \
+    } while (0)
+
+    wait_vm<3 * GW>();                             // tile 0 landed: younger than W(0) are W(1) W(2) W(3)
+    __builtin_amdgcn_s_barrier();
+    CPT_SB();
+    CPT_A_TOUCH(0);
+    ldfrag(0, 0, 0); ldfrag(0, 1, 1);
+    CPT_SB();
+    if (trace) tr1 = clock64();
+
+    constexpr bool LATE_ = ABL < 4;          // ABL 4: round-3 first version, refill issued right behind the barrier
+    // one K-tile: tile t sits in W slot B and A buffer B (B = t % 4).  KIND 0: steady state (issues A(t+3), W(t+4)); 5: the same, t = 0; 1: issues
+    // A(t+3) only (t = nt - 4); 2: t = nt - 3; 3: t = nt - 2; 4: last tile (no successor)
+#define CPT_TILE(B, KIND, T)                                                                                       \
+    do {                                                                                                           \
+        constexpr int NB_ = ((B) + 1) & 3, PB_ = ((B) + 3) & 3;                                                     \
+        touch(0); CPT_SB(); ldfrag(B, 2, 2); CPT_SB(); CPT_MMA(B, 0); CPT_SB();                                     \
+        touch(1); CPT_SB(); ldfrag(B, 3, 3); CPT_SB(); CPT_MMA(B, 1); CPT_SB();                                     \
+        touch(2); touch(3); CPT_SB();              /* this wave's reads of tile t are retired before the barrier */ \
+        if ((KIND) != 4) {                                                                                         \
+            if ((KIND) == 5) wait_vm<2 * GW>(); else if ((KIND) <= 1) wait_vm<2 * GW + GA>();                       \
+            else if ((KIND) == 2) wait_vm<GW + GA>(); else wait_vm<0>();                                            \
+            CPT_SB();                                                                                              \
+            __builtin_amdgcn_s_barrier();          /* tile t+1 visible to all waves; nobody still reads tile t */   \
+            CPT_SB();                                                                                              \
+            CPT_A_TOUCH(NB_);                                                                                      \
+        }                                                                                                          \
+        if (LATE_) { CPT_MMA(B, 2); CPT_SB(); }                                                                     \
+        if ((KIND) != 4) {                                                                                         \
+            if ((KIND) <= 1 || (KIND) == 5) { CPT_A_LOAD(PB_, (T) + 3); CPT_SB(); }                                 \
+            if (!LATE_ && ((KIND) == 0 || (KIND) == 5)) { stage_w(B, (T) + 4); CPT_SB(); }                          \
+            ldfrag(NB_, 0, 0); CPT_SB();                                                                            \
+        }                                                                                                          \
+        if (!LATE_) { CPT_MMA(B, 2); CPT_SB(); }                                                                    \
+        if (LATE_) { CPT_MMA(B, 3); CPT_SB(); }                                                                     \
+        if (LATE_ && ((KIND) == 0 || (KIND) == 5)) { stage_w(B, (T) + 4); CPT_SB(); }                               \
+        if ((KIND) != 4) { ldfrag(NB_, 1, 1); CPT_SB(); }                                                           \
+        if (!LATE_) { CPT_MMA(B, 3); CPT_SB(); }                                                                    \
+    } while (0)
+
+    // KIND 2 waits for tile nt-2's successor nt-1: younger than A(nt-1) nothing was issued -> but W(nt-1) is OLDER than A(nt-2)?
+    // Order near the end: ... A(nt-3) W(nt-2) | A(nt-2) W(nt-1) | A(nt-1).  Tile t+1 needs A(t+1) and W(t+1):
+    //   t = nt-4 (KIND 1): younger than A(nt-3): W(nt-2) A(nt-2) W(nt-1)      = 2 GW + GA   (A(nt-1) is issued after this wait)
+    //   t = nt-3 (KIND 2): younger than A(nt-2): W(nt-1) A(nt-1)              = GW + GA
+    //   t = nt-2 (KIND 3): younger than A(nt-1): nothing                      = 0
+    const int groups = nt / 4 - 1;
+    CPT_TILE(0, 5, 0);
+    CPT_TILE(1, 0, 1);
+    CPT_TILE(2, 0, 2);
+    CPT_TILE(3, 0, 3);
+    int t = 4;
+    for (int g = 1; g < groups; ++g, t += 4) {
+        CPT_TILE(0, 0, t);
+        CPT_TILE(1, 0, t + 1);
+        CPT_TILE(2, 0, t + 2);
+        CPT_TILE(3, 0, t + 3);
+    }
+    CPT_TILE(0, 1, t);
+    CPT_TILE(1, 2, t + 1);
+    CPT_TILE(2, 3, t + 2);
+    CPT_TILE(3, 4, t + 3);
+#undef CPT_TILE
+#undef CPT_MMA
+#undef CPT_A_LOAD
+#undef CPT_A_TOUCH
+#undef CPT_SB
+    if (trace) tr2 = clock64();
+
+    // ---- epilogue: gemm.hip's per-wave slab epilogue (CPT_EPI_LNPROD3, interior-tile instance): the same arithmetic per element and the
+    // same order in the row sums (bit-identical outputs), but EIGHT columns per lane in the read-back instead of four: half the
+    // vector-memory instructions, 16-byte hi / 8-byte lo accesses, and the stores write-through (common.h CPT_ST_AUX).
+    __syncthreads();                                  // every wave is done reading the W ring
+    constexpr int WCOLS = NJ * 32, CPW = WCOLS * 4 + 16, CH = WCOLS / 4, C8 = WCOLS / 8, NIT = 16 * C8 / 64, NSL = 2;
+    constexpr int SIDE = 32 * 8 + 2 * WCOLS * 4, P = 3;
+    static_assert((16 * CPW + SIDE) * NWV <= LDS_BYTES, "per-wave slabs must fit in the ring");
+    static_assert(NIT * 64 == 16 * C8 && (64 * P) % C8 == 0, "read-back fills whole waves; column chunk repeats with period P");
+    unsigned char* slab = smem + wave * (16 * CPW);
+    unsigned char* side = smem + NWV * (16 * CPW) + wave * SIDE;
+    const int wrow0 = m0 + wm * 32, wcol0 = n0 + wn * WCOLS;
+    const bool fold_resid = g_in != nullptr;
+    const auto rsH = __builtin_amdgcn_make_buffer_rsrc((void*)out_hi, 0, (int)min((size_t)M * ldo * 2, (size_t)0x7fffffff), 0x00020000);
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)out_lo, 0, (int)min((size_t)M * ldo, (size_t)0x7fffffff), 0x00020000);
+    f32x4 bv[P][2];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int col = wcol0 + ((q * 64 + lane) % C8) * 8;
+        bv[q][0] = bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[q][1] = bias ? *reinterpret_cast<const f32x4*>(bias + col + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float2* side_row = reinterpret_cast<float2*>(side);
+    float* side_g = reinterpret_cast<float*>(side + 32 * 8);
+    float* side_t = side_g + WCOLS;
+    if (lane < 32) {
+        float2 ms = {0.f, 1.f};
+        if (fold_resid) {
+            float sum, sq;
+            sum_parts(st_in, st_in_parts, wrow0 + lane, sum, sq);
+            ln_mean_rstd(sum, sq, inv_h, eps, ms.x, ms.y);
+        }
+        side_row[lane] = ms;
+    }
+    if (lane < CH) {
+        const f32x4 g4 = fold_resid ? *reinterpret_cast<const f32x4*>(g_in + wcol0 + lane * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 t4 = fold_resid ? *reinterpret_cast<const f32x4*>(b_in + wcol0 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(side_g + lane * 4) = g4;
+        *reinterpret_cast<f32x4*>(side_t + lane * 4) = t4;
+    }
+    struct Aux { u32x4 h[NIT]; u32x2_t l[NIT]; };
+    auto load_aux = [&](int sl, Aux& a) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 64 + lane, rr = idx / C8, c8 = idx % C8;
+            const size_t off = (size_t)(wrow0 + sl * 16 + rr) * ldr + wcol0 + c8 * 8;
+            a.h[it] = *reinterpret_cast<const u32x4*>(resid_hi + off);
+            a.l[it] = *reinterpret_cast<const u32x2_t*>(resid_lo + off);
+        }
+    };
+    Aux aux_a, aux_b;
+    load_aux(0, aux_a);
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int rr = (r8 & 3) + 8 * (r8 >> 2) + 4 * (lane >> 5);
+                *reinterpret_cast<float*>(slab + rr * CPW + (j * 32 + (lane & 31)) * 4) = acc[j][sl * 8 + r8];
+            }
+        if (sl + 1 < NSL) load_aux(sl + 1, aux_b);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        Aux& ax = (sl & 1) ? aux_b : aux_a;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 64 + lane, rr = idx / C8, c8 = idx % C8;
+            const int row = wrow0 + sl * 16 + rr, col = wcol0 + c8 * 8;
+            const float2 ms = side_row[sl * 16 + rr];
+            const float mu = ms.x, rs = ms.y;
+            u32x2_t hq[2]; unsigned lq[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {          // the two 4-column quads of this lane's 8 columns
+                f32x4 v = *reinterpret_cast<const f32x4*>(slab + rr * CPW + c8 * 32 + hf * 16);
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(side_g + c8 * 8 + hf * 4);
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(side_t + c8 * 8 + hf * 4);
+                const f32x4 rr4 = r3_decode(u32x2_t{ax.h[it][2 * hf], ax.h[it][2 * hf + 1]}, ax.l[it][hf]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] + bv[it % P][hf][e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e];
+                    x += ln_apply(rr4[e], mu, rs, g4[e], t4[e]);
+                    v[e] = x;
+                }
+                r3_encode(v, hq[hf], lq[hf]);
+                *reinterpret_cast<f32x4*>(slab + rr * CPW + c8 * 32 + hf * 16) = v;      // finished values back for the row sums
+            }
+            const unsigned eo = (unsigned)row * (unsigned)ldo + (unsigned)col;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{hq[0][0], hq[0][1], hq[1][0], hq[1][1]}, rsH, eo * 2u, 0, CPT_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{lq[0], lq[1]}, rsL, eo, 0, CPT_ST_AUX);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int r16 = lane >> 2, part = lane & 3;
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH / 4; ++k) {
+            const f32x4 f = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (part * (CH / 4) + k) * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sm += f[e]; sq += f[e] * f[e]; }
+        }
+        sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
+        sm += __shfl_xor(sm, 2, 64); sq += __shfl_xor(sq, 2, 64);
+        const int srow = wrow0 + sl * 16 + r16;
+        if (part == 0)
+            *reinterpret_cast<float2*>(st_out + 2 * ((size_t)srow * st_out_slots + wcol0 / WCOLS)) = float2{sm, sq};
+    }
+    if (trace && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* tp = trace + (size_t)(blockIdx.x - npf) * 8;
+        tp[0] = tr0; tp[1] = tr1; tp[2] = tr2; tp[3] = tw0; tp[4] = clock64();
+        tp[5] = wall_clock64();                                  // (3, 5: the 100 MHz chip-wide counter at start / end)
+        tp[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        tp[7] = blockIdx.x;
+    }
+#endif
+}
+
+// row-major [M][ld] <-> panel
+__global__ __launch_bounds__(256) void panel_pack_kernel(const uint4* __restrict__ src, int ld8, uint4* __restrict__ dst, int M, int K16, int to_panel) {
+    const size_t n = (size_t)(M / 32) * K16 * 64;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < n; u += (size_t)gridDim.x * 256) {
+        const int l = (int)(u & 63);
+        const size_t q = u >> 6;
+        const int kk = (int)(q % K16);
+        const int rb = (int)(q / K16);
+        const size_t rm = (size_t)(rb * 32 + (l & 31)) * ld8 + kk * 2 + (l >> 5);
+        if (to_panel) dst[u] = src[rm]; else dst[rm] = src[u];
+    }
+}
+
+}  // namespace
+
+extern long long* g_gemm_trace;
+extern int g_trace_k;       // diagnostics: stamp only launches of this K (0: all)
+int g_prod_abl = 0;          // timing experiments (cpt_set_tuning key 13), see prod3_panel_kernel
+void set_prod_abl(int v) { g_prod_abl = v; }
+
+int panel_eligible(int M, int N, int K) { return M > 0 && M % TM == 0 && N > 0 && N % TN == 0 && K >= 512 && K % 256 == 0 && (size_t)M * K * 2 <= (size_t)0x7fffffff; }
+
+int panel_pack(const void* src, int ld, void* dst, int M, int K, int to_panel, hipStream_t s) {
+    if (M <= 0 || K <= 0 || M % 32 || K % 16 || ld % 8) return CPT_ERR_SHAPE;
+    if (!src || !dst) return CPT_ERR_NULL;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return CPT_ERR_ALIGN;
+    const size_t n = (size_t)M * K / 8;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    panel_pack_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const uint4*)src, ld / 8, (uint4*)dst, M, K / 16, to_panel);
+    return CPT_OK;
+}
+
+int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
+                        const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
+                        void* out_hi, void* out_lo, float* st_out, int ldo, int M, int N, int K, hipStream_t s,
+                        const void* pf0, size_t pf0_bytes, const void* pf1, size_t pf1_bytes) {
+    if (!panel_eligible(M, N, K) || ldw % 8) return CPT_ERR_SHAPE;
+    if (((uintptr_t)pf0 | (uintptr_t)pf1) & 15) return CPT_ERR_ALIGN;
+    if (!A_panel || !W || !resid_hi || !resid_lo || !out_hi || !out_lo || !st_out) return CPT_ERR_NULL;
+    if ((size_t)M * ldo * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;      // 32-bit store offsets
+    if (ldo % 8 || ldr % 8 || (((uintptr_t)A_panel | (uintptr_t)W | (uintptr_t)out_hi | (uintptr_t)out_lo | (uintptr_t)resid_hi | (uintptr_t)resid_lo |
+                                 (uintptr_t)bias | (uintptr_t)g_in | (uintptr_t)b_in) & 15))
+        return CPT_ERR_ALIGN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        for (const void* k : {(const void*)prod3_panel_kernel<0>, (const void*)prod3_panel_kernel<1>, (const void*)prod3_panel_kernel<2>, (const void*)prod3_panel_kernel<3>, (const void*)prod3_panel_kernel<4>}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+        }
+        attr_done = true;
+    }
+    const int ntile = (M / TM) * (N / TN);
+    // extra workgroups on the CUs the tiles leave idle: they read the next launches' weights (prefetch_region)
+    const int npf = ((pf0 && pf0_bytes) || (pf1 && pf1_bytes)) ? (std::max(0, std::min(CPT_PREFETCH_WGS, 256 - ntile)) & ~7) : 0;
+    if (!npf) { pf0 = nullptr; pf1 = nullptr; }
+    const int nwg = ntile + npf;
+#define CPT_LAUNCH(ABL) prod3_panel_kernel<ABL><<<dim3(nwg), dim3(512), LDS_BYTES, s>>>(                                                         \
+        (const bf16*)A_panel, (const bf16*)W, ldw, bias, (const bf16*)resid_hi, (const signed char*)resid_lo, ldr, st_in, ln_stat_parts(hidden), g_in, b_in, \
+        eps, 1.0f / (float)hidden, (bf16*)out_hi, (signed char*)out_lo, ldo, st_out, ln_stat_slots(N), M, N, K, (g_trace_k == 0 || g_trace_k == K) ? g_gemm_trace : nullptr, \
+        pf0, pf0_bytes, pf1, pf1_bytes)
+    switch (g_prod_abl) {
+        case 1: CPT_LAUNCH(1); break;
+        case 2: CPT_LAUNCH(2); break;
+        case 3: CPT_LAUNCH(3); break;
+        case 4: CPT_LAUNCH(4); break;
+        default: CPT_LAUNCH(0); break;
+    }
+#undef CPT_LAUNCH
+    return CPT_OK;
+}
+
+}  // namespace cpt

@@ -88,12 +88,23 @@ int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bi
 int gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
                   const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
                   void* out_hi, void* out_lo, float* st_out, int ldo, int M, int N, int K, hipStream_t s);
+// round 3: the same producer with A read from its fragment-major ("panel") copy straight into registers (gemm_prod.hip);
+// panel[M / 32][K / 16][64][8] bf16, see panel_pack; needs panel_eligible(M, N, K)
+int panel_eligible(int M, int N, int K);
+int panel_pack(const void* src, int ld, void* dst, int M, int K, int to_panel, hipStream_t s);     // to_panel 0: the inverse
+int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
+                        const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
+                        void* out_hi, void* out_lo, float* st_out, int ldo, int M, int N, int K, hipStream_t s,
+                        const void* pf0 = nullptr, size_t pf0_bytes = 0, const void* pf1 = nullptr, size_t pf1_bytes = 0);
+// pf0 / pf1: regions (the NEXT launches' weight matrices) that the launch's spare workgroups read into the Infinity Cache (common.h prefetch_region)
 int r3_split(const float* x, void* hi_bf16, void* lo_i8, size_t n, hipStream_t s);
 int r3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, hipStream_t s);
 int ln_stat_parts(int n_cols);      // 96-column blocks of a gemm_ln_prod of n_cols columns
 int ln_stat_slots(int n_cols);      // slots per row of the partial row-sum table [M][slots][2] it fills
 int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
-                 float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s);
+                 float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s, int out_panel = 0,
+                 const void* pf = nullptr, size_t pf_bytes = 0);      // pf: prefetch region of the panel form (as gemm_ln_prod3_panel)
+// out_panel (gelu form, ffn_up_2pass_legal shapes): out_lp leaves in the fragment-major panel layout (gemm_prod.hip) instead of row-major
 // fused QKV projection + self-attention (bf16, L <= 128); st_in NULL: plain bias, else LayerNorm folded (colc/cold);
 // config 1: two workgroups per CU (2-stage ring), 2: one workgroup per CU (3-stage ring)
 int gemm_qkv_attn(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
@@ -105,7 +116,7 @@ void set_q3_trace(void* p);  // cpt_debug_gemm_trace: per-workgroup phase stamps
 void set_q3_abl(int v);     // diagnostic builds (-DCPT_ABLATION): ablation bits of the kernel, see qkv_attn3.hip
 int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
                    const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads,
-                   int K, hipStream_t s, int w_tiled = 0);     // w_tiled: W is the K-tile-major copy made by retile_k32
+                   int K, hipStream_t s, int w_tiled = 0, int ctx_panel = 0);     // w_tiled: W is the K-tile-major copy made by retile_k32; ctx_panel: ctx leaves in the panel layout (gemm_prod.hip), rows padded to a multiple of 32
 // dst[K / 32][N][32] = src[N][K] (bf16): every K-tile of 32 of all rows contiguous (64 bytes per row, rows adjacent)
 int retile_k32(const void* src, void* dst, int N, int K, hipStream_t s);
 int select_regions(const float* logits, int V, const int64_t* color_ids, int C, const int* query_first, int Q,
@@ -123,8 +134,10 @@ void set_gemm_skew(int v);
 int ffn_up_2pass_legal(int M, int N, int K);
 int ffn_up_2pass_preferred(int M, int N, int K);
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
-                      float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s);
+                      float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s, int out_panel = 0,
+                      const void* pf = nullptr, size_t pf_bytes = 0);
 void set_ffn_dma_late(int v);
+void set_prod_abl(int v);    // timing experiments of the panel producer (gemm_prod.hip)
 void set_gemm_trace(void* p);
 void set_gemm_trace_filter(int epi, int k);
 

@@ -54,14 +54,14 @@ struct Q3Args {
     const float* colc; const float* cold;
     float eps, inv_h;
     const int64_t* mask;                   // [B][L] or NULL
-    bf16* ctx; int ldo;
+    bf16* ctx; int ldo;                    // PANEL instantiation: ctx is the fragment-major panel copy [M / 32][hidden / 16][64][8] (gemm_prod.hip), ldo ignored
     int M, K, L, heads;
     long long* trace;                      // diagnostics (cpt_debug_gemm_trace): 8 int64 per workgroup, shader-clock stamps + HW ids
 };
 
 // ABL (diagnostic instantiations, cpt_set_tuning key 1): 1 = no operand DMA after the prologue, 2 = no attention phase,
 // 4 = no MFMA in the K loop, 8 = no fragment reads in the K loop
-template <bool LN, int ABL = 0>
+template <bool LN, int ABL = 0, bool PANEL = false>
 __global__ __launch_bounds__(Q3_NW * 64, 3) void qkv3_attn_kernel(Q3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -326,8 +326,13 @@ __global__ __launch_bounds__(Q3_NW * 64, 3) void qkv3_attn_kernel(Q3Args a) {
             bf16x8 fq[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const bf16x8*>(sQ + att_koff16(q, 2 * ks + fh));
+            if constexpr (PANEL) {
+                attn_core_bf16<4, true, true>(fq, sK, sV, sMask, lane, q < Ls, nullptr, nullptr, Ls, DropSpec{}, 0, 0, nullptr,
+                                              (void*)a.ctx, (int)min((size_t)((M + 31) & ~31) * hd64 * 2, (size_t)0x7fffffff), m0 + min(q, Ls - 1), (h0 + hh) * 8, hd64 >> 4);
+            } else {
             bf16* crow = a.ctx + ((size_t)m0 + min(q, Ls - 1)) * a.ldo + (h0 + hh) * 64;
             attn_core_bf16<4, true>(fq, sK, sV, sMask, lane, q < Ls, crow, nullptr, Ls);
+            }
         }
     }
     if (a.trace && tid == 0) {
@@ -339,9 +344,9 @@ __global__ __launch_bounds__(Q3_NW * 64, 3) void qkv3_attn_kernel(Q3Args a) {
 #endif
 }
 
-template <bool LN, int ABL = 0>
+template <bool LN, int ABL = 0, bool PANEL = false>
 int q3_launch(const Q3Args& a, int B, hipStream_t s) {
-    auto kern = qkv3_attn_kernel<LN, ABL>;
+    auto kern = qkv3_attn_kernel<LN, ABL, PANEL>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q3_LDS);
@@ -363,10 +368,11 @@ int qkv_attn3_eligible(int L, int heads, int K) { return L > 0 && L <= 128 && he
 // Same contract as gemm_qkv_attn (gemm.hip): st_in == NULL -> x W^T + bias, else the LayerNorm-folded form.
 int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
                    const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads,
-                   int K, hipStream_t s, int w_tiled) {
+                   int K, hipStream_t s, int w_tiled, int ctx_panel) {
     if (B <= 0 || !qkv_attn3_eligible(L, heads, K) || lda % 8 || ldw % 8 || ldo % 4 || (st_in && ln_stat_slots(hidden) > 8)) return CPT_ERR_SHAPE;
     if (!A || !W || !ctx || (st_in && (!colc || !cold))) return CPT_ERR_NULL;
-    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)bias | (uintptr_t)colc | (uintptr_t)cold) & 15) || ((uintptr_t)ctx & 7)) return CPT_ERR_ALIGN;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)bias | (uintptr_t)colc | (uintptr_t)cold) & 15) || ((uintptr_t)ctx & (ctx_panel ? 15 : 7))) return CPT_ERR_ALIGN;
+    if (ctx_panel && (heads * 64) % 16) return CPT_ERR_SHAPE;
     Q3Args a;
     a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias; a.w_tiled = w_tiled ? 1 : 0;
     if (w_tiled && ldw != K) return CPT_ERR_SHAPE;
@@ -384,6 +390,7 @@ int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* 
         case 15: return q3_launch<true, 15>(a, B, s);
         default: break;
     }
+    if (ctx_panel) return st_in ? q3_launch<true, 0, true>(a, B, s) : q3_launch<false, 0, true>(a, B, s);
     return st_in ? q3_launch<true>(a, B, s) : q3_launch<false>(a, B, s);
 }
 int g_q3_abl = 0;

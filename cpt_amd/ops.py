@@ -192,6 +192,35 @@ def gemm_ln_prod3(a, w, bias, resid_hi, resid_lo, st_in=None, g_in=None, b_in=No
     return out_hi, out_lo, st_out
 
 
+def panel_pack(a, to_panel=True, K=None):
+    """Row-major bf16 [M, K] -> the fragment-major panel copy [M/32][K/16][64][8] the panel producers read (flat tensor), or back."""
+    _need_cuda(a)
+    if to_panel:
+        M, K = a.shape
+        out = torch.empty(M * K, device=a.device, dtype=torch.bfloat16)
+        L.check(L.lib().cpt_panel_pack(a.data_ptr(), a.stride(0), out.data_ptr(), M, K, 1, L.stream_ptr()), "cpt_panel_pack")
+        return out
+    M = a.numel() // K
+    out = torch.empty((M, K), device=a.device, dtype=torch.bfloat16)
+    L.check(L.lib().cpt_panel_pack(a.data_ptr(), K, out.data_ptr(), M, K, 0, L.stream_ptr()), "cpt_panel_pack")
+    return out
+
+
+def gemm_ln_prod3_panel(a_panel, K, w, bias, resid_hi, resid_lo, st_in=None, g_in=None, b_in=None, eps=1e-12, hidden=None):
+    """gemm_ln_prod3 with A given as its panel copy (panel_pack): A goes straight to registers, only W through LDS."""
+    _need_cuda(a_panel, w, bias, resid_hi, resid_lo)
+    M = a_panel.numel() // K
+    N = w.size(0)
+    hidden = hidden or N
+    out_hi = torch.empty((M, N), device=w.device, dtype=torch.bfloat16)
+    out_lo = torch.empty((M, N), device=w.device, dtype=torch.int8)
+    st_out = torch.zeros((M, ln_stat_slots(N), 2), device=w.device, dtype=torch.float32)
+    L.check(L.lib().cpt_gemm_ln_prod3_panel(a_panel.data_ptr(), w.data_ptr(), w.stride(0), L.ptr(bias), resid_hi.data_ptr(), resid_lo.data_ptr(),
+                                            resid_hi.stride(0), L.ptr(st_in), L.ptr(g_in), L.ptr(b_in), float(eps), hidden, out_hi.data_ptr(),
+                                            out_lo.data_ptr(), st_out.data_ptr(), out_hi.stride(0), M, N, K, L.stream_ptr()), "cpt_gemm_ln_prod3_panel")
+    return out_hi, out_lo, st_out
+
+
 def gemm_ln_cons(a, wf, st_in, colc, cold, eps, hidden, gelu):
     """[gelu]( rstd * (a @ wf.T - mean * colc) + cold ): bf16 a[M,K], wf[N,K]; st_in from row_stats_table / gemm_ln_prod."""
     _need_cuda(a, wf, st_in, colc, cold)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CPT_ABI_VERSION 3     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32 (round 3) */
+#define CPT_ABI_VERSION 4     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3) */
 
 enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2 };
 enum { CPT_EPI_NONE = 0, CPT_EPI_GELU = 1, CPT_EPI_TANH = 2, CPT_EPI_RESID = 3 };
@@ -337,6 +337,17 @@ int cpt_gemm_ln_prod3(const void* A_bf16, int lda, const void* W_bf16, int ldw, 
                       int ldr, const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi, void* out_lo,
                       float* st_out, int ldo, int M, int N, int K, void* stream);
 int cpt_resid3_split(const float* x, void* hi_bf16, void* lo_i8, size_t n, void* stream);
+/* Round 3 (ABI 4): the producer with its A operand in the fragment-major "panel" layout
+ *   panel[M / 32][K / 16][64][8] bf16: element (row, k) at (((row / 32) (K / 16) + k / 16) 64 + ((k % 16) / 8) 32 + row % 32) 8 + k % 8
+ * (every v_mfma_f32_32x32x16_bf16 A operand of a 32-row block is one contiguous KiB), read straight into registers: only W rides
+ * the LDS ring.  Inside cpt_model_fwd the attention kernel and the FFN-up epilogue write ctx / h in this layout; results are
+ * bit-identical to cpt_gemm_ln_prod3 on the row-major tensor.  M % 128 == 0, N % 192 == 0, K % 256 == 0, K >= 512.
+ *   cpt_panel_pack: row-major bf16 [M][ld] -> panel (to_panel = 1) or back (to_panel = 0, ld = leading dimension of the row-major side);
+ *                   M % 32 == 0, K % 16 == 0. */
+int cpt_panel_pack(const void* src_bf16, int ld, void* dst_bf16, int M, int K, int to_panel, void* stream);
+int cpt_gemm_ln_prod3_panel(const void* A_panel, const void* W_bf16, int ldw, const float* bias, const void* resid_hi, const void* resid_lo,
+                            int ldr, const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi, void* out_lo,
+                            float* st_out, int ldo, int M, int N, int K, void* stream);
 int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, void* stream);
 
 /* Weight-gradient GEMM in the TN form (what cpt_train_bwd runs for dW = dY^T . X, fewshot/refcoco_cpt.py:248's autograd of
@@ -397,6 +408,12 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 10 bf16 weight gradients of cpt_train_bwd: 1 (default) = TN GEMM (operands read as stored, split-K partials reduced in
  *          order), 0 = explicit operand transposes + NT GEMM
  *   key 11 fused QKV + attention, form 3: 1 (default) = read cpt_layer_fold.w_qkv_t when given, 0 = always the row-major weight
+ *   key 12 FFN-up two-pass kernel: 1 (default) = refill DMA issued behind the first k-step after the barrier, 0 = right behind it
+ *   key 13 timing experiments of the panel producer (gemm_prod.hip); 0 (default) = the shipped kernel
+ *   key 14 panel mode of the fused bf16 encoder: 1 (default) = ctx / FFN activation in the fragment-major panel layout where shapes allow
+ *          (cpt_gemm_ln_prod3_panel), 0 = row-major tensors (cpt_gemm_ln_prod3)
+ *   key 15 panel mode: 1 (default) = launches that leave CUs idle carry 16 workgroups that read the next launch's weights into the
+ *          Infinity Cache, 0 = no prefetch workgroups
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at

@@ -27,6 +27,39 @@ def _dev(b, dev):
     return {k: v.to(dev) for k, v in b.items()}
 
 
+def test_config2_panel_mode_is_bit_identical(dev):
+    """Round 3: at the bench size (B = 64, L = 70 + 50) the fused bf16 encoder runs in PANEL mode -- the attention kernel and the
+    FFN-up epilogue write ctx / h as MFMA A fragments, the LayerNorm producers read them straight into registers, every big
+    output store is write-through.  Same bits as the row-major encoder (cpt_set_tuning(14, 0)), for the [MASK]-row logits, the
+    pooled output and the all-row sequence output; a ragged attention mask included; repeated runs identical."""
+    from cpt_amd import _lib as L
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    cfg = cfgmod.oscar_base()
+    sd = synth.init_state_dict(cfg, 88, head="cpt")
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(sd)
+    m.tie_weights()
+    m.to(dev).eval().set_compute_dtype("bf16")
+    d = _dev(synth.make_batch(64, cfg, seed=5, vary_regions=True), dev)
+
+    def run():
+        with torch.no_grad():
+            return m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0].clone()
+    on = run()
+    again = run()
+    L.check(L.lib().cpt_set_tuning(14, 0))
+    off = run()
+    L.check(L.lib().cpt_set_tuning(14, 1))
+    assert torch.isfinite(on).all()
+    assert torch.equal(on, again)
+    assert torch.equal(on, off)
+    # and the rows of the big batch reproduce a 4-sequence batch (which runs the row-major kernels: below the panel shapes)
+    ds = {k: v[:4].contiguous() for k, v in d.items()}
+    with torch.no_grad():
+        small = m(ds["input_ids"], ds["segment_ids"], ds["attention_mask"], img_feats=ds["img_feats"], mask_token_pos=ds["mask_token_pos"])[0]
+    assert torch.equal(on[:4], small)
+
+
 def test_config4_gqa_12_layers_b256(dev):
     from cpt_amd.modeling_rec import REC_MLM_CPT
     cfg = cfgmod.oscar_base()

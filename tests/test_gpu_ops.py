@@ -458,6 +458,37 @@ def test_gemm_ln_prod3_matches_fp32_producer(dev, K):
             assert torch.equal(s_hi, o_hi[:Ms]) and torch.equal(s_lo, o_lo[:Ms]) and torch.equal(s_st, st3[:Ms])
 
 
+@pytest.mark.parametrize("K", [768, 3072])
+def test_gemm_ln_prod3_panel_is_bit_identical(dev, K):
+    """Round 3: the producer that reads A from its fragment-major panel copy straight into registers (gemm_prod.hip) against the
+    row-major producer on the same operands: hi, lo and the partial row sums bit for bit, with and without the on-the-fly residual
+    LayerNorm; the panel copy round-trips through cpt_panel_pack; 20 back-to-back launches give identical bits."""
+    from cpt_amd import ops
+    rng = _rng(K + 5)
+    M, H = 640, 768
+    x = (_t(rng, M, H, scale=1.2) + 0.3).to(dev)
+    hi, lo = ops.resid3_split(x)
+    st = ops.row_stats_table(x)
+    a = _t(rng, M, K).to(torch.bfloat16).to(dev)
+    w = _t(rng, H, K, scale=0.03).to(torch.bfloat16).to(dev)
+    bias, g, bt = _t(rng, H, scale=0.1).to(dev), (1 + _t(rng, H, scale=0.1)).to(dev), _t(rng, H, scale=0.1).to(dev)
+    ap = ops.panel_pack(a)
+    assert torch.equal(ops.panel_pack(ap, to_panel=False, K=K), a)
+    # the documented layout: element (row, k) at (((row / 32) (K / 16) + k / 16) 64 + ((k % 16) / 8) 32 + row % 32) 8 + k % 8
+    rows = torch.arange(M, device=dev)[:, None]
+    ks = torch.arange(K, device=dev)[None, :]
+    idx = (((rows // 32) * (K // 16) + ks // 16) * 64 + ((ks % 16) // 8) * 32 + rows % 32) * 8 + ks % 8
+    assert torch.equal(ap[idx.reshape(-1)].view(M, K), a)
+    for fold in (True, False):
+        gi, bi, si = (g, bt, st) if fold else (None, None, None)
+        r_hi, r_lo, r_st = ops.gemm_ln_prod3(a, w, bias, hi, lo, si, gi, bi, 1e-12, H)
+        p_hi, p_lo, p_st = ops.gemm_ln_prod3_panel(ap, K, w, bias, hi, lo, si, gi, bi, 1e-12, H)
+        assert torch.equal(p_hi, r_hi) and torch.equal(p_lo, r_lo) and torch.equal(p_st, r_st)
+        for _ in range(20):
+            q_hi, q_lo, q_st = ops.gemm_ln_prod3_panel(ap, K, w, bias, hi, lo, si, gi, bi, 1e-12, H)
+            assert torch.equal(q_hi, r_hi) and torch.equal(q_lo, r_lo) and torch.equal(q_st, r_st)
+
+
 @pytest.mark.parametrize("Mbig,Msmall", [(7680, 840), (7680, 120), (1000, 77)])
 def test_operators_are_batch_invariant(dev, Mbig, Msmall):
     """Rows [0, Msmall) of a big problem equal the same rows run as their own problem, bit for bit, for the four GEMM forms of

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Developer A/B build of libcpt_hip.so with extra compiler flags: tools/build_variant.sh NAME "-DCPT_WT=0 ..." -> tools/dbg/libcpt_NAME.so
+# (git-ignored; run it with CPT_LIB_PATH=tools/dbg/libcpt_NAME.so, e.g. through tools/ab_libs.sh)
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+obj=/tmp/cpt_variant_$name
+mkdir -p $obj $root/tools/dbg
+pids=()
+for f in $root/cpt_amd/csrc/*.hip; do
+  b=$(basename $f .hip)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -I$root/include $@ -c $f -o $obj/$b.o &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o $root/tools/dbg/libcpt_$name.so $obj/*.o
+echo $root/tools/dbg/libcpt_$name.so
