@@ -461,13 +461,18 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
               if (panel) {
                   // next layer's QKV weight (the copy its launch will read) and attention-output weight
                   const void* nq = nullptr; const void* na = nullptr;
+                  size_t nqb = (size_t)3 * H * H * 2, nab = (size_t)H * H * 2;
                   if (pfw && l + 1 < d.layers) {
                       const cpt_layer_fold& fn = m->fold[l + 1];
                       nq = (fn.w_qkv_t && g_qkv_tiled) ? fn.w_qkv_t : fn.w_qkv_f;
                       na = m->layers[l + 1].w_ao;
+                  } else if (pfw && (flags & CPT_OUT_MASK_LOGITS) && m->w_dec && m->w_tr) {
+                      // last layer: the MLM head's weights (transform dense, then the 47 MB tied decoder table streamed once by 64 rows)
+                      nq = m->w_tr; nqb = (size_t)H * H * 2;
+                      na = m->w_dec; nab = (size_t)d.vocab * H * 2;
                   }
                   TRY(cpt::gemm_ln_prod3_panel(ffn, y.w_out, I, y.b_out, a_lp, a_lo, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_lp, x_lo, st2, H, M, H, I, s,
-                                               nq, (size_t)3 * H * H * 2, na, (size_t)H * H * 2), "gemm(ffn down, LN producer, panel A)");
+                                               nq, nqb, na, nab), "gemm(ffn down, LN producer, panel A)");
               } else
               if (r3) TRY(cpt::gemm_ln_prod3(ffn, I, y.w_out, I, y.b_out, a_lp, a_lo, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_lp, x_lo, st2, H, M, H, I, s),
                           "gemm(ffn down, LN producer, 3-byte residual)");

@@ -18,6 +18,15 @@
 #include "common.h"
 #include "kernels.h"
 
+// A/B switches (developer builds, tools/build_variant.sh): CPT_PROD_SIDE 0 = side data loaded where the epilogue starts, 1 = requested
+// ahead of the first tile, 2 (default) = right behind the first tile; CPT_PROD_AUX0 0 = first residual slice loaded where the epilogue starts
+#ifndef CPT_PROD_SIDE
+#define CPT_PROD_SIDE 2
+#endif
+#ifndef CPT_PROD_AUX0
+#define CPT_PROD_AUX0 1
+#endif
+
 namespace cpt {
 namespace {
 
@@ -27,7 +36,9 @@ constexpr int W_SLOT = TN * RB;                // 24 KB
 constexpr int GW = TN / 8 / NWV;               // LDS-DMA pieces per wave per K-tile (3)
 constexpr int GA = 4;                          // A fragment loads per wave per K-tile (one per k-step)
 constexpr int NJ = 3;                          // wave tile 32 x 96
-constexpr int LDS_BYTES = ST * W_SLOT;         // 96 KB; the epilogue's slabs reuse it
+constexpr int RING_BYTES = ST * W_SLOT;        // 96 KB; the epilogue's slabs reuse it
+constexpr int SIDE = 32 * 8 + 3 * 96 * 4;      // per-wave side data: (mean, rstd) of its 32 rows, residual LayerNorm gain / shift and bias of its 96 columns
+constexpr int LDS_BYTES = RING_BYTES + NWV * SIDE;
 constexpr int GROUP_M = 4;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -132,14 +143,37 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    // Side data of the epilogue (bias, the residual LayerNorm's gain / shift, the partial row sums of this wave's 32 rows): requested in the
+    // prologue right BEHIND the first tile (ahead of it their HBM round trip held the first tile back: prologue 5.4 k -> 7.9 k ticks), by
+    // inline asm (for a load it can see hipcc waits vmcnt(0) while LDS-DMA is in flight); always NSIDE loads (absent operands read a
+    // dummy address) so that the counted waits are constants; parked in the LDS side area behind the ring after iteration 0's wait.
+    const int wrow0 = m0 + wm * 32, wcol0 = n0 + wn * 96;
+    const bool fold_resid = g_in != nullptr;
+    constexpr int NSIDE = 7;
+    f32x4 sd_b, sd_g, sd_t, sd_s[4];
+#define CPT_SIDE_LOADS()                                                                                                        \
+    do {                                                                                                                        \
+        const int c4 = wcol0 + min(lane, 23) * 4;                                                                                \
+        const float* dummy = reinterpret_cast<const float*>(W);                                                                  \
+        const int slots = (st_in_parts + 1) & ~1, nq = slots >> 1;                                                               \
+        const f32x4* base = fold_resid ? reinterpret_cast<const f32x4*>(st_in + (size_t)(wrow0 + (lane & 31)) * slots * 2)      \
+                                       : reinterpret_cast<const f32x4*>(dummy);                                                 \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sd_b) : "v"(bias ? bias + c4 : dummy));                            \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sd_g) : "v"(fold_resid ? g_in + c4 : dummy));                      \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sd_t) : "v"(fold_resid ? b_in + c4 : dummy));                      \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                            \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sd_s[q]) : "v"(base + (fold_resid ? min(q, nq - 1) : 0)));     \
+    } while (0)
     // Issue order (per wave), the one every counted wait below assumes:
-    //   A(0) A(1) A(2) W(0) W(1) W(2) W(3) | iteration t: A(t+3) W(t+4) ...
-    // (prologue: the register loads first -- interleaved with the W pieces the first tile took 5.0 k instead of 3.1 k ticks to land)
+    //   A(0) W(0) side A(1) A(2) W(1) W(2) W(3) | iteration t: A(t+3) W(t+4) ...
     // Loads complete in issue order, so "tile t+1 has landed" (its A fragments, older: its W pieces) = at most the ops issued
     // after A(t+1) outstanding: W(t+2), A(t+2), W(t+3) = 2 GW + GA -- except in iteration 0, where W(1) is the younger one of
     // tile 1's two parts and only W(2) W(3) may stay in flight.
-    CPT_A_LOAD(0, 0); CPT_A_LOAD(1, 1); CPT_A_LOAD(2, 2); CPT_SB();
-    stage_w(0, 0); stage_w(1, 1); stage_w(2, 2); stage_w(3, 3); CPT_SB();
+    if (CPT_PROD_SIDE == 1) { CPT_SIDE_LOADS(); CPT_SB(); }
+    CPT_A_LOAD(0, 0); CPT_SB(); stage_w(0, 0); CPT_SB();
+    if (CPT_PROD_SIDE == 2) { CPT_SIDE_LOADS(); CPT_SB(); }
+    CPT_A_LOAD(1, 1); CPT_A_LOAD(2, 2); CPT_SB();
+    stage_w(1, 1); stage_w(2, 2); stage_w(3, 3); CPT_SB();
 
     bf16x8 fb[4][NJ];
     auto ldfrag = [&](int slot, int ks, int pb) {
@@ -160,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
         acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][2], acc[2], 0, 0, 0);                           \
     } while (0)
 
-    wait_vm<3 * GW>();                             // tile 0 landed: younger than W(0) are W(1) W(2) W(3)
+    wait_vm<(CPT_PROD_SIDE == 2 ? NSIDE : 0) + 2 * GA + 3 * GW>();            // tile 0 landed: younger than W(0) are the side data, A(1) A(2), W(1) W(2) W(3)
     __builtin_amdgcn_s_barrier();
     CPT_SB();
     CPT_A_TOUCH(0);
@@ -168,6 +202,42 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
     CPT_SB();
     if (trace) tr1 = clock64();
 
+    // the side data has landed with tile 1 (it is older): (mean, rstd) of the wave's rows and the column vectors go to the LDS side area
+#define CPT_SIDE_PARK()                                                                                                         \
+    do {                                                                                                                        \
+        asm volatile("" : "+v"(sd_b), "+v"(sd_g), "+v"(sd_t), "+v"(sd_s[0]), "+v"(sd_s[1]), "+v"(sd_s[2]), "+v"(sd_s[3]));       \
+        unsigned char* side_ = smem + RING_BYTES + wave * SIDE;                                                                  \
+        if (lane < 32) {                                                                                                         \
+            float2 ms = {0.f, 1.f};                                                                                              \
+            if (fold_resid) {     /* the arithmetic of sum_parts_n<4> (slot order, unused slots skipped by select) */           \
+                float sum = 0.f, sq = 0.f;                                                                                       \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                  \
+                    const bool u0 = 2 * q < st_in_parts, u1 = 2 * q + 1 < st_in_parts;                                           \
+                    sum += u0 ? sd_s[q][0] : 0.f; sq += u0 ? sd_s[q][1] : 0.f;                                                   \
+                    sum += u1 ? sd_s[q][2] : 0.f; sq += u1 ? sd_s[q][3] : 0.f;                                                   \
+                }                                                                                                                \
+                ln_mean_rstd(sum, sq, inv_h, eps, ms.x, ms.y);                                                                   \
+            }                                                                                                                    \
+            reinterpret_cast<float2*>(side_)[lane] = ms;                                                                         \
+        }                                                                                                                        \
+        if (lane < 24) {                                                                                                         \
+            *reinterpret_cast<f32x4*>(side_ + 256 + lane * 16) = fold_resid ? sd_g : f32x4{1.f, 1.f, 1.f, 1.f};                  \
+            *reinterpret_cast<f32x4*>(side_ + 256 + 384 + lane * 16) = fold_resid ? sd_t : f32x4{0.f, 0.f, 0.f, 0.f};            \
+            *reinterpret_cast<f32x4*>(side_ + 256 + 768 + lane * 16) = bias ? sd_b : f32x4{0.f, 0.f, 0.f, 0.f};                  \
+        }                                                                                                                        \
+    } while (0)
+    // residual rows of the first epilogue slice (16 rows x 96 columns per wave: 16-byte hi + 8-byte lo per lane, three per lane), by asm loads
+    constexpr int C8 = 12, NIT = 3;
+    u32x4 ax0h[NIT]; u32x2_t ax0l[NIT];
+#define CPT_AUX0()                                                                                                              \
+    do {                                                                                                                        \
+        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                                    \
+            const int idx = it * 64 + lane, rr = idx / C8, c8 = idx % C8;                                                         \
+            const size_t off = (size_t)(wrow0 + rr) * ldr + wcol0 + c8 * 8;                                                       \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ax0h[it]) : "v"(resid_hi + off));                               \
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ax0l[it]) : "v"(resid_lo + off));                               \
+        }                                                                                                                       \
+    } while (0)
     constexpr bool LATE_ = ABL < 4;          // ABL 4: round-3 first version, refill issued right behind the barrier
     // one K-tile: tile t sits in W slot B and A buffer B (B = t % 4).  KIND 0: steady state (issues A(t+3), W(t+4)); 5: the same, t = 0; 1: issues
     // A(t+3) only (t = nt - 4); 2: t = nt - 3; 3: t = nt - 2; 4: last tile (no successor)
@@ -184,6 +254,8 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
             __builtin_amdgcn_s_barrier();          /* tile t+1 visible to all waves; nobody still reads tile t */   \
             CPT_SB();                                                                                              \
             CPT_A_TOUCH(NB_);                                                                                      \
+            if ((KIND) == 5 && CPT_PROD_SIDE != 0) { CPT_SIDE_PARK(); CPT_SB(); }                                    \
+            if ((KIND) == 3 && CPT_PROD_AUX0) { CPT_AUX0(); CPT_SB(); }   /* nothing else is in flight: the first residual slice rides under the last tile */ \
         }                                                                                                          \
         if (LATE_) { CPT_MMA(B, 2); CPT_SB(); }                                                                     \
         if ((KIND) != 4) {                                                                                         \
@@ -220,6 +292,9 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
     CPT_TILE(2, 3, t + 2);
     CPT_TILE(3, 4, t + 3);
 #undef CPT_TILE
+#undef CPT_AUX0
+#undef CPT_SIDE_PARK
+#undef CPT_SIDE_LOADS
 #undef CPT_MMA
 #undef CPT_A_LOAD
 #undef CPT_A_TOUCH
@@ -230,40 +305,39 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
     // same order in the row sums (bit-identical outputs), but EIGHT columns per lane in the read-back instead of four: half the
     // vector-memory instructions, 16-byte hi / 8-byte lo accesses, and the stores write-through (common.h CPT_ST_AUX).
     __syncthreads();                                  // every wave is done reading the W ring
-    constexpr int WCOLS = NJ * 32, CPW = WCOLS * 4 + 16, CH = WCOLS / 4, C8 = WCOLS / 8, NIT = 16 * C8 / 64, NSL = 2;
-    constexpr int SIDE = 32 * 8 + 2 * WCOLS * 4, P = 3;
-    static_assert((16 * CPW + SIDE) * NWV <= LDS_BYTES, "per-wave slabs must fit in the ring");
-    static_assert(NIT * 64 == 16 * C8 && (64 * P) % C8 == 0, "read-back fills whole waves; column chunk repeats with period P");
+    constexpr int WCOLS = NJ * 32, CPW = WCOLS * 4 + 16, CH = WCOLS / 4, NSL = 2, P = 3;
+    static_assert(16 * CPW * NWV <= RING_BYTES, "per-wave slabs must fit in the ring");
+    static_assert(C8 == WCOLS / 8 && NIT * 64 == 16 * C8 && (64 * P) % C8 == 0, "read-back fills whole waves; column chunk repeats with period P");
     unsigned char* slab = smem + wave * (16 * CPW);
-    unsigned char* side = smem + NWV * (16 * CPW) + wave * SIDE;
-    const int wrow0 = m0 + wm * 32, wcol0 = n0 + wn * WCOLS;
-    const bool fold_resid = g_in != nullptr;
+    unsigned char* side = smem + RING_BYTES + wave * SIDE;
     const auto rsH = __builtin_amdgcn_make_buffer_rsrc((void*)out_hi, 0, (int)min((size_t)M * ldo * 2, (size_t)0x7fffffff), 0x00020000);
     const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)out_lo, 0, (int)min((size_t)M * ldo, (size_t)0x7fffffff), 0x00020000);
+    float2* side_row = reinterpret_cast<float2*>(side);
+    float* side_g = reinterpret_cast<float*>(side + 256);
+    float* side_t = side_g + WCOLS;
+    float* side_b = side_t + WCOLS;
+    if (CPT_PROD_SIDE == 0) {     // A/B: side data fetched here, as gemm.hip does
+        if (lane < 32) {
+            float2 ms = {0.f, 1.f};
+            if (fold_resid) {
+                float sum, sq;
+                sum_parts(st_in, st_in_parts, wrow0 + lane, sum, sq);
+                ln_mean_rstd(sum, sq, inv_h, eps, ms.x, ms.y);
+            }
+            side_row[lane] = ms;
+        }
+        if (lane < CH) {
+            *reinterpret_cast<f32x4*>(side_g + lane * 4) = fold_resid ? *reinterpret_cast<const f32x4*>(g_in + wcol0 + lane * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+            *reinterpret_cast<f32x4*>(side_t + lane * 4) = fold_resid ? *reinterpret_cast<const f32x4*>(b_in + wcol0 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(side_b + lane * 4) = bias ? *reinterpret_cast<const f32x4*>(bias + wcol0 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     f32x4 bv[P][2];
 #pragma unroll
     for (int q = 0; q < P; ++q) {
-        const int col = wcol0 + ((q * 64 + lane) % C8) * 8;
-        bv[q][0] = bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bv[q][1] = bias ? *reinterpret_cast<const f32x4*>(bias + col + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    float2* side_row = reinterpret_cast<float2*>(side);
-    float* side_g = reinterpret_cast<float*>(side + 32 * 8);
-    float* side_t = side_g + WCOLS;
-    if (lane < 32) {
-        float2 ms = {0.f, 1.f};
-        if (fold_resid) {
-            float sum, sq;
-            sum_parts(st_in, st_in_parts, wrow0 + lane, sum, sq);
-            ln_mean_rstd(sum, sq, inv_h, eps, ms.x, ms.y);
-        }
-        side_row[lane] = ms;
-    }
-    if (lane < CH) {
-        const f32x4 g4 = fold_resid ? *reinterpret_cast<const f32x4*>(g_in + wcol0 + lane * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
-        const f32x4 t4 = fold_resid ? *reinterpret_cast<const f32x4*>(b_in + wcol0 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(side_g + lane * 4) = g4;
-        *reinterpret_cast<f32x4*>(side_t + lane * 4) = t4;
+        const int lc = ((q * 64 + lane) % C8) * 8;
+        bv[q][0] = *reinterpret_cast<const f32x4*>(side_b + lc);
+        bv[q][1] = *reinterpret_cast<const f32x4*>(side_b + lc + 4);
     }
     struct Aux { u32x4 h[NIT]; u32x2_t l[NIT]; };
     auto load_aux = [&](int sl, Aux& a) {
@@ -276,7 +350,11 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
         }
     };
     Aux aux_a, aux_b;
-    load_aux(0, aux_a);
+    if (CPT_PROD_AUX0) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax0h[0]), "+v"(ax0h[1]), "+v"(ax0h[2]), "+v"(ax0l[0]), "+v"(ax0l[1]), "+v"(ax0l[2]) : : "memory");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) { aux_a.h[it] = ax0h[it]; aux_a.l[it] = ax0l[it]; }
+    } else load_aux(0, aux_a);
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) {
 #pragma unroll
@@ -379,7 +457,7 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
                         const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
                         void* out_hi, void* out_lo, float* st_out, int ldo, int M, int N, int K, hipStream_t s,
                         const void* pf0, size_t pf0_bytes, const void* pf1, size_t pf1_bytes) {
-    if (!panel_eligible(M, N, K) || ldw % 8) return CPT_ERR_SHAPE;
+    if (!panel_eligible(M, N, K) || ldw % 8 || (st_in && ln_stat_parts(hidden) > 8)) return CPT_ERR_SHAPE;     // (the prologue fetches 8 slots of partial row sums)
     if (((uintptr_t)pf0 | (uintptr_t)pf1) & 15) return CPT_ERR_ALIGN;
     if (!A_panel || !W || !resid_hi || !resid_lo || !out_hi || !out_lo || !st_out) return CPT_ERR_NULL;
     if ((size_t)M * ldo * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;      // 32-bit store offsets
