@@ -406,10 +406,14 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         Scope p(CPT_K_IMG, s);
         void* imgp = ws + w.imgp;
         TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
-        TRY(gm(CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, pre, CPT_F32, H, B * Li, H), "gemm(img_embedding)");
+        // bf16: K split over two workgroups per tile, the LayerNorm pass adds the two partial matrices (gemm_img_proj)
+        const bool split2 = lp && d.img_dim_pad >= 128 && d.img_dim_pad % 64 == 0 && (size_t)2 * B * Li <= (size_t)M;
+        if (split2) TRY(cpt::gemm_img_proj(imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, pre, H, B * Li, H, d.img_dim_pad, s), "gemm(img_embedding, split K)");
+        else TRY(gm(CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, pre, CPT_F32, H, B * Li, H), "gemm(img_embedding)");
         const bool iln = d.use_img_ln && m->img_ln_g;
         TRY(cpt::layernorm_rows_ex(pre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, r3 ? nullptr : x_f32,
-                                   lp ? x_lp : nullptr, dt, B * Li, H, Li, L, Lt, 0, s, nullptr, nullptr, nullptr, r3 ? x_lo : nullptr), "layernorm(img)");
+                                   lp ? x_lp : nullptr, dt, B * Li, H, Li, L, Lt, 0, s, split2 ? pre + (size_t)B * Li * H : nullptr, nullptr, nullptr,
+                                   r3 ? x_lo : nullptr), "layernorm(img)");
     }
     // (a5-a9) encoder
     const int mask3 = (flags & CPT_ATTN_MASK_3D) ? 1 : 0;

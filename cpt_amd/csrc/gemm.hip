@@ -1179,6 +1179,17 @@ int gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, con
     return CPT_ERR_DTYPE;
 }
 
+// Region projection of the bf16 path (modeling_bert.py:261 img_embedding: M = B * regions rows, K = 2054 padded to 2112, N = hidden): K split
+// over TWO workgroups per 128 x 192 tile -- 200 workgroups of 16-17 K-tiles at B = 64 instead of 200 of 33 with 64-row tiles -- each
+// writing its own fp32 partial matrix (out, then out + M * ldo; bias in the first); the LayerNorm pass that follows adds the two
+// (layernorm_rows_ex resid).  Always split, whatever M: a row's bits must not depend on the batch it travels in.
+int gemm_img_proj(const void* A, int lda, const void* W, int ldw, const float* bias, float* out2, int ldo, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K < 128 || K % 64 || lda % 8 || ldw % 8 || N % 4 || ldo % 4) return CPT_ERR_SHAPE;
+    if (!A || !W || !out2) return CPT_ERR_NULL;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out2 | (uintptr_t)bias) & 15)) return CPT_ERR_ALIGN;
+    return launch_pipe<bf16, CPT_EPI_NONE, float, 128, 192, 4, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, out2, ldo, M, N, K, s, 2);
+}
+
 int g_splitk_target = 384;
 void set_splitk_target(int v) { g_splitk_target = v; }
 

@@ -118,40 +118,30 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
         }
     };
 
-    // side data (the tile's column vectors and row statistics): the global loads go FIRST, so that the compiler's wait for
-    // them does not drain the operand DMA issued behind them
+    // Side data (the tile's column vectors and its 384 rows' partial LayerNorm sums): requested by INLINE ASM right behind the first
+    // K-tile's DMA and parked in LDS after the first barrier (round 3).  Round 2 loaded them with plain loads AHEAD of the DMA -- hipcc
+    // waits vmcnt(0) for a plain load's first use while LDS-DMA is in flight, so they had to come first, and the wave sat through
+    // their round trip before it issued the first operand tile: two round trips in the prologue instead of one.
     float* side_c = reinterpret_cast<float*>(smem + SIDE_C);
     float* side_d = reinterpret_cast<float*>(smem + SIDE_D);
     float2* side_st = reinterpret_cast<float2*>(smem + SIDE_ST);
-    f32x4 cd = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 64) cd = *reinterpret_cast<const f32x4*>(colc + n0 + tid * 4);
-    else if (tid < 128) cd = *reinterpret_cast<const f32x4*>(cold + n0 + (tid - 64) * 4);
-    float2 ms_mine = {0.f, 1.f};
-    if (tid < TM) {
-        const int row = min(m0 + tid, M - 1);
+    constexpr int NSIDE = 7;                       // asm loads per lane: one column-vector quad + six quads of partial sums (always issued)
+    f32x4 cd, sv[6];
+    stage_a(0, 0); stage_w(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const float* cdp = tid < 64 ? colc + n0 + tid * 4 : cold + n0 + (min(tid, 127) - 64) * 4;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cd) : "v"(cdp));
+        const int row = min(m0 + min(tid, TM - 1), M - 1);
         const int slots = (st_parts + 1) & ~1, nq = slots >> 1;
         const f32x4* base = reinterpret_cast<const f32x4*>(st_in + (size_t)row * slots * 2);
-        f32x4 v[6];                                // up to 12 slots (hidden <= 1152), all loads in flight together
 #pragma unroll
-        for (int q = 0; q < 6; ++q) v[q] = base[min(q, nq - 1)];
-        float sum = 0.f, sq = 0.f;                 // slot order: bit-reproducible (gemm.hip sum_parts)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const bool u0 = 2 * q < st_parts, u1 = 2 * q + 1 < st_parts;
-            sum += u0 ? v[q][0] : 0.f; sq += u0 ? v[q][1] : 0.f;
-            sum += u1 ? v[q][2] : 0.f; sq += u1 ? v[q][3] : 0.f;
-        }
-        float mu, rs;
-        ln_mean_rstd(sum, sq, inv_h, eps, mu, rs);
-        ms_mine = float2{mu, rs};
+        for (int q = 0; q < 6; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sv[q]) : "v"(base + min(q, nq - 1)));   // up to 12 slots (hidden <= 1152)
     }
-    __builtin_amdgcn_sched_barrier(0);             // (loads stay ahead of the DMA in program order: the compiler's counted wait for them passes the DMA)
-    stage_a(0, 0); stage_w(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     stage_a(1, 1); stage_w(1, 1);
     stage_w(2, 2);
-    if (tid < 64) *reinterpret_cast<f32x4*>(side_c + tid * 4) = cd;
-    else if (tid < 128) *reinterpret_cast<f32x4*>(side_d + (tid - 64) * 4) = cd;
-    if (tid < TM) side_st[tid] = ms_mine;
+    __builtin_amdgcn_sched_barrier(0);
 
     f32x16 acc0[MI][NJ], acc1[MI][NJ];
 #pragma unroll
@@ -261,13 +251,31 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
         }
     };
 
-    // issued so far per wave: A0 W0 A1 W1 W2 = 3 4 3 4 4 pieces; tile 0 is complete when at most 11 are outstanding
-    wait_vm<GA + 2 * GW>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // side data written
-    __builtin_amdgcn_s_barrier();                               // tile 0 and the side data visible to every wave
+    // issued so far per wave: A0 W0 | side | A1 W1 W2 = 3 4 | 7 | 3 4 4; tile 0 is complete when at most 7 + 11 are outstanding
+    wait_vm<NSIDE + GA + 2 * GW>();
+    __builtin_amdgcn_s_barrier();                               // tile 0 visible to every wave
     if (trace) tr1 = clock64();
     CPT_SB();
     rd_b(0, 0, 0); rd_a(0, 0, 0); rd_a(1, 0, 0); rd_a(2, 0, 0);
+    CPT_SB();
+    // the side data (issued with tile 0) has landed too: reduce the partial sums in slot order (bit-reproducible, gemm.hip sum_parts) and
+    // park everything in LDS; its first readers (pass 0's epilogue pieces under pass 1) sit behind many K-tile barriers
+    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(cd), "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]) : "n"(GA + 2 * GW) : "memory");
+    CPT_SB();
+    if (tid < 64) *reinterpret_cast<f32x4*>(side_c + tid * 4) = cd;
+    else if (tid < 128) *reinterpret_cast<f32x4*>(side_d + (tid - 64) * 4) = cd;
+    if (tid < TM) {
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const bool u0 = 2 * q < st_parts, u1 = 2 * q + 1 < st_parts;
+            sum += u0 ? sv[q][0] : 0.f; sq += u0 ? sv[q][1] : 0.f;
+            sum += u1 ? sv[q][2] : 0.f; sq += u1 ? sv[q][3] : 0.f;
+        }
+        float mu, rs;
+        ln_mean_rstd(sum, sq, inv_h, eps, mu, rs);
+        side_st[tid] = float2{mu, rs};
+    }
     CPT_SB();
 
     // Steady state of iteration `it` (K-tile it of 2 NT): after its last fragment reads are retired, wait for tile it+1

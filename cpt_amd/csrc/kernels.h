@@ -80,6 +80,8 @@ int gemm_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias
 // bf16 NT GEMM, fp32 out (+ bias, + resid), K split for small row counts; CPT_ERR_SHAPE = not worth it / not applicable (caller: plain gemm)
 int gemm_nt_split(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr, float* out, int ldo, int M, int N, int K,
                   void* partials, size_t partial_bytes, hipStream_t s);
+// bf16 region projection: two fp32 partial matrices out2[2][M][ldo] (K split in two; bias in the first), summed by the LayerNorm pass behind it
+int gemm_img_proj(const void* A, int lda, const void* W, int ldw, const float* bias, float* out2, int ldo, int M, int N, int K, hipStream_t s);
 int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s);
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
