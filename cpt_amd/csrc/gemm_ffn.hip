@@ -44,7 +44,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // PANEL: out is the fragment-major panel copy [M / 32][N / 16][64][8] the FFN-down producer reads (gemm_prod.hip), rows padded to a
 // multiple of 32 by the caller; every 16-byte store of a half-wave then lands in one contiguous 512 bytes.
-template <int NT, bool LATE = true, bool PANEL = false>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
+// PIPE: pass 0's epilogue retires under pass 1's K loop (round 2).  Measured in the model in round 3 (ablation build): the pieces ADD
+// 17 k ticks to pass 1 (46.0 k vs 29.1 k without them) while the same work takes 8.8 k ticks when it runs exposed behind the loop
+// (VALU issued between dependent MFMAs costs more than its issue slots, and both waves of a SIMD pay it) -- PIPE = false runs both
+// epilogues behind pass 1.
+#ifndef CPT_FFN_PIPE
+#define CPT_FFN_PIPE 0
+#endif
+template <int NT, bool LATE = true, bool PANEL = false, bool PIPE = (CPT_FFN_PIPE != 0)>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
 __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                                                               bf16* __restrict__ out, int ldo, int M, int N,
                                                               const float* __restrict__ st_in, int st_parts, const float* __restrict__ colc,
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
         constexpr int NP = MI * NJ * 2;            // 12 pairs
         const int it = NT + kt;
         const int a_s = it & 1, w_s = it % NW_, w_s1 = (it + 1) % NW_;
-        const bool epi = kt < NP && !(abl & 8);
+        const bool epi = PIPE && kt < NP && !(abl & 8);
         const bool more = kt + 1 < NT;
         u32x2 k0 = {0, 0}, k1 = {0, 0};
         CPT_KSTEP(acc1, 0, a_s, w_s, 1, true);
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
     if (trace) tr2 = clock64();
     // pairs of pass 0 that did not fit under pass 1 (NT < 12), then pass 1's own epilogue (exposed)
 #pragma unroll
-    for (int p = NT; p < MI * NJ * 2; ++p) {
+    for (int p = PIPE ? NT : 0; p < MI * NJ * 2; ++p) {
         const u32x2 k0 = epi_quad(acc0[p >> 2][(p >> 1) & 1], 0, p, 0), k1 = epi_quad(acc0[p >> 2][(p >> 1) & 1], 0, p, 1);
         epi_store(0, p, k0, k1);
     }

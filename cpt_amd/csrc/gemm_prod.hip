@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void panel_pack_kernel(const uint4* __restrict
 }  // namespace
 
 extern long long* g_gemm_trace;
-extern int g_trace_k;       // diagnostics: stamp only launches of this K (0: all)
+extern int g_trace_k, g_trace_epi;       // diagnostics: stamp only launches of this K (0: all) / this epilogue id (-1: all; the producers are 11)
 int g_prod_abl = 0;          // timing experiments (cpt_set_tuning key 13), see prod3_panel_kernel
 void set_prod_abl(int v) { g_prod_abl = v; }
 
@@ -479,7 +479,7 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     const int nwg = ntile + npf;
 #define CPT_LAUNCH(ABL) prod3_panel_kernel<ABL><<<dim3(nwg), dim3(512), LDS_BYTES, s>>>(                                                         \
         (const bf16*)A_panel, (const bf16*)W, ldw, bias, (const bf16*)resid_hi, (const signed char*)resid_lo, ldr, st_in, ln_stat_parts(hidden), g_in, b_in, \
-        eps, 1.0f / (float)hidden, (bf16*)out_hi, (signed char*)out_lo, ldo, st_out, ln_stat_slots(N), M, N, K, (g_trace_k == 0 || g_trace_k == K) ? g_gemm_trace : nullptr, \
+        eps, 1.0f / (float)hidden, (bf16*)out_hi, (signed char*)out_lo, ldo, st_out, ln_stat_slots(N), M, N, K, ((g_trace_epi < 0 || g_trace_epi == 11) && (g_trace_k == 0 || g_trace_k == K)) ? g_gemm_trace : nullptr, \
         pf0, pf0_bytes, pf1, pf1_bytes)
     switch (g_prod_abl) {
         case 1: CPT_LAUNCH(1); break;

@@ -359,7 +359,7 @@ int q3_launch(const Q3Args& a, int B, hipStream_t s) {
 
 }  // namespace
 
-extern int g_q3_abl;
+extern int g_q3_abl, g_trace_epi;
 long long* g_q3_trace = nullptr;
 void set_q3_trace(void* p) { g_q3_trace = (long long*)p; }
 // (K = hidden <= 768: the rows' partial LayerNorm sums fit 8 slots = the 8 KB the kernel parks them in)
@@ -377,7 +377,7 @@ int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* 
     a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias; a.w_tiled = w_tiled ? 1 : 0;
     if (w_tiled && ldw != K) return CPT_ERR_SHAPE;
     a.st_in = st_in; a.st_parts = ln_stat_parts(hidden); a.colc = colc; a.cold = cold; a.eps = eps; a.inv_h = 1.0f / (float)hidden;
-    a.trace = g_q3_trace;
+    a.trace = (g_trace_epi < 0 || g_trace_epi == 10) ? g_q3_trace : nullptr;      // (diagnostics: trace filter by epilogue id, 10 = fused QKV + attention)
     a.mask = mask; a.ctx = (bf16*)ctx; a.ldo = ldo; a.M = B * L; a.K = K; a.L = L; a.heads = heads;
     if (st_in) switch (g_q3_abl) {        // diagnostic instantiations (tools/abl_sweep.sh): cpt_set_tuning(1, bits)
         case 1: return q3_launch<true, 1>(a, B, s);

@@ -35,7 +35,7 @@ def main():
     nwg = (M // 128) * 4
     for name, K in (("attn_out", 768), ("ffn_down", 3072)):
         tr = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
-        lib.cpt_set_tuning(8, 255 | (K << 8))
+        lib.cpt_set_tuning(8, 11 | (K << 8))
         lib.cpt_debug_gemm_trace(C.c_void_p(tr.data_ptr()))
         for _ in range(3):
             fwd()

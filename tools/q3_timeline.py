@@ -28,7 +28,7 @@ for _ in range(3):
     fwd()
 buf = torch.zeros(4096 * 8, device=dev, dtype=torch.int64)
 L.check(L.lib().cpt_set_tuning(1, abl))
-L.check(L.lib().cpt_set_tuning(8, 255 | (1 << 8)))     # the panel producers share the trace buffer: stamp none of them (no launch has K = 1)
+L.check(L.lib().cpt_set_tuning(8, 10))     # the GEMMs share the trace buffer: stamp only the fused QKV + attention launches (epilogue id 10)
 L.lib().cpt_debug_gemm_trace(buf.data_ptr())
 fwd()
 torch.cuda.synchronize()
