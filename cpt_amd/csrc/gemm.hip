@@ -174,7 +174,6 @@ struct EpiX {
     int seq_len, heads;    // ATTN: tokens per sequence (<= 128), attention heads
     int w_rows;            // NN form: rows of W that exist (0: K); rows beyond read as zero (K rounded up to a K-tile multiple)
     int skew;              // two-workgroups-per-CU shapes: start delay of every second workgroup (see skew_start)
-    int out_panel_k16;     // direct epilogue (LNCONS*): != 0 -> out leaves in the fragment-major panel layout (common.h panel_unit), value = N / 16
 };
 
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
@@ -658,10 +657,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                         const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
                         const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
                         const int c8 = wcol0 + j * 32 + 16 * gp + 8 * fh;
-                        if (rok && (FULL || c8 < N) && !(abl & 64)) {
-                            if (!LNPROD && ex.out_panel_k16) *reinterpret_cast<u32x4*>(out_lp + (size_t)panel_unit(row, c8 >> 3, ex.out_panel_k16) * 8) = w;
-                            else *reinterpret_cast<u32x4*>(out_lp + (size_t)row * ldo + c8) = w;
-                        }
+                        if (rok && (FULL || c8 < N) && !(abl & 64)) *reinterpret_cast<u32x4*>(out_lp + (size_t)row * ldo + c8) = w;
                     }
                 if constexpr (LNPROD) {
                     sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
@@ -1415,11 +1411,6 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
     EpiX ex = {};
     ex.st_in = st_in; ex.st_in_parts = ln_stat_parts(hidden); ex.colc = colc; ex.cold = cold; ex.eps = eps; ex.inv_h = 1.0f / (float)hidden;
     const int v = g_gemm_variant >= 3 ? g_gemm_variant : 3;
-    if (out_panel && v == 19 && gelu && M % 32 == 0 && N % 16 == 0) {     // experiment: the one-pass 384 x 256 tile with panel output
-        ex.out_panel_k16 = N / 16;
-        launch_fast<bf16, CPT_EPI_LNCONS_GELU, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
-        return CPT_OK;
-    }
     if (out_panel) {      // output in the panel layout of the FFN-down producer (gemm_prod.hip): the two-pass kernel only
         if (!gelu || !ffn_up_2pass_legal(M, N, K)) return CPT_ERR_SHAPE;
         void* tr = ((g_trace_epi < 0 || g_trace_epi == CPT_EPI_LNCONS_GELU) && (g_trace_k == 0 || g_trace_k == K)) ? (void*)g_gemm_trace : nullptr;

@@ -16,12 +16,14 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--n", type=int, default=768, help="output columns (192: one column tile per row tile, 60 workgroups -- no sibling tiles share A rows)")
+    ap.add_argument("--no-cold", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    M, H, I = a.batch * 120, 768, 3072
+    M, H, I = a.batch * 120, a.n, 3072
     torch.manual_seed(0)
     lib = L.lib()
-    for name, K in (("attn_out", H), ("ffn_down", I)):
+    for name, K in (("attn_out", 768), ("ffn_down", I)):
         x = torch.randn(M, H, device=dev) * 1.2 + 0.3
         hi, lo = ops.resid3_split(x)
         st = ops.row_stats_table(x)
@@ -85,6 +87,8 @@ def main():
                 print("          per XCD (workgroups, mean duration, mean K loop): " + "  ".join(
                     "%d: %d %.0f %.0f" % (x, int((xcc == x).sum()), dur[xcc == x].mean().item(), (t[:, 2] - t[:, 1]).float()[xcc == x].mean().item()) for x in range(8)), flush=True)
         lib.cpt_set_tuning(13, 0)
+        if a.no_cold:
+            continue
         # operand temperature, as inside the model: caches flushed by a 1 GiB fill, then chosen operands touched again
         big = torch.empty(1 << 28, dtype=torch.float32, device=dev)
         actp2 = actp.clone()

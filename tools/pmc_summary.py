@@ -10,6 +10,10 @@ import sys
 def family(name, prev):
     if "ffn_up_2pass_kernel" in name:
         return "gemm_ffn_up(+gelu)"                     # gemm_ffn.hip: the two-pass 384 x 256 FFN-up kernel
+    if "qkv3_attn_kernel" in name:
+        return "gemm_qkv_attn"                          # qkv_attn3.hip: QKV projection + attention, one workgroup per (sequence, three heads)
+    if "prod3_panel_kernel" in name:                    # gemm_prod.hip: LayerNorm producers reading A from its panel copy
+        return "gemm_attn_out" if prev in ("attention", "gemm_qkv_attn") else "gemm_ffn_down"
     if "gemm_pipe_kernel" in name:
         # template arguments: <T, EPI, OT, ...>; EPI 0 none, 1 gelu, 3 resid, 6 / 11 LN producer, 7/8 LN consumer (+gelu), 9/10 fused QKV + attention
         if "Li9EDF16b" in name or "Li10EDF16b" in name:

@@ -15,7 +15,7 @@ python bench.py --steps 5 --warmup 2 --mode train --workload gqa > $O/${T}_bench
 python bench.py --steps 5 --warmup 2 --mode train --workload vcr > $O/${T}_bench_train_vcr_large_b8_bf16.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --all-rows --no-cpu > $O/${T}_bench_b64_bf16_allrows.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rm -rf $O/${T}_prof; rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu --no-roofline > $O/${T}_bench_under_rocprof.json 2> $O/${T}_prof.log
+rm -rf $O/${T}_prof; rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu --no-roofline --no-extra > $O/${T}_bench_under_rocprof.json 2> $O/${T}_prof.log
 rm -rf $O/${T}_prof_train; rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof_train -- python $R/bench.py --steps 10 --warmup 3 --mode train --no-cpu > $O/${T}_bench_train_under_rocprof.json 2> $O/${T}_prof_train.log
 cd $R
 find $O/${T}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${T}_bench_b64_bf16_kernel_stats.csv
@@ -23,4 +23,7 @@ find $O/${T}_prof_train -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $
 # keep the merge-back small
 rm -rf $O/${T}_prof $O/${T}_prof_train
 find $O/${T}_pmc -name "*.csv" -size +1M -delete 2>/dev/null
+python tools/panel_model_trace.py > $O/${T}_panel_model_trace.txt 2>&1
+python tools/q3_timeline.py > $O/${T}_q3_timeline.txt 2>&1
+python tools/panel_bench.py --rounds 2 > $O/${T}_panel_bench.txt 2>&1
 ls -la $O | grep ${T}_
