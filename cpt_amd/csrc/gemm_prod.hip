@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
         if (pf1) prefetch_region(pf1, pf1_bytes, blockIdx.x, npf, threadIdx.x, 512, smem);
         return;
     }
-    long long tr0 = 0, tr1 = 0, tr2 = 0, tw0 = 0;
+    long long tr0 = 0, tr1 = 0, tr2 = 0, tw0 = 0, tra = 0, trb = 0;
     if (trace) { tr0 = clock64(); tw0 = wall_clock64(); }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,11 +169,13 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
     // Loads complete in issue order, so "tile t+1 has landed" (its A fragments, older: its W pieces) = at most the ops issued
     // after A(t+1) outstanding: W(t+2), A(t+2), W(t+3) = 2 GW + GA -- except in iteration 0, where W(1) is the younger one of
     // tile 1's two parts and only W(2) W(3) may stay in flight.
+    if (trace) tra = clock64();
     if (CPT_PROD_SIDE == 1) { CPT_SIDE_LOADS(); CPT_SB(); }
     CPT_A_LOAD(0, 0); CPT_SB(); stage_w(0, 0); CPT_SB();
     if (CPT_PROD_SIDE == 2) { CPT_SIDE_LOADS(); CPT_SB(); }
     CPT_A_LOAD(1, 1); CPT_A_LOAD(2, 2); CPT_SB();
     stage_w(1, 1); stage_w(2, 2); stage_w(3, 3); CPT_SB();
+    if (trace) trb = clock64();
 
     bf16x8 fb[4][NJ];
     auto ldfrag = [&](int slot, int ks, int pb) {
@@ -415,8 +417,8 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
         long long* tp = trace + (size_t)(blockIdx.x - npf) * 8;
         tp[0] = tr0; tp[1] = tr1; tp[2] = tr2; tp[3] = tw0; tp[4] = clock64();
         tp[5] = wall_clock64();                                  // (3, 5: the 100 MHz chip-wide counter at start / end)
-        tp[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        tp[7] = blockIdx.x;
+        tp[6] = tra - tr0;                                      // prologue split: set-up (index math, descriptors) ...
+        tp[7] = trb - tra;                                      // ... issue of the prologue's loads (then, up to stamp 1: wait for tile 0)
     }
 #endif
 }

@@ -79,8 +79,8 @@ def main():
             wdur = (t[:, 5] - t[:, 3]).float() * 0.01
             ghz = (dur / wdur).mean().item() * 1e-3
             print("%-9s panel kernel abl %d: %.2f us; mean ticks per workgroup: prologue %.0f  K loop %.0f (%.0f per K-tile)  epilogue %.0f | whole: mean %.0f max %.0f "
-                  "min %.0f; shader clock %.2f GHz; workgroup wall time mean %.2f max %.2f us; first start -> last end %.2f us; start spread mean %.2f max %.2f us"
-                  % (name, abl, us, pro, kl, kl / (K // 64), ep, dur.mean().item(), dur.max().item(), dur.min().item(), ghz, wdur.mean().item(), wdur.max().item(),
+                  "min %.0f; prologue = set-up %.0f + issue %.0f + wait; shader clock %.2f GHz; workgroup wall time mean %.2f max %.2f us; first start -> last end %.2f us; start spread mean %.2f max %.2f us"
+                  % (name, abl, us, pro, kl, kl / (K // 64), ep, dur.mean().item(), dur.max().item(), dur.min().item(), t[:, 6].float().mean().item(), t[:, 7].float().mean().item(), ghz, wdur.mean().item(), wdur.max().item(),
                      span, late.mean().item(), late.max().item()), flush=True)
             if False:
                 xcc = t[:, 6] & 15
