@@ -561,9 +561,11 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
             if (pre_ln) {
                 const cpt_layer& yl = m->layers[d.layers - 1];
                 float* rf = (float*)(ws + w.rows_f32);
-                if (r3) TRY(cpt::r3_merge(x_lp, x_lo, b->mask_pos, rf, B, L, H, 1, s), "resid3_merge([MASK] pre-LN)");
-                else TRY(cpt::gather_rows(x_f32, CPT_F32, b->mask_pos, rf, B, L, H, s), "gather([MASK] pre-LN)");
+                if (r3) TRY(cpt::head_rows_ln3(x_lp, x_lo, b->mask_pos, yl.ln2_g, yl.ln2_b, d.ln_eps, g, B, L, H, s), "gather + merge + layernorm([MASK] rows)");
+                else {
+                TRY(cpt::gather_rows(x_f32, CPT_F32, b->mask_pos, rf, B, L, H, s), "gather([MASK] pre-LN)");
                 TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, g, dt, B, H, B, 0, 0, s), "layernorm([MASK] rows)");
+                }
             } else {
                 TRY(cpt::gather_rows(x_lp, dt, b->mask_pos, g, B, L, H, s), "gather([MASK])");
             }
@@ -571,8 +573,16 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         }
         float* t1 = (float*)(ws + w.t1);
         void* t2 = ws + w.t2;
+        // bf16, [MASK] rows only: the transform GEMM splits K over workgroups (4 tiles of 12 K-tiles each would run on 4 CUs), the pass
+        // behind it adds the partial matrices, applies GELU and the LayerNorm.  The split depends on H only: same bits for every batch.
+        const int hs = cpt::head_transform_splits(H);
+        if (lp && !all && H % 64 == 0 && hs > 1 && (size_t)hs * R <= (size_t)M) {
+            TRY(cpt::gemm_head_transform(rows, H, m->w_tr, H, m->b_tr, pre, R, H, H, s), "gemm(head transform, split K)");
+            TRY(cpt::head_finish(pre, hs, m->tr_ln_g, m->tr_ln_b, d.ln_eps, t2, R, H, s), "reduce + gelu + layernorm(head)");
+        } else {
         TRY(gm(CPT_EPI_GELU, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, t1, CPT_F32, H, R, H), "gemm(head transform)");
         TRY(cpt::layernorm_rows(t1, m->tr_ln_g, m->tr_ln_b, d.ln_eps, lp ? nullptr : (float*)t2, lp ? t2 : nullptr, dt, R, H, R, 0, 0, s), "layernorm(head)");
+        }
         TRY(gm(CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, R, d.vocab), "gemm(decoder)");
         if (flags & CPT_OUT_LOSS) {
             hipError_t e = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);

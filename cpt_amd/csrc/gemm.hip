@@ -1186,6 +1186,18 @@ int gemm_img_proj(const void* A, int lda, const void* W, int ldw, const float* b
     return launch_pipe<bf16, CPT_EPI_NONE, float, 128, 192, 4, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, out2, ldo, M, N, K, s, 2);
 }
 
+// Head transform of the bf16 path (BertPredictionHeadTransform.dense on the B [MASK] rows: 64 x 768 x 768 at B = 64 ran as FOUR workgroups
+// of 12 K-tiles in sequence, 14 us): K split over S workgroups per 64 x 192 tile, each writing its own fp32 partial matrix
+// partials[S][M][N] (bias in the first); rowops.hip head_finish adds them in split order, applies GELU and the LayerNorm.  S depends on K
+// only (two K-tiles per split), never on the batch.
+int head_transform_splits(int K) { const int nt = K / 64; return nt >= 4 ? nt / 2 : 1; }
+int gemm_head_transform(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K < 64 || K % 64 || lda % 8 || ldw % 8 || N % 4) return CPT_ERR_SHAPE;
+    if (!A || !W || !partials) return CPT_ERR_NULL;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)partials | (uintptr_t)bias) & 15)) return CPT_ERR_ALIGN;
+    return launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, partials, N, M, N, K, s, head_transform_splits(K));
+}
+
 int g_splitk_target = 384;
 void set_splitk_target(int v) { g_splitk_target = v; }
 

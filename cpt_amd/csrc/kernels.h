@@ -82,6 +82,12 @@ int gemm_nt_split(const void* A, int lda, const void* W, int ldw, const float* b
                   void* partials, size_t partial_bytes, hipStream_t s);
 // bf16 region projection: two fp32 partial matrices out2[2][M][ldo] (K split in two; bias in the first), summed by the LayerNorm pass behind it
 int gemm_img_proj(const void* A, int lda, const void* W, int ldw, const float* bias, float* out2, int ldo, int M, int N, int K, hipStream_t s);
+// MLM head on the [MASK] rows, bf16 path (round 3): gather + 3-byte merge + LayerNorm in one launch; transform GEMM with K split over
+// workgroups (partials[S][M][N], S = head_transform_splits(K)); reduction + GELU + LayerNorm in one launch
+int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, void* out_bf16, int R, int L, int H, hipStream_t s);
+int head_transform_splits(int K);
+int gemm_head_transform(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s);
+int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s);
 int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s);
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,

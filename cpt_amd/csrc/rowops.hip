@@ -392,6 +392,66 @@ int r3_merge(const void* hi, const void* lo, const int64_t* pos, float* out, int
     return CPT_OK;
 }
 
+// ---- MLM head on the [MASK] rows, bf16 throughput path (round 3) -----------------------------------------------------------
+// head_rows_ln3: row b of the output = LayerNorm(decode(hi, lo)[b * L + pos[b]]) as bf16: the gather / merge pass and the LayerNorm pass
+// of the head's input rows in one launch (one wave per row).  The same arithmetic as r3_merge + layernorm_rows.
+__global__ __launch_bounds__(ROW_THREADS) void head_rows_ln3_kernel(const u32x2_t* __restrict__ hi, const unsigned* __restrict__ lo, const int64_t* __restrict__ pos,
+                                                                    const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                                                    bf16* __restrict__ out, int R, int L, int H) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    long p = pos ? pos[r] : 0;
+    p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+    const size_t src = ((size_t)r * L + p) * (H / 4);
+    const int nv = (H + 255) / 256;
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (i < nv && c * 4 < H) v[i] = r3_decode(hi[src + c], lo[src + c]);
+    }
+    float mean, rstd;
+    ln_stats(v, nv, lane, H, mean, rstd, eps);
+    ln_write<bf16>(v, nv, lane, H, mean, rstd, g, bta, nullptr, out + (size_t)r * H);
+}
+int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, void* out_bf16, int R, int L, int H, hipStream_t s) {
+    if (!hi || !lo || !g || !bta || !out_bf16) return CPT_ERR_NULL;
+    if (R <= 0 || L <= 0 || H <= 0 || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
+    head_rows_ln3_kernel<<<dim3((R + 3) / 4), dim3(ROW_THREADS), 0, s>>>((const u32x2_t*)hi, (const unsigned*)lo, pos, g, bta, eps, (bf16*)out_bf16, R, L, H);
+    return CPT_OK;
+}
+// head_finish: row r of the output = LayerNorm(gelu(sum over the S split-K partial matrices of row r)) as bf16 (the bias rides in partial 0):
+// the reduction of the K-split transform GEMM, BertPredictionHeadTransform's GELU and its LayerNorm in one launch.  Partials are added
+// in split order (deterministic); GELU = the bf16 path's gelu_fast, as the GEMM epilogue it replaces.
+__global__ __launch_bounds__(ROW_THREADS) void head_finish_kernel(const f32x4* __restrict__ part, int S, const float* __restrict__ g, const float* __restrict__ bta,
+                                                                  float eps, bf16* __restrict__ out, int R, int H) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int nv = (H + 255) / 256, q = H / 4;
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (i < nv && c * 4 < H) {
+            f32x4 a = part[(size_t)r * q + c];
+            for (int k = 1; k < S; ++k) { const f32x4 b = part[((size_t)k * R + r) * q + c]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+            const f32x2 g0 = gelu_fast2(f32x2{a[0], a[1]}), g1 = gelu_fast2(f32x2{a[2], a[3]});
+            v[i] = f32x4{g0[0], g0[1], g1[0], g1[1]};
+        }
+    }
+    float mean, rstd;
+    ln_stats(v, nv, lane, H, mean, rstd, eps);
+    ln_write<bf16>(v, nv, lane, H, mean, rstd, g, bta, nullptr, out + (size_t)r * H);
+}
+int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s) {
+    if (!partials || !g || !bta || !out_bf16) return CPT_ERR_NULL;
+    if (R <= 0 || S <= 0 || H <= 0 || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
+    head_finish_kernel<<<dim3((R + 3) / 4), dim3(ROW_THREADS), 0, s>>>((const f32x4*)partials, S, g, bta, eps, (bf16*)out_bf16, R, H);
+    return CPT_OK;
+}
+
 // ---- cross entropy over rows (ignore_index = -1) ----------------------------------------------
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                       float* __restrict__ loss, float* __restrict__ dlogits, int R, int V) {
