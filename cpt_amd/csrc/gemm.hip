@@ -1036,7 +1036,8 @@ static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bi
                        OT* out, int ldo, int M, int N, int K, hipStream_t s, int splitk = 1, const EpiX* ex = nullptr) {
     constexpr int LDS = STAGES * (TBM + TBN) * ROWB;     // the epilogue's per-wave slabs reuse the ring
     auto kern = gemm_pipe_kernel<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP, FD, OCC, TN>;
-    static bool attr_done = false;
+    static bool attr_done_dev[CPT_MAX_DEV] = {};
+    bool& attr_done = attr_done_dev[current_device_slot()];
     if (LDS > 64 * 1024 && !attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
@@ -1446,7 +1447,8 @@ static int launch_qkv_attn(const bf16* A, int lda, const bf16* W, int ldw, const
                            int M, int N, int K, const EpiX& ex, int B, hipStream_t s) {
     constexpr int LDS = STAGES * (128 + 192) * ROWB;
     auto kern = gemm_pipe_kernel<bf16, EPI, bf16, 128, 192, 4, 2, STAGES, 1, FD, OCC>;
-    static bool attr_done = false;
+    static bool attr_done_dev[CPT_MAX_DEV] = {};
+    bool& attr_done = attr_done_dev[current_device_slot()];
     if (LDS > 64 * 1024 && !attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;

@@ -393,7 +393,8 @@ int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int 
                  const float* colc, const float* cold, float eps, float inv_h, long long* trace, int abl, hipStream_t s,
                  const void* pf = nullptr, size_t pf_bytes = 0) {
     auto kern = ffn_up_2pass_kernel<NT, LATE, PANEL>;
-    static bool attr_done = false;
+    static bool attr_done_dev[CPT_MAX_DEV] = {};
+    bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;

@@ -466,7 +466,8 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     if (ldo % 8 || ldr % 8 || (((uintptr_t)A_panel | (uintptr_t)W | (uintptr_t)out_hi | (uintptr_t)out_lo | (uintptr_t)resid_hi | (uintptr_t)resid_lo |
                                  (uintptr_t)bias | (uintptr_t)g_in | (uintptr_t)b_in) & 15))
         return CPT_ERR_ALIGN;
-    static bool attr_done = false;
+    static bool attr_done_dev[CPT_MAX_DEV] = {};
+    bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
         for (const void* k : {(const void*)prod3_panel_kernel<0>, (const void*)prod3_panel_kernel<1>, (const void*)prod3_panel_kernel<2>, (const void*)prod3_panel_kernel<3>, (const void*)prod3_panel_kernel<4>}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -6,6 +6,10 @@
 
 namespace cpt {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: the launchers remember it per (kernel, device), not per process
+constexpr int CPT_MAX_DEV = 64;
+inline int current_device_slot() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= CPT_MAX_DEV) d = 0; return d; }
+
 int gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias,
          const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
          hipStream_t s);

@@ -347,7 +347,8 @@ __global__ __launch_bounds__(Q3_NW * 64, 3) void qkv3_attn_kernel(Q3Args a) {
 template <bool LN, int ABL = 0, bool PANEL = false>
 int q3_launch(const Q3Args& a, int B, hipStream_t s) {
     auto kern = qkv3_attn_kernel<LN, ABL, PANEL>;
-    static bool attr_done = false;
+    static bool attr_done_dev[CPT_MAX_DEV] = {};
+    bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q3_LDS);
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;

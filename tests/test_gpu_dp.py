@@ -237,7 +237,8 @@ def test_rccl_path_on_one_gpu():
         got = r[(mode, wire)]
         ptol, ltol = (2e-6, 1e-5) if (mode == "fp32" and wire is None) else (4e-3, 5e-2)
         if wire is None:
-            assert got["losses"][0] == l1[0], (mode, got["losses"], l1)
+            # (the mean over the labelled rows is accumulated with fp32 atomics in ce_rows: the row order, hence the last bit, may differ between runs)
+            assert abs(got["losses"][0] - l1[0]) <= 2e-7 * max(1.0, abs(l1[0])), (mode, got["losses"], l1)
             for k, v in m.state_dict().items():
                 if k.startswith("bert.encoder.") and k.endswith("weight") and v.dim() == 2:      # GEMM-produced gradients: no atomics on their path
                     assert torch.equal(got["sd1"][k], v.cpu()), (mode, k)
