@@ -202,11 +202,12 @@ __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__
     const float* src = x + (size_t)r * K + c;
     float v[8];
     if (c + 8 <= K && (K & 1) == 0) {
+        // rows of K = 2054 floats start on 8-byte boundaries only: two 16-byte loads from 8-byte-aligned addresses (legal: the HSA target runs
+        // in unaligned-access mode) instead of four 8-byte ones -- half the load instructions of this HBM-bound pass
+        typedef f32x4 f32x4_a8 __attribute__((aligned(8)));
+        const f32x4 t0 = *reinterpret_cast<const f32x4_a8*>(src), t1 = *reinterpret_cast<const f32x4_a8*>(src + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float2 t = *reinterpret_cast<const float2*>(src + 2 * e);
-            v[2 * e] = t.x; v[2 * e + 1] = t.y;
-        }
+        for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = c + e < K ? src[e] : 0.f;
