@@ -116,6 +116,14 @@ def test_ln_producer_race_screen(dev, K):
     hi, lo = ops.resid3_split(resid)
     bad = _screen(dev, lambda s: ops.gemm_ln_prod3(a, w, bias, hi, lo, st_in, g, bt, 1e-12, N), n=300)
     assert bad == 0, "3-byte producer: %d of the launches differed from the first one" % bad
+    # round 3: the panel producer (A straight into registers by asm loads, W through the LDS ring, ONE hand-counted vmcnt for both
+    # queues, side data and the first residual slice prefetched by asm loads): the kind of synchronisation a timing change would break
+    ap = ops.panel_pack(a)
+    ref = ops.gemm_ln_prod3(a, w, bias, hi, lo, st_in, g, bt, 1e-12, N)
+    got = ops.gemm_ln_prod3_panel(ap, K, w, bias, hi, lo, st_in, g, bt, 1e-12, N)
+    assert all(torch.equal(u, v) for u, v in zip(ref, got))
+    bad = _screen(dev, lambda s: ops.gemm_ln_prod3_panel(ap, K, w, bias, hi, lo, st_in, g, bt, 1e-12, N), n=LAUNCHES if K < 3000 else 300)
+    assert bad == 0, "panel producer: %d of the launches differed from the first one" % bad
 
 
 def test_fused_qkv_attention_race_screen(dev):
