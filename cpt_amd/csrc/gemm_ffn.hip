@@ -428,7 +428,7 @@ int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const flo
     if ((size_t)((M + 31) & ~31) * (out_panel ? N : ldo) * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;      // 32-bit store offsets
     if (out_panel) {
         if (N % 16) return CPT_ERR_SHAPE;
-        if ((uintptr_t)pf & 15) return CPT_ERR_ALIGN;
+        if ((uintptr_t)pf & 15) pf = nullptr;          // (a prefetch region is a hint: dropped when the 16-byte loads cannot take it)
         if (K == 768) return launch_2pass<12, true, true>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s, pf, pf_bytes);
         return launch_2pass<16, true, true>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s, pf, pf_bytes);
     }

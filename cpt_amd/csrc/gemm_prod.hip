@@ -460,7 +460,8 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
                         void* out_hi, void* out_lo, float* st_out, int ldo, int M, int N, int K, hipStream_t s,
                         const void* pf0, size_t pf0_bytes, const void* pf1, size_t pf1_bytes) {
     if (!panel_eligible(M, N, K) || ldw % 8 || (st_in && ln_stat_parts(hidden) > 8)) return CPT_ERR_SHAPE;     // (the prologue fetches 8 slots of partial row sums)
-    if (((uintptr_t)pf0 | (uintptr_t)pf1) & 15) return CPT_ERR_ALIGN;
+    if ((uintptr_t)pf0 & 15) pf0 = nullptr;          // (a prefetch region is a hint: one the 16-byte loads cannot take is dropped, not an error)
+    if ((uintptr_t)pf1 & 15) pf1 = nullptr;
     if (!A_panel || !W || !resid_hi || !resid_lo || !out_hi || !out_lo || !st_out) return CPT_ERR_NULL;
     if ((size_t)M * ldo * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;      // 32-bit store offsets
     if (ldo % 8 || ldr % 8 || (((uintptr_t)A_panel | (uintptr_t)W | (uintptr_t)out_hi | (uintptr_t)out_lo | (uintptr_t)resid_hi | (uintptr_t)resid_lo |
