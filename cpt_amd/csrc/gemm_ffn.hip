@@ -409,6 +409,8 @@ int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int 
 
 }  // namespace
 
+int g_ffn_2pass_min_tiles = 192;      // (cpt_set_tuning key 16: experiments with half batches on two streams)
+void set_ffn_2pass_min_tiles(int v) { g_ffn_2pass_min_tiles = v; }
 int g_ffn_dma_late = 1;      // A/B switch (cpt_set_tuning key 12): 0 = refill DMA issued right behind the barrier (round 2)
 void set_ffn_dma_late(int v) { g_ffn_dma_late = v; }
 
@@ -418,7 +420,7 @@ int ffn_up_2pass_preferred(int M, int N, int K) {
     if (!ffn_up_2pass_legal(M, N, K)) return 0;
     // one workgroup per CU per round: worth it only when the 384 x 256 tiles fill most of the 256 CUs (B = 64 x L = 120:
     // 240 tiles); below that the 128 x 192 two-per-CU shape has 4x the workgroups
-    return (long)((M + TM - 1) / TM) * (N / TN) >= 192;
+    return (long)((M + TM - 1) / TM) * (N / TN) >= g_ffn_2pass_min_tiles;
 }
 
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,

@@ -414,6 +414,7 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *          (cpt_gemm_ln_prod3_panel), 0 = row-major tensors (cpt_gemm_ln_prod3)
  *   key 15 panel mode: 1 (default) = launches that leave CUs idle carry 16 workgroups that read the next launch's weights into the
  *          Infinity Cache, 0 = no prefetch workgroups
+ *   key 16 FFN-up two-pass kernel (and with it panel mode) from this many 384 x 256 tiles on (default 192; experiments with small batches)
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
