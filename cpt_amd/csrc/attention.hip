@@ -35,7 +35,8 @@ __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >>
 template <typename T, int NKB>
 __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kernel(
     const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
-    T* __restrict__ probs, int B, int L, int heads, DropSpec dr, int mask3) {
+    T* __restrict__ probs, int B, int L, int heads, DropSpec dr, int mask3, int ctx_panel) {
+    // ctx_panel (bf16 inference, round 3): ctx leaves in the fragment-major panel layout of the attn-out producer (gemm_prod.hip)
     // mask3: attn_mask is [B][L][L] (one row per query, modeling_bert.py:215-216) instead of [B][L]: the per-key LDS vector
     // then only marks the padding keys and every lane adds its own query's row from global memory
     typedef typename FragOf<T>::type frag_t;
@@ -112,6 +113,10 @@ __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kerne
     if constexpr (LPT) {     // bf16: the shared core (attn_core.h); everything below is the fp32 parity path
         T* crow = ctx + ((size_t)b * L + min(q, L - 1)) * H + h * HD;
         T* prow = probs ? probs + (((size_t)b * heads + h) * L + min(q, L - 1)) * L : nullptr;
+        if (ctx_panel)
+            attn_core_bf16<NKB, VSWZ, true>(fq, sK, sV, sMask, lane, q < L, nullptr, nullptr, L, dr, (uint32_t)blockIdx.x, min(q, L - 1), mrow,
+                                            (void*)ctx, (int)min((size_t)(((size_t)B * L + 31) & ~(size_t)31) * H * 2, (size_t)0x7fffffff), b * L + min(q, L - 1), h * 8, H >> 4);
+        else
         attn_core_bf16<NKB, VSWZ>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)blockIdx.x, min(q, L - 1), mrow);
         return;
     }
@@ -222,7 +227,7 @@ static size_t att_lds_bytes() {
 }
 
 template <typename T, int NKB>
-static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3) {
+static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3, int ctx_panel) {
     const size_t lds = att_lds_bytes<T, NKB>();
     auto kern = attention_kernel<T, NKB>;
     if (lds > 64 * 1024) {
@@ -230,26 +235,27 @@ static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* pro
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
     }
     dim3 grid(B * heads, (L + 127) / 128), block(ATT_THREADS);
-    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads, dr, mask3);
+    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads, dr, mask3, ctx_panel);
     return CPT_OK;
 }
 
 template <typename T>
-static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3) {
-    if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3);
-    if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3);
-    if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3);
-    if (L <= 288) return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3);
+static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3, int ctx_panel) {
+    if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
+    if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
+    if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
+    if (L <= 288) return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
     return CPT_ERR_SHAPE;
 }
 
 int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s,
-              const DropSpec* drop, int mask_3d) {
+              const DropSpec* drop, int mask_3d, int ctx_panel) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
     if (!qkv || !ctx) return CPT_ERR_NULL;
+    if (ctx_panel && (dtype != CPT_BF16 || probs || ((uintptr_t)ctx & 15) || ((size_t)B * L) % 32)) return CPT_ERR_SHAPE;     // panel output: bf16 inference, whole 32-row blocks
     const DropSpec dr = drop ? *drop : DropSpec{};
-    if (dtype == CPT_BF16) return att_dispatch<bf16>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d);
-    if (dtype == CPT_F32) return att_dispatch<float>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d);
+    if (dtype == CPT_BF16) return att_dispatch<bf16>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d, ctx_panel);
+    if (dtype == CPT_F32) return att_dispatch<float>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d, 0);
     return CPT_ERR_DTYPE;
 }
 

@@ -424,8 +424,14 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     // Panel mode (round 3): the attention kernel writes ctx and the FFN-up epilogue writes h as MFMA A fragments (gemm_prod.hip), the two
     // LayerNorm producers read them straight into registers; same bits as the row-major kernels.  Needs the (sequence, three heads)
     // attention form, the two-pass FFN-up kernel and tile-aligned shapes; everything else keeps the row-major tensors.
-    const bool panel = r3 && fuse_attn && g_fuse_attn == 3 && g_panel && cpt::qkv_attn3_eligible(L, d.heads, H) && cpt::ffn_up_2pass_preferred(M, I, H) &&
+    const bool fused3 = fuse_attn && g_fuse_attn == 3 && cpt::qkv_attn3_eligible(L, d.heads, H);
+    const bool two_kernel = lp && !fuse_attn && !mask3;        // L > 128 (the GQA shape): QKV GEMM, then the stand-alone attention kernel writes the panel
+    const bool panel = r3 && g_panel && (fused3 || two_kernel) && cpt::ffn_up_2pass_preferred(M, I, H) &&
                        cpt::panel_eligible(M, H, H) && cpt::panel_eligible(M, H, I);
+    // h (FFN-up -> FFN-down) in the panel layout only when the producers run as ONE round of tiles: over several rounds (GQA shape, 1680 tiles)
+    // the panel producer's longer pipeline fill is paid per tile and loses to the row-major kernel on the K = 3072 launch (4.05 vs 3.84 ms per
+    // step); ctx stays in the panel layout there -- the attention kernel's stores are what gains (2.20 -> 1.91 ms per step)
+    const bool panel_ffn = panel && (long)(M / 128) * (H / 192) <= 256;
     const bool pfw = panel && g_prefetch;           // spare workgroups prefetch the next launch's weights (common.h prefetch_region)
     if (fold) {
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
@@ -450,7 +456,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
               if (l == 0) TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
               else TRY(cpt::gemm_ln_cons(x_lp, H, f.w_qkv_f, H, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, 0, qkv, 3 * H, M, 3 * H, H, s), "gemm(qkv, folded LN)"); }
             { Scope p(CPT_K_ATTN, s);
-              TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s, nullptr, mask3), "attention"); }
+              TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s, nullptr, mask3, panel), "attention"); }
             }
             { Scope p(CPT_K_GEMM_AO, s);
               if (panel) TRY(cpt::gemm_ln_prod3_panel(ctx, y.w_ao, H, y.b_ao, x_lp, x_lo, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
@@ -462,9 +468,9 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
               TRY(cpt::gemm_ln_prod(ctx, H, y.w_ao, H, y.b_ao, x_f32, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
                                     a_f32, a_lp, st1, H, M, H, H, s), "gemm(attn out, LN producer)"); }
             { Scope p(CPT_K_GEMM_FFN1, s);
-              TRY(cpt::gemm_ln_cons(a_lp, H, f.w_in_f, H, st1, f.c_in, f.d_in, d.ln_eps, H, 1, ffn, I, M, I, H, s, panel, pfw ? y.w_out : nullptr, (size_t)H * I * 2), "gemm(ffn up, folded LN)"); }
+              TRY(cpt::gemm_ln_cons(a_lp, H, f.w_in_f, H, st1, f.c_in, f.d_in, d.ln_eps, H, 1, ffn, I, M, I, H, s, panel_ffn, pfw ? y.w_out : nullptr, (size_t)H * I * 2), "gemm(ffn up, folded LN)"); }
             { Scope p(CPT_K_GEMM_FFN2, s);
-              if (panel) {
+              if (panel_ffn) {
                   // next layer's QKV weight (the copy its launch will read) and attention-output weight
                   const void* nq = nullptr; const void* na = nullptr;
                   size_t nqb = (size_t)3 * H * H * 2, nab = (size_t)H * H * 2;

@@ -24,7 +24,8 @@ int layernorm_rows(const float* x, const float* g, const float* bta, float eps, 
                    hipStream_t s);
 
 int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B,
-              int L, int heads, hipStream_t s, const DropSpec* drop = nullptr, int mask_3d = 0);   // mask_3d: attn_mask is [B][L][L]
+              int L, int heads, hipStream_t s, const DropSpec* drop = nullptr, int mask_3d = 0,   // mask_3d: attn_mask is [B][L][L]
+              int ctx_panel = 0);   // ctx_panel (bf16 inference): ctx leaves in the panel layout of the attn-out producer (gemm_prod.hip)
 
 int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s);
 int split3(const float* x, int ld, void* out_bf16, int R, int K, int weight_order, hipStream_t s);
