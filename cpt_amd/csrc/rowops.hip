@@ -436,8 +436,16 @@ __global__ __launch_bounds__(ROW_THREADS) void head_finish_kernel(const f32x4* _
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         if (i < nv && c * 4 < H) {
-            f32x4 a = part[(size_t)r * q + c];
-            for (int k = 1; k < S; ++k) { const f32x4 b = part[((size_t)k * R + r) * q + c]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+            // all partials of this chunk requested before the first add (a loop over a run-time S issued them one round trip at a time)
+            constexpr int SMAX = 8;
+            f32x4 pb[SMAX];
+#pragma unroll
+            for (int k = 0; k < SMAX; ++k) pb[k] = part[((size_t)min(k, S - 1) * R + r) * q + c];
+            f32x4 a = pb[0];
+#pragma unroll
+            for (int k = 1; k < SMAX; ++k)
+                if (k < S) { a[0] += pb[k][0]; a[1] += pb[k][1]; a[2] += pb[k][2]; a[3] += pb[k][3]; }
+            for (int k = SMAX; k < S; ++k) { const f32x4 b = part[((size_t)k * R + r) * q + c]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
             const f32x2 g0 = gelu_fast2(f32x2{a[0], a[1]}), g1 = gelu_fast2(f32x2{a[2], a[3]});
             v[i] = f32x4{g0[0], g0[1], g1[0], g1[1]};
         }
