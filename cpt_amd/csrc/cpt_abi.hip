@@ -478,10 +478,10 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                       const cpt_layer_fold& fn = m->fold[l + 1];
                       nq = (fn.w_qkv_t && g_qkv_tiled) ? fn.w_qkv_t : fn.w_qkv_f;
                       na = m->layers[l + 1].w_ao;
-                  } else if (pfw && (flags & CPT_OUT_MASK_LOGITS) && m->w_dec && m->w_tr) {
+                  } else if (pfw && (flags & CPT_OUT_MASK_LOGITS) && m->w_tr) {
                       // last layer: the MLM head's weights (transform dense, then the 47 MB tied decoder table streamed once by 64 rows)
-                      nq = m->w_tr; nqb = (size_t)H * H * 2;
-                      na = m->w_dec; nab = (size_t)d.vocab * H * 2;
+                      nq = m->w_tr; nqb = (size_t)H * H * 2;          // (the 47 MB decoder table is streamed by the head's first launch, which has the chip to itself)
+                      na = nullptr; nab = 0;
                   }
                   TRY(cpt::gemm_ln_prod3_panel(ffn, y.w_out, I, y.b_out, a_lp, a_lo, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_lp, x_lo, st2, H, M, H, I, s,
                                                nq, nqb, na, nab), "gemm(ffn down, LN producer, panel A)");
@@ -569,7 +569,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
             if (pre_ln) {
                 const cpt_layer& yl = m->layers[d.layers - 1];
                 float* rf = (float*)(ws + w.rows_f32);
-                if (r3) TRY(cpt::head_rows_ln3(x_lp, x_lo, b->mask_pos, yl.ln2_g, yl.ln2_b, d.ln_eps, g, B, L, H, s), "gather + merge + layernorm([MASK] rows)");
+                if (r3) TRY(cpt::head_rows_ln3(x_lp, x_lo, b->mask_pos, yl.ln2_g, yl.ln2_b, d.ln_eps, g, B, L, H, s,
+                                               g_prefetch ? m->w_dec : nullptr, (size_t)d.vocab * H * 2), "gather + merge + layernorm([MASK] rows)");
                 else {
                 TRY(cpt::gather_rows(x_f32, CPT_F32, b->mask_pos, rf, B, L, H, s), "gather([MASK] pre-LN)");
                 TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, g, dt, B, H, B, 0, 0, s), "layernorm([MASK] rows)");

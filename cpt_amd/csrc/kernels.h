@@ -89,7 +89,8 @@ int gemm_nt_split(const void* A, int lda, const void* W, int ldw, const float* b
 int gemm_img_proj(const void* A, int lda, const void* W, int ldw, const float* bias, float* out2, int ldo, int M, int N, int K, hipStream_t s);
 // MLM head on the [MASK] rows, bf16 path (round 3): gather + 3-byte merge + LayerNorm in one launch; transform GEMM with K split over
 // workgroups (partials[S][M][N], S = head_transform_splits(K)); reduction + GELU + LayerNorm in one launch
-int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, void* out_bf16, int R, int L, int H, hipStream_t s);
+int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, void* out_bf16, int R, int L, int H, hipStream_t s,
+                  const void* pf = nullptr, size_t pf_bytes = 0);     // pf: region (the decoder's weight table) that leading blocks of the launch read into the Infinity Cache
 int head_transform_splits(int K);
 int gemm_head_transform(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s);
 int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s);

@@ -398,9 +398,17 @@ int r3_merge(const void* hi, const void* lo, const int64_t* pos, float* out, int
 // of the head's input rows in one launch (one wave per row).  The same arithmetic as r3_merge + layernorm_rows.
 __global__ __launch_bounds__(ROW_THREADS) void head_rows_ln3_kernel(const u32x2_t* __restrict__ hi, const unsigned* __restrict__ lo, const int64_t* __restrict__ pos,
                                                                     const float* __restrict__ g, const float* __restrict__ bta, float eps,
-                                                                    bf16* __restrict__ out, int R, int L, int H) {
+                                                                    bf16* __restrict__ out, int R, int L, int H,
+                                                                    const void* __restrict__ pf, size_t pf_bytes, int pf_blocks) {
+    // The launch has R / 4 blocks of real work (16 at B = 64) on a 256-CU chip: pf_blocks LEADING blocks stream the vocabulary decoder's
+    // weight table (47 MB, read once by the GEMM three launches later) into the Infinity Cache meanwhile (common.h prefetch_region)
+    __shared__ __attribute__((aligned(16))) unsigned char pf_scratch[4 * 1024];
+    if ((int)blockIdx.x < pf_blocks) {
+        prefetch_region(pf, pf_bytes, blockIdx.x, pf_blocks, threadIdx.x, ROW_THREADS, pf_scratch);
+        return;
+    }
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+    const int r = (blockIdx.x - pf_blocks) * (ROW_THREADS / 64) + (threadIdx.x >> 6);
     if (r >= R) return;
     long p = pos ? pos[r] : 0;
     p = p < 0 ? 0 : (p >= L ? L - 1 : p);
@@ -416,10 +424,14 @@ __global__ __launch_bounds__(ROW_THREADS) void head_rows_ln3_kernel(const u32x2_
     ln_stats(v, nv, lane, H, mean, rstd, eps);
     ln_write<bf16>(v, nv, lane, H, mean, rstd, g, bta, nullptr, out + (size_t)r * H);
 }
-int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, void* out_bf16, int R, int L, int H, hipStream_t s) {
+int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, void* out_bf16, int R, int L, int H, hipStream_t s,
+                  const void* pf, size_t pf_bytes) {
     if (!hi || !lo || !g || !bta || !out_bf16) return CPT_ERR_NULL;
     if (R <= 0 || L <= 0 || H <= 0 || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
-    head_rows_ln3_kernel<<<dim3((R + 3) / 4), dim3(ROW_THREADS), 0, s>>>((const u32x2_t*)hi, (const unsigned*)lo, pos, g, bta, eps, (bf16*)out_bf16, R, L, H);
+    const int nb = (R + 3) / 4;
+    const int pfb = (pf && pf_bytes && !((uintptr_t)pf & 15) && nb < 224) ? 224 - (nb & ~7) : 0;      // (a hint: dropped when misaligned or when the rows fill the chip)
+    head_rows_ln3_kernel<<<dim3(nb + pfb), dim3(ROW_THREADS), 0, s>>>((const u32x2_t*)hi, (const unsigned*)lo, pos, g, bta, eps, (bf16*)out_bf16, R, L, H,
+                                                                       pfb ? pf : nullptr, pf_bytes, pfb);
     return CPT_OK;
 }
 // head_finish: row r of the output = LayerNorm(gelu(sum over the S split-K partial matrices of row r)) as bf16 (the bias rides in partial 0):
