@@ -82,6 +82,7 @@ _SIGS = {
                                    C.POINTER(Dropout)]),
     "cpt_train_bwd_ex": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(ModelGrads), C.c_float, vp, vp, C.c_size_t, vp,
                                    BUCKET_CB, vp, C.POINTER(Dropout)]),
+    "cpt_train_zero_grads": (C.c_int, [C.POINTER(Model), C.POINTER(ModelGrads), C.c_int, vp]),
     "cpt_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_adamw": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                             C.c_int, C.c_float, vp]),
@@ -157,8 +158,8 @@ def lib():
             fn = getattr(l, name)        # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if l.cpt_version() != 4:
-            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 4" % l.cpt_version())
+        if l.cpt_version() != 5:
+            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 5" % l.cpt_version())
         _lib = l
     return _lib
 

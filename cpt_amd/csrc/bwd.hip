@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
-    // reduce dg/db over the 4 waves, one atomic per column per workgroup
+    // reduce dg/db over the 4 waves, one atomic per column per workgroup  (one pass over a [3][4][H] staging array: the 16 KB
+    // one-sum-at-a-time form that lets eight workgroups share a CU was measured SLOWER, 19.5 vs 16.8 us at 3840 rows -- the kernel
+    // is bound by its per-row dependency chain, not by occupancy)
 #pragma unroll
     for (int i = 0; i < LNB_MAXV; ++i)
 #pragma unroll
@@ -374,6 +376,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     atomicAdd(c < H ? &dg[c] : (c < 2 * H ? &db[c - H] : &dbias[c - 2 * H]), a);
 }
 
+int g_lnb_rpb = 0;       // cpt_set_tuning(17, rows): rows per workgroup of the two-stage form (0: 4 = one row per wave); multiples of 4
+void set_lnb_rpb(int v) { g_lnb_rpb = v > 0 ? (v + 3) / 4 * 4 : 0; }
+
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
            float* part, size_t part_bytes, const DropSpec* drop, float* dbias) {
@@ -385,7 +390,7 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
     // rows per block: with atomics fewer blocks = fewer dgamma/dbeta atomics (2*H per block); with a partial-sum buffer (two-stage
     // column sums) one row per wave keeps 4x the rows in flight: the kernel is latency-bound otherwise (22 -> ~10 us at 3840 rows)
     int rpb = R >= 2048 ? 16 : 8;
-    if (g && part && R >= 1024 && (size_t)((R + 3) / 4) * nsum * H * 4 <= part_bytes) rpb = 4; else part = nullptr;
+    if (g && part && R >= 1024 && (size_t)((R + 3) / 4) * nsum * H * 4 <= part_bytes) rpb = g_lnb_rpb > 0 ? g_lnb_rpb : 4; else part = nullptr;
     dim3 grid((R + rpb - 1) / rpb), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
 #define LNB(LPT, GI) ln_bwd_kernel<LPT, GI><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias)
@@ -558,16 +563,30 @@ int tanh_bwd(const float* dy, const float* y, float* dx, void* dx_lp, int lp_dty
     return CPT_OK;
 }
 
-// dst[R][K] += src[R][Kp]  (drop the zero padding of the img weight gradient)
+// dst[R][K] = src[R][Kp]  (drop the zero padding of the img weight gradient; like every Linear weight gradient it is WRITTEN, not added)
 __global__ __launch_bounds__(256) void unpad_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int K, int Kp) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)R * K) return;
     const int r = (int)(idx / K), c = (int)(idx % K);
-    dst[idx] += src[(size_t)r * Kp + c];
+    dst[idx] = src[(size_t)r * Kp + c];
 }
 int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s) {
     const size_t n = (size_t)R * K;
     unpad_add_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(src, dst, R, K, Kp);
+    return CPT_OK;
+}
+
+// One launch that clears up to ZS_MAX small tensors (the gradient vectors the backward adds into with atomics): the table rides in the
+// kernel arguments, blockIdx.x = segment, blockIdx.y strides over it.
+__global__ __launch_bounds__(256) void zero_segments_kernel(ZeroSegs z) {
+    float* p = z.p[blockIdx.x];
+    const unsigned n = z.n[blockIdx.x];
+    for (unsigned i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) p[i] = 0.f;
+}
+int zero_segments(const ZeroSegs& z, hipStream_t s) {
+    if (z.count <= 0) return CPT_OK;
+    if (z.count > ZS_MAX) return CPT_ERR_SHAPE;
+    zero_segments_kernel<<<dim3((unsigned)z.count, 8), dim3(256), 0, s>>>(z);
     return CPT_OK;
 }
 
@@ -798,7 +817,10 @@ __device__ __forceinline__ int kq_off_tr(int row, int chunk) {
 template <int NKB, bool TR = false>
 __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
                                                             const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int B, int L, int heads,
-                                                            DropSpec dr) {
+                                                            DropSpec dr, float* __restrict__ dbias) {
+    // dbias (optional, [3 * heads * 64]): += column sums of dqkv over this (sequence, head)'s rows = the gradient of the stacked
+    // Q|K|V bias (replaces a colsum launch over the M x 3H tensor): every lane owns one column of its 32 x 32 block, the two
+    // half-waves hold the two row halves
     constexpr int LP = NKB * 32;
     constexpr int TROW = LP * 2 + 8;                  // bytes per transposed-tile row (pad: conflict-free b64 reads)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -971,12 +993,18 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
             }
         }
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db) {
+            float cs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = qb * 32 + acc_row(r, lane);
-                if (q < L) dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = (bf16)(o[db][r] * 0.125f);
+                if (q < L) { dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = (bf16)(o[db][r] * 0.125f); cs += o[db][r] * 0.125f; }
             }
+            if (dbias) {
+                cs += __shfl_xor(cs, 32, 64);
+                if (lane < 32) atomicAdd(&dbias[h * 64 + db * 32 + lane], cs);
+            }
+        }
     }
     } else {
     for (int qb = wave; qb < NKB; qb += 4) {
@@ -1046,12 +1074,18 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
             }
         }
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db) {
+            float cs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = qb * 32 + acc_row(r, lane);
-                if (q < L) dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = (bf16)(o[db][r] * 0.125f);
+                if (q < L) { dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = (bf16)(o[db][r] * 0.125f); cs += o[db][r] * 0.125f; }
             }
+            if (dbias) {
+                cs += __shfl_xor(cs, 32, 64);
+                if (lane < 32) atomicAdd(&dbias[h * 64 + db * 32 + lane], cs);
+            }
+        }
     }
     }
     __syncthreads();
@@ -1106,21 +1140,31 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
             }
         }
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db) {
+            float ck = 0.f, cv = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + acc_row(r, lane);
                 if (key < L) {
                     dbase[(size_t)key * ldq + H + db * 32 + acc_col(lane)] = (bf16)(aK[db][r] * 0.125f);
                     dbase[(size_t)key * ldq + 2 * H + db * 32 + acc_col(lane)] = (bf16)aV[db][r];
+                    ck += aK[db][r] * 0.125f; cv += aV[db][r];
                 }
             }
+            if (dbias) {
+                ck += __shfl_xor(ck, 32, 64); cv += __shfl_xor(cv, 32, 64);
+                if (lane < 32) {
+                    atomicAdd(&dbias[H + h * 64 + db * 32 + lane], ck);
+                    atomicAdd(&dbias[2 * H + h * 64 + db * 32 + lane], cv);
+                }
+            }
+        }
     }
 }
 
 template <int NKB, bool TR = false>
 static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int heads, const DropSpec& dr,
-                                hipStream_t s) {
+                                hipStream_t s, float* dbias) {
     constexpr int LP = NKB * 32;
     const size_t lds = (size_t)4 * LP * 128 + (TR ? 0 : (size_t)3 * 64 * (LP * 2 + 8)) + (size_t)4 * LP * sizeof(float);
     auto k = attn_bwd_mfma_kernel<NKB, TR>;
@@ -1130,7 +1174,7 @@ static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         done = true;
     }
-    k<<<dim3(B * heads), dim3(256), lds, s>>>((const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, heads, dr);
+    k<<<dim3(B * heads), dim3(256), lds, s>>>((const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, heads, dr, dbias);
     return CPT_OK;
 }
 
@@ -1148,21 +1192,21 @@ int attention_bwd_supported(int dtype, int L, int has_drop) {
 }
 
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
-                  const DropSpec* drop) {
+                  const DropSpec* drop, float* dbias) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
     const DropSpec dr = drop ? *drop : DropSpec{};
     // L <= 128: the transpose-read kernel needs 68 KB of LDS and 209 registers -> two workgroups per CU (B * heads = 384 workgroups
     // in one round instead of two): 43.6 vs 51.2 us at B = 32 (rocprofv3)
-    if (dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L > 64 && L <= 128) return attn_bwd_mfma_launch<4, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
+    if (dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L > 64 && L <= 128) return attn_bwd_mfma_launch<4, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
     if (dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 128) {
-        if (L <= 32) return attn_bwd_mfma_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
-        if (L <= 64) return attn_bwd_mfma_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
-        return attn_bwd_mfma_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
+        if (L <= 32) return attn_bwd_mfma_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+        if (L <= 64) return attn_bwd_mfma_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+        return attn_bwd_mfma_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
     }
     if (dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 288) {      // GQA / VCR shapes: transpose-read variant
-        if (L <= 160) return attn_bwd_mfma_launch<5, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
-        if (L <= 224) return attn_bwd_mfma_launch<7, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
-        return attn_bwd_mfma_launch<9, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s);
+        if (L <= 160) return attn_bwd_mfma_launch<5, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+        if (L <= 224) return attn_bwd_mfma_launch<7, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+        return attn_bwd_mfma_launch<9, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
     }
     const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + (dr.thresh ? 3 : 2) * AB_QB * (L + 1) + L) * sizeof(float);
     if (lds > 160 * 1024) return CPT_ERR_SHAPE;            // L <= ~176 in this round (RefCOCO L = 120)
@@ -1180,6 +1224,7 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
     else if (dtype == CPT_F32) { if (L <= 128) ABK(float, 32); else ABK(float, 44); }
     else return CPT_ERR_DTYPE;
 #undef ABK
+    if (dbias) return colsum(dqkv, dtype, 3 * heads * 64, dbias, B * L, 3 * heads * 64, s);      // the generic kernels leave the bias sums to a pass of their own
     return CPT_OK;
 }
 

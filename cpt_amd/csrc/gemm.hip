@@ -173,6 +173,7 @@ struct EpiX {
     const int64_t* mask;   // ATTN: [B][L] attention mask (1 keep / 0 drop) or NULL
     int seq_len, heads;    // ATTN: tokens per sequence (<= 128), attention heads
     int w_rows;            // NN form: rows of W that exist (0: K); rows beyond read as zero (K rounded up to a K-tile multiple)
+    float* colsum;         // GELUGRAD (training backward): += column sums of the finished output = the gradient of the bias in front of the GELU
     int skew;              // two-workgroups-per-CU shapes: start delay of every second workgroup (see skew_start)
 };
 
@@ -865,6 +866,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         };
         Aux aux_a, aux_b;
         if constexpr (FULL && HAS_RESID) load_aux(0, aux_a);
+        // GELUGRAD: column sums of the finished values.  A lane meets only P distinct column chunks over the read-back iterations
+        // (as for bv above), so the sums ride in P register quads through all slices; the lanes that share a chunk are combined
+        // once at the end through the wave's LDS side area (P * 4 ds_add_f32 per lane -- LDS float atomics inside the loop cost
+        // 57 us per launch), then one global atomic per column.  MEASURED (FFN-down data gradient, M = 3840): the 184 k global atomics
+        // of the launch (1900 per 128-byte line, all at the end of its one round) add 16 us, the stand-alone column-sum launch
+        // costs 7.7 -- so the training step leaves this off (cpt_set_tuning key 18 bit 0) and keeps the colsum launch for b_in
+        f32x4 cs[GG ? P : 1];
+#pragma unroll
+        for (int q = 0; q < (GG ? P : 1); ++q) cs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl) {
             const int i = sl >> 1, half = sl & 1;
@@ -945,6 +955,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     } else {
                         *reinterpret_cast<f32x4_u*>(out + (size_t)row * ldo + col) = v;
                     }
+                    if constexpr (GG) {
+                        if (ex.colsum) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) cs[it % P][e] += v[e];
+                        }
+                    }
                     if constexpr (LNPROD && !R3) {
                         T* olp = reinterpret_cast<T*>(ex.out_lp) + (size_t)row * ldo + col;
                         if constexpr (sizeof(T) == 2) {
@@ -977,6 +993,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                                 if constexpr (EPI == CPT_EPI_ATOMIC && sizeof(OT) == 4) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, x);
                                 else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
                                 if constexpr (LNPROD) reinterpret_cast<T*>(ex.out_lp)[(size_t)row * ldo + col + e] = from_f32<T>(x);
+                                if constexpr (GG) { if (ex.colsum) atomicAdd(ex.colsum + col + e, x); }
                                 }
                                 fin[e] = x;
                             }
@@ -1005,6 +1022,22 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
                     *reinterpret_cast<float2*>(ex.st_out + 2 * ((size_t)srow * ex.st_out_slots + wcol0 / WCOLS)) = float2{sm, sq};
             }
             // (LDS operations of one wave execute in issue order: the next slice's writes cannot pass these reads)
+        }
+        if constexpr (FULL && GG) {
+            if (ex.colsum) {
+                for (int c = lane; c < WCOLS; c += 64) side_g[c] = 0.f;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    const int ch = (q * 64 + lane) % CH;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)      // explicit LDS atomic (ds_add_f32): a flat fp32 atomic add that lands in the LDS aperture is dropped
+                        __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)(side_g + ch * 4 + e), cs[q][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int c = lane; c < WCOLS; c += 64)
+                    if (!GUARD || wcol0 + c < N) atomicAdd(ex.colsum + wcol0 + c, side_g[c]);
+            }
         }
     };
     if (abl & 8) { if (acc[0][0][0] == 12345.678f) out[0] = from_f32<OT>(1.f); }     // ablation: no epilogue
@@ -1250,7 +1283,8 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
     const int tiles = (M / 128) * (N / (w192 ? 192 : 128)), nt = K / 64;
     int S = 256 / tiles;
     if (S > 8) S = 8;
-    if (S > nt / 3) S = nt / 3;                        // at least three K-tiles (one ring) per split
+    if (S > nt / 6) S = nt / 6;                        // at least six K-tiles per split: a short contraction (4 sequences per GPU: 8 K-tiles) is all
+                                                       // pipeline fill, splitting it only adds the partial matrices and the reduction launch
     const size_t mat = (size_t)M * N * 4;
     if (!partials) S = 1;
     while (S > 1 && (size_t)S * mat > partial_bytes) --S;
@@ -1311,7 +1345,7 @@ int gemm_nn_eligible(int M, int N, int K, int lda, int ldw) {
 }
 
 int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
-            hipStream_t s, int w_rows, void* partials, size_t partial_bytes, const void* gelu_u, int ldu) {
+            hipStream_t s, int w_rows, void* partials, size_t partial_bytes, const void* gelu_u, int ldu, float* gelu_colsum) {
     if (!gemm_nn_eligible(M, N, K, lda, ldw)) return CPT_ERR_SHAPE;
     if (!A || !W || !out) return CPT_ERR_NULL;
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)resid | (uintptr_t)partials) & 15)) return CPT_ERR_ALIGN;
@@ -1323,6 +1357,7 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
     const bool small = wg128 < 200 && n192;
     EpiX ex = {};
     ex.w_rows = w_rows;
+    ex.colsum = gelu_u ? gelu_colsum : nullptr;
     // few output tiles and a long contraction (the decoder's data gradient: 32 x 768 outputs over K = 30528 ran on 4 CUs for 220 us):
     // split K over up to 64 workgroups per tile, partial matrices added in split order
     if (out_dtype == CPT_F32 && (!resid || ldr == N) && partials && ldo == N && n192) {

@@ -50,11 +50,14 @@ int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int6
               int type_vocab, hipStream_t s);
 int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s);
 int tanh_bwd(const float* dy, const float* y, float* dx, void* dx_lp, int lp_dtype, size_t n, hipStream_t s);
-int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s);
+int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s);     // dst = src without the padding columns (overwrites)
+constexpr int ZS_MAX = 224;
+struct ZeroSegs { float* p[ZS_MAX]; unsigned n[ZS_MAX]; int count; };     // 2.7 KB of kernel arguments
+int zero_segments(const ZeroSegs& z, hipStream_t s);
 int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
                hipStream_t s);
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
-                  const DropSpec* drop = nullptr);
+                  const DropSpec* drop = nullptr, float* dbias = nullptr);     // dbias [3H]: += column sums of dqkv (the stacked Q|K|V bias gradient)
 // y = dropout(x) (+ resid): x, y fp32 [R][H] (in place allowed), y_lp optional copy in lp_dtype; element index of the mask =
 // row * H + col.  Forward of the hidden dropouts and, with resid = NULL, their backward (the mask applied to a gradient).
 int attention_bwd_supported(int dtype, int L, int has_drop);
@@ -77,7 +80,8 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
 // nn.Linear weight as stored); bf16 operands, out fp32 (optionally + fp32 resid) or bf16
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw);
 int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
-            hipStream_t s, int w_rows = 0, void* partials = nullptr, size_t partial_bytes = 0, const void* gelu_u = nullptr, int ldu = 0);
+            hipStream_t s, int w_rows = 0, void* partials = nullptr, size_t partial_bytes = 0, const void* gelu_u = nullptr, int ldu = 0,
+            float* gelu_colsum = nullptr);     // gelu_colsum [N] (with gelu_u): += column sums of out (fp32, before the bf16 rounding) = the gradient of the bias in front of the GELU
 // gelu_u (bf16 out only): out = (A.W) * gelu'(u) with u bf16 [M][ldu] -- the GELU backward fused into the data-gradient GEMM
 // w_rows: rows of W that exist when K was rounded up to a multiple of 64 (A's extra columns must be zero); partials: split-K scratch
 // u = A.W^T + bias (bf16) and h = gelu(u) (bf16) from one bf16 GEMM (training forward of BertIntermediate)
@@ -139,6 +143,8 @@ int argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids, in
 int fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* colc,
                     float* cold, int N, int K, hipStream_t s);
 void set_splitk_target(int v);
+void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
+void set_lnb_rpb(int v);     // LayerNorm backward: rows per workgroup of the two-stage column-sum form (experiments)
 void set_wgrad_tn(int v);    // 1 (default): bf16 weight gradients through the TN GEMM; 0: explicit operand transposes
 void set_attn_bwd_variant(int v);
 void set_gemm_variant(int v);

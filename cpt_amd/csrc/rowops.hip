@@ -509,10 +509,63 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     }
 }
 
+// V <= 32 K (every vocabulary of section 8): 1024 threads per row, the row read ONCE into registers (32 values per thread) for the
+// maximum, the exponential sum and the gradient -- the 256-thread three-pass form above took 54 us for 32 rows of 30522
+constexpr int CE_NV = 32;
+__global__ __launch_bounds__(1024) void ce_rows_reg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                           float* __restrict__ loss, float* __restrict__ dlogits, int R, int V) {
+    __shared__ float red[32];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const long lab = labels[r];
+    const float* x = logits + (size_t)r * V;
+    float* d = dlogits ? dlogits + (size_t)r * V : nullptr;
+    if (lab < 0 || lab >= V) {            // ignored row: no loss, zero gradient
+        if (d) for (int c = tid; c < V; c += 1024) d[c] = 0.f;
+        return;
+    }
+    const int lane = tid & 63, w = tid >> 6;
+    float xv[CE_NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CE_NV; ++i) {
+        const int c = i * 1024 + tid;
+        xv[i] = c < V ? x[c] : -INFINITY;
+        m = fmaxf(m, xv[i]);
+    }
+    m = wave_max(m);
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CE_NV; ++i) { xv[i] = expf(xv[i] - m); sum += xv[i]; }      // exp(-inf) = 0 beyond V
+    sum = wave_sum(sum);
+    if (lane == 0) red[16 + w] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += red[16 + k];
+    if (tid == 0) {
+        atomicAdd(&loss[0], m + logf(sum) - x[lab]);
+        atomicAdd(&loss[1], 1.0f);
+    }
+    if (d) {
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int i = 0; i < CE_NV; ++i) {
+            const int c = i * 1024 + tid;
+            if (c < V) d[c] = xv[i] * inv - (c == lab ? 1.f : 0.f);
+        }
+    }
+}
+
 int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V, hipStream_t s) {
     if (R <= 0 || V <= 0) return CPT_ERR_SHAPE;
     if (!logits || !labels || !loss) return CPT_ERR_NULL;
-    ce_rows_kernel<<<dim3(R), dim3(256), 0, s>>>(logits, labels, loss, dlogits, R, V);
+    if (V <= CE_NV * 1024) ce_rows_reg_kernel<<<dim3(R), dim3(1024), 0, s>>>(logits, labels, loss, dlogits, R, V);
+    else ce_rows_kernel<<<dim3(R), dim3(256), 0, s>>>(logits, labels, loss, dlogits, R, V);
     return CPT_OK;
 }
 

@@ -14,6 +14,11 @@ using cpt::abi_fail;
 
 namespace cpt { int g_wgrad_tn = 1; void set_wgrad_tn(int v) { g_wgrad_tn = v; } }
 using cpt::g_wgrad_tn;
+// cpt_set_tuning(18, bits): bias-gradient column sums inside their producers -- bit 0: b_in in the GELU-gradient epilogue of
+// dgrad(ffn down) (off: its end-of-launch atomics cost more than the colsum launch, gemm.hip), bit 1: b_qkv in the attention
+// backward kernel (on: 43.3 vs 42.0 us per launch, no colsum launch); a cleared bit runs the stand-alone colsum launch instead
+namespace cpt { int g_bias_fuse = 2; void set_bias_fuse(int v) { g_bias_fuse = v; } }
+using cpt::g_bias_fuse;
 
 namespace {
 
@@ -312,11 +317,11 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     // out[rows][Kout] = dY[rows][Nout] . Wt[Nout][Kout]  (+ resid), Wt given as the Linear weight [Nout][Kout]
     constexpr int NOT_FUSED = 1 << 20;       // dgrad(..., gelu_u): the shape has no fused GELU-gradient epilogue
     auto dgrad = [&](const void* dY, int ldy, int Nout_p, const void* Wt, int ldw, int Nout, int Kout, int rows,
-                     const float* resid, void* out, int out_dt, const char* what, const void* gelu_u = nullptr) -> int {
+                     const float* resid, void* out, int out_dt, const char* what, const void* gelu_u = nullptr, float* gelu_colsum = nullptr) -> int {
         // bf16, tile-aligned: the NN form reads the weight as stored (transpose reads in LDS)
         // (Nout < Nout_p: the K-tile padding columns of dY are zero and the weight rows beyond Nout read as zero)
         if (g_wgrad_tn && dt == CPT_BF16 && cpt::gemm_nn_eligible(rows, Kout, Nout_p, ldy, ldw)) {
-            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes, gelu_u, Kout), what);
+            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes, gelu_u, Kout, gelu_colsum), what);
             return CPT_OK;
         }
         if (gelu_u) return NOT_FUSED;   // caller runs the unfused pair (dgrad, then gelu_bwd)
@@ -401,13 +406,15 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_h), I, I, M, Mp, gy.w_out, I, "wgrad(ffn down)");
         if (rc) return rc;
         // h = gelu(u); u = a W_in^T + b_in: bf16 runs the GELU backward in the epilogue of the data-gradient GEMM
-        rc = dt == CPT_BF16 ? dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)+gelu_bwd", LB(l, w.o_u)) : NOT_FUSED;
+        // ... and sums its columns into the bias gradient (round 3: no colsum launch over the M x I tensor)
+        rc = dt == CPT_BF16 ? dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)+gelu_bwd+bias", LB(l, w.o_u), (g_bias_fuse & 1) ? gy.b_in : nullptr) : NOT_FUSED;
         if (rc == NOT_FUSED) {
             rc = dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)");
             if (rc) return rc;
             TRY(cpt::gelu_bwd(dbig, LB(l, w.o_u), dbig, dt, (size_t)M * I, s), "gelu_bwd");
+            TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
         } else if (rc) return rc;
-        TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
+        else if (!(g_bias_fuse & 1)) TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
         rc = wgrad(dbig, dt, I, I, LB(l, w.o_a), H, H, M, Mp, gy.w_in, H, "wgrad(ffn up)");
         if (rc) return rc;
         rc = dgrad(dbig, I, I, y.w_in, H, I, H, M, dpre, da, CPT_F32, "dgrad(ffn up)+residual");
@@ -428,8 +435,8 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         rc = dgrad(dpre_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
         if (rc) return rc;
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
-        TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention_bwd");
-        TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
+        TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr, (g_bias_fuse & 2) ? gy.b_qkv : nullptr), "attention_bwd+bias");
+        if (!(g_bias_fuse & 2)) TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
         rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)");
         if (rc) return rc;
         rc = dgrad(dbig, 3 * H, 3 * H, y.w_qkv, H, 3 * H, H, M, dpre, dx, CPT_F32, "dgrad(qkv)+residual");
@@ -447,9 +454,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         TRY(cpt::ln_bwd(dx, (const float*)(ws + w.imgpre), iln ? m->img_ln_g : nullptr, d.img_ln_eps, dimg, dt == CPT_BF16 ? dimg_lp : nullptr, dt,
                         iln ? g->img_ln_g : nullptr, iln ? g->img_ln_b : nullptr, R, H, Li, L, Lt, 0, s), "ln_bwd(img)");
         TRY(cpt::colsum(dimg, CPT_F32, H, g->b_img, R, H, s), "colsum(b_img)");
-        float* gimg = (float*)(ws + w.gimg);
-        e = hipMemsetAsync(gimg, 0, (size_t)H * Dp * 4, s);
-        if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero img grad temp: %s", hipGetErrorString(e));
+        float* gimg = (float*)(ws + w.gimg);      // (written whole by the weight-gradient GEMM: nothing to clear)
         rc = wgrad(dt == CPT_BF16 ? dimg_lp : (const void*)dimg, dt, H, H, ws + w.imgp, Dp, Dp, R, Rp, gimg, Dp, "wgrad(img_embedding)");
         if (rc) return rc;
         TRY(cpt::unpad_add(gimg, g->w_img, H, d.img_dim, Dp, s), "unpad(img weight grad)");
@@ -458,6 +463,51 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
                        d.ln_eps, g->word_emb, g->pos_emb, g->type_emb, g->emb_ln_g, g->emb_ln_b, B, Lt, L, H, d.vocab, d.max_pos,
                        d.type_vocab, s), "embed_bwd");
     ready(0);
+    return CPT_OK;
+}
+
+// What cpt_train_bwd needs cleared, in one launch (+ one memset for a table the chosen head does not overwrite): Linear weight
+// gradients are WRITTEN by their GEMMs (and the tied word-embedding table by the decoder's), so only the vectors and small tables
+// that take atomic adds are cleared -- 0.3 MB instead of the 447 MB of a whole-buffer fill per step.
+int cpt_train_zero_grads(const cpt_model* m, const cpt_model_grads* g, int Li, void* stream) {
+    if (!m || !g || !g->layers) return abi_fail(CPT_ERR_NULL, "cpt_train_zero_grads: null argument");
+    const cpt_dims& d = m->dims;
+    hipStream_t s = (hipStream_t)stream;
+    const bool nsp = !m->w_tr && !m->w_dec;
+    const size_t H = d.hidden, I = d.inter;
+    cpt::ZeroSegs z;
+    z.count = 0;
+    bool ovf = false;
+    auto seg = [&](float* p, size_t n) {
+        if (!p || !n) return;
+        if (z.count >= cpt::ZS_MAX) { ovf = true; return; }
+        z.p[z.count] = p; z.n[z.count] = (unsigned)n; ++z.count;
+    };
+    auto big = [&](float* p, size_t n) -> int {
+        if (!p || !n) return CPT_OK;
+        hipError_t e = hipMemsetAsync(p, 0, n * 4, s);
+        return e == hipSuccess ? CPT_OK : abi_fail(CPT_ERR_HIP - (int)e, "cpt_train_zero_grads: %s", hipGetErrorString(e));
+    };
+    seg(g->pos_emb, (size_t)d.max_pos * H); seg(g->type_emb, (size_t)d.type_vocab * H);
+    seg(g->emb_ln_g, H); seg(g->emb_ln_b, H); seg(g->b_img, H); seg(g->img_ln_g, H); seg(g->img_ln_b, H);
+    for (int l = 0; l < d.layers; ++l) {
+        const cpt_layer_grads& y = g->layers[l];
+        seg(y.b_qkv, 3 * H); seg(y.b_ao, H); seg(y.ln1_g, H); seg(y.ln1_b, H);
+        seg(y.b_in, I); seg(y.b_out, H); seg(y.ln2_g, H); seg(y.ln2_b, H);
+    }
+    seg(g->b_tr, H); seg(g->tr_ln_g, H); seg(g->tr_ln_b, H); seg(g->b_dec, (size_t)d.vocab);
+    seg(g->b_pool, H); seg(g->b_rel, (size_t)d.n_rel);
+    if (ovf) return abi_fail(CPT_ERR_SHAPE, "cpt_train_zero_grads: more than %d gradient vectors (layers = %d)", cpt::ZS_MAX, d.layers);
+    TRY(cpt::zero_segments(z, s), "zero_segments");
+    int rc;
+    if (nsp) {      // no decoder GEMM writes the word table: the lookup gradient adds into it
+        if ((rc = big(g->word_emb, (size_t)d.vocab * H))) return rc;
+        if ((rc = big(g->w_tr, H * H))) return rc;
+    } else {        // the MLM path leaves the pooler / relation head without a gradient
+        if ((rc = big(g->w_pool, H * H))) return rc;
+        if ((rc = big(g->w_rel, (size_t)d.n_rel * H))) return rc;
+    }
+    if (Li <= 0 && (rc = big(g->w_img, H * (size_t)d.img_dim))) return rc;      // no regions: the projection gets no gradient
     return CPT_OK;
 }
 

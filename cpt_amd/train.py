@@ -208,8 +208,9 @@ class _MLMLoss(torch.autograd.Function):
             st.sync.begin_backward()      # reduce-scatters of an unconsumed earlier backward may still read st.grad: wait BEFORE touching it
         if accumulate:
             keep = st.grad.clone()
-        st.grad.zero_()
         g, _ = st.gdesc
+        # only what the backward ADDS into (bias / LayerNorm vectors, small tables) is cleared; weight gradients are written whole
+        L.check(L.lib().cpt_train_zero_grads(C.byref(m), C.byref(g), int(bt.Li), L.stream_ptr()), "cpt_train_zero_grads")
         # the early reduce-scatter only when this backward completes the gradient: not while accumulating, not under no_sync()
         sync = st.sync if not (accumulate or st.defer) else None
         st.sent_version = None

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CPT_ABI_VERSION 4     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3) */
+#define CPT_ABI_VERSION 5     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads */
 
 enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2 };
 enum { CPT_EPI_NONE = 0, CPT_EPI_GELU = 1, CPT_EPI_TANH = 2, CPT_EPI_RESID = 3 };
@@ -207,6 +207,12 @@ int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
  * (vector gradients are accumulated with atomics); uses the workspace cpt_train_fwd filled. */
 int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* Clears what cpt_train_bwd ADDS into -- the bias / LayerNorm gradient vectors and the small embedding tables (atomic
+ * accumulation), plus any table the model's head does not overwrite -- in one launch.  Linear weight gradients (and, with the MLM
+ * head, the tied word-embedding table) are WRITTEN by cpt_train_bwd, so a caller that runs this before every backward never
+ * clears them: 0.3 MB per step instead of the whole 447 MB gradient buffer (replaces optimizer.zero_grad(),
+ * Oscar/oscar/fewshot/refcoco_cpt.py:247-249).  Li = region slots of the batch that follows (0: w_img is cleared too). */
+int cpt_train_zero_grads(const cpt_model* m, const cpt_model_grads* g, int Li, void* stream);
 /* Data-parallel fine-tuning (the reference wraps the model in DistributedDataParallel, whose bucketed gradient
  * all-reduce overlaps backward: Oscar/oscar/fewshot/refcoco_cpt.py:516-522).  The parameters form
  * dims.layers + 2 BUCKETS: 0 = embedding tables + embeddings.LayerNorm + region projection (+ its LayerNorm),
@@ -415,6 +421,9 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 15 panel mode: 1 (default) = launches that leave CUs idle carry 16 workgroups that read the next launch's weights into the
  *          Infinity Cache, 0 = no prefetch workgroups
  *   key 16 FFN-up two-pass kernel (and with it panel mode) from this many 384 x 256 tiles on (default 192; experiments with small batches)
+ *   key 17 LayerNorm backward, two-stage column-sum form: rows per workgroup (default 0 = 4, one row per wave; experiments)
+ *   key 18 training backward, bias-gradient column sums inside their producers: bit 0 = b_in in the GELU-gradient epilogue, bit 1 = b_qkv
+ *          in the attention backward kernel (default 2: bit 0 measured slower than the launch it replaces); a cleared bit runs the stand-alone column-sum launch
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
