@@ -173,6 +173,7 @@ struct EpiX {
     const int64_t* mask;   // ATTN: [B][L] attention mask (1 keep / 0 drop) or NULL
     int seq_len, heads;    // ATTN: tokens per sequence (<= 128), attention heads
     int w_rows;            // NN form: rows of W that exist (0: K); rows beyond read as zero (K rounded up to a K-tile multiple)
+    size_t split_stride;   // split-K partial matrices: elements between two splits' outputs (0: M * ldo)
     float* colsum;         // GELUGRAD (training backward): += column sums of the finished output = the gradient of the bias in front of the GELU
     int skew;              // two-workgroups-per-CU shapes: start delay of every second workgroup (see skew_start)
 };
@@ -193,11 +194,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // rows alternate between the two halves of the bank row -> one more bit from row >> 1); always inside an aligned group of 8 chunks
 __device__ __forceinline__ int tn_swz(int row, int cpr) { return (cpr % 16 == 0) ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
 
+// The kernel body as an inlined device function: gemm_pipe_kernel runs it on the launch's one problem (bid_x = blockIdx.x),
+// gemm_tn_group2_kernel (weight gradients, round 3) on one of TWO problems that share a launch.
 template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1, int TN = 0>
-__global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_pipe_kernel(
+__device__ __forceinline__ void gemm_pipe_body(
     const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
-    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace_arg, int abl_arg, EpiX ex) {
+    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace_arg, int abl_arg, EpiX ex, const int bid_x) {
 #if defined(__HIP_DEVICE_COMPILE__)   // body uses gfx950-only builtins/types (buffer rsrc, "v" asm): device pass only
     // Ablation bits (cpt_set_tuning key 1) exist only in -DCPT_ABLATION builds: as run-time tests they put nine scalar
     // branches into every K-loop iteration (measured: FFN-up +7 us), so the shipped kernels compile them away.
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     // units of 1024 cycles, bits 8.. = log2 of the block-id stride that separates the two co-resident workgroups.
     if constexpr (OCC == 2) {
         const int amount = ex.skew & 255, sh = ex.skew >> 8;
-        if (amount > 0 && ((blockIdx.x >> sh) & 1))
+        if (amount > 0 && ((bid_x >> sh) & 1))
             for (int i = 0; i < amount; ++i) __builtin_amdgcn_s_sleep(16);
     }
 
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
         // one workgroup per (sequence, head): rows = the sequence's tokens, columns = that head's Q | K | V slices.
         // XCD x owns a contiguous range of (sequence, head) pairs, so a sequence's 12 heads share one L2.
         static_assert(TBM == 128 && TBN == 192 && MI == 1 && NJ == 3, "fused attention: 128 tokens x (64 Q | 64 K | 64 V)");
-        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int nwg = gridDim.x, bid = bid_x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int lid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         att_b = lid0 / ex.heads;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     } else
     {
         const int tm = (M + TBM - 1) / TBM, tn = (N + TBN - 1) / TBN;
-        const int nwg = tm * tn * splitk, bid = blockIdx.x;
+        const int nwg = tm * tn * splitk, bid = bid_x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int lid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         const int lid = lid0 / splitk;
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     static_assert(DIRECT || (16 * CPW + SIDE) * NW <= STAGES * STAGE_BYTES, "per-wave slabs must fit in the ring");
     static_assert(DIRECT || (MI * 32 <= 64 && CH <= 64), "side area is filled by one wave pass");
     if (split != 0) bias = nullptr;                   // split-K: the bias is added once
-    if constexpr (TN != 0 || EPI == CPT_EPI_NONE) out += (size_t)split * M * ldo; // split-K (TN / NN forms, gemm_nt_split): every split writes its own partial matrix; split = 0 when K is not split: every split writes its own partial matrix (reduced in slot order afterwards)
+    if constexpr (TN != 0 || EPI == CPT_EPI_NONE) out += (size_t)split * (ex.split_stride ? ex.split_stride : (size_t)M * ldo); // split-K (TN / NN forms, gemm_nt_split): every split writes its own partial matrix; split = 0 when K is not split: every split writes its own partial matrix (reduced in slot order afterwards)
     if constexpr (DIRECT) {
         // ---- direct epilogue: the accumulators are TRANSPOSED (operands swapped in mma): lane = output row
         // (wrow0 + 32 i + (lane & 31)), register quad g of block j = the four consecutive columns
@@ -1048,13 +1051,36 @@ __global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_
     }   // !DIRECT
     if (trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long* t = trace + (size_t)blockIdx.x * 8;
+        long long* t = trace + (size_t)bid_x * 8;
         t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = tr3; t[4] = clock64();
         t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13
         t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
-        t[7] = blockIdx.x;
+        t[7] = bid_x;
     }
 #endif
+}
+
+template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1, int TN = 0>
+__global__ __launch_bounds__(WM * WN * 64, OCC * ((WM * WN + 3) / 4)) void gemm_pipe_kernel(
+    const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+    const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
+    OT* __restrict__ out, int ldo, int M, int N, int K, int splitk, long long* __restrict__ trace_arg, int abl_arg, EpiX ex) {
+    gemm_pipe_body<T, EPI, OT, TBM, TBN, WM, WN, STAGES, EP, FD, OCC, TN>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, splitk, trace_arg, abl_arg, ex,
+                                                                          (int)blockIdx.x);
+}
+
+// Two TN problems (weight gradients of one encoder layer that share the contraction rows) in ONE launch: workgroups [0, wg0) take
+// problem 0, the rest problem 1.  96 + 96 tiles (the two FFN weights) fill 192 CUs with the whole contraction each instead of two
+// launches of 96 tiles x 2 splits + two reduction launches; 24 + 72 tiles (attention output + Q|K|V) split the contraction
+// in two instead of in eight and in three.  wg0 is a multiple of 8, so a workgroup keeps its XCD under the per-problem tile map.
+struct TnProb { const bf16* A; const bf16* W; float* out; int lda, ldw, ldo, M, N; size_t split_stride; };
+template <int TBN>
+__global__ __launch_bounds__(512, 2) void gemm_tn_group2_kernel(TnProb p0, TnProb p1, int K, int splitk, int wg0, EpiX ex) {
+    const bool second = (int)blockIdx.x >= wg0;
+    const TnProb& p = second ? p1 : p0;
+    ex.split_stride = p.split_stride;
+    gemm_pipe_body<bf16, CPT_EPI_NONE, float, 128, TBN, 4, 2, 3, 1, 4, 1, 1>(p.A, p.lda, p.W, p.ldw, nullptr, nullptr, 0, p.out, p.ldo, p.M, p.N, K, splitk,
+                                                                            nullptr, 0, ex, (int)blockIdx.x - (second ? wg0 : 0));
 }
 
 long long* g_gemm_trace = nullptr;
@@ -1299,6 +1325,71 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
         const size_t n4 = mat / 16;
         const int blocks = (int)std::min<size_t>((n4 + 255) / 256, 2048);
         reduce_partials_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S);
+    }
+    return CPT_OK;
+}
+
+// two partial-matrix sets reduced by one launch (the two problems of gemm_tn_pair)
+__global__ __launch_bounds__(256) void reduce_partials2_kernel(const f32x4* __restrict__ part, size_t stride4, int S, f32x4* __restrict__ out0, size_t n40,
+                                                               f32x4* __restrict__ out1, size_t n41) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n40 + n41; i += (size_t)gridDim.x * 256) {
+        f32x4 a = part[i];
+        for (int k = 1; k < S; ++k) { const f32x4 b = part[(size_t)k * stride4 + i]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+        if (i < n40) out0[i] = a; else out1[i - n40] = a;
+    }
+}
+
+// Two weight gradients that contract over the same K rows in one launch (gemm_tn_group2_kernel).  CPT_ERR_SHAPE: not applicable
+// (shapes of different tile classes, first problem's workgroups not a multiple of 8, ...) -- the caller runs two gemm_tn instead.
+int gemm_tn_pair(const void* A0, int lda0, const void* W0, int ldw0, float* out0, int M0, int N0,
+                 const void* A1, int lda1, const void* W1, int ldw1, float* out1, int M1, int N1,
+                 int K, int k_rows, void* partials, size_t partial_bytes, hipStream_t s) {
+    if (!gemm_tn_eligible(M0, N0, K, lda0, ldw0, N0) || !gemm_tn_eligible(M1, N1, K, lda1, ldw1, N1)) return CPT_ERR_SHAPE;
+    if (k_rows < 0 || k_rows > K) return CPT_ERR_SHAPE;
+    if (!A0 || !W0 || !out0 || !A1 || !W1 || !out1) return CPT_ERR_NULL;
+    if ((((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)out0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)out1 | (uintptr_t)partials) & 15)) return CPT_ERR_ALIGN;
+    if ((size_t)K * (size_t)std::max(std::max(lda0, ldw0), std::max(lda1, ldw1)) * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;
+    const bool w192 = N0 % 192 == 0 && N1 % 192 == 0;
+    if (!w192 && (N0 % 128 || N1 % 128)) return CPT_ERR_SHAPE;
+    const int tbn = w192 ? 192 : 128;
+    const int t0 = (M0 / 128) * (N0 / tbn), t1 = (M1 / 128) * (N1 / tbn), nt = K / 64;
+    int S = 256 / (t0 + t1);
+    if (S > 8) S = 8;
+    if (S > nt / 6) S = nt / 6;
+    const size_t mat0 = (size_t)M0 * N0, mat1 = (size_t)M1 * N1;
+    if (!partials) S = 1;
+    while (S > 1 && (size_t)S * (mat0 + mat1) * 4 > partial_bytes) --S;
+    if (S < 1) S = 1;
+    if ((t0 * S) % 8) return CPT_ERR_SHAPE;
+    EpiX ex = {};
+    ex.w_rows = k_rows;
+    ex.skew = g_gemm_skew;
+    TnProb p0 = {(const bf16*)A0, (const bf16*)W0, out0, lda0, ldw0, N0, M0, N0, 0};
+    TnProb p1 = {(const bf16*)A1, (const bf16*)W1, out1, lda1, ldw1, N1, M1, N1, 0};
+    if (S > 1) {
+        p0.out = (float*)partials; p1.out = (float*)partials + mat0;
+        p0.split_stride = p1.split_stride = mat0 + mat1;
+    }
+    const int nwg = (t0 + t1) * S;
+    static bool attr_done_dev[2][CPT_MAX_DEV] = {};
+    bool& attr_done = attr_done_dev[w192 ? 0 : 1][current_device_slot()];
+#define CPT_TN_G2(TBN_)                                                                                                            \
+    do {                                                                                                                           \
+        constexpr int LDS = 3 * (128 + TBN_) * ROWB;                                                                               \
+        auto kern = gemm_tn_group2_kernel<TBN_>;                                                                                   \
+        if (LDS > 64 * 1024 && !attr_done) {                                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+            if (e != hipSuccess) return CPT_ERR_HIP - (int)e;                                                                      \
+            attr_done = true;                                                                                                      \
+        }                                                                                                                          \
+        kern<<<dim3(nwg), dim3(512), LDS, s>>>(p0, p1, K, S, t0 * S, ex);                                                          \
+    } while (0)
+    if (w192) CPT_TN_G2(192); else CPT_TN_G2(128);
+#undef CPT_TN_G2
+    if (S > 1) {
+        const size_t n40 = mat0 / 4, n41 = mat1 / 4;
+        const int blocks = (int)std::min<size_t>((n40 + n41 + 255) / 256, 2048);
+        reduce_partials2_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const f32x4*)partials, (mat0 + mat1) / 4, S, (f32x4*)out0, n40, (f32x4*)out1, n41);
     }
     return CPT_OK;
 }

@@ -76,6 +76,11 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
 int gemm_tn_eligible(int M, int N, int K, int lda, int ldw, int ldo);
 int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
             hipStream_t s, int k_rows = 0);     // k_rows: rows of A / W that exist when K was rounded up to a multiple of 64
+// two such products over the same K rows in one launch (the weight gradients of a layer's two FFN matrices, or of its attention
+// output and Q|K|V matrices); outputs dense (ldo = N).  CPT_ERR_SHAPE: not applicable, run two gemm_tn
+int gemm_tn_pair(const void* A0, int lda0, const void* W0, int ldw0, float* out0, int M0, int N0,
+                 const void* A1, int lda1, const void* W1, int ldw1, float* out1, int M1, int N1,
+                 int K, int k_rows, void* partials, size_t partial_bytes, hipStream_t s);
 // out[M][N] = A[M][K] . W[K][N] (+ resid): W stored with the contraction index as its slow dimension (data gradients against an
 // nn.Linear weight as stored); bf16 operands, out fp32 (optionally + fp32 resid) or bf16
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw);
@@ -143,6 +148,7 @@ int argmax_columns(const float* logits, int V, const int64_t* ids, int n_ids, in
 int fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* colc,
                     float* cold, int N, int K, hipStream_t s);
 void set_splitk_target(int v);
+void set_wgrad_pair(int v);  // training backward: the layer's weight gradients as two paired launches (1, default) or four single ones (0)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
 void set_lnb_rpb(int v);     // LayerNorm backward: rows per workgroup of the two-stage column-sum form (experiments)
 void set_wgrad_tn(int v);    // 1 (default): bf16 weight gradients through the TN GEMM; 0: explicit operand transposes

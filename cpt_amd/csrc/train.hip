@@ -17,6 +17,9 @@ using cpt::g_wgrad_tn;
 // cpt_set_tuning(18, bits): bias-gradient column sums inside their producers -- bit 0: b_in in the GELU-gradient epilogue of
 // dgrad(ffn down) (off: its end-of-launch atomics cost more than the colsum launch, gemm.hip), bit 1: b_qkv in the attention
 // backward kernel (on: 43.3 vs 42.0 us per launch, no colsum launch); a cleared bit runs the stand-alone colsum launch instead
+// cpt_set_tuning(19, v): 1 (default) = a layer's four weight gradients run as two paired launches (gemm_tn_pair), 0 = four single ones
+namespace cpt { int g_wgrad_pair = 1; void set_wgrad_pair(int v) { g_wgrad_pair = v; } }
+using cpt::g_wgrad_pair;
 namespace cpt { int g_bias_fuse = 2; void set_bias_fuse(int v) { g_bias_fuse = v; } }
 using cpt::g_bias_fuse;
 
@@ -314,6 +317,16 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         TRY(cpt::gemm(dt, CPT_EPI_NONE, tA, rows_p, tB, rows_p, nullptr, nullptr, 0, out, CPT_F32, ldo, Nout, Kout, rows_p, s), what);
         return CPT_OK;
     };
+    // two weight gradients over the same rows in one launch (bf16, tile-aligned shapes); false = not applicable, the caller runs two wgrad
+    auto wgrad_pair = [&](const void* dY0, int ldy0, int Nout0, const void* X0, int ldx0, int Kout0, float* out0,
+                          const void* dY1, int ldy1, int Nout1, const void* X1, int ldx1, int Kout1, float* out1, int& rc_out, const char* what) -> bool {
+        rc_out = CPT_OK;
+        if (!(g_wgrad_tn && g_wgrad_pair && dt == CPT_BF16)) return false;
+        const int r = cpt::gemm_tn_pair(dY0, ldy0, X0, ldx0, out0, Nout0, Kout0, dY1, ldy1, X1, ldx1, out1, Nout1, Kout1, Mp, M, tA, w.tA_bytes, s);
+        if (r == CPT_ERR_SHAPE) return false;
+        rc_out = abi_check(r, what);
+        return true;
+    };
     // out[rows][Kout] = dY[rows][Nout] . Wt[Nout][Kout]  (+ resid), Wt given as the Linear weight [Nout][Kout]
     constexpr int NOT_FUSED = 1 << 20;       // dgrad(..., gelu_u): the shape has no fused GELU-gradient epilogue
     auto dgrad = [&](const void* dY, int ldy, int Nout_p, const void* Wt, int ldw, int Nout, int Kout, int rows,
@@ -403,8 +416,8 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         if (ph) TRY(cpt::dropout_rows(dpre, nullptr, dmask, dt == CPT_BF16 ? dmask_lp : nullptr, dt, M, H, drop_spec(drop, 3 + 3 * l, false), s), "dropout_bwd(ffn down)");
         TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_out, M, H, s), "colsum(b_out)");
         }
-        rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_h), I, I, M, Mp, gy.w_out, I, "wgrad(ffn down)");
-        if (rc) return rc;
+        // (weight gradients: the two FFN matrices share one launch behind the GELU backward, attention output and Q|K|V one behind
+        // the attention backward -- their operands stay untouched until then; shapes the pair kernel does not take run one by one)
         // h = gelu(u); u = a W_in^T + b_in: bf16 runs the GELU backward in the epilogue of the data-gradient GEMM
         // ... and sums its columns into the bias gradient (round 3: no colsum launch over the M x I tensor)
         rc = dt == CPT_BF16 ? dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)+gelu_bwd+bias", LB(l, w.o_u), (g_bias_fuse & 1) ? gy.b_in : nullptr) : NOT_FUSED;
@@ -415,8 +428,14 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
         } else if (rc) return rc;
         else if (!(g_bias_fuse & 1)) TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
-        rc = wgrad(dbig, dt, I, I, LB(l, w.o_a), H, H, M, Mp, gy.w_in, H, "wgrad(ffn up)");
-        if (rc) return rc;
+        if (wgrad_pair(dpre_in, H, H, LB(l, w.o_h), I, I, gy.w_out, dbig, I, I, LB(l, w.o_a), H, H, gy.w_in, rc, "wgrad(ffn down | ffn up)")) {
+            if (rc) return rc;
+        } else {
+            rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_h), I, I, M, Mp, gy.w_out, I, "wgrad(ffn down)");
+            if (rc) return rc;
+            rc = wgrad(dbig, dt, I, I, LB(l, w.o_a), H, H, M, Mp, gy.w_in, H, "wgrad(ffn up)");
+            if (rc) return rc;
+        }
         rc = dgrad(dbig, I, I, y.w_in, H, I, H, M, dpre, da, CPT_F32, "dgrad(ffn up)+residual");
         if (rc) return rc;
         // a = LN1(pre1); pre1 = ctx W_ao^T + b_ao + x_in
@@ -430,15 +449,19 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         if (ph) TRY(cpt::dropout_rows(dpre, nullptr, dmask, dt == CPT_BF16 ? dmask_lp : nullptr, dt, M, H, drop_spec(drop, 2 + 3 * l, false), s), "dropout_bwd(attn out)");
         TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_ao, M, H, s), "colsum(b_ao)");
         }
-        rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_ctx), H, H, M, Mp, gy.w_ao, H, "wgrad(attn out)");
-        if (rc) return rc;
         rc = dgrad(dpre_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
         if (rc) return rc;
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
         TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr, (g_bias_fuse & 2) ? gy.b_qkv : nullptr), "attention_bwd+bias");
         if (!(g_bias_fuse & 2)) TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
-        rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)");
-        if (rc) return rc;
+        if (wgrad_pair(dpre_in, H, H, LB(l, w.o_ctx), H, H, gy.w_ao, dbig, 3 * H, 3 * H, LB(l, w.o_xin), H, H, gy.w_qkv, rc, "wgrad(attn out | qkv)")) {
+            if (rc) return rc;
+        } else {
+            rc = wgrad(dpre_in, dt, H, H, LB(l, w.o_ctx), H, H, M, Mp, gy.w_ao, H, "wgrad(attn out)");
+            if (rc) return rc;
+            rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)");
+            if (rc) return rc;
+        }
         rc = dgrad(dbig, 3 * H, 3 * H, y.w_qkv, H, 3 * H, H, M, dpre, dx, CPT_F32, "dgrad(qkv)+residual");
         if (rc) return rc;
         ready(1 + l);

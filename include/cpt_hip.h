@@ -424,6 +424,8 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 17 LayerNorm backward, two-stage column-sum form: rows per workgroup (default 0 = 4, one row per wave; experiments)
  *   key 18 training backward, bias-gradient column sums inside their producers: bit 0 = b_in in the GELU-gradient epilogue, bit 1 = b_qkv
  *          in the attention backward kernel (default 2: bit 0 measured slower than the launch it replaces); a cleared bit runs the stand-alone column-sum launch
+ *   key 19 training backward: 1 (default) = a layer's weight gradients as two paired launches (the two FFN matrices; attention output +
+ *          Q|K|V), 0 = four launches with their own split-K reductions
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at

@@ -375,3 +375,35 @@ def test_bias_gradients_summed_inside_their_producers(dev, B):
             rel = float((got[n] - ref[n]).norm()) / den
             # the fused sums take the fp32 values, the launches the bf16-rounded tensor: 2^-9 relative per element, averaging out
             assert rel < 2e-3, (bits, n, rel)
+
+
+@pytest.mark.parametrize("B", [4, 32])
+def test_paired_weight_gradient_launches_match_single_ones(dev, B):
+    """Round 3: a layer's four weight gradients as two paired launches (gemm_tn_pair: FFN down | FFN up without a K split, attention
+    output | Q|K|V with the contraction split in two) against four single launches with their own split-K reductions (cpt_set_tuning
+    key 19 = 0): same operands, a different summation split -> equal to fp32 rounding."""
+    from cpt_amd import _lib as L
+    from cpt_amd import train as T
+    cfg = cfgmod.oscar_base()
+    m = _model(cfg, 23, dev, "bf16", dropout=0.1)
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, cfg, seed=13).items()}
+    names = ["bert.encoder.layer.%d.%s" % (l, n) for l in (0, 5, 11)
+             for n in ("attention.self.query.weight", "attention.self.value.weight", "attention.output.dense.weight",
+                       "intermediate.dense.weight", "output.dense.weight")]
+    params = dict(m.named_parameters())
+
+    def grads(pair):
+        L.check(L.lib().cpt_set_tuning(19, pair), "cpt_set_tuning")
+        T.set_dropout_seed(m, 17)
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
+                    mask_token_pos=b["mask_token_pos"])
+        loss.backward()
+        return {n: params[n].grad.double().clone() for n in names}
+
+    ref, got = grads(0), grads(1)
+    for n in names:
+        rel = float((got[n] - ref[n]).norm()) / (float(ref[n].norm()) + 1e-30)
+        assert rel < 1e-5, (n, rel)
+        assert float(ref[n].norm()) > 0, n
