@@ -676,20 +676,23 @@ int dropout_mask(int kind, unsigned char* out, int n0, int n1, int n2, const Dro
 // ---- attention backward (generic, fp32 math on LDS tiles; one workgroup per (sequence, head)) ----
 // Recomputes P = softmax(QK^T/8 + mask) per 32-query block, then
 //   dV += P^T dO,  dP = dO V^T,  dS = P (dP - rowsum(dP P)),  dQ = dS K / 8,  dK += dS^T Q / 8.
+// QB = query rows per block; VG (round 3, 176 < L <= 288 in the fp32 parity mode: the GQA / VCR few-shot lengths 210 / 265): V is not
+// held in LDS but read from global memory (74 KB per head, L2-resident) and the query block shrinks to 16 rows -- 140 KB at
+// L = 288 with dropout instead of the 240 KB the QB = 32 / V-in-LDS form would need.
 constexpr int AB_QB = 32, AB_D = 64;
-template <typename T, int MAXE>
+template <typename T, int MAXE, int QB = AB_QB, bool VG = false>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
                                                        const T* __restrict__ dctx, T* __restrict__ dqkv, int B, int L, int heads,
                                                        DropSpec dr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LP1 = L + 1;
     float* sK = reinterpret_cast<float*>(smem);          // [L][65]
-    float* sV = sK + L * 65;                              // [L][65]
-    float* sQ = sV + L * 65;                              // [32][65]
-    float* sO = sQ + AB_QB * 65;                          // [32][65]  (dO block)
-    float* sP = sO + AB_QB * 65;                          // [32][L+1]
-    float* sS = sP + AB_QB * LP1;                         // [32][L+1]  (dP then dS)
-    float* sM = sS + AB_QB * LP1;                         // [L] additive mask
+    float* sV = sK + L * 65;                              // [L][65]  (VG: absent)
+    float* sQ = sV + (VG ? 0 : L * 65);                   // [QB][65]
+    float* sO = sQ + QB * 65;                          // [32][65]  (dO block)
+    float* sP = sO + QB * 65;                          // [32][L+1]
+    float* sS = sP + QB * LP1;                         // [32][L+1]  (dP then dS)
+    float* sM = sS + QB * LP1;                         // [L] additive mask
     float* sW = sM + L;                                   // [32][L+1] dropout multipliers (0 or 1/(1-p)); only with dropout
     const bool drop = dr.thresh != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     for (int idx = tid; idx < L * AB_D; idx += 256) {
         const int r = idx / AB_D, c = idx % AB_D;
         sK[r * 65 + c] = to_f32(base[(size_t)r * ldq + H + c]);
-        sV[r * 65 + c] = to_f32(base[(size_t)r * ldq + 2 * H + c]);
+        if (!VG) sV[r * 65 + c] = to_f32(base[(size_t)r * ldq + 2 * H + c]);
     }
     for (int j = tid; j < L; j += 256) sM[j] = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + j]) * -10000.0f : 0.f;
 
@@ -711,10 +714,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) { accK[k] = 0.f; accV[k] = 0.f; }
 
-    for (int q0 = 0; q0 < L; q0 += AB_QB) {
-        const int nq = min(AB_QB, L - q0);
+    for (int q0 = 0; q0 < L; q0 += QB) {
+        const int nq = min(QB, L - q0);
         __syncthreads();
-        for (int idx = tid; idx < AB_QB * AB_D; idx += 256) {
+        for (int idx = tid; idx < QB * AB_D; idx += 256) {
             const int r = idx / AB_D, c = idx % AB_D;
             const bool ok = r < nq;
             sQ[r * 65 + c] = ok ? to_f32(base[(size_t)(q0 + r) * ldq + c]) : 0.f;
@@ -722,13 +725,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         }
         __syncthreads();
         // scores and dP for the block
-        for (int idx = tid; idx < AB_QB * L; idx += 256) {
+        for (int idx = tid; idx < QB * L; idx += 256) {
             const int i = idx / L, j = idx % L;
             float s = 0.f, dp = 0.f;
 #pragma unroll 8
             for (int d = 0; d < AB_D; ++d) {
                 s += sQ[i * 65 + d] * sK[j * 65 + d];
-                dp += sO[i * 65 + d] * sV[j * 65 + d];
+                dp += sO[i * 65 + d] * (VG ? to_f32(base[(size_t)j * ldq + 2 * H + d]) : sV[j * 65 + d]);
             }
             sP[i * LP1 + j] = s * 0.125f + sM[j];
             if (drop) {      // dp arrives as the gradient of the DROPPED probabilities: d/dP = mask / (1-p) times it
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         }
         __syncthreads();
         // softmax rows + dS: wave w owns rows w, w+4, ...
-        for (int i = wave; i < AB_QB; i += 4) {
+        for (int i = wave; i < QB; i += 4) {
             float m = -INFINITY;
             for (int j = lane; j < L; j += 64) m = fmaxf(m, sP[i * LP1 + j]);
             m = wave_max(m);
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         }
         __syncthreads();
         // dQ block
-        for (int idx = tid; idx < AB_QB * AB_D; idx += 256) {
+        for (int idx = tid; idx < QB * AB_D; idx += 256) {
             const int i = idx / AB_D, d = idx % AB_D;
             if (i < nq) {
                 float a = 0.f;
@@ -1181,6 +1184,7 @@ static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void
 int g_attn_bwd_variant = 1;      // 1: transpose-read MFMA kernels for bf16 (L <= 288); 0: generic kernel always; 2: L <= 128 through the older MFMA kernel with transposed tile copies
 void set_attn_bwd_variant(int v) { g_attn_bwd_variant = v; }
 
+static size_t attn_bwd_vg_lds(int L, int has_drop) { return ((size_t)L * 65 + 2 * 16 * 65 + (has_drop ? 3 : 2) * 16 * (L + 1) + L) * sizeof(float); }
 // Whether attention_bwd has a kernel for (dtype, L, dropout on the probabilities): asked by cpt_train_fwd so that an unsupported
 // combination is rejected BEFORE the forward runs, not after it
 int attention_bwd_supported(int dtype, int L, int has_drop) {
@@ -1188,7 +1192,8 @@ int attention_bwd_supported(int dtype, int L, int has_drop) {
     if (dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 288) return 1;
     if (dtype != CPT_BF16 && dtype != CPT_F32) return 0;
     const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + (has_drop ? 3 : 2) * AB_QB * (L + 1) + L) * sizeof(float);
-    return lds <= 160 * 1024;
+    if (lds <= 160 * 1024) return 1;
+    return L <= 288 && attn_bwd_vg_lds(L, has_drop) <= 160 * 1024;      // V from global memory, 16-query blocks
 }
 
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
@@ -1208,10 +1213,27 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
         if (L <= 224) return attn_bwd_mfma_launch<7, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
         return attn_bwd_mfma_launch<9, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
     }
-    const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + (dr.thresh ? 3 : 2) * AB_QB * (L + 1) + L) * sizeof(float);
-    if (lds > 160 * 1024) return CPT_ERR_SHAPE;            // L <= ~176 in this round (RefCOCO L = 120)
+    size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + (dr.thresh ? 3 : 2) * AB_QB * (L + 1) + L) * sizeof(float);
+    const bool vg = lds > 160 * 1024;                      // beyond L ~ 176: the form that reads V from global memory (L <= 288)
+    if (vg) {
+        lds = attn_bwd_vg_lds(L, dr.thresh ? 1 : 0);
+        if (L > 288 || lds > 160 * 1024) return CPT_ERR_SHAPE;
+    }
     dim3 grid(B * heads), block(256);
     hipError_t e;
+#define ABKV(TT)                                                                                                      \
+    do {                                                                                                              \
+        auto k = attn_bwd_kernel<TT, 72, 16, true>;                                                                   \
+        if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)             \
+            return CPT_ERR_HIP - (int)e;                                                                              \
+        k<<<grid, block, lds, s>>>((const TT*)qkv, attn_mask, (const TT*)dctx, (TT*)dqkv, B, L, heads, dr);           \
+    } while (0)
+    if (vg) {
+        if (dtype == CPT_BF16) ABKV(bf16); else if (dtype == CPT_F32) ABKV(float); else return CPT_ERR_DTYPE;
+        if (dbias) return colsum(dqkv, dtype, 3 * heads * 64, dbias, B * L, 3 * heads * 64, s);
+        return CPT_OK;
+    }
 #define ABK(TT, ME)                                                                                                   \
     do {                                                                                                              \
         auto k = attn_bwd_kernel<TT, ME>;                                                                             \
@@ -1224,6 +1246,7 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
     else if (dtype == CPT_F32) { if (L <= 128) ABK(float, 32); else ABK(float, 44); }
     else return CPT_ERR_DTYPE;
 #undef ABK
+#undef ABKV
     if (dbias) return colsum(dqkv, dtype, 3 * heads * 64, dbias, B * L, 3 * heads * 64, s);      // the generic kernels leave the bias sums to a pass of their own
     return CPT_OK;
 }

@@ -87,9 +87,11 @@ def test_exported_masks_match_cpu_restatement_and_rate(dev):
 
 
 # (165, 45) and (165, 100): the GQA and VCR few-shot sequence lengths (Oscar/cmds/gqa/_cpt_fsl_base.sh:19,27; BASELINE config 5):
-# bf16 runs the transpose-read MFMA attention backward (csrc/bwd.hip, 128 < L <= 288), fp32 at L = 145 the generic kernel
+# bf16 runs the transpose-read MFMA attention backward (csrc/bwd.hip, 128 < L <= 288), fp32 at L = 145 the generic kernel,
+# fp32 at L = 210 / 265 its 16-query-block form that reads V from global memory
 @pytest.mark.parametrize("mode,Lt,Li", [("fp32", 20, 6), ("bf16", 20, 6), ("fp32", 60, 40), ("bf16", 60, 40),
-                                        ("fp32", 100, 45), ("bf16", 100, 45), ("bf16", 165, 45), ("bf16", 165, 100)])
+                                        ("fp32", 100, 45), ("bf16", 100, 45), ("bf16", 165, 45), ("bf16", 165, 100),
+                                        ("fp32", 165, 45), ("fp32", 165, 100)])     # fp32 beyond L = 176: V read from global memory (round 3)
 def test_loss_and_gradients_match_oracle_with_the_same_masks(dev, mode, Lt, Li):
     p = 0.1
     cfg = cfgmod.tiny(max_position_embeddings=max(96, Lt))
