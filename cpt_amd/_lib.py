@@ -46,7 +46,8 @@ class Model(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("B", C.c_int32), ("Lt", C.c_int32), ("Li", C.c_int32)] + [(n, C.c_void_p) for n in
-                ("input_ids", "token_type", "position_ids", "attn_mask", "img_feats", "mask_pos", "labels")]
+                ("input_ids", "token_type", "position_ids", "attn_mask", "img_feats", "mask_pos", "labels")] + \
+               [("n_rows", C.c_int32), ("row_seq", C.c_void_p)]
 
 
 class LayerGrads(C.Structure):
@@ -76,6 +77,7 @@ _SIGS = {
     "cpt_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.c_int]),
     "cpt_model_fwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), C.c_int, vp, C.c_size_t, vp]),
     "cpt_train_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int]),
+    "cpt_train_workspace_bytes_rows": (C.c_size_t, [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.c_int]),
     "cpt_train_fwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), vp, C.c_size_t, vp]),
     "cpt_train_bwd": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(ModelGrads), C.c_float, vp, C.c_size_t, vp]),
     "cpt_train_fwd_ex": (C.c_int, [C.POINTER(Model), C.POINTER(Batch), C.POINTER(Outputs), vp, C.c_size_t, vp, BUCKET_CB, vp,

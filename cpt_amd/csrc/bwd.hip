@@ -535,14 +535,17 @@ int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int6
 // ---- small helpers ------------------------------------------------------------------------------------
 // dst[b*L + pos[b]][:] += src[b][:]   (gradient of the [MASK]-row gather)
 __global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __restrict__ src, const int64_t* __restrict__ pos,
-                                                               float* __restrict__ dst, int L, int H) {
+                                                               float* __restrict__ dst, int L, int H, const int64_t* __restrict__ seq, int n_seq) {
     const int b = blockIdx.x;
     long p = pos ? pos[b] : 0;
     p = p < 0 ? 0 : (p >= L ? L - 1 : p);
-    for (int c = threadIdx.x; c < H; c += 256) dst[((size_t)b * L + p) * H + c] += src[(size_t)b * H + c];
+    long q = seq ? seq[b] : b;                    // seq: source row b belongs to position pos[b] of sequence seq[b] (label grids)
+    q = q < 0 ? 0 : (q >= n_seq ? n_seq - 1 : q);
+    // (atomic: a clamped or repeated (sequence, position) pair must not lose an update)
+    for (int c = threadIdx.x; c < H; c += 256) atomicAdd(&dst[((size_t)q * L + p) * H + c], src[(size_t)b * H + c]);
 }
-int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s) {
-    scatter_rows_add_kernel<<<dim3(B), dim3(256), 0, s>>>(src, pos, dst, L, H);
+int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s, const int64_t* seq, int n_seq) {
+    scatter_rows_add_kernel<<<dim3(B), dim3(256), 0, s>>>(src, pos, dst, L, H, seq, seq ? n_seq : B);
     return CPT_OK;
 }
 

@@ -31,7 +31,7 @@ int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStre
 int split3(const float* x, int ld, void* out_bf16, int R, int K, int weight_order, hipStream_t s);
 
 int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H,
-                hipStream_t s);
+                hipStream_t s, const int64_t* seq = nullptr, int n_seq = 0);      // seq: row b = position pos[b] of sequence seq[b] (of n_seq)
 
 int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V,
             hipStream_t s);
@@ -48,7 +48,7 @@ int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int6
               const float* posw, const float* typew, const float* g, float eps, float* dword, float* dposw,
               float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,
               int type_vocab, hipStream_t s);
-int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s);
+int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s, const int64_t* seq = nullptr, int n_seq = 0);
 int tanh_bwd(const float* dy, const float* y, float* dx, void* dx_lp, int lp_dtype, size_t n, hipStream_t s);
 int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s);     // dst = src without the padding columns (overwrites)
 constexpr int ZS_MAX = 224;

@@ -340,18 +340,20 @@ int retile_k32(const void* src, void* dst, int N, int K, hipStream_t s) {
 
 // ---- gather rows: out[b] = src[b*L + pos[b]] ---------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int64_t* __restrict__ pos,
-                                                          uint4* __restrict__ out, int B, int L, int chunks) {
+                                                          uint4* __restrict__ out, int B, int L, int chunks, const int64_t* __restrict__ seq, int n_seq) {
     const int b = blockIdx.x;
     long p = pos ? pos[b] : 0;
     p = p < 0 ? 0 : (p >= L ? L - 1 : p);
-    const uint4* s = src + ((size_t)b * L + p) * chunks;
+    long q = seq ? seq[b] : b;                    // seq: output row b is position pos[b] of sequence seq[b] (label grids)
+    q = q < 0 ? 0 : (q >= n_seq ? n_seq - 1 : q);
+    const uint4* s = src + ((size_t)q * L + p) * chunks;
     for (int c = threadIdx.x; c < chunks; c += 256) out[(size_t)b * chunks + c] = s[c];
 }
 
-int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H, hipStream_t s) {
+int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H, hipStream_t s, const int64_t* seq, int n_seq) {
     const int esz = dtype == CPT_BF16 ? 2 : 4;
     if (B <= 0 || L <= 0 || (H * esz) % 16) return CPT_ERR_SHAPE;
-    gather_rows_kernel<<<dim3(B), dim3(256), 0, s>>>((const uint4*)src, pos, (uint4*)out, B, L, H * esz / 16);
+    gather_rows_kernel<<<dim3(B), dim3(256), 0, s>>>((const uint4*)src, pos, (uint4*)out, B, L, H * esz / 16, seq, seq ? n_seq : B);
     return CPT_OK;
 }
 

@@ -37,12 +37,13 @@ struct TrainLayout {
     int Mp, Bp, Vp, Rp;
 };
 
-TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li) {
+// Rh: rows the head runs on -- the labelled positions (cpt_batch.n_rows), or one per sequence
+TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
     const size_t es = d.dtype == CPT_BF16 ? 2 : 4;
     const size_t L = (size_t)Lt + Li, M = (size_t)B * L, H = d.hidden, I = d.inter, V = d.vocab, Dp = d.img_dim_pad;
     const size_t R = (size_t)B * Li;
     TrainLayout w;
-    w.Mp = up64((int)M); w.Bp = up64(B); w.Vp = up64((int)V); w.Rp = up64((int)std::max<size_t>(R, 1));
+    w.Mp = up64((int)M); w.Bp = up64(Rh); w.Vp = up64((int)V); w.Rp = up64((int)std::max<size_t>(R, 1));
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t p = o; o += al(bytes); return p; };
     w.x_f32 = take(M * H * 4);
@@ -58,10 +59,10 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li) {
     w.xout = take(M * H * es);
     w.imgp = take(R * Dp * es);
     w.imgpre = take(R * H * 4);
-    w.rows = take((size_t)B * H * es);
-    w.uh = take((size_t)B * H * 4);
-    w.t2 = take((size_t)B * H * es);
-    w.dlogits = take((size_t)B * V * 4);
+    w.rows = take((size_t)Rh * H * es);
+    w.uh = take((size_t)Rh * H * 4);
+    w.t2 = take((size_t)Rh * H * es);
+    w.dlogits = take((size_t)Rh * V * 4);
     w.loss = take(256);
     // backward temporaries
     w.dx = take(M * H * 4);
@@ -77,11 +78,11 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li) {
     w.tB = take(w.tB_bytes);
     w.wT = take(std::max<size_t>({3 * H * H, I * H, H * (size_t)w.Vp}) * es);
     w.gimg = take(H * Dp * 4);
-    w.dl_lp = take((size_t)B * w.Vp * es);
-    w.dt2 = take((size_t)B * H * 4);
-    w.duh = take((size_t)B * H * 4);
-    w.duh_lp = take((size_t)B * H * es);
-    w.drows = take((size_t)B * H * 4);
+    w.dl_lp = take((size_t)Rh * w.Vp * es);
+    w.dt2 = take((size_t)Rh * H * 4);
+    w.duh = take((size_t)Rh * H * 4);
+    w.duh_lp = take((size_t)Rh * H * es);
+    w.drows = take((size_t)Rh * H * 4);
     w.dimg = take(R * H * 4);
     w.dimg_lp = take(R * H * es);
     w.dmask = take(M * H * 4);        // dropout: masked gradient of a dense output (the unmasked one feeds the residual path)
@@ -93,6 +94,8 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li) {
 int check_common(const cpt_model* m, const cpt_batch* b, void* ws, size_t ws_bytes, const TrainLayout& w, const char* who) {
     const cpt_dims& d = m->dims;
     if (b->B <= 0 || b->Lt <= 0 || b->Li < 0) return abi_fail(CPT_ERR_SHAPE, "%s: bad batch shape", who);
+    if (b->n_rows < 0 || (long)b->n_rows > (long)b->B * (b->Lt + b->Li) || (b->n_rows > 0 && !b->row_seq))
+        return abi_fail(CPT_ERR_SHAPE, "%s: n_rows %d needs row_seq and at most B * L = %ld rows", who, b->n_rows, (long)b->B * (b->Lt + b->Li));
     if (d.heads <= 0 || d.hidden != d.heads * 64) return abi_fail(CPT_ERR_SHAPE, "%s: head_dim must be 64", who);
     if (d.dtype != CPT_F32 && d.dtype != CPT_BF16) return abi_fail(CPT_ERR_DTYPE, "%s: dtype %d", who, d.dtype);
     if (d.img_dim_pad < d.img_dim || d.img_dim_pad % 64) return abi_fail(CPT_ERR_ALIGN, "%s: img_dim_pad must be a multiple of 64 for training", who);
@@ -143,7 +146,11 @@ extern "C" {
 
 size_t cpt_train_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li) {
     if (!d || B <= 0 || Lt <= 0 || Li < 0) return 0;
-    return train_layout(*d, B, Lt, Li).total;
+    return train_layout(*d, B, Lt, Li, B).total;
+}
+size_t cpt_train_workspace_bytes_rows(const cpt_dims* d, int B, int Lt, int Li, int n_rows) {
+    if (!d || B <= 0 || Lt <= 0 || Li < 0 || n_rows < 0 || (long)n_rows > (long)B * (Lt + Li)) return 0;
+    return train_layout(*d, B, Lt, Li, n_rows > 0 ? n_rows : B).total;
 }
 
 int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
@@ -157,10 +164,11 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     if (int rcd = check_drop(drop, "cpt_train_fwd")) return rcd;
     const bool ph = drop && drop->p_hidden > 0.f, pa = drop && drop->p_attn > 0.f;
     const cpt_dims& d = m->dims;
-    const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li);
+    const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li, b->n_rows > 0 ? b->n_rows : b->B);
     int rc = check_common(m, b, workspace, workspace_bytes, w, "cpt_train_fwd");
     if (rc) return rc;
     const bool nsp = !m->w_tr && !m->w_dec;
+    if (nsp && b->n_rows > 0) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: label grids (n_rows) belong to the MLM head, not the NSP head");
     if (!o->loss || (nsp ? !o->rel : !o->logits)) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: loss and logits (NSP head: rel) outputs are required");
     hipStream_t s = (hipStream_t)stream;
     const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, dt = d.dtype;
@@ -260,14 +268,16 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         if (e2 != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e2, "save loss: %s", hipGetErrorString(e2));
         return CPT_OK;
     }
-    TRY(cpt::gather_rows(ws + w.xout, dt, b->mask_pos, rows, B, L, H, s), "gather([MASK])");
-    TRY(cpt::gemm(dt, CPT_EPI_NONE, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, uh, CPT_F32, H, B, H, H, s), "gemm(head transform)");
+    // Rh head rows: the [MASK] position of every sequence, or the n_rows labelled positions of a label grid (row_seq, mask_pos)
+    const int Rh = b->n_rows > 0 ? b->n_rows : B;
+    TRY(cpt::gather_rows(ws + w.xout, dt, b->mask_pos, rows, Rh, L, H, s, b->n_rows > 0 ? b->row_seq : nullptr, B), "gather([MASK])");
+    TRY(cpt::gemm(dt, CPT_EPI_NONE, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, uh, CPT_F32, H, Rh, H, H, s), "gemm(head transform)");
     TRY(cpt::layernorm_rows_ex(uh, m->tr_ln_g, m->tr_ln_b, d.ln_eps, dt == CPT_F32 ? (float*)t2 : nullptr,
-                               dt == CPT_F32 ? nullptr : t2, dt, B, H, B, 0, 0, 1, s), "gelu+layernorm(head)");
-    TRY(cpt::gemm(dt, CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, B, d.vocab, H, s), "gemm(decoder)");
+                               dt == CPT_F32 ? nullptr : t2, dt, Rh, H, Rh, 0, 0, 1, s), "gelu+layernorm(head)");
+    TRY(cpt::gemm(dt, CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, Rh, d.vocab, H, s), "gemm(decoder)");
     hipError_t e = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);
     if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero loss: %s", hipGetErrorString(e));
-    TRY(cpt::ce_rows(o->logits, b->labels, o->loss, (float*)(ws + w.dlogits), B, d.vocab, s), "ce_rows");
+    TRY(cpt::ce_rows(o->logits, b->labels, o->loss, (float*)(ws + w.dlogits), Rh, d.vocab, s), "ce_rows");
     e = hipMemcpyAsync(ws + w.loss, o->loss, 2 * sizeof(float), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "save loss: %s", hipGetErrorString(e));
     return CPT_OK;
@@ -284,7 +294,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     if (int rcd = check_drop(drop, "cpt_train_bwd")) return rcd;
     const bool ph = drop && drop->p_hidden > 0.f, pa = drop && drop->p_attn > 0.f;
     const cpt_dims& d = m->dims;
-    const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li);
+    const TrainLayout w = train_layout(d, b->B, b->Lt, b->Li, b->n_rows > 0 ? b->n_rows : b->B);
     int rc = check_common(m, b, workspace, workspace_bytes, w, "cpt_train_bwd");
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -350,6 +360,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     void* duh_lp = ws + w.duh_lp;
     float* drows = (float*)(ws + w.drows);
     const bool nsp = !m->w_tr && !m->w_dec;
+    const int Rh = (!nsp && b->n_rows > 0) ? b->n_rows : B;      // head rows (see cpt_train_fwd)
     if (nsp) {
         if (!g->w_pool || !g->b_pool || !g->w_rel || !g->b_rel) return abi_fail(CPT_ERR_NULL, "cpt_train_bwd: NSP head needs the w_pool / b_pool / w_rel / b_rel gradient tensors");
         const int NR = d.n_rel, NRp = 64;
@@ -369,24 +380,24 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         rc = dgrad(dpo, H, H, m->w_pool, H, H, H, B, nullptr, drows, CPT_F32, "dgrad(pooler)");
         if (rc) return rc;
     } else {
-    TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, loss_scale_dev, dl_lp, dt, B, V, Vp, s), "scale(dlogits)");
-    TRY(cpt::colsum(dl_lp, dt, Vp, g->b_dec, B, V, s), "colsum(cls.bias)");
-    rc = dgrad(dl_lp, Vp, Vp, m->w_dec, H, V, H, B, nullptr, dt2, CPT_F32, "dgrad(decoder)");
+    TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, loss_scale_dev, dl_lp, dt, Rh, V, Vp, s), "scale(dlogits)");
+    TRY(cpt::colsum(dl_lp, dt, Vp, g->b_dec, Rh, V, s), "colsum(cls.bias)");
+    rc = dgrad(dl_lp, Vp, Vp, m->w_dec, H, V, H, Rh, nullptr, dt2, CPT_F32, "dgrad(decoder)");
     if (rc) return rc;
-    rc = wgrad(dl_lp, dt, Vp, V, ws + w.t2, H, H, B, Bp, g->word_emb, H, "wgrad(decoder)");
+    rc = wgrad(dl_lp, dt, Vp, V, ws + w.t2, H, H, Rh, Bp, g->word_emb, H, "wgrad(decoder)");
     if (rc) return rc;
     TRY(cpt::ln_bwd(dt2, (const float*)(ws + w.uh), m->tr_ln_g, d.ln_eps, duh, dt == CPT_BF16 ? duh_lp : nullptr, dt, g->tr_ln_g,
-                    g->tr_ln_b, B, H, B, 0, 0, 1, s), "ln_bwd(head)");
+                    g->tr_ln_b, Rh, H, Rh, 0, 0, 1, s), "ln_bwd(head)");
     const void* duh_in = dt == CPT_BF16 ? duh_lp : (const void*)duh;
-    TRY(cpt::colsum(duh, CPT_F32, H, g->b_tr, B, H, s), "colsum(transform bias)");
-    rc = wgrad(duh_in, dt, H, H, ws + w.rows, H, H, B, Bp, g->w_tr, H, "wgrad(head transform)");
+    TRY(cpt::colsum(duh, CPT_F32, H, g->b_tr, Rh, H, s), "colsum(transform bias)");
+    rc = wgrad(duh_in, dt, H, H, ws + w.rows, H, H, Rh, Bp, g->w_tr, H, "wgrad(head transform)");
     if (rc) return rc;
-    rc = dgrad(duh_in, H, H, m->w_tr, H, H, H, B, nullptr, drows, CPT_F32, "dgrad(head transform)");
+    rc = dgrad(duh_in, H, H, m->w_tr, H, H, H, Rh, nullptr, drows, CPT_F32, "dgrad(head transform)");
     if (rc) return rc;
     }
     hipError_t e = hipMemsetAsync(dx, 0, (size_t)M * H * 4, s);
     if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero dx: %s", hipGetErrorString(e));
-    TRY(cpt::scatter_rows_add(drows, nsp ? nullptr : b->mask_pos, dx, B, L, H, s), "scatter([MASK] / [CLS] rows)");
+    TRY(cpt::scatter_rows_add(drows, nsp ? nullptr : b->mask_pos, dx, Rh, L, H, s, b->n_rows > 0 ? b->row_seq : nullptr, B), "scatter([MASK] / [CLS] rows)");
     // gradient buckets: the host callback runs right AFTER the last launch that writes the bucket's gradients has
     // been enqueued on `stream` (the tied word-embedding table belongs to bucket 0: its lookup gradient comes last)
     auto ready = [&](int bucket) { if (grads_ready) grads_ready(user, bucket); };

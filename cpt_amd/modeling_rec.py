@@ -59,7 +59,14 @@ class REC_MLM_CPT(_EngineMixin, BertPreTrainedModel):
                 # (fewshot/refcoco_cpt.py:231-233, 245-247) -> recover the slot per row
                 grid = masked_lm_labels != -1
                 if not bool((grid.sum(1) == 1).all()):
-                    raise NotImplementedError("cpt_amd: training expects exactly one labelled position per sequence")
+                    # any label grid (modeling_rec.py:147-150 takes whatever the (B, L) tensor holds, e.g. several masked words
+                    # per sequence): the head runs on the labelled positions, in row-major order of the grid
+                    idx = grid.nonzero()
+                    if idx.size(0) == 0:
+                        raise ValueError("cpt_amd: masked_lm_labels holds no labelled position (the reference's loss would be NaN)")
+                    seq, pos = idx[:, 0].contiguous(), idx[:, 1].contiguous()
+                    return mlm_loss_with_grad(self, input_ids, token_type_ids, attention_mask, masked_lm_labels[seq, pos], position_ids,
+                                              img_feats, pos, row_seq=seq)
                 mask_token_pos = grid.long().argmax(1)
                 labels = masked_lm_labels[torch.arange(grid.size(0), device=grid.device), mask_token_pos]
             return mlm_loss_with_grad(self, input_ids, token_type_ids, attention_mask, labels, position_ids,

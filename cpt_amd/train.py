@@ -112,10 +112,10 @@ class _TrainState(object):
                 g.b_dec = gp(hp + "bias")
             self.gdesc = (g, layers)
 
-    def workspace(self, B, Lt, Li):
+    def workspace(self, B, Lt, Li, n_rows=0):
         eng = self.eng
         m, _ = eng.descriptor()
-        need = L.lib().cpt_train_workspace_bytes(C.byref(m.dims), B, Lt, Li)
+        need = L.lib().cpt_train_workspace_bytes_rows(C.byref(m.dims), B, Lt, Li, n_rows)
         if need == 0:
             raise RuntimeError("cpt_amd: cpt_train_workspace_bytes rejected the batch shape")
         if self.ws is None or self.ws.numel() < need or self.ws.device != eng.flat.device:
@@ -149,8 +149,9 @@ class _MLMLoss(torch.autograd.Function):
     def forward(ctx, trigger, eng, tensors, drop):
         ctx.eng = eng
         st = _state(eng)
-        ids, seg, mask, pos, feats, mpos, labels = tensors
+        ids, seg, mask, pos, feats, mpos, labels, rseq = tensors
         B, Lt = ids.shape
+        R = int(rseq.numel()) if rseq is not None else 0        # label grid: R labelled rows (else one per sequence)
         Li = feats.size(1) if feats is not None else 0
         m, _ = eng.descriptor()
         dev = eng.flat.device
@@ -159,15 +160,16 @@ class _MLMLoss(torch.autograd.Function):
             logits = torch.empty((B, m.dims.n_rel), device=dev, dtype=torch.float32)
             o = L.Outputs(rel=logits.data_ptr(), loss=loss_acc.data_ptr())
         else:
-            logits = torch.empty((B, eng.cfg.vocab_size), device=dev, dtype=torch.float32)
+            logits = torch.empty((R if R else B, eng.cfg.vocab_size), device=dev, dtype=torch.float32)
             o = L.Outputs(logits=logits.data_ptr(), loss=loss_acc.data_ptr())
         bt = L.Batch(B=B, Lt=Lt, Li=Li, input_ids=ids.data_ptr(), token_type=L.ptr(seg), position_ids=L.ptr(pos),
-                     attn_mask=L.ptr(mask), img_feats=L.ptr(feats), mask_pos=L.ptr(mpos), labels=labels.data_ptr())
+                     attn_mask=L.ptr(mask), img_feats=L.ptr(feats), mask_pos=L.ptr(mpos), labels=labels.data_ptr(),
+                     n_rows=R, row_seq=L.ptr(rseq))
         if st.saved is not None and st.ws is not None:
             # the activations of an earlier training forward are still waiting for their backward; the workspace is
             # per engine, so this forward overwrites them (their backward will raise instead of using the wrong ones)
             pass
-        ws = st.workspace(B, Lt, Li)
+        ws = st.workspace(B, Lt, Li, R)
         errs = []
 
         def before_bucket(_user, k):
@@ -240,12 +242,14 @@ class _MLMLoss(torch.autograd.Function):
         return None, None, None, None
 
 
-def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels, position_ids, img_feats, mask_token_pos):
+def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels, position_ids, img_feats, mask_token_pos, row_seq=None):
     """(loss, prediction_scores) with autograd history, as REC_MLM_CPT.forward returns them
     (modeling_rec.py:147-152).  ``mask_token_pos`` is required: the loss only sees the [MASK] rows
     (fewshot/refcoco_cpt.py:231-233 puts -1 everywhere else).  For NSPCPT (head "nsp", modeling_vcr.py:115-129)
     ``labels`` are the (B,) next-sentence labels (-1 ignored), ``mask_token_pos`` is None and the second result is
-    the (B, num_contrast_classes) relation scores."""
+    the (B, num_contrast_classes) relation scores.
+    ``row_seq`` (label grids with any number of labelled positions per sequence): ``labels`` / ``mask_token_pos`` then list the R
+    labelled positions, ``row_seq`` (R,) the sequence each belongs to; the second result is the (R, V) scores of those rows."""
     eng = model._engine()
     if mask_token_pos is None and eng.head != "nsp":
         raise NotImplementedError("cpt_amd: training needs mask_token_pos (the (B, L) label grid of the reference has "
@@ -270,7 +274,7 @@ def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels,
     tensors = (prep(input_ids, torch.int64, "input_ids"), prep(token_type_ids, torch.int64, "token_type_ids"),
                prep(attention_mask, torch.int64, "attention_mask"), prep(position_ids, torch.int64, "position_ids"),
                prep(img_feats, torch.float32, "img_feats"), prep(mask_token_pos, torch.int64, "mask_token_pos"),
-               prep(labels, torch.int64, "labels"))
+               prep(labels, torch.int64, "labels"), prep(row_seq, torch.int64, "row_seq"))
     trigger = torch.zeros((), device=eng.flat.device, requires_grad=True)
     loss, logits = _MLMLoss.apply(trigger, eng, tensors, dropout_for(model, st))
     return (loss, logits)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CPT_ABI_VERSION 5     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads */
+#define CPT_ABI_VERSION 5     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads, cpt_batch.n_rows / row_seq */
 
 enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2 };
 enum { CPT_EPI_NONE = 0, CPT_EPI_GELU = 1, CPT_EPI_TANH = 2, CPT_EPI_RESID = 3 };
@@ -143,6 +143,12 @@ typedef struct {
     const float* img_feats;       /* [B][Li][img_dim] fp32, or NULL when Li == 0 */
     const int64_t* mask_pos;      /* [B] position of [MASK] per sequence (rows mode) or NULL */
     const int64_t* labels;        /* rows mode: [B] target id (-1 ignored); all-rows: [B][L]; or NULL */
+    /* ABI 5, training only (0 / NULL: one labelled position per sequence, as above): an arbitrary label grid
+     * (masked_lm_labels of modeling_rec.py:147-150 with any number of labelled positions per sequence) as n_rows labelled
+     * positions -- position mask_pos[r] of sequence row_seq[r] carries labels[r]; the MLM head, the loss and o->logits
+     * [n_rows][V] run over those rows (cpt_train_workspace_bytes_rows sizes the workspace) */
+    int32_t n_rows;
+    const int64_t* row_seq;       /* [n_rows] sequence index of every labelled row, ascending; NULL with n_rows = 0 */
 } cpt_batch;
 
 enum {
@@ -196,6 +202,7 @@ typedef struct {           /* gradients of cpt_model: the MLM-head fields (w_tr 
 } cpt_model_grads;
 
 size_t cpt_train_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li);
+size_t cpt_train_workspace_bytes_rows(const cpt_dims* d, int B, int Lt, int Li, int n_rows);   /* with cpt_batch.n_rows labelled rows (0: B) */
 /* forward: o->logits [B][V] and o->loss[2] = {sum of row losses, labelled-row count} are written;
  * b->mask_pos and b->labels ([B], -1 = ignored) are required.
  * A model WITHOUT the MLM head (w_tr, w_dec NULL) but with w_pool and w_rel trains the NSP-CPT head instead
