@@ -47,7 +47,7 @@ class Model(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("B", C.c_int32), ("Lt", C.c_int32), ("Li", C.c_int32)] + [(n, C.c_void_p) for n in
                 ("input_ids", "token_type", "position_ids", "attn_mask", "img_feats", "mask_pos", "labels")] + \
-               [("n_rows", C.c_int32), ("row_seq", C.c_void_p)]
+               [("n_rows", C.c_int32), ("mask_3d", C.c_int32), ("row_seq", C.c_void_p)]
 
 
 class LayerGrads(C.Structure):

@@ -686,7 +686,7 @@ constexpr int AB_QB = 32, AB_D = 64;
 template <typename T, int MAXE, int QB = AB_QB, bool VG = false>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
                                                        const T* __restrict__ dctx, T* __restrict__ dqkv, int B, int L, int heads,
-                                                       DropSpec dr) {
+                                                       DropSpec dr, int mask3d) {      // mask3d: attn_mask is [B][L][L], one row per query (modeling_bert.py:215-216)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LP1 = L + 1;
     float* sK = reinterpret_cast<float*>(smem);          // [L][65]
@@ -709,7 +709,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         sK[r * 65 + c] = to_f32(base[(size_t)r * ldq + H + c]);
         if (!VG) sV[r * 65 + c] = to_f32(base[(size_t)r * ldq + 2 * H + c]);
     }
-    for (int j = tid; j < L; j += 256) sM[j] = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + j]) * -10000.0f : 0.f;
+    for (int j = tid; j < L; j += 256) sM[j] = (attn_mask && !mask3d) ? (1.0f - (float)attn_mask[(size_t)b * L + j]) * -10000.0f : 0.f;
+    const int64_t* m3 = (attn_mask && mask3d) ? attn_mask + (size_t)b * L * L : nullptr;
 
     // this thread's share of the dK / dV accumulators: elements e = tid + 256*k of the [L][64] tiles
     float accK[MAXE], accV[MAXE];                          // MAXE >= L*64/256
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
                 s += sQ[i * 65 + d] * sK[j * 65 + d];
                 dp += sO[i * 65 + d] * (VG ? to_f32(base[(size_t)j * ldq + 2 * H + d]) : sV[j * 65 + d]);
             }
-            sP[i * LP1 + j] = s * 0.125f + sM[j];
+            sP[i * LP1 + j] = s * 0.125f + (m3 ? (1.0f - (float)m3[(size_t)min(q0 + i, L - 1) * L + j]) * -10000.0f : sM[j]);
             if (drop) {      // dp arrives as the gradient of the DROPPED probabilities: d/dP = mask / (1-p) times it
                 const float wgt = drop_attn_one(dr, (uint32_t)blockIdx.x, min(q0 + i, L - 1), j) ? dr.scale : 0.f;
                 sW[i * LP1 + j] = wgt;
@@ -1190,9 +1191,9 @@ void set_attn_bwd_variant(int v) { g_attn_bwd_variant = v; }
 static size_t attn_bwd_vg_lds(int L, int has_drop) { return ((size_t)L * 65 + 2 * 16 * 65 + (has_drop ? 3 : 2) * 16 * (L + 1) + L) * sizeof(float); }
 // Whether attention_bwd has a kernel for (dtype, L, dropout on the probabilities): asked by cpt_train_fwd so that an unsupported
 // combination is rejected BEFORE the forward runs, not after it
-int attention_bwd_supported(int dtype, int L, int has_drop) {
+int attention_bwd_supported(int dtype, int L, int has_drop, int mask_3d) {
     if (L <= 0) return 0;
-    if (dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 288) return 1;
+    if (!mask_3d && dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 288) return 1;
     if (dtype != CPT_BF16 && dtype != CPT_F32) return 0;
     const size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + (has_drop ? 3 : 2) * AB_QB * (L + 1) + L) * sizeof(float);
     if (lds <= 160 * 1024) return 1;
@@ -1200,18 +1201,21 @@ int attention_bwd_supported(int dtype, int L, int has_drop) {
 }
 
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
-                  const DropSpec* drop, float* dbias) {
+                  const DropSpec* drop, float* dbias, int mask_3d) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
     const DropSpec dr = drop ? *drop : DropSpec{};
+    // a [B][L][L] mask (one row per query) goes through the generic kernels, which read it per score; the MFMA kernels keep one
+    // additive mask value per key in LDS
+    const bool mfma_ok = !(mask_3d && attn_mask);
     // L <= 128: the transpose-read kernel needs 68 KB of LDS and 209 registers -> two workgroups per CU (B * heads = 384 workgroups
     // in one round instead of two): 43.6 vs 51.2 us at B = 32 (rocprofv3)
-    if (dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L > 64 && L <= 128) return attn_bwd_mfma_launch<4, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
-    if (dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 128) {
+    if (mfma_ok && dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L > 64 && L <= 128) return attn_bwd_mfma_launch<4, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+    if (mfma_ok && dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 128) {
         if (L <= 32) return attn_bwd_mfma_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
         if (L <= 64) return attn_bwd_mfma_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
         return attn_bwd_mfma_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
     }
-    if (dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 288) {      // GQA / VCR shapes: transpose-read variant
+    if (mfma_ok && dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 288) {      // GQA / VCR shapes: transpose-read variant
         if (L <= 160) return attn_bwd_mfma_launch<5, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
         if (L <= 224) return attn_bwd_mfma_launch<7, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
         return attn_bwd_mfma_launch<9, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
@@ -1230,7 +1234,7 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
         if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)             \
             return CPT_ERR_HIP - (int)e;                                                                              \
-        k<<<grid, block, lds, s>>>((const TT*)qkv, attn_mask, (const TT*)dctx, (TT*)dqkv, B, L, heads, dr);           \
+        k<<<grid, block, lds, s>>>((const TT*)qkv, attn_mask, (const TT*)dctx, (TT*)dqkv, B, L, heads, dr, mask_3d);  \
     } while (0)
     if (vg) {
         if (dtype == CPT_BF16) ABKV(bf16); else if (dtype == CPT_F32) ABKV(float); else return CPT_ERR_DTYPE;
@@ -1243,7 +1247,7 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
         if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)             \
             return CPT_ERR_HIP - (int)e;                                                                              \
-        k<<<grid, block, lds, s>>>((const TT*)qkv, attn_mask, (const TT*)dctx, (TT*)dqkv, B, L, heads, dr);           \
+        k<<<grid, block, lds, s>>>((const TT*)qkv, attn_mask, (const TT*)dctx, (TT*)dqkv, B, L, heads, dr, mask_3d);  \
     } while (0)
     if (dtype == CPT_BF16) { if (L <= 128) ABK(bf16, 32); else ABK(bf16, 44); }
     else if (dtype == CPT_F32) { if (L <= 128) ABK(float, 32); else ABK(float, 44); }

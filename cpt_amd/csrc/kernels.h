@@ -57,10 +57,10 @@ int zero_segments(const ZeroSegs& z, hipStream_t s);
 int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
                hipStream_t s);
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
-                  const DropSpec* drop = nullptr, float* dbias = nullptr);     // dbias [3H]: += column sums of dqkv (the stacked Q|K|V bias gradient)
+                  const DropSpec* drop = nullptr, float* dbias = nullptr, int mask_3d = 0);     // dbias [3H]: += column sums of dqkv (the stacked Q|K|V bias gradient); mask_3d: attn_mask is [B][L][L]
 // y = dropout(x) (+ resid): x, y fp32 [R][H] (in place allowed), y_lp optional copy in lp_dtype; element index of the mask =
 // row * H + col.  Forward of the hidden dropouts and, with resid = NULL, their backward (the mask applied to a gradient).
-int attention_bwd_supported(int dtype, int L, int has_drop);
+int attention_bwd_supported(int dtype, int L, int has_drop, int mask_3d = 0);
 int dropout_rows(const float* x, const float* resid, float* y, void* y_lp, int lp_dtype, int R, int H, const DropSpec& d, hipStream_t s);
 // keep-mask export (tests): kind 0 hidden [R][H]; kind 1 attention [BH][L][L]; out = 1 keep / 0 drop
 int dropout_mask(int kind, unsigned char* out, int n0, int n1, int n2, const DropSpec& d, hipStream_t s);

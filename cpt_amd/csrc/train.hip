@@ -173,10 +173,11 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     hipStream_t s = (hipStream_t)stream;
     const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, dt = d.dtype;
     if (L > 288) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: sequence length %d > 288", L);
-    if (!cpt::attention_bwd_supported(dt, L, pa ? 1 : 0))       // reject here, not after the forward has run (the backward's attention kernel sets the limit)
+    const int m3d = (b->mask_3d && b->attn_mask) ? 1 : 0;
+    if (!cpt::attention_bwd_supported(dt, L, pa ? 1 : 0, m3d))       // reject here, not after the forward has run (the backward's attention kernel sets the limit)
     {
         int lmax = L;
-        while (lmax > 0 && !cpt::attention_bwd_supported(dt, lmax, pa ? 1 : 0)) --lmax;
+        while (lmax > 0 && !cpt::attention_bwd_supported(dt, lmax, pa ? 1 : 0, m3d)) --lmax;
         return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: no attention backward for dtype %d at sequence length %d%s (longest supported: %d)", dt, L,
                         pa ? " with attention dropout" : "", lmax);
     }
@@ -219,7 +220,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         void* xnext = l + 1 < d.layers ? LB(l + 1, w.o_xin) : (void*)(ws + w.xout);
         TRY(cpt::gemm(dt, CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
-        TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention");
+        TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr, m3d), "attention");
         if (ph) {   // LN(dropout(dense(ctx)) + x): the residual add moves from the GEMM epilogue into the dropout pass
             if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, nullptr, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
             // dropout + residual + LayerNorm in one row pass (pre1 = dropout(dense) + x is stored for the backward pass)
@@ -463,7 +464,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         rc = dgrad(dpre_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
         if (rc) return rc;
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
-        TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr, (g_bias_fuse & 2) ? gy.b_qkv : nullptr), "attention_bwd+bias");
+        TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr, (g_bias_fuse & 2) ? gy.b_qkv : nullptr, (b->mask_3d && b->attn_mask) ? 1 : 0), "attention_bwd+bias");
         if (!(g_bias_fuse & 2)) TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
         if (wgrad_pair(dpre_in, H, H, LB(l, w.o_ctx), H, H, gy.w_ao, dbig, 3 * H, 3 * H, LB(l, w.o_xin), H, H, gy.w_qkv, rc, "wgrad(attn out | qkv)")) {
             if (rc) return rc;

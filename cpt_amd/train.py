@@ -164,7 +164,7 @@ class _MLMLoss(torch.autograd.Function):
             o = L.Outputs(logits=logits.data_ptr(), loss=loss_acc.data_ptr())
         bt = L.Batch(B=B, Lt=Lt, Li=Li, input_ids=ids.data_ptr(), token_type=L.ptr(seg), position_ids=L.ptr(pos),
                      attn_mask=L.ptr(mask), img_feats=L.ptr(feats), mask_pos=L.ptr(mpos), labels=labels.data_ptr(),
-                     n_rows=R, row_seq=L.ptr(rseq))
+                     n_rows=R, row_seq=L.ptr(rseq), mask_3d=1 if (mask is not None and mask.dim() == 3) else 0)
         if st.saved is not None and st.ws is not None:
             # the activations of an earlier training forward are still waiting for their backward; the workspace is
             # per engine, so this forward overwrites them (their backward will raise instead of using the wrong ones)
@@ -269,8 +269,8 @@ def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels,
             raise RuntimeError("cpt_amd: %s must be on the GPU" % name)
         return t.to(dt).contiguous()
 
-    if attention_mask is not None and attention_mask.dim() != 2:
-        raise NotImplementedError("cpt_amd: only 2-D attention_mask is supported")
+    if attention_mask is not None and attention_mask.dim() not in (2, 3):
+        raise NotImplementedError("cpt_amd: attention_mask must be (B, L) or (B, L, L) (modeling_bert.py:213-218)")
     tensors = (prep(input_ids, torch.int64, "input_ids"), prep(token_type_ids, torch.int64, "token_type_ids"),
                prep(attention_mask, torch.int64, "attention_mask"), prep(position_ids, torch.int64, "position_ids"),
                prep(img_feats, torch.float32, "img_feats"), prep(mask_token_pos, torch.int64, "mask_token_pos"),

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CPT_ABI_VERSION 5     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads, cpt_batch.n_rows / row_seq */
+#define CPT_ABI_VERSION 5     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads, cpt_batch.n_rows / mask_3d / row_seq */
 
 enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2 };
 enum { CPT_EPI_NONE = 0, CPT_EPI_GELU = 1, CPT_EPI_TANH = 2, CPT_EPI_RESID = 3 };
@@ -148,6 +148,8 @@ typedef struct {
      * positions -- position mask_pos[r] of sequence row_seq[r] carries labels[r]; the MLM head, the loss and o->logits
      * [n_rows][V] run over those rows (cpt_train_workspace_bytes_rows sizes the workspace) */
     int32_t n_rows;
+    int32_t mask_3d;              /* ABI 5, training only: 1 = attn_mask is [B][L][L], one mask row per query (modeling_bert.py:215-216; inference
+                                   * passes CPT_ATTN_MASK_3D instead); the attention backward then runs its generic kernel */
     const int64_t* row_seq;       /* [n_rows] sequence index of every labelled row, ascending; NULL with n_rows = 0 */
 } cpt_batch;
 

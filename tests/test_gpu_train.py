@@ -436,9 +436,62 @@ def test_label_grid_with_several_labelled_positions_per_sequence(dev, mode):
                                                  masked_lm_labels=grid, img_feats=b["img_feats"])
     ref_loss.backward()
     ltol, gtol, stol = (1e-4, 2e-4, 1e-4) if mode == "fp32" else (3e-2, 8e-2, 5e-2)
-    assert abs(loss.item() - float(ref_loss)) < ltol, (loss.item(), float(ref_loss))
+    assert abs(loss.item() - float(ref_loss.detach())) < ltol, (loss.item(), float(ref_loss.detach()))
     picked = ref_scores.detach()[grid != -1]                       # row-major order of the grid = the order of our rows
     assert float((scores.cpu() - picked).abs().max()) < stol * max(1.0, float(picked.abs().max()))
+    n = 0
+    for name, prm in m.named_parameters():
+        rg = leaves[name].grad if name in leaves else None
+        if rg is None or float(rg.abs().max()) == 0.0:
+            continue
+        rel, mx = _rel(prm.grad, rg)
+        assert rel < gtol or mx < (1e-9 if mode == "fp32" else 2e-6), (name, rel, mx)
+        n += 1
+    assert n > 30
+
+
+@pytest.mark.parametrize("mode,Lt,Li,p", [("fp32", 20, 6, 0.0), ("bf16", 20, 6, 0.0), ("fp32", 100, 45, 0.0), ("bf16", 165, 45, 0.0), ("fp32", 20, 6, 0.1)])
+def test_training_with_a_three_dimensional_attention_mask(dev, mode, Lt, Li, p):
+    """Round 3: attention_mask (B, L, L), one mask row per query (modeling_bert.py:215-216), in the TRAINING step:
+    the forward attention kernel reads it per query, the backward runs the generic kernels (they read the mask per score; the MFMA
+    kernels hold one value per key).  Loss and every gradient against autograd over the oracle (with the exported dropout masks when
+    p > 0); L = 145 and 210 take the long-sequence instantiations."""
+    from oracle import cpt_oracle as O
+    cfg = cfgmod.tiny(max_position_embeddings=max(96, Lt))
+    m = _model(cfg, 41, dev, mode, dropout=p)
+    B = 3
+    b = synth.make_batch(B, cfg, seed=6, max_seq_len=Lt, img_seq_len=Li, vary_regions=True)
+    Lq = Lt + Li
+    rng = np.random.Generator(np.random.PCG64(12))
+    per_q = torch.from_numpy((rng.random((B, Lq, Lq)) < 0.7).astype(np.int64)) * b["attention_mask"][:, None, :]
+    per_q[:, torch.arange(Lq), torch.arange(Lq)] = 1
+    d = {k: v.to(dev) for k, v in b.items()}
+    drop = None
+    if p > 0:
+        from cpt_amd import train as T
+        from tests.test_gpu_dropout import _drop_dict, SEED
+        T.set_dropout_seed(m, SEED, step=0)     # the key test_gpu_dropout's mask export uses; the first forward is step 1
+    loss, _ = m(d["input_ids"], d["segment_ids"], per_q.to(dev), img_feats=d["img_feats"], masked_lm_labels=d["colors"],
+                mask_token_pos=d["mask_token_pos"])
+    loss.backward()
+    if p > 0:
+        drop = _drop_dict(dev, cfg, p, 1, B, Lq)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    leaves = {k: t.clone().requires_grad_(True) for k, t in sd.items() if k != "cls.decoder.weight"}
+    work = dict(leaves)
+    work["cls.decoder.weight"] = leaves["bert.embeddings.word_embeddings.weight"]
+    grid = torch.full((B, Lq), -1, dtype=torch.long)
+    grid[torch.arange(B), b["mask_token_pos"]] = b["colors"]
+    ref_loss, _ = O.rec_mlm_cpt_forward(work, cfg.to_dict(), b["input_ids"], b["segment_ids"], per_q, masked_lm_labels=grid,
+                                        img_feats=b["img_feats"], mask_rows_only=b["mask_token_pos"], drop=drop)
+    ref_loss.backward()
+    ltol, gtol = (2e-4, 2e-4) if mode == "fp32" else (4e-2, 8e-2)
+    assert abs(loss.item() - float(ref_loss.detach())) < ltol, (loss.item(), float(ref_loss.detach()))
+    two = O.rec_mlm_cpt_forward(sd | {"cls.decoder.weight": sd["bert.embeddings.word_embeddings.weight"]}, cfg.to_dict(), b["input_ids"],
+                                b["segment_ids"], b["attention_mask"], masked_lm_labels=grid, img_feats=b["img_feats"],
+                                mask_rows_only=b["mask_token_pos"])[0]
+    if p == 0:
+        assert abs(float(two) - float(ref_loss.detach())) > 1e-4          # the per-query mask matters
     n = 0
     for name, prm in m.named_parameters():
         rg = leaves[name].grad if name in leaves else None
