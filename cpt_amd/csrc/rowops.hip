@@ -69,7 +69,12 @@ __device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lan
     }
 }
 
-template <typename LP, bool GELU_IN>
+// Round 3: LN_RPW rows per wave with every row's loads issued before the first row is reduced (a wave with ONE row kept 3 KB in
+// flight and the kernel ran at the latency of its load -> reduce -> store chain: 3.9-4.6 TB/s on Infinity-Cache-resident rows).
+// Per-row arithmetic and order are unchanged: same bits.
+// Chosen per launch: two rows per wave from 24576 rows on (> 256 MB working sets: 3.85 -> 4.9 TB/s for the bf16-only output form); below
+// that one row per wave keeps twice the waves on the chip, which is what hides the latency of a small launch (7680 rows: 9.1 vs 11.3 us).
+template <typename LP, bool GELU_IN, int LN_RPW>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
@@ -78,39 +83,54 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     // BertSelfOutput / BertOutput): the row that is normalised is dropout(x) + resid, written to pre_out for the backward pass --
     // the same arithmetic, in the same order, as the dropout_rows pass this replaces
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
-    if (r >= R) return;
+    const int r0 = (blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6)) * LN_RPW;
+    if (r0 >= R) return;
     const int nv = (H + 255) / 256;
-    f32x4 v[MAXV];
-    const float* xr = x + (size_t)r * H;
+    f32x4 v[LN_RPW][MAXV], rr[LN_RPW][MAXV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (i < nv && c < H) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + c);
-            if (GELU_IN) {
+    for (int u = 0; u < LN_RPW; ++u) {
+        const int r = r0 + u;
+        if (r >= R) continue;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[i][j] = gelu_erf(v[i][j]);
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (i < nv && c < H) {
+                v[u][i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
+                if (resid) rr[u][i] = *reinterpret_cast<const f32x4*>(resid + (size_t)r * H + c);
             }
-            if (dr.thresh != 0) {
-                bool keep[4];
-                drop_hidden4(dr, ((uint64_t)r * H + c) >> 2, keep);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[i][j] = keep[j] ? v[i][j] * dr.scale : 0.f;
-            }
-            if (resid) {
-                const f32x4 rr = *reinterpret_cast<const f32x4*>(resid + (size_t)r * H + c);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[i][j] += rr[j];
-            }
-            if (pre_out) *reinterpret_cast<f32x4*>(pre_out + (size_t)r * H + c) = v[i];
         }
     }
-    float mean = 0.f, rstd = 1.f;
-    if (g) ln_stats(v, nv, lane, H, mean, rstd, eps);
-    const size_t orow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
-    ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
-                 out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
+#pragma unroll
+    for (int u = 0; u < LN_RPW; ++u) {
+        const int r = r0 + u;
+        if (r >= R) continue;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (i < nv && c < H) {
+                if (GELU_IN) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][i][j] = gelu_erf(v[u][i][j]);
+                }
+                if (dr.thresh != 0) {
+                    bool keep[4];
+                    drop_hidden4(dr, ((uint64_t)r * H + c) >> 2, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][i][j] = keep[j] ? v[u][i][j] * dr.scale : 0.f;
+                }
+                if (resid) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][i][j] += rr[u][i][j];
+                }
+                if (pre_out) *reinterpret_cast<f32x4*>(pre_out + (size_t)r * H + c) = v[u][i];
+            }
+        }
+        float mean = 0.f, rstd = 1.f;
+        if (g) ln_stats(v[u], nv, lane, H, mean, rstd, eps);
+        const size_t orow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
+        ln_write<LP>(v[u], nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
+                     out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
+    }
 }
 
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
@@ -121,9 +141,14 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
     const DropSpec dr = drop ? *drop : DropSpec{};
     if (grp_stride == 0 && grp != R) grp_stride = grp;
-    dim3 grid((R + 3) / 4), block(ROW_THREADS);
+    const int rpw = R >= 24576 ? 2 : 1;
+    dim3 grid((R + 4 * rpw - 1) / (4 * rpw)), block(ROW_THREADS);
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
-#define LNK(LPT, GI) layernorm_rows_kernel<LPT, GI><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo)
+#define LNK(LPT, GI)                                                                                                                              \
+    do {                                                                                                                                          \
+        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo); \
+        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo);          \
+    } while (0)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
     else      { if (gelu_in) LNK(float, true); else LNK(float, false); }
 #undef LNK
@@ -193,34 +218,49 @@ int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const fl
 // ---- pad + cast: x[R][K] f32 -> out[R][Kp] T ---------------------------------------------------
 // One thread per 8 output elements: four 8-byte loads (rows of x are 8-byte aligned when K is even, e.g. the
 // 2054-float region features) and one 16-byte (bf16) / two 16-byte (f32) stores.
+// Round 3: four chunks per thread (grid-stride apart, so a wave's accesses stay contiguous), all eight 16-byte loads in flight
+// before the first store.  Measured: 13.7 vs 13.2 us for the 26 MB region-feature read -- no gain over one chunk per thread, so the
+// pass is not bound by bytes in flight (its rows start on 8-byte boundaries: every 16-byte load straddles).
+constexpr int PC_UNR = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__ x, T* __restrict__ out, int R, int K, int Kp) {
     const int cpr = Kp / 8;                                   // 8-element chunks per output row
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)R * cpr) return;
-    const int r = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
-    const float* src = x + (size_t)r * K + c;
-    float v[8];
-    if (c + 8 <= K && (K & 1) == 0) {
-        // rows of K = 2054 floats start on 8-byte boundaries only: two 16-byte loads from 8-byte-aligned addresses (legal: the HSA target runs
-        // in unaligned-access mode) instead of four 8-byte ones -- half the load instructions of this HBM-bound pass
-        typedef f32x4 f32x4_a8 __attribute__((aligned(8)));
-        const f32x4 t0 = *reinterpret_cast<const f32x4_a8*>(src), t1 = *reinterpret_cast<const f32x4_a8*>(src + 4);
+    const size_t total = (size_t)R * cpr, stride = (size_t)gridDim.x * 256;
+    const size_t idx0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float v[PC_UNR][8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
-    } else {
+    for (int u = 0; u < PC_UNR; ++u) {
+        const size_t idx = idx0 + u * stride;
+        if (idx >= total) continue;
+        const int r = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
+        const float* src = x + (size_t)r * K + c;
+        if (c + 8 <= K && (K & 1) == 0) {
+            // rows of K = 2054 floats start on 8-byte boundaries only: two 16-byte loads from 8-byte-aligned addresses (legal: the HSA target runs
+            // in unaligned-access mode) instead of four 8-byte ones -- half the load instructions of this HBM-bound pass
+            typedef f32x4 f32x4_a8 __attribute__((aligned(8)));
+            const f32x4 t0 = *reinterpret_cast<const f32x4_a8*>(src), t1 = *reinterpret_cast<const f32x4_a8*>(src + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = c + e < K ? src[e] : 0.f;
+            for (int e = 0; e < 4; ++e) { v[u][e] = t0[e]; v[u][4 + e] = t1[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[u][e] = c + e < K ? src[e] : 0.f;
+        }
     }
-    T* dst = out + (size_t)r * Kp + c;
-    if constexpr (sizeof(T) == 2) {
-        bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        *reinterpret_cast<bf16x8*>(dst) = o;
-    } else {
-        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    for (int u = 0; u < PC_UNR; ++u) {
+        const size_t idx = idx0 + u * stride;
+        if (idx >= total) continue;
+        const int r = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
+        T* dst = out + (size_t)r * Kp + c;
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[u][e];
+            *reinterpret_cast<bf16x8*>(dst) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[u][0], v[u][1], v[u][2], v[u][3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[u][4], v[u][5], v[u][6], v[u][7]};
+        }
     }
 }
 
@@ -243,7 +283,7 @@ int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStre
     dim3 block(256);
     if (Kp % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)x % 8) == 0) {
         const size_t n = (size_t)R * (Kp / 8);
-        dim3 grid((unsigned)((n + 255) / 256));
+        dim3 grid((unsigned)((n + 256 * PC_UNR - 1) / (256 * PC_UNR)));
         if (dtype == CPT_BF16) pad_cast_kernel<bf16><<<grid, block, 0, s>>>(x, (bf16*)out, R, K, Kp);
         else pad_cast_kernel<float><<<grid, block, 0, s>>>(x, (float*)out, R, K, Kp);
         return CPT_OK;
