@@ -1542,6 +1542,9 @@ int gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const float* b
 
 // Consumer: A is the bf16 copy of a pre-LayerNorm tensor, Wf the gain-folded weight;
 // out = [gelu]( rstd[m] * (A.Wf^T - mean[m] * colc[n]) + cold[n] )  ==  [gelu]( LayerNorm(A) . W^T + bias )
+int g_qkv_2pass = 1;
+void set_qkv_2pass(int v) { g_qkv_2pass = v; }
+
 int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
                  float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s, int out_panel, const void* pf, size_t pf_bytes) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
@@ -1559,6 +1562,10 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
         void* tr = ((g_trace_epi < 0 || g_trace_epi == CPT_EPI_LNCONS_GELU) && (g_trace_k == 0 || g_trace_k == K)) ? (void*)g_gemm_trace : nullptr;
         return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, tr, g_gemm_abl, s);
     }
+    // round 3: the stand-alone QKV projection (attention not fused: L > 128) through the GELU-less two-pass kernel when its 384 x 256 tiles
+    // fill the chip (key 20 = 0: the 384 x 192 pipe kernel as before); same accumulation order, same bits
+    if (!gelu && g_qkv_2pass && ((v == 3 && ffn_up_2pass_preferred(M, N, K)) || (v == 20 && ffn_up_2pass_legal(M, N, K))))
+        return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, nullptr, g_gemm_abl, s, 0, nullptr, 0, 0);
     if (gelu) launch_fast<bf16, CPT_EPI_LNCONS_GELU, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
     else launch_fast<bf16, CPT_EPI_LNCONS, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
     return CPT_OK;

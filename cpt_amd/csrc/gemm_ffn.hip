@@ -51,7 +51,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CPT_FFN_PIPE
 #define CPT_FFN_PIPE 0
 #endif
-template <int NT, bool LATE = true, bool PANEL = false, bool PIPE = (CPT_FFN_PIPE != 0)>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
+// GELU = false (round 3): the same kernel as a plain LayerNorm-consumer GEMM -- the stand-alone QKV projection of the shapes whose attention
+// does not fuse (L > 128: GQA 165 + 45, VCR 165 + 100), which ran on the 384 x 192 pipe kernel at 2/3 of this kernel's rate per CU.
+template <int NT, bool LATE = true, bool PANEL = false, bool GELU = true, bool PIPE = (CPT_FFN_PIPE != 0)>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
 __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                                                               bf16* __restrict__ out, int ldo, int M, int N,
                                                               const float* __restrict__ st_in, int st_parts, const float* __restrict__ colc,
@@ -240,6 +242,10 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
         f32x4 x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] = ln_fold(a[4 * g + e], ms.x, ms.y, c4[e], d4[e]);
+        if constexpr (!GELU) {
+            bf16x4 p4 = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+            return __builtin_bit_cast(u32x2, p4);
+        }
         const f32x2 g0 = gelu_fast2(f32x2{x[0], x[1]}), g1 = gelu_fast2(f32x2{x[2], x[3]});
         bf16x4 p4 = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
         return __builtin_bit_cast(u32x2, p4);
@@ -388,11 +394,11 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
 #endif
 }
 
-template <int NT, bool LATE = true, bool PANEL = false>
+template <int NT, bool LATE = true, bool PANEL = false, bool GELU = true>
 int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int ldo, int M, int N, const float* st_in, int st_parts,
                  const float* colc, const float* cold, float eps, float inv_h, long long* trace, int abl, hipStream_t s,
                  const void* pf = nullptr, size_t pf_bytes = 0) {
-    auto kern = ffn_up_2pass_kernel<NT, LATE, PANEL>;
+    auto kern = ffn_up_2pass_kernel<NT, LATE, PANEL, GELU>;
     static bool attr_done_dev[CPT_MAX_DEV] = {};
     bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
@@ -425,8 +431,14 @@ int ffn_up_2pass_preferred(int M, int N, int K) {
 
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
                       float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s, int out_panel,
-                      const void* pf, size_t pf_bytes) {
+                      const void* pf, size_t pf_bytes, int gelu) {
     if (!ffn_up_2pass_legal(M, N, K)) return CPT_ERR_SHAPE;
+    if (!gelu) {        // plain LayerNorm-consumer form (QKV projection): row-major output only
+        if (out_panel) return CPT_ERR_SHAPE;
+        if (lda % 8 || ldw % 8 || ldo % 8 || (((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)out | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
+        if (K == 768) return launch_2pass<12, true, false, false>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s);
+        return launch_2pass<16, true, false, false>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s);
+    }
     if ((size_t)((M + 31) & ~31) * (out_panel ? N : ldo) * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;      // 32-bit store offsets
     if (out_panel) {
         if (N % 16) return CPT_ERR_SHAPE;

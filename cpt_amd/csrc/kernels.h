@@ -149,6 +149,7 @@ int fold_ln_weights(const float* W, const float* gamma, const float* beta, const
                     float* cold, int N, int K, hipStream_t s);
 void set_splitk_target(int v);
 void set_wgrad_pair(int v);  // training backward: the layer's weight gradients as two paired launches (1, default) or four single ones (0)
+void set_qkv_2pass(int v);   // stand-alone LayerNorm-consumer QKV projection through the GELU-less two-pass kernel (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
 void set_lnb_rpb(int v);     // LayerNorm backward: rows per workgroup of the two-stage column-sum form (experiments)
 void set_wgrad_tn(int v);    // 1 (default): bf16 weight gradients through the TN GEMM; 0: explicit operand transposes
@@ -161,7 +162,7 @@ int ffn_up_2pass_legal(int M, int N, int K);
 int ffn_up_2pass_preferred(int M, int N, int K);
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
                       float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s, int out_panel = 0,
-                      const void* pf = nullptr, size_t pf_bytes = 0);
+                      const void* pf = nullptr, size_t pf_bytes = 0, int gelu = 1);     // gelu 0: plain LayerNorm-consumer GEMM (stand-alone QKV projection)
 void set_ffn_dma_late(int v);
 void set_prod_abl(int v);    // timing experiments of the panel producer (gemm_prod.hip)
 void set_gemm_trace(void* p);

@@ -305,6 +305,33 @@ def test_ln_consumer_kernels_are_bit_identical(dev):
         assert torch.equal(outs[3][:960], outs[(v, "small")]), "variant %d, 960-row problem" % v
 
 
+@pytest.mark.parametrize("M,N,K", [(53760, 2304, 768), (8480, 3072, 1024), (7680, 2304, 768)])
+def test_qkv_projection_two_pass_kernel_is_bit_identical(dev, M, N, K):
+    """Round 3: the stand-alone QKV projection with the LayerNorm folded (sequences longer than 128, whose attention does not fuse: the
+    GQA and VCR shapes, Oscar-base and Oscar-large widths) runs the GELU-less form of the two-pass 384 x 256 kernel when its tiles fill
+    the chip; cpt_set_tuning(20, 0) keeps the 384 x 192 pipelined kernel.  Same accumulation order and epilogue arithmetic: same BITS,
+    also for a 960-row slice (which takes the small-problem tile shapes)."""
+    from cpt_amd import ops, _lib as L
+    rng = _rng(M + N)
+    x = _t(rng, M, K, scale=1.3) + 0.4
+    a = x.to(torch.bfloat16).to(dev)
+    st = ops.row_stats_table(x.to(dev))
+    wf = _t(rng, N, K, scale=0.04).to(torch.bfloat16).to(dev)
+    colc = wf.float().sum(1).contiguous()
+    cold = _t(rng, N, scale=0.1).to(dev)
+    two = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, False)
+    small = ops.gemm_ln_cons(a[:960], wf, st[:960], colc, cold, 1e-12, K, False)
+    L.check(L.lib().cpt_set_tuning(20, 0))
+    pipe = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, False)
+    assert torch.equal(two, pipe)
+    assert torch.equal(two[:960], small)
+    xs = x[:256]
+    ref = ((xs.to(torch.bfloat16).float() - xs.mean(1, keepdim=True)) / xs.var(1, unbiased=False, keepdim=True).add(1e-12).sqrt()) @ wf.float().cpu().T
+    # (loose sanity bound against fp32 math of the folded form; the operator's parity test is test_gemm_ln_cons)
+    got = two[:256].float().cpu() - cold.cpu()
+    assert float((got - ref).abs().max()) < 0.05 * float(ref.abs().max()) + 0.05
+
+
 @pytest.mark.parametrize("K,M,N", [(3840, 768, 768), (3840, 2304, 768), (3840, 768, 3072), (1600, 768, 2112), (960, 1024, 1024),
                                    (192, 128, 192), (64, 128, 128), (53760, 768, 768), (2120, 1024, 4096), (100, 128, 128)])
 def test_gemm_tn_weight_gradient_form(dev, K, M, N):
