@@ -35,7 +35,12 @@ __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >>
 template <typename T, int NKB>
 __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kernel(
     const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
-    T* __restrict__ probs, int B, int L, int heads, DropSpec dr, int mask3, int ctx_panel) {
+    T* __restrict__ probs, int B, int L, int heads, DropSpec dr, int mask3, int ctx_panel, int remap) {
+    // remap (round 3, sequences of several 128-query tiles): a 1-D grid whose workgroups id, id + 8, .. (same XCD -- workgroups go to
+    // the XCDs round robin -- dispatched back to back) are the query tiles of ONE (sequence, head), so the K / V rows the tiles share are
+    // fetched from memory once and hit that XCD's L2 for the other tiles.  With the (pair, tile) grid the tiles of a pair ran 3072
+    // workgroups apart: at B = 256, L = 210 the launch read K / V twice from HBM (the 248 MB QKV tensor does not stay in the Infinity
+    // Cache) and ran at the rate of that traffic, 413 MB in 157 us.
     // ctx_panel (bf16 inference, round 3): ctx leaves in the fragment-major panel layout of the attn-out producer (gemm_prod.hip)
     // mask3: attn_mask is [B][L][L] (one row per query, modeling_bert.py:215-216) instead of [B][L]: the per-key LDS vector
     // then only marks the padding keys and every lane adds its own query's row from global memory
@@ -56,8 +61,15 @@ __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kerne
     float* sMask = reinterpret_cast<float*>(sV + V_BYTES); // LP floats
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int q0 = blockIdx.y * 128 + wave * 32;
+    int bh = blockIdx.x, qt = blockIdx.y;
+    if (remap) {
+        const int nqt = (L + 127) / 128, id = blockIdx.x, slot = id >> 3;
+        qt = slot % nqt;
+        bh = (slot / nqt) * 8 + (id & 7);
+        if (bh >= B * heads) return;          // (pairs are padded to a multiple of 8; uniform per workgroup, ahead of the barrier)
+    }
+    const int b = bh / heads, h = bh % heads;
+    const int q0 = qt * 128 + wave * 32;
     const int H = heads * HD;
     const size_t ldq = (size_t)3 * H;
     const T* base = qkv + (size_t)b * L * ldq + h * HD;
@@ -114,10 +126,10 @@ __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kerne
         T* crow = ctx + ((size_t)b * L + min(q, L - 1)) * H + h * HD;
         T* prow = probs ? probs + (((size_t)b * heads + h) * L + min(q, L - 1)) * L : nullptr;
         if (ctx_panel)
-            attn_core_bf16<NKB, VSWZ, true>(fq, sK, sV, sMask, lane, q < L, nullptr, nullptr, L, dr, (uint32_t)blockIdx.x, min(q, L - 1), mrow,
+            attn_core_bf16<NKB, VSWZ, true>(fq, sK, sV, sMask, lane, q < L, nullptr, nullptr, L, dr, (uint32_t)bh, min(q, L - 1), mrow,
                                             (void*)ctx, (int)min((size_t)(((size_t)B * L + 31) & ~(size_t)31) * H * 2, (size_t)0x7fffffff), b * L + min(q, L - 1), h * 8, H >> 4);
         else
-        attn_core_bf16<NKB, VSWZ>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)blockIdx.x, min(q, L - 1), mrow);
+        attn_core_bf16<NKB, VSWZ>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)bh, min(q, L - 1), mrow);
         return;
     }
 
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kerne
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 bool keep[4];
-                drop_attn_row4(dr, (uint32_t)blockIdx.x, min(q, L - 1), kb * 8 + 2 * g + fh, keep);
+                drop_attn_row4(dr, (uint32_t)bh, min(q, L - 1), kb * 8 + 2 * g + fh, keep);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) st[kb][4 * g + j] = keep[j] ? st[kb][4 * g + j] * dr.scale : 0.f;
             }
@@ -219,6 +231,9 @@ __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kerne
         }
 }
 
+int g_attn_remap = 1;       // cpt_set_tuning(21, v): 0 = the (pair, tile) grid of rounds 1-2 (A/B)
+void set_attn_qt_all(int v) { g_attn_remap = v; }
+
 template <typename T, int NKB>
 static size_t att_lds_bytes() {
     constexpr int LP = NKB * 32;
@@ -234,8 +249,10 @@ static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* pro
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
     }
-    dim3 grid(B * heads, (L + 127) / 128), block(ATT_THREADS);
-    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads, dr, mask3, ctx_panel);
+    const int nqt = (L + 127) / 128;
+    const int remap = (nqt > 1 && g_attn_remap) ? 1 : 0;
+    dim3 grid(remap ? ((B * heads + 7) / 8 * 8) * nqt : B * heads, remap ? 1 : nqt), block(ATT_THREADS);
+    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads, dr, mask3, ctx_panel, remap);
     return CPT_OK;
 }
 

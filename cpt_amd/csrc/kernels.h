@@ -149,6 +149,7 @@ int fold_ln_weights(const float* W, const float* gamma, const float* beta, const
                     float* cold, int N, int K, hipStream_t s);
 void set_splitk_target(int v);
 void set_wgrad_pair(int v);  // training backward: the layer's weight gradients as two paired launches (1, default) or four single ones (0)
+void set_attn_qt_all(int v); // stand-alone attention, L > 128: the query tiles of a (sequence, head) as neighbouring workgroups of one XCD (1, default)
 void set_qkv_2pass(int v);   // stand-alone LayerNorm-consumer QKV projection through the GELU-less two-pass kernel (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
 void set_lnb_rpb(int v);     // LayerNorm backward: rows per workgroup of the two-stage column-sum form (experiments)
