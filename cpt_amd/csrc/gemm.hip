@@ -1149,7 +1149,12 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         for (int i = 0; i < 9; ++i) {
             if (cand[i].bm == 0 || (heavy_epi && (i == 3 || i == 4))) continue;
             const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
-            const long cost = ((wgs + cand[i].slots - 1) / cand[i].slots) * cand[i].round_cost;
+            long rc = cand[i].round_cost;
+            // round 3 (measured on the Oscar-large shapes, M = 8480, N = 1024): with a residual-type epilogue the 128 x 384 shape (8 waves of
+            // 64 x 96 on a 2-stage ring) runs a round in ~2.2x the time of a 128 x 192 round, not 1.6x: attn-out 65 vs 43 us, FFN-down
+            // 133 vs 108 us for one round of it against two rounds of 128 x 192
+            if (heavy_epi && i == 2) rc = 720;
+            const long cost = ((wgs + cand[i].slots - 1) / cand[i].slots) * rc;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; pick = i; }
         }
     } else if (variant == 11) pick = 1;
@@ -1564,7 +1569,9 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
     }
     // round 3: the stand-alone QKV projection (attention not fused: L > 128) through the GELU-less two-pass kernel when its 384 x 256 tiles
     // fill the chip (key 20 = 0: the 384 x 192 pipe kernel as before); same accumulation order, same bits
-    if (!gelu && g_qkv_2pass && ((v == 3 && ffn_up_2pass_preferred(M, N, K)) || (v == 20 && ffn_up_2pass_legal(M, N, K))))
+    // (only when its tiles fill their rounds: M = 8480, N = 3072 makes 23 x 12 = 276 tiles = 1.08 rounds, where 192 x 192 tiles take 1.70 vs 1.97 ms per step)
+    const long t2p = (long)((M + 383) / 384) * (N / 256), r2p = (t2p + 255) / 256;
+    if (!gelu && g_qkv_2pass && ((v == 3 && ffn_up_2pass_preferred(M, N, K) && t2p * 5 >= r2p * 256 * 4) || (v == 20 && ffn_up_2pass_legal(M, N, K))))
         return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, nullptr, g_gemm_abl, s, 0, nullptr, 0, 0);
     if (gelu) launch_fast<bf16, CPT_EPI_LNCONS_GELU, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
     else launch_fast<bf16, CPT_EPI_LNCONS, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
