@@ -68,7 +68,8 @@ int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char
                float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s);
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
-                      const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr);
+                      const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr,
+                      const float* x2 = nullptr);     // x2: second split-K partial matrix (the row that is processed is x + x2)
 // resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients
@@ -150,6 +151,7 @@ int fold_ln_weights(const float* W, const float* gamma, const float* beta, const
 void set_splitk_target(int v);
 void set_wgrad_pair(int v);  // training backward: the layer's weight gradients as two paired launches (1, default) or four single ones (0)
 void set_attn_qt_all(int v); // stand-alone attention, L > 128: the query tiles of a (sequence, head) as neighbouring workgroups of one XCD (1, default)
+void set_fwd_split2(int v);  // training forward: FFN-down as two split-K partial matrices summed by the LayerNorm pass (1, default)
 void set_qkv_2pass(int v);   // stand-alone LayerNorm-consumer QKV projection through the GELU-less two-pass kernel (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
 void set_lnb_rpb(int v);     // LayerNorm backward: rows per workgroup of the two-stage column-sum form (experiments)

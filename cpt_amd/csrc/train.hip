@@ -20,6 +20,10 @@ using cpt::g_wgrad_tn;
 // cpt_set_tuning(19, v): 1 (default) = a layer's four weight gradients run as two paired launches (gemm_tn_pair), 0 = four single ones
 namespace cpt { int g_wgrad_pair = 1; void set_wgrad_pair(int v) { g_wgrad_pair = v; } }
 using cpt::g_wgrad_pair;
+// cpt_set_tuning(22, v): 1 (default) = the FFN-down of the training forward runs on 128 x 192 tiles with K split in two (gemm_img_proj's
+// kernel) and the dropout + residual + LayerNorm pass adds the two partial matrices, 0 = 64 x 192 tiles over the whole K
+namespace cpt { int g_fwd_split2 = 1; void set_fwd_split2(int v) { g_fwd_split2 = v; } }
+using cpt::g_fwd_split2;
 namespace cpt { int g_bias_fuse = 2; void set_bias_fuse(int v) { g_bias_fuse = v; } }
 using cpt::g_bias_fuse;
 
@@ -237,6 +241,18 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_a), H, y.w_in, H, y.b_in, nullptr, 0, LB(l, w.o_u), dt, I, M, I, H, s), "gemm(ffn up)");
         TRY(cpt::gelu_fwd(LB(l, w.o_u), LB(l, w.o_h), dt, (size_t)M * I, s), "gelu");
         }
+        // round 3: at row counts where 128-row tiles would leave half the chip idle (M = 3840: 120 tiles) and K is long, the FFN-down runs
+        // 128 x 192 tiles with K split over two workgroups (240 workgroups at twice the arithmetic intensity of the 64 x 192 tiles) and the row
+        // pass that follows adds the two partial matrices
+        const bool split2 = g_fwd_split2 && dt == CPT_BF16 && g_wgrad_tn && M >= 2048 && M <= 6144 && I >= 2048 && I % 128 == 0 && H % 192 == 0 &&
+                            (size_t)2 * M * H * 4 <= w.tA_bytes;
+        if (split2) {
+            float* part = (float*)(ws + w.tA);
+            TRY(cpt::gemm_img_proj(LB(l, w.o_h), I, y.w_out, I, y.b_out, part, H, M, H, I, s), "gemm(ffn down, K split in two)");
+            const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
+            TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
+                                       a_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre2), nullptr, part + (size_t)M * H), "partials+dropout(ffn down)+residual+layernorm");
+        } else
         if (ph) {
             if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);

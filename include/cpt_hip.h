@@ -439,6 +439,8 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *          the GELU-less form of the two-pass 384 x 256 kernel when its tiles fill the chip, 0 = the 384 x 192 pipelined kernel
  *   key 21 stand-alone attention kernel, sequences longer than 128: 1 (default) = the 128-query tiles of a (sequence, head) are neighbouring
  *          workgroups of one XCD (their shared K / V rows are fetched from memory once), 0 = the (pair, tile) grid
+ *   key 22 training forward, FFN-down at 2048..6144 rows: 1 (default) = 128 x 192 tiles with K split over two workgroups, the two partial
+ *          matrices added by the dropout + residual + LayerNorm pass behind it; 0 = 64 x 192 tiles over the whole K
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at

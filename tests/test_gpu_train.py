@@ -501,3 +501,35 @@ def test_training_with_a_three_dimensional_attention_mask(dev, mode, Lt, Li, p):
         assert rel < gtol or mx < (1e-9 if mode == "fp32" else 2e-6), (name, rel, mx)
         n += 1
     assert n > 30
+
+
+def test_forward_ffn_down_split_in_two_matches_the_unsplit_form(dev):
+    """Round 3: at 2048..6144 rows the training forward runs the FFN-down on 128 x 192 tiles with K split over two workgroups and lets the
+    dropout + residual + LayerNorm pass add the two partial matrices (cpt_set_tuning key 22).  Against the 64 x 192 form over the whole K
+    (key 22 = 0): the same bf16 products in another fp32 summation order -- loss to 1e-4, gradients to the bf16 band."""
+    from cpt_amd import _lib as L
+    from cpt_amd import train as T
+    cfg = cfgmod.oscar_base(num_hidden_layers=4)
+    m = _model(cfg, 29, dev, "bf16", dropout=0.1)
+    b = {k: v.to(dev) for k, v in synth.make_batch(32, cfg, seed=19).items()}
+    params = dict(m.named_parameters())
+
+    def run(v):
+        L.check(L.lib().cpt_set_tuning(22, v), "cpt_set_tuning")
+        T.set_dropout_seed(m, 23)
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
+                    mask_token_pos=b["mask_token_pos"])
+        loss.backward()
+        return loss.item(), {n: p.grad.double().clone() for n, p in params.items() if p.grad is not None}
+
+    l0, g0 = run(0)
+    l1, g1 = run(1)
+    assert abs(l0 - l1) < 1e-4 * max(1.0, abs(l0)), (l0, l1)
+    assert l0 != l1 or any(not torch.equal(g0[n], g1[n]) for n in g0)          # (the split path really ran: some bit differs)
+    for n in g0:
+        if ".key.bias" in n:
+            continue
+        rel = float((g0[n] - g1[n]).norm()) / (float(g0[n].norm()) + 1e-30)
+        assert rel < 2e-2, (n, rel)
