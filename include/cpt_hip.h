@@ -212,8 +212,9 @@ size_t cpt_train_workspace_bytes_rows(const cpt_dims* d, int B, int Lt, int Li, 
  * CrossEntropyLoss(ignore_index=-1) over b->labels [B]; o->rel [B][n_rel] is written instead of o->logits, b->mask_pos is not used. */
 int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
                   size_t workspace_bytes, void* stream);
-/* backward of loss = loss_scale * mean over labelled rows; g's tensors must be zero on entry
- * (vector gradients are accumulated with atomics); uses the workspace cpt_train_fwd filled. */
+/* backward of loss = loss_scale * mean over labelled rows; g's tensors must be zero on entry, or cleared by
+ * cpt_train_zero_grads (vector gradients are accumulated with atomics, Linear weight gradients are written whole);
+ * uses the workspace cpt_train_fwd filled. */
 int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
                   void* workspace, size_t workspace_bytes, void* stream);
 /* Clears what cpt_train_bwd ADDS into -- the bias / LayerNorm gradient vectors and the small embedding tables (atomic
