@@ -376,8 +376,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     atomicAdd(c < H ? &dg[c] : (c < 2 * H ? &db[c - H] : &dbias[c - 2 * H]), a);
 }
 
-int g_lnb_rpb = 0;       // cpt_set_tuning(17, rows): rows per workgroup of the two-stage form (0: 4 = one row per wave); multiples of 4
-void set_lnb_rpb(int v) { g_lnb_rpb = v > 0 ? (v + 3) / 4 * 4 : 0; }
+int g_lnb_rpb = 0;       // cpt_set_tuning(17, rows): rows per workgroup of the two-stage form (0: 8 from 2048 rows on, else 4 = one row per wave)
+void set_lnb_rpb(int v) { g_lnb_rpb = v > 0 ? v : 0; }
 
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
@@ -390,7 +390,7 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
     // rows per block: with atomics fewer blocks = fewer dgamma/dbeta atomics (2*H per block); with a partial-sum buffer (two-stage
     // column sums) one row per wave keeps 4x the rows in flight: the kernel is latency-bound otherwise (22 -> ~10 us at 3840 rows)
     int rpb = R >= 2048 ? 16 : 8;
-    if (g && part && R >= 1024 && (size_t)((R + 3) / 4) * nsum * H * 4 <= part_bytes) rpb = g_lnb_rpb > 0 ? g_lnb_rpb : 4; else part = nullptr;
+    if (g && part && R >= 1024 && (size_t)((R + 3) / 4) * nsum * H * 4 <= part_bytes) rpb = g_lnb_rpb > 0 ? g_lnb_rpb : (R >= 2048 ? 8 : 4); else part = nullptr;      // 8: two rows per wave, half the partial rows (3840 rows: 5.83 vs 5.89 ms per step; 960 blocks of 4 rows are 1.25 rounds of the 3 blocks per CU the 48 KB staging array allows)
     dim3 grid((R + rpb - 1) / rpb), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
 #define LNB(LPT, GI) ln_bwd_kernel<LPT, GI><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias)

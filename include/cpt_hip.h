@@ -431,7 +431,7 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 15 panel mode: 1 (default) = launches that leave CUs idle carry 16 workgroups that read the next launch's weights into the
  *          Infinity Cache, 0 = no prefetch workgroups
  *   key 16 FFN-up two-pass kernel (and with it panel mode) from this many 384 x 256 tiles on (default 192; experiments with small batches)
- *   key 17 LayerNorm backward, two-stage column-sum form: rows per workgroup (default 0 = 4, one row per wave; experiments)
+ *   key 17 LayerNorm backward, two-stage column-sum form: rows per workgroup (default 0 = 8 from 2048 rows on, else 4; experiments)
  *   key 18 training backward, bias-gradient column sums inside their producers: bit 0 = b_in in the GELU-gradient epilogue, bit 1 = b_qkv
  *          in the attention backward kernel (default 2: bit 0 measured slower than the launch it replaces); a cleared bit runs the stand-alone column-sum launch
  *   key 19 training backward: 1 (default) = a layer's weight gradients as two paired launches (the two FFN matrices; attention output +
