@@ -154,6 +154,7 @@ static int g_fold_ln = 1;      // bf16 mode with cpt_model.fold: fold the encode
 static int g_fuse_attn = 3;    // bf16, L <= 128: QKV projection + attention in one kernel (0 = two kernels; 1 = one workgroup per (sequence, head), two per CU; 2 = same, one per CU; 3 = one workgroup per (sequence, three heads) where heads % 3 == 0, else 1)
 static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
 static int g_panel = 1;        // fused bf16 encoder: ctx and the FFN activation travel in the fragment-major panel layout and the LayerNorm producers read them straight into registers (gemm_prod.hip) where the shapes allow
+static int g_x3_fuse = 1;      // bf16x3 parity mode: split copies written by the producing kernels (FFN-up GELU epilogue, LayerNorm passes) instead of stand-alone split3 passes (cpt_set_tuning key 23)
 static int g_prefetch = 1;     // panel mode: the 240-tile launches carry 16 workgroups that read the next launch's weights into the Infinity Cache (common.h prefetch_region)
 static int g_resid3 = 1;       // fused bf16 encoder: residual stream in the 3-byte form (bf16 hi + int8 lo) instead of fp32 + bf16 copies
 
@@ -161,7 +162,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
         g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1;
         cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
-        cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_ffn_2pass_min_tiles(192); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0); cpt::set_lnb_rpb(0); cpt::set_bias_fuse(2); cpt::set_wgrad_pair(1); cpt::set_qkv_2pass(1); cpt::set_fwd_split2(1); cpt::set_attn_qt_all(1);
+        cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_ffn_2pass_min_tiles(192); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0); cpt::set_lnb_rpb(0); cpt::set_bias_fuse(2); cpt::set_wgrad_pair(1); cpt::set_qkv_2pass(1); cpt::set_fwd_split2(1); g_x3_fuse = 1; cpt::set_attn_qt_all(1);
         return CPT_OK;
     }
     if (key == 4) { g_lp_resid = value; return CPT_OK; }
@@ -186,6 +187,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 20) { cpt::set_qkv_2pass(value); return CPT_OK; }
     if (key == 21) { cpt::set_attn_qt_all(value); return CPT_OK; }
     if (key == 22) { cpt::set_fwd_split2(value); return CPT_OK; }
+    if (key == 23) { g_x3_fuse = value; return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
 }
@@ -379,6 +381,11 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const int dt = x3 ? CPT_F32 : d.dtype;
     const bool lp = dt == CPT_BF16;
     void* splitbuf = ws + w.split;
+    // bf16x3, round 3: the FFN-up's GELU epilogue writes h as the split copy the FFN-down reads (key 23).  The fp32 FFN activation is then
+    // never materialised, and its region [M][I] fp32 holds the FFN-up's own split input [M][3H] bf16 (asplit).  (The LayerNorm passes writing
+    // the split inputs of QKV / FFN-up themselves was built too: the two stand-alone passes it saves cost what its strided 8-byte stores
+    // add to the LayerNorm launches -- 5.78-5.94 vs 5.84 ms -- so they stay.)
+    const bool x3f = x3 && g_x3_fuse && d.inter % 8 == 0 && (size_t)d.inter * 4 >= (size_t)3 * d.hidden * 2;
     auto gm = [&](int epi, const void* A, int lda, const void* W, int K, const float* bias, const float* resid, int ldr, void* out,
                   int out_dt, int ldo, int Mr, int N) -> int {
         if (!x3) return cpt::gemm(dt, epi, A, lda, W, K, bias, resid, ldr, out, out_dt, ldo, Mr, N, K, s);
@@ -394,6 +401,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     float* a_f32 = (float*)(ws + w.a_f32);
     void* a_lp = ws + w.a_lp;
     void* ffn = ws + w.ffn;
+    void* asplit = ffn;                                                                     // bf16x3 fused mode: see x3f above
 
     // 3-byte residual stream (common.h r3_encode): the pre-LayerNorm sums live as bf16 hi (x_lp / a_lp, the GEMM operands) +
     // int8 lo (the head of the x_f32 / a_f32 regions, which hold no fp32 tensor in this mode); the producers read and write
@@ -524,10 +532,20 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
           TRY(gm(lpr ? 5 : CPT_EPI_RESID, ctx, H, y.w_ao, H, y.b_ao, lpr ? (const float*)x_lp : x_f32, H, pre, CPT_F32, H, M, H), "gemm(attn out)"); }
         { Scope p(CPT_K_LN, s);
           TRY(cpt::layernorm_rows(pre, y.ln1_g, y.ln1_b, d.ln_eps, lpr ? nullptr : a_f32, lp ? a_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(attn)"); }
+        if (x3f) {
+            // bf16x3 (round 3): the FFN-up's GELU epilogue writes h as the split copy the FFN-down reads; its own input split sits in the
+            // (then unused) fp32 h region
+            { Scope p(CPT_K_GEMM_FFN1, s);
+              TRY(cpt::split3((const float*)a_lp, H, asplit, M, H, 0, s), "split3(ffn up input)");
+              TRY(cpt::gemm_gelu_x3(asplit, 3 * H, y.w_in, 3 * H, y.b_in, splitbuf, M, I, 3 * H, s), "gemm(ffn up, split output)"); }
+            { Scope p(CPT_K_GEMM_FFN2, s);
+              TRY(cpt::gemm(CPT_BF16, CPT_EPI_RESID, splitbuf, 3 * I, y.w_out, 3 * I, y.b_out, a_f32, H, pre, CPT_F32, H, M, H, 3 * I, s), "gemm(ffn down)"); }
+        } else {
         { Scope p(CPT_K_GEMM_FFN1, s);
           TRY(gm(CPT_EPI_GELU, a_lp, H, y.w_in, H, y.b_in, nullptr, 0, ffn, dt, I, M, I), "gemm(ffn up)"); }
         { Scope p(CPT_K_GEMM_FFN2, s);
           TRY(gm(lpr ? 5 : CPT_EPI_RESID, ffn, I, y.w_out, I, y.b_out, lpr ? (const float*)a_lp : a_f32, H, pre, CPT_F32, H, M, H), "gemm(ffn down)"); }
+        }
         { Scope p(CPT_K_LN, s);
           TRY(cpt::layernorm_rows(pre, y.ln2_g, y.ln2_b, d.ln_eps, (lpr && !(last && (flags & CPT_OUT_SEQ))) ? nullptr : x_f32, lp ? x_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(ffn)"); }
     }

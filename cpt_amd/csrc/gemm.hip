@@ -144,6 +144,7 @@ constexpr int CPT_EPI_ATTN = 9;        // internal: fused QKV projection + self-
 constexpr int CPT_EPI_ATTN_LN = 10;    // internal: same, A operand is a pre-LayerNorm tensor (LayerNorm folded like LNCONS)
 constexpr int CPT_EPI_GELU2 = 12;      // internal (training forward): writes u = A.W^T + bias (bf16, to EpiX.out_lp) AND gelu(u) (to out): BertIntermediate
 constexpr int CPT_EPI_GELUGRAD = 13;   // internal (training backward): out = (A.W) * gelu'(u), u (compute dtype) passed in the residual slot: dgrad of BertOutput.dense + gelu backward
+constexpr int CPT_EPI_GELU_X3 = 14;    // internal (bf16x3 parity mode): gelu(A.W^T + bias) written as the [hi | hi | lo] bf16 split copy the NEXT three-term GEMM reads (out [M][3N], EpiX.x3_k = N)
 constexpr int CPT_EPI_LNPROD3 = 11;    // internal: LNPROD with the residual stream in the 3-byte form (bf16 hi + int8 lo, see r3_encode): in and out
 
 // ---------------------------------------------------------------------------------------------
@@ -174,6 +175,7 @@ struct EpiX {
     int seq_len, heads;    // ATTN: tokens per sequence (<= 128), attention heads
     int w_rows;            // NN form: rows of W that exist (0: K); rows beyond read as zero (K rounded up to a K-tile multiple)
     size_t split_stride;   // split-K partial matrices: elements between two splits' outputs (0: M * ldo)
+    int x3_k;              // GELU_X3: columns of one part of the split copy (= N)
     float* colsum;         // GELUGRAD (training backward): += column sums of the finished output = the gradient of the bias in front of the GELU
     int skew;              // two-workgroups-per-CU shapes: start delay of every second workgroup (see skew_start)
 };
@@ -744,7 +746,9 @@ __device__ __forceinline__ void gemm_pipe_body(
     constexpr bool HAS_RESID = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || LNPROD || GG;
     constexpr bool GELU2 = EPI == CPT_EPI_GELU2;      // pre-activation stored too; the GELU is taken of the STORED (bf16-rounded) value, as the two-kernel form did
     static_assert(!GELU2 || (sizeof(T) == 2 && sizeof(OT) == 2), "GELU2: bf16 in, bf16 out");
-    constexpr bool DO_GELU = EPI == CPT_EPI_GELU || EPI == CPT_EPI_LNCONS_GELU || GELU2;
+    constexpr bool X3 = EPI == CPT_EPI_GELU_X3;
+    static_assert(!X3 || (sizeof(T) == 2 && sizeof(OT) == 2), "GELU_X3: bf16 in, bf16 split copy out");
+    constexpr bool DO_GELU = EPI == CPT_EPI_GELU || EPI == CPT_EPI_LNCONS_GELU || GELU2 || X3;
     const T* resid_lp = reinterpret_cast<const T*>(resid);      // EPI_RESID_LP: same rows, compute dtype; LNPROD3: the hi part
     const bool fold_resid = LNPROD && ex.g_in != nullptr;       // residual = LayerNorm(resid; st_in, g_in, b_in)
     // fp32 outputs without residual (e.g. the vocabulary decoder, ldo = 30522): rows are only 8-byte aligned, but 16-byte
@@ -947,6 +951,15 @@ __device__ __forceinline__ void gemm_pipe_body(
                         *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16*>(ex.out_lp) + (size_t)row * ldo + col) = hq;
                         *reinterpret_cast<unsigned*>(ex.out_lo + (size_t)row * ldo + col) = lq;
                     } else
+                    if constexpr (X3) {          // hi = bf16(x), lo = bf16(x - hi); row layout hi | hi | lo (rowops.hip split3, activation order)
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
+                        OT* o3 = out + (size_t)row * ldo + col;
+                        *reinterpret_cast<bf16x4*>(o3) = hi;
+                        *reinterpret_cast<bf16x4*>(o3 + ex.x3_k) = hi;
+                        *reinterpret_cast<bf16x4*>(o3 + 2 * ex.x3_k) = lo;
+                    } else
                     if constexpr (sizeof(OT) == 2) {
                         bf16x4 pk;
 #pragma unroll
@@ -994,6 +1007,11 @@ __device__ __forceinline__ void gemm_pipe_body(
                                     ex.out_lo[(size_t)row * ldo + col + e] = lq;
                                 } else {
                                 if constexpr (EPI == CPT_EPI_ATOMIC && sizeof(OT) == 4) atomicAdd(reinterpret_cast<float*>(out) + (size_t)row * ldo + col + e, x);
+                                else if constexpr (X3) {
+                                    const OT hi1 = from_f32<OT>(x);
+                                    OT* o3 = out + (size_t)row * ldo + col + e;
+                                    o3[0] = hi1; o3[ex.x3_k] = hi1; o3[2 * ex.x3_k] = from_f32<OT>(x - to_f32(hi1));
+                                }
                                 else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
                                 if constexpr (LNPROD) reinterpret_cast<T*>(ex.out_lp)[(size_t)row * ldo + col + e] = from_f32<T>(x);
                                 if constexpr (GG) { if (ex.colsum) atomicAdd(ex.colsum + col + e, x); }
@@ -1547,6 +1565,19 @@ int gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const float* b
 
 // Consumer: A is the bf16 copy of a pre-LayerNorm tensor, Wf the gain-folded weight;
 // out = [gelu]( rstd[m] * (A.Wf^T - mean[m] * colc[n]) + cold[n] )  ==  [gelu]( LayerNorm(A) . W^T + bias )
+// bf16x3 parity mode, FFN-up (round 3): gelu(A'.W'^T + bias) over K' = 3K written straight as the [M][hi | hi | lo] split copy of h that the
+// FFN-down's three-term GEMM reads -- no fp32 h, no stand-alone split3 pass over the M x I tensor
+int gemm_gelu_x3(const void* A3, int lda, const void* W3, int ldw, const float* bias, void* out_split, int M, int N, int K3, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K3 <= 0 || K3 % 64 || lda % 8 || ldw % 8 || N % 8) return CPT_ERR_SHAPE;
+    if (!A3 || !W3 || !out_split) return CPT_ERR_NULL;
+    if ((((uintptr_t)A3 | (uintptr_t)W3 | (uintptr_t)out_split | (uintptr_t)bias) & 15)) return CPT_ERR_ALIGN;
+    EpiX ex = {};
+    ex.x3_k = N;
+    launch_fast<bf16, CPT_EPI_GELU_X3, bf16>(g_gemm_variant >= 3 ? g_gemm_variant : 3, (const bf16*)A3, lda, (const bf16*)W3, ldw, bias, nullptr, 0,
+                                            (bf16*)out_split, 3 * N, M, N, K3, s, &ex);
+    return CPT_OK;
+}
+
 int g_qkv_2pass = 1;
 void set_qkv_2pass(int v) { g_qkv_2pass = v; }
 

@@ -151,6 +151,8 @@ int fold_ln_weights(const float* W, const float* gamma, const float* beta, const
 void set_splitk_target(int v);
 void set_wgrad_pair(int v);  // training backward: the layer's weight gradients as two paired launches (1, default) or four single ones (0)
 void set_attn_qt_all(int v); // stand-alone attention, L > 128: the query tiles of a (sequence, head) as neighbouring workgroups of one XCD (1, default)
+// bf16x3 parity mode: FFN-up over the split operands (K3 = 3K) with the GELU epilogue writing h's [M][hi | hi | lo] split copy (ld 3N)
+int gemm_gelu_x3(const void* A3, int lda, const void* W3, int ldw, const float* bias, void* out_split, int M, int N, int K3, hipStream_t s);
 void set_fwd_split2(int v);  // training forward: FFN-down as two split-K partial matrices summed by the LayerNorm pass (1, default)
 void set_qkv_2pass(int v);   // stand-alone LayerNorm-consumer QKV projection through the GELU-less two-pass kernel (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)

@@ -442,6 +442,8 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *          workgroups of one XCD (their shared K / V rows are fetched from memory once), 0 = the (pair, tile) grid
  *   key 22 training forward, FFN-down at 2048..6144 rows: 1 (default) = 128 x 192 tiles with K split over two workgroups, the two partial
  *          matrices added by the dropout + residual + LayerNorm pass behind it; 0 = 64 x 192 tiles over the whole K
+ *   key 23 bf16x3 parity mode: 1 (default) = the FFN-up's GELU epilogue writes the split copy of its output that the FFN-down reads, 0 = an
+ *          fp32 tensor and a stand-alone cpt_split3 pass
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
