@@ -142,3 +142,39 @@ def test_fused_qkv_attention_race_screen(dev):
             return (m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"])[0].clone(),)
     bad = _screen(dev, fwd, n=200)
     assert bad == 0, "%d of the forwards differed from the first one" % bad
+
+
+@pytest.mark.parametrize("B", [32, 4])
+def test_training_step_weight_gradients_race_screen(dev, B):
+    """Round 3: the paired weight-gradient launches (two TN problems per launch, split-K partials reduced by one launch), the fused
+    Q|K|V bias sums, the split-K FFN-down forward and the segment clear that replaced the whole-buffer fill, as the TRAINING STEP runs
+    them: 60 forward + backward passes of one batch under the memory-thrashing side stream; every GEMM-written gradient and the loss
+    must equal the first pass bit for bit (the vector gradients and the loss sum take atomics: fp32 rounding only)."""
+    from cpt_amd import config as cfgmod, synth, train as T
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    cfg = cfgmod.oscar_base(num_hidden_layers=2)
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.1
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, 3, head="cpt"))
+    m.tie_weights()
+    m.to(dev).train()
+    m.set_compute_dtype("bf16")
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, cfg, seed=2).items()}
+    names = [n for n, p in m.named_parameters() if p.dim() == 2 and "embeddings" not in n and "pooler" not in n]
+    params = dict(m.named_parameters())
+
+    def launch(_slot):
+        T.set_dropout_seed(m, 77)
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
+                    mask_token_pos=b["mask_token_pos"])
+        loss.backward()
+        losses.append(loss.detach().clone())
+        return tuple(params[n].grad.clone() for n in names)
+
+    losses = []
+    bad = _screen(dev, launch, n=60, ring=1)
+    assert bad == 0, "%d tensors of the later passes differed from the first pass" % bad
+    ls = torch.stack(losses).double()
+    assert float((ls - ls[0]).abs().max()) <= 1e-6 * float(ls[0].abs()), ls        # row losses are added with atomics
