@@ -1452,6 +1452,29 @@ int gemm_nt_split(const void* A, int lda, const void* W, int ldw, const float* b
     return CPT_OK;
 }
 
+// The same decisions as gemm_nt_split / the training forward's two-way split, but the partial matrices are LEFT for the consumer (the
+// dropout + residual + LayerNorm pass adds them in split order): few rows -> 64 x 192 tiles, K over up to 16 workgroups per tile;
+// 2048..6144 rows with a long K -> 128 x 192 tiles, K over two workgroups (M = 3840: 240 workgroups instead of 120).
+int gemm_nt_partials(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, size_t partial_bytes, int M, int N, int K,
+                     hipStream_t s, int* S_out) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8 || N % 4 || !partials || !S_out) return CPT_ERR_SHAPE;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)partials | (uintptr_t)bias) & 15)) return CPT_ERR_ALIGN;
+    const size_t mat = (size_t)M * N * 4;
+    const int nt = K / 64;
+    if (M >= 2048 && M <= 6144 && K >= 2048 && K % 128 == 0 && N % 192 == 0 && 2 * mat <= partial_bytes) {
+        *S_out = 2;
+        return launch_pipe<bf16, CPT_EPI_NONE, float, 128, 192, 4, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, partials, N, M, N, K, s, 2);
+    }
+    const long tiles = (long)((M + 63) / 64) * ((N + 191) / 192);
+    int S = (int)(256 / tiles);
+    if (S > 16) S = 16;
+    if (S > nt / 3) S = nt / 3;
+    while (S > 1 && (size_t)S * mat > partial_bytes) --S;
+    if (S < 3) return CPT_ERR_SHAPE;
+    *S_out = S;
+    return launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, partials, N, M, N, K, s, S);
+}
+
 // ---- NN form: out[M][N] = A[M][K] . W[K][N] (+ resid), W = an nn.Linear weight [out_features = K][in_features = N] as stored:
 // the data gradients dX = dY . W of the backward pass without a transposed weight copy --------------------------------------
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw) {

@@ -69,7 +69,7 @@ int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
                       const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr,
-                      const float* x2 = nullptr);     // x2: second split-K partial matrix (the row that is processed is x + x2)
+                      int x_parts = 1, size_t x_stride = 0);     // x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
 // resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients
@@ -95,6 +95,10 @@ int gemm_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias
 // bf16 NT GEMM, fp32 out (+ bias, + resid), K split for small row counts; CPT_ERR_SHAPE = not worth it / not applicable (caller: plain gemm)
 int gemm_nt_split(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr, float* out, int ldo, int M, int N, int K,
                   void* partials, size_t partial_bytes, hipStream_t s);
+// bf16 NT GEMM into split-K partial matrices partials[S][M][N] (bias in the first) for a consumer that adds them itself (layernorm_rows_ex x_parts):
+// returns S >= 2 in *S_out, or CPT_ERR_SHAPE when the problem does not call for a split (the caller runs the plain GEMM)
+int gemm_nt_partials(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, size_t partial_bytes, int M, int N, int K,
+                     hipStream_t s, int* S_out);
 // bf16 region projection: two fp32 partial matrices out2[2][M][ldo] (K split in two; bias in the first), summed by the LayerNorm pass behind it
 int gemm_img_proj(const void* A, int lda, const void* W, int ldw, const float* bias, float* out2, int ldo, int M, int N, int K, hipStream_t s);
 // MLM head on the [MASK] rows, bf16 path (round 3): gather + 3-byte merge + LayerNorm in one launch; transform GEMM with K split over

@@ -78,8 +78,9 @@ template <typename LP, bool GELU_IN, int LN_RPW>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
-    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, const float* __restrict__ x2) {      // x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
-    // x2 (round 3): second split-K partial matrix of the dense layer in front (x + x2 is the layer's output; training forward of the FFN-down)
+    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride) {      // x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
+    // x_parts / x_stride (round 3): x is x_parts split-K partial matrices of the dense layer in front, x_stride elements apart; the row that is
+    // processed is their sum in split order (training forward: no reduction launch between the GEMM and this pass)
     // resid / dr / pre_out (training forward of LN(dropout(dense) + residual), modeling_bert.py:85-86,145 with the third-party
     // BertSelfOutput / BertOutput): the row that is normalised is dropout(x) + resid, written to pre_out for the backward pass --
     // the same arithmetic, in the same order, as the dropout_rows pass this replaces
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
             const int c = (lane + 64 * i) * 4;
             if (i < nv && c < H) {
                 v[u][i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
-                if (x2) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(x2 + (size_t)r * H + c);
+                for (int k = 1; k < x_parts; ++k) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(x + (size_t)k * x_stride + (size_t)r * H + c);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[u][i][j] += t[j];
                 }
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
 
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
-                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, const float* x2) {
+                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride) {
+    if (x_parts < 1 || x_parts > 64) return CPT_ERR_SHAPE;
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
     if (R <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
@@ -152,8 +154,8 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
 #define LNK(LPT, GI)                                                                                                                              \
     do {                                                                                                                                          \
-        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x2); \
-        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x2);          \
+        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride); \
+        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride);          \
     } while (0)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
     else      { if (gelu_in) LNK(float, true); else LNK(float, false); }

@@ -225,6 +225,23 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         TRY(cpt::gemm(dt, CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
         TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr, m3d), "attention");
+        // round 3: where the dense layer's K is split over workgroups (few rows; or 2048..6144 rows with a long K), its partial matrices go
+        // straight to the row pass behind it, which adds them in split order -- no reduction launch in between (cpt_set_tuning key 22)
+        int Sp = 0;
+        auto dense_parts = [&](const void* A, int lda, const void* W, int K, const float* bias, const char* what) -> int {      // CPT_OK: Sp partial matrices at tA
+            Sp = 0;
+            if (!(g_fwd_split2 && dt == CPT_BF16 && g_wgrad_tn)) return CPT_ERR_SHAPE;
+            const int r = cpt::gemm_nt_partials(A, lda, W, K, bias, (float*)(ws + w.tA), w.tA_bytes, M, H, K, s, &Sp);
+            if (r == CPT_ERR_SHAPE) return r;
+            return abi_check(r, what);
+        };
+        const float* part = (const float*)(ws + w.tA);
+        if (int rp = dense_parts(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, "gemm(attn out, K split)"); rp != CPT_ERR_SHAPE) {
+            if (rp) return rp;
+            const cpt::DropSpec sp = drop_spec(drop, 2 + 3 * l, false);
+            TRY(cpt::layernorm_rows_ex(part, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
+                                       x_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre1), nullptr, Sp, (size_t)M * H), "partials+dropout(attn out)+residual+layernorm");
+        } else
         if (ph) {   // LN(dropout(dense(ctx)) + x): the residual add moves from the GEMM epilogue into the dropout pass
             if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, nullptr, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
             // dropout + residual + LayerNorm in one row pass (pre1 = dropout(dense) + x is stored for the backward pass)
@@ -241,17 +258,13 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_a), H, y.w_in, H, y.b_in, nullptr, 0, LB(l, w.o_u), dt, I, M, I, H, s), "gemm(ffn up)");
         TRY(cpt::gelu_fwd(LB(l, w.o_u), LB(l, w.o_h), dt, (size_t)M * I, s), "gelu");
         }
-        // round 3: at row counts where 128-row tiles would leave half the chip idle (M = 3840: 120 tiles) and K is long, the FFN-down runs
-        // 128 x 192 tiles with K split over two workgroups (240 workgroups at twice the arithmetic intensity of the 64 x 192 tiles) and the row
-        // pass that follows adds the two partial matrices
-        const bool split2 = g_fwd_split2 && dt == CPT_BF16 && g_wgrad_tn && M >= 2048 && M <= 6144 && I >= 2048 && I % 128 == 0 && H % 192 == 0 &&
-                            (size_t)2 * M * H * 4 <= w.tA_bytes;
-        if (split2) {
-            float* part = (float*)(ws + w.tA);
-            TRY(cpt::gemm_img_proj(LB(l, w.o_h), I, y.w_out, I, y.b_out, part, H, M, H, I, s), "gemm(ffn down, K split in two)");
+        // (FFN-down the same way: at M = 3840 two 128 x 192 half-K workgroups per tile, 240 workgroups at twice the arithmetic intensity of the
+        // 64 x 192 tiles; at 480 rows eight K slices per 64 x 192 tile)
+        if (int rp = dense_parts(LB(l, w.o_h), I, y.w_out, I, y.b_out, "gemm(ffn down, K split)"); rp != CPT_ERR_SHAPE) {
+            if (rp) return rp;
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
-                                       a_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre2), nullptr, part + (size_t)M * H), "partials+dropout(ffn down)+residual+layernorm");
+                                       a_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre2), nullptr, Sp, (size_t)M * H), "partials+dropout(ffn down)+residual+layernorm");
         } else
         if (ph) {
             if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
