@@ -255,21 +255,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         return;
     }
-    for (int r = r0 + wave; r < r1; r += 4) {
-        const size_t yrow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
-        f32x4 xv[LNB_MAXV], dv[LNB_MAXV], uv[LNB_MAXV];
-        float s = 0.f;
+    // round 3: the NEXT row's x and dy are requested before this row is reduced (a wave walks two rows at eight rows per workgroup: the second
+    // row's memory round trip used to start only after the first row's four wave reductions and stores)
+    f32x4 nx[LNB_MAXV], nd[LNB_MAXV];
+    auto fetch = [&](int r) {
+        const size_t yr = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
 #pragma unroll
         for (int i = 0; i < LNB_MAXV; ++i) {
             const int c = (lane + 64 * i) * 4;
             if (i < nv && c < H) {
-                xv[i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
+                nx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
+                nd[i] = *reinterpret_cast<const f32x4*>(dy + yr * H + c);
+            }
+        }
+    };
+    if (r0 + wave < r1) fetch(r0 + wave);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        f32x4 xv[LNB_MAXV], dv[LNB_MAXV], uv[LNB_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i) { xv[i] = nx[i]; dv[i] = nd[i]; }
+        if (r + 4 < r1) fetch(r + 4);
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (i < nv && c < H) {
                 if (GELU_IN) {
                     uv[i] = xv[i];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xv[i][j] = gelu_erf(uv[i][j]);
                 }
-                dv[i] = *reinterpret_cast<const f32x4*>(dy + yrow * H + c);
                 s += xv[i][0] + xv[i][1] + xv[i][2] + xv[i][3];
             }
         }
