@@ -1101,6 +1101,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group2_kernel(TnProb p0, TnPro
                                                                             nullptr, 0, ex, (int)blockIdx.x - (second ? wg0 : 0));
 }
 
+// ... and three: FFN down | FFN up | attention output (96 + 96 + 24 tiles at hidden 768: 216 CUs with the whole contraction each)
+template <int TBN>
+__global__ __launch_bounds__(512, 2) void gemm_tn_group3_kernel(TnProb p0, TnProb p1, TnProb p2, int K, int wg0, int wg1, EpiX ex) {
+    const int bid = (int)blockIdx.x;
+    const int which = bid >= wg1 ? 2 : (bid >= wg0 ? 1 : 0);
+    const TnProb& p = which == 2 ? p2 : (which == 1 ? p1 : p0);
+    gemm_pipe_body<bf16, CPT_EPI_NONE, float, 128, TBN, 4, 2, 3, 1, 4, 1, 1>(p.A, p.lda, p.W, p.ldw, nullptr, nullptr, 0, p.out, p.ldo, p.M, p.N, K, 1,
+                                                                            nullptr, 0, ex, bid - (which == 2 ? wg1 : (which == 1 ? wg0 : 0)));
+}
+
 long long* g_gemm_trace = nullptr;
 int g_trace_epi = -1, g_trace_k = 0;       // diagnostic builds: stamp only launches of this epilogue / this K (-1 / 0: all)
 void set_gemm_trace_filter(int epi, int k) { g_trace_epi = epi == 255 ? -1 : epi; g_trace_k = k; }
@@ -1414,6 +1424,43 @@ int gemm_tn_pair(const void* A0, int lda0, const void* W0, int ldw0, float* out0
         const int blocks = (int)std::min<size_t>((n40 + n41 + 255) / 256, 2048);
         reduce_partials2_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const f32x4*)partials, (mat0 + mat1) / 4, S, (f32x4*)out0, n40, (f32x4*)out1, n41);
     }
+    return CPT_OK;
+}
+
+// Three weight gradients over the same K rows in one launch, each workgroup with the whole contraction (no partial matrices): applicable
+// when the three problems' 128 x 192 tiles fit one round of the chip and the block ranges start on multiples of 8 (XCD map).
+int gemm_tn_triple_eligible(int M0, int N0, int M1, int N1, int M2, int N2, int K) {
+    if (!gemm_tn_eligible(M0, N0, K, 8, 8, N0) || !gemm_tn_eligible(M1, N1, K, 8, 8, N1) || !gemm_tn_eligible(M2, N2, K, 8, 8, N2)) return 0;
+    if (N0 % 192 || N1 % 192 || N2 % 192) return 0;
+    const int t0 = (M0 / 128) * (N0 / 192), t1 = (M1 / 128) * (N1 / 192), t2 = (M2 / 128) * (N2 / 192);
+    return t0 + t1 + t2 <= 256 && t0 % 8 == 0 && (t0 + t1) % 8 == 0;
+}
+int gemm_tn_triple(const void* A0, int lda0, const void* W0, int ldw0, float* out0, int M0, int N0,
+                   const void* A1, int lda1, const void* W1, int ldw1, float* out1, int M1, int N1,
+                   const void* A2, int lda2, const void* W2, int ldw2, float* out2, int M2, int N2, int K, int k_rows, hipStream_t s) {
+    if (!gemm_tn_triple_eligible(M0, N0, M1, N1, M2, N2, K)) return CPT_ERR_SHAPE;
+    if (lda0 % 8 || ldw0 % 8 || lda1 % 8 || ldw1 % 8 || lda2 % 8 || ldw2 % 8 || k_rows < 0 || k_rows > K) return CPT_ERR_SHAPE;
+    if (!A0 || !W0 || !out0 || !A1 || !W1 || !out1 || !A2 || !W2 || !out2) return CPT_ERR_NULL;
+    if ((((uintptr_t)A0 | (uintptr_t)W0 | (uintptr_t)out0 | (uintptr_t)A1 | (uintptr_t)W1 | (uintptr_t)out1 | (uintptr_t)A2 | (uintptr_t)W2 | (uintptr_t)out2) & 15)) return CPT_ERR_ALIGN;
+    const int mx = std::max(std::max(std::max(lda0, ldw0), std::max(lda1, ldw1)), std::max(lda2, ldw2));
+    if ((size_t)K * (size_t)mx * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;
+    const int t0 = (M0 / 128) * (N0 / 192), t1 = (M1 / 128) * (N1 / 192), t2 = (M2 / 128) * (N2 / 192);
+    EpiX ex = {};
+    ex.w_rows = k_rows;
+    ex.skew = g_gemm_skew;
+    TnProb p0 = {(const bf16*)A0, (const bf16*)W0, out0, lda0, ldw0, N0, M0, N0, 0};
+    TnProb p1 = {(const bf16*)A1, (const bf16*)W1, out1, lda1, ldw1, N1, M1, N1, 0};
+    TnProb p2 = {(const bf16*)A2, (const bf16*)W2, out2, lda2, ldw2, N2, M2, N2, 0};
+    constexpr int LDS = 3 * (128 + 192) * ROWB;
+    auto kern = gemm_tn_group3_kernel<192>;
+    static bool attr_done_dev[CPT_MAX_DEV] = {};
+    bool& attr_done = attr_done_dev[current_device_slot()];
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+        attr_done = true;
+    }
+    kern<<<dim3(t0 + t1 + t2), dim3(512), LDS, s>>>(p0, p1, p2, K, t0, t0 + t1, ex);
     return CPT_OK;
 }
 

@@ -82,6 +82,11 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
 int gemm_tn_pair(const void* A0, int lda0, const void* W0, int ldw0, float* out0, int M0, int N0,
                  const void* A1, int lda1, const void* W1, int ldw1, float* out1, int M1, int N1,
                  int K, int k_rows, void* partials, size_t partial_bytes, hipStream_t s);
+// ... and three (FFN down | FFN up | attention output), every workgroup over the whole K; gemm_tn_triple_eligible says whether the shapes fit one round
+int gemm_tn_triple_eligible(int M0, int N0, int M1, int N1, int M2, int N2, int K);
+int gemm_tn_triple(const void* A0, int lda0, const void* W0, int ldw0, float* out0, int M0, int N0,
+                   const void* A1, int lda1, const void* W1, int ldw1, float* out1, int M1, int N1,
+                   const void* A2, int lda2, const void* W2, int ldw2, float* out2, int M2, int N2, int K, int k_rows, hipStream_t s);
 // out[M][N] = A[M][K] . W[K][N] (+ resid): W stored with the contraction index as its slow dimension (data gradients against an
 // nn.Linear weight as stored); bf16 operands, out fp32 (optionally + fp32 resid) or bf16
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw);

@@ -17,8 +17,9 @@ using cpt::g_wgrad_tn;
 // cpt_set_tuning(18, bits): bias-gradient column sums inside their producers -- bit 0: b_in in the GELU-gradient epilogue of
 // dgrad(ffn down) (off: its end-of-launch atomics cost more than the colsum launch, gemm.hip), bit 1: b_qkv in the attention
 // backward kernel (on: 43.3 vs 42.0 us per launch, no colsum launch); a cleared bit runs the stand-alone colsum launch instead
-// cpt_set_tuning(19, v): 1 (default) = a layer's four weight gradients run as two paired launches (gemm_tn_pair), 0 = four single ones
-namespace cpt { int g_wgrad_pair = 1; void set_wgrad_pair(int v) { g_wgrad_pair = v; } }
+// cpt_set_tuning(19, v): 2 (default) = FFN down | FFN up | attention output in ONE launch (216 workgroups, whole contraction each) + Q|K|V alone
+// with its own three-way split, where the shapes allow it (else as 1); 1 = two paired launches (gemm_tn_pair); 0 = four single ones
+namespace cpt { int g_wgrad_pair = 2; void set_wgrad_pair(int v) { g_wgrad_pair = v; } }
 using cpt::g_wgrad_pair;
 // cpt_set_tuning(22, v): 1 (default) = the FFN-down of the training forward runs on 128 x 192 tiles with K split in two (gemm_img_proj's
 // kernel) and the dropout + residual + LayerNorm pass adds the two partial matrices, 0 = 64 x 192 tiles over the whole K
@@ -36,7 +37,7 @@ struct TrainLayout {
     size_t x_f32, a_f32, layer0, layer_stride;
     size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2;     // offsets inside a layer block
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
-    size_t dx, dpre, da, dpre_lp, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
+    size_t dx, dpre, da, dpre_lp, dlp2, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
     size_t total, tA_bytes, tB_bytes;
     int Mp, Bp, Vp, Rp;
 };
@@ -73,6 +74,7 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
     w.dpre = take(M * H * 4);
     w.da = take(M * H * 4);
     w.dpre_lp = take(M * H * es);
+    w.dlp2 = take(M * H * es);        // round 3: the attention-side LayerNorm backward's low-precision output when the FFN-side one must outlive it (three-problem weight-gradient launch)
     w.dctx = take(M * H * es);
     w.dbig = take(M * std::max(3 * H, I) * es);
     const size_t cols = std::max<size_t>({(size_t)w.Mp, (size_t)w.Bp, (size_t)w.Rp});
@@ -469,6 +471,12 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
         } else if (rc) return rc;
         else if (!(g_bias_fuse & 1)) TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
+        // round 3: where the three problems' tiles fit one round (hidden 768: 96 + 96 + 24), the two FFN weight gradients wait for the attention
+        // output's and share ONE launch with it behind the attention-side LayerNorm backward (which then writes its low-precision output
+        // to a second buffer: the FFN-side one is still an operand); Q|K|V runs alone behind the attention backward
+        const bool triple = g_wgrad_tn && g_wgrad_pair >= 2 && dt == CPT_BF16 && cpt::gemm_tn_triple_eligible(H, I, I, H, H, H, Mp);
+        if (triple) {
+        } else
         if (wgrad_pair(dpre_in, H, H, LB(l, w.o_h), I, I, gy.w_out, dbig, I, I, LB(l, w.o_a), H, H, gy.w_in, rc, "wgrad(ffn down | ffn up)")) {
             if (rc) return rc;
         } else {
@@ -482,7 +490,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         // a = LN1(pre1); pre1 = ctx W_ao^T + b_ao + x_in
         if (fuse_db) {
             const cpt::DropSpec sp1 = drop_spec(drop, 2 + 3 * l, false);
-            TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, ph ? dmask_lp : dpre_lp, dt, gy.ln1_g, gy.ln1_b,
+            TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, triple ? (void*)(ws + w.dlp2) : (ph ? dmask_lp : dpre_lp), dt, gy.ln1_g, gy.ln1_b,
                             M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes, ph ? &sp1 : nullptr, gy.b_ao), "ln_bwd(attn)+dropout+bias");
         } else {
         TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln1_g, gy.ln1_b,
@@ -490,11 +498,19 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         if (ph) TRY(cpt::dropout_rows(dpre, nullptr, dmask, dt == CPT_BF16 ? dmask_lp : nullptr, dt, M, H, drop_spec(drop, 2 + 3 * l, false), s), "dropout_bwd(attn out)");
         TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_ao, M, H, s), "colsum(b_ao)");
         }
-        rc = dgrad(dpre_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
+        const void* dao_in = triple ? (const void*)(ws + w.dlp2) : dpre_in;      // gradient entering the attention output's dense layer
+        if (triple)
+            TRY(cpt::gemm_tn_triple(dpre_in, H, LB(l, w.o_h), I, gy.w_out, H, I, dbig, I, LB(l, w.o_a), H, gy.w_in, I, H,
+                                    dao_in, H, LB(l, w.o_ctx), H, gy.w_ao, H, H, Mp, M, s), "wgrad(ffn down | ffn up | attn out)");
+        rc = dgrad(dao_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
         if (rc) return rc;
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
         TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr, (g_bias_fuse & 2) ? gy.b_qkv : nullptr, (b->mask_3d && b->attn_mask) ? 1 : 0), "attention_bwd+bias");
         if (!(g_bias_fuse & 2)) TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
+        if (triple) {
+            rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)");
+            if (rc) return rc;
+        } else
         if (wgrad_pair(dpre_in, H, H, LB(l, w.o_ctx), H, H, gy.w_ao, dbig, 3 * H, 3 * H, LB(l, w.o_xin), H, H, gy.w_qkv, rc, "wgrad(attn out | qkv)")) {
             if (rc) return rc;
         } else {

@@ -434,8 +434,9 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 17 LayerNorm backward, two-stage column-sum form: rows per workgroup (default 0 = 8 from 2048 rows on, else 4; experiments)
  *   key 18 training backward, bias-gradient column sums inside their producers: bit 0 = b_in in the GELU-gradient epilogue, bit 1 = b_qkv
  *          in the attention backward kernel (default 2: bit 0 measured slower than the launch it replaces); a cleared bit runs the stand-alone column-sum launch
- *   key 19 training backward: 1 (default) = a layer's weight gradients as two paired launches (the two FFN matrices; attention output +
- *          Q|K|V), 0 = four launches with their own split-K reductions
+ *   key 19 training backward, a layer's weight gradients: 2 (default) = FFN down | FFN up | attention output in one launch + Q|K|V alone where the
+ *          shapes fit one round (else as 1), 1 = two paired launches (the two FFN matrices; attention output + Q|K|V), 0 = four launches with
+ *          their own split-K reductions
  *   key 20 stand-alone QKV projection with the LayerNorm folded (sequences longer than 128: attention runs as its own kernel): 1 (default) =
  *          the GELU-less form of the two-pass 384 x 256 kernel when its tiles fill the chip, 0 = the 384 x 192 pipelined kernel
  *   key 21 stand-alone attention kernel, sequences longer than 128: 1 (default) = the 128-query tiles of a (sequence, head) are neighbouring
