@@ -30,16 +30,25 @@
 namespace cpt {
 namespace {
 
-constexpr int TM = 128, TN = 192, NWV = 8, RB = 128;
+constexpr int TM = 128, TN = 192, RB = 128;
 constexpr int ST = 4;                          // W ring depth = A register buffers
 constexpr int W_SLOT = TN * RB;                // 24 KB
-constexpr int GW = TN / 8 / NWV;               // LDS-DMA pieces per wave per K-tile (3)
 constexpr int GA = 4;                          // A fragment loads per wave per K-tile (one per k-step)
-constexpr int NJ = 3;                          // wave tile 32 x 96
 constexpr int RING_BYTES = ST * W_SLOT;        // 96 KB; the epilogue's slabs reuse it
-constexpr int SIDE = 32 * 8 + 3 * 96 * 4;      // per-wave side data: (mean, rstd) of its 32 rows, residual LayerNorm gain / shift and bias of its 96 columns
-constexpr int LDS_BYTES = RING_BYTES + NWV * SIDE;
 constexpr int GROUP_M = 4;
+// Two wave shapes of the same tile (round 4), same MFMA order over K, same epilogue arithmetic -> the same bits:
+//   NWV = 8: 4 x 2 waves of 32 x 96 (two per SIMD).  The two waves of a row pair load the SAME A fragments (TA / L1 traffic 2x).
+//   NWV = 4: 4 x 1 waves of 32 x 192 (one per SIMD, up to 512 registers): every A fragment is loaded once, half the wave
+//            instructions outside the MFMAs (profiles/r04_kloop_vs_hipblaslt.md: against hipBLASLt's 4-wave winner the 8-wave kernel
+//            spends the same CYCLES but 1.5x the L1 accesses and 2.5x the waves, and the chip clocks 10 % lower under its power cap).
+template <int NWV> struct Shape {
+    static constexpr int WN = NWV / 4;                          // waves along N
+    static constexpr int NJ = TN / 32 / WN;                     // 32-column blocks per wave (3 / 6)
+    static constexpr int WCOLS = NJ * 32;                       // 96 / 192
+    static constexpr int GW = TN / 8 / NWV;                     // LDS-DMA pieces per wave per K-tile (3 / 6)
+    static constexpr int SIDE = 32 * 8 + 3 * WCOLS * 4;         // per-wave side data: (mean, rstd) of its 32 rows, residual LayerNorm gain / shift and bias of its columns
+    static constexpr int LDS_BYTES = RING_BYTES + NWV * SIDE;
+};
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -54,8 +63,8 @@ __device__ __forceinline__ void a_load(u32x4& d, unsigned voff, const i32x4& rs,
 
 // ABL (timing experiments only, cpt_set_tuning key 13; results are garbage for 1-3): 1 = the wn = 1 waves skip their A loads (half the
 // A load instructions), 2 = no A loads, 3 = no W LDS-DMA, 4 = refill issued right behind the barrier (correct results)
-template <int ABL>
-__global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
+template <int ABL, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     const bf16* __restrict__ Ap, const bf16* __restrict__ W, int ldw, const float* __restrict__ bias,
     const bf16* __restrict__ resid_hi, const signed char* __restrict__ resid_lo, int ldr,
     const float* __restrict__ st_in, int st_in_parts, const float* __restrict__ g_in, const float* __restrict__ b_in, float eps, float inv_h,
@@ -64,20 +73,22 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
     const void* __restrict__ pf0, size_t pf0_bytes, const void* __restrict__ pf1, size_t pf1_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef Shape<NWV> SH;
+    constexpr int WN = SH::WN, NJ = SH::NJ, WCOLS = SH::WCOLS, GW = SH::GW, SIDE = SH::SIDE;
     // The FIRST gridDim.x - tiles workgroups prefetch the next launches' weights into the Infinity Cache (common.h prefetch_region):
     // dispatched ahead of the tiles they start at once on CUs of their own (behind the tiles they queued for a busy CU and ran
     // as a tail: attn-out 22.3 -> 23.0 us); their count is a multiple of 8, so block id -> XCD is the same for the tiles.
     const int npf = gridDim.x - (M / TM) * (N / TN);
     if ((int)blockIdx.x < npf) {
-        if (pf0) prefetch_region(pf0, pf0_bytes, blockIdx.x, npf, threadIdx.x, 512, smem);
-        if (pf1) prefetch_region(pf1, pf1_bytes, blockIdx.x, npf, threadIdx.x, 512, smem);
+        if (pf0) prefetch_region(pf0, pf0_bytes, blockIdx.x, npf, threadIdx.x, NWV * 64, smem);
+        if (pf1) prefetch_region(pf1, pf1_bytes, blockIdx.x, npf, threadIdx.x, NWV * 64, smem);
         return;
     }
     long long tr0 = 0, tr1 = 0, tr2 = 0, tw0 = 0, tra = 0, trb = 0;
     if (trace) { tr0 = clock64(); tw0 = wall_clock64(); }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 31, fh = lane >> 5;
 
     // XCD-first, then GROUP_M row tiles per group (as gemm.hip)
@@ -147,13 +158,13 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
     // prologue right BEHIND the first tile (ahead of it their HBM round trip held the first tile back: prologue 5.4 k -> 7.9 k ticks), by
     // inline asm (for a load it can see hipcc waits vmcnt(0) while LDS-DMA is in flight); always NSIDE loads (absent operands read a
     // dummy address) so that the counted waits are constants; parked in the LDS side area behind the ring after iteration 0's wait.
-    const int wrow0 = m0 + wm * 32, wcol0 = n0 + wn * 96;
+    const int wrow0 = m0 + wm * 32, wcol0 = n0 + wn * WCOLS;
     const bool fold_resid = g_in != nullptr;
     constexpr int NSIDE = 7;
     f32x4 sd_b, sd_g, sd_t, sd_s[4];
 #define CPT_SIDE_LOADS()                                                                                                        \
     do {                                                                                                                        \
-        const int c4 = wcol0 + min(lane, 23) * 4;                                                                                \
+        const int c4 = wcol0 + min(lane, WCOLS / 4 - 1) * 4;                                                                              \
         const float* dummy = reinterpret_cast<const float*>(W);                                                                  \
         const int slots = (st_in_parts + 1) & ~1, nq = slots >> 1;                                                               \
         const f32x4* base = fold_resid ? reinterpret_cast<const f32x4*>(st_in + (size_t)(wrow0 + (lane & 31)) * slots * 2)      \
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
         const unsigned char* sw = smem + slot * W_SLOT;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            fb[pb][j] = *reinterpret_cast<const bf16x8*>(sw + ldsoff(wn * 96 + j * 32 + fr, ks * 2 + fh));
+            fb[pb][j] = *reinterpret_cast<const bf16x8*>(sw + ldsoff(wn * WCOLS + j * 32 + fr, ks * 2 + fh));
     };
     auto touch = [&](int pb) {
 #pragma unroll
@@ -191,9 +202,8 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
 #define CPT_MMA(BUF, KS)                                                                                           \
     do {                                                                                                           \
         const bf16x8 a_ = __builtin_bit_cast(bf16x8, afr[BUF][KS]);                                                 \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][0], acc[0], 0, 0, 0);                           \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][1], acc[1], 0, 0, 0);                           \
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][2], acc[2], 0, 0, 0);                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_)                                                           \
+            acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][j_], acc[j_], 0, 0, 0);                    \
     } while (0)
 
     wait_vm<(CPT_PROD_SIDE == 2 ? NSIDE : 0) + 2 * GA + 3 * GW>();            // tile 0 landed: younger than W(0) are the side data, A(1) A(2), W(1) W(2) W(3)
@@ -222,14 +232,14 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
             }                                                                                                                    \
             reinterpret_cast<float2*>(side_)[lane] = ms;                                                                         \
         }                                                                                                                        \
-        if (lane < 24) {                                                                                                         \
+        if (lane < WCOLS / 4) {                                                                                                  \
             *reinterpret_cast<f32x4*>(side_ + 256 + lane * 16) = fold_resid ? sd_g : f32x4{1.f, 1.f, 1.f, 1.f};                  \
-            *reinterpret_cast<f32x4*>(side_ + 256 + 384 + lane * 16) = fold_resid ? sd_t : f32x4{0.f, 0.f, 0.f, 0.f};            \
-            *reinterpret_cast<f32x4*>(side_ + 256 + 768 + lane * 16) = bias ? sd_b : f32x4{0.f, 0.f, 0.f, 0.f};                  \
+            *reinterpret_cast<f32x4*>(side_ + 256 + WCOLS * 4 + lane * 16) = fold_resid ? sd_t : f32x4{0.f, 0.f, 0.f, 0.f};      \
+            *reinterpret_cast<f32x4*>(side_ + 256 + WCOLS * 8 + lane * 16) = bias ? sd_b : f32x4{0.f, 0.f, 0.f, 0.f};            \
         }                                                                                                                        \
     } while (0)
     // residual rows of the first epilogue slice (16 rows x 96 columns per wave: 16-byte hi + 8-byte lo per lane, three per lane), by asm loads
-    constexpr int C8 = 12, NIT = 3;
+    constexpr int C8 = WCOLS / 8, NIT = 16 * C8 / 64;
     u32x4 ax0h[NIT]; u32x2_t ax0l[NIT];
 #define CPT_AUX0()                                                                                                              \
     do {                                                                                                                        \
@@ -272,6 +282,79 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
         if (!LATE_) { CPT_MMA(B, 3); CPT_SB(); }                                                                    \
     } while (0)
 
+    // ---- NWV = 4 (round 4): one wave per SIMD, so nothing but this wave's own stream can keep the matrix pipe busy: every LDS read,
+    // A load and LDS-DMA piece is issued BETWEEN two MFMAs (an MFMA holds the pipe for 32 cycles; the few issue slots of the filler
+    // behind it are free), instead of in blocks between the six-MFMA groups (first version: 1227 ticks per K-tile against 768 of MFMA;
+    // the blocks' issue time was exposed).  Per K-tile of tile t in slot B:
+    //   k-step 0: MFMA j | reads of tile t's k-steps 2 AND 3 (two per MFMA): all of tile t's reads are issued 6+ MFMAs ahead of the barrier
+    //   k-step 1: MFMA j | A(t+3) fragment loads; before the last MFMA: lgkmcnt(0) (reads retired) + counted vmcnt (tile t+1 landed);
+    //             s_barrier right behind the last MFMA (it runs while the waves meet)
+    //   k-step 2: MFMA j | read of tile t+1's k-step 0, fragment j | W(t+4) piece j into slot B (dead since the barrier)
+    //   k-step 3: MFMA j | read of tile t+1's k-step 1, fragment j
+    // Issue order per wave: A(0) W(0) side A(1) A(2) W(1) W(2) W(3) | iteration t: A(t+3) ... W(t+4).  "Tile t+1 landed" leaves in flight what is
+    // younger than A(t+1): W(t+2) A(t+2) W(t+3) A(t+3) = 2 GW + 2 GA (t = 0: younger than W(1): W(2) W(3) A(3) = 2 GW + GA);
+    // t = nt-3: W(nt-1) A(nt-1) = GW + GA; t = nt-2: nothing.
+#define CPT_MF1(BUF, KS, J) acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[BUF][KS]), fb[KS][J], acc[J], 0, 0, 0)
+#define CPT_RD1(SLOT, KS, J) fb[KS][J] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * W_SLOT + ldsoff((J) * 32 + fr, (KS) * 2 + fh))
+#define CPT_AL1(BUF, T, KS) do { if (ABL != 2) a_load<(KS) * 1024>(afr[BUF][KS], voffa, rsA, a_base + (T) * 4096); } while (0)
+#define CPT_SW1(SLOT, T, I)                                                                                                      \
+    do {                                                                                                                         \
+        if (ABL != 3) {                                                                                                          \
+            auto lds_ = (__attribute__((address_space(3))) void*)(smem + (SLOT) * W_SLOT + ((I) * NWV + wave) * 1024);           \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lds_, 16, voffw[I], (T) * 128, 0, 0);                                   \
+        }                                                                                                                        \
+    } while (0)
+#define CPT_K0(B, J) CPT_MF1(B, 0, J); CPT_SB(); CPT_RD1(B, 2, J); CPT_RD1(B, 3, J); CPT_SB();
+#define CPT_K1(B, KIND, T, J) CPT_MF1(B, 1, J); CPT_SB(); if ((KIND) <= 1 || (KIND) == 5) { CPT_AL1(((B) + 3) & 3, (T) + 3, J); CPT_SB(); }
+#define CPT_K2(B, KIND, T, J) CPT_MF1(B, 2, J); CPT_SB(); if ((KIND) != 4) { CPT_RD1(((B) + 1) & 3, 0, J); } if ((KIND) == 0 || (KIND) == 5) { CPT_SW1(B, (T) + 4, J); } CPT_SB();
+#define CPT_K3(B, KIND, J) CPT_MF1(B, 3, J); CPT_SB(); if ((KIND) != 4) { CPT_RD1(((B) + 1) & 3, 1, J); CPT_SB(); }
+#define CPT_TILE4(B, KIND, T)                                                                                      \
+    do {                                                                                                           \
+        constexpr int NB_ = ((B) + 1) & 3;                                                                          \
+        CPT_K0(B, 0) CPT_K0(B, 1) CPT_K0(B, 2) CPT_K0(B, 3) CPT_K0(B, 4) CPT_K0(B, 5)                               \
+        CPT_K1(B, KIND, T, 0) CPT_K1(B, KIND, T, 1) CPT_K1(B, KIND, T, 2) CPT_K1(B, KIND, T, 3)                     \
+        CPT_MF1(B, 1, 4); CPT_SB();                                                                                 \
+        if ((KIND) != 4) {                                                                                         \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* this wave's reads of tile t are retired */   \
+            if ((KIND) == 5) wait_vm<2 * GW + GA>(); else if ((KIND) <= 1) wait_vm<2 * GW + 2 * GA>();              \
+            else if ((KIND) == 2) wait_vm<GW + GA>(); else wait_vm<0>();                                            \
+            CPT_SB();                                                                                              \
+        }                                                                                                          \
+        CPT_MF1(B, 1, 5); CPT_SB();                                                                                 \
+        if ((KIND) != 4) {                                                                                         \
+            __builtin_amdgcn_s_barrier();          /* tile t+1 visible to all waves; nobody still reads tile t */   \
+            CPT_SB();                                                                                              \
+            CPT_A_TOUCH(NB_);                                                                                      \
+            if ((KIND) == 5 && CPT_PROD_SIDE != 0) { CPT_SIDE_PARK(); CPT_SB(); }                                    \
+            if ((KIND) == 3 && CPT_PROD_AUX0) { CPT_AUX0(); CPT_SB(); }                                              \
+        }                                                                                                          \
+        CPT_K2(B, KIND, T, 0) CPT_K2(B, KIND, T, 1) CPT_K2(B, KIND, T, 2) CPT_K2(B, KIND, T, 3) CPT_K2(B, KIND, T, 4) CPT_K2(B, KIND, T, 5) \
+        CPT_K3(B, KIND, 0) CPT_K3(B, KIND, 1) CPT_K3(B, KIND, 2) CPT_K3(B, KIND, 3) CPT_K3(B, KIND, 4) CPT_K3(B, KIND, 5)  \
+    } while (0)
+
+    if constexpr (NWV == 4) {
+    // KIND 2 waits for tile nt-2's successor nt-1: younger than A(nt-1) nothing was issued -> but W(nt-1) is OLDER than A(nt-2)?
+    // Order near the end: ... A(nt-3) W(nt-2) | A(nt-2) W(nt-1) | A(nt-1).  Tile t+1 needs A(t+1) and W(t+1):
+    //   t = nt-4 (KIND 1): younger than A(nt-3): W(nt-2) A(nt-2) W(nt-1)      = 2 GW + GA   (A(nt-1) is issued after this wait)
+    //   t = nt-3 (KIND 2): younger than A(nt-2): W(nt-1) A(nt-1)              = GW + GA
+    //   t = nt-2 (KIND 3): younger than A(nt-1): nothing                      = 0
+    const int groups = nt / 4 - 1;
+    CPT_TILE4(0, 5, 0);
+    CPT_TILE4(1, 0, 1);
+    CPT_TILE4(2, 0, 2);
+    CPT_TILE4(3, 0, 3);
+    int t = 4;
+    for (int g = 1; g < groups; ++g, t += 4) {
+        CPT_TILE4(0, 0, t);
+        CPT_TILE4(1, 0, t + 1);
+        CPT_TILE4(2, 0, t + 2);
+        CPT_TILE4(3, 0, t + 3);
+    }
+    CPT_TILE4(0, 1, t);
+    CPT_TILE4(1, 2, t + 1);
+    CPT_TILE4(2, 3, t + 2);
+    CPT_TILE4(3, 4, t + 3);
+    } else {
     // KIND 2 waits for tile nt-2's successor nt-1: younger than A(nt-1) nothing was issued -> but W(nt-1) is OLDER than A(nt-2)?
     // Order near the end: ... A(nt-3) W(nt-2) | A(nt-2) W(nt-1) | A(nt-1).  Tile t+1 needs A(t+1) and W(t+1):
     //   t = nt-4 (KIND 1): younger than A(nt-3): W(nt-2) A(nt-2) W(nt-1)      = 2 GW + GA   (A(nt-1) is issued after this wait)
@@ -293,7 +376,17 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
     CPT_TILE(1, 2, t + 1);
     CPT_TILE(2, 3, t + 2);
     CPT_TILE(3, 4, t + 3);
+    }
 #undef CPT_TILE
+#undef CPT_TILE4
+#undef CPT_K0
+#undef CPT_K1
+#undef CPT_K2
+#undef CPT_K3
+#undef CPT_MF1
+#undef CPT_RD1
+#undef CPT_AL1
+#undef CPT_SW1
 #undef CPT_AUX0
 #undef CPT_SIDE_PARK
 #undef CPT_SIDE_LOADS
@@ -307,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
     // same order in the row sums (bit-identical outputs), but EIGHT columns per lane in the read-back instead of four: half the
     // vector-memory instructions, 16-byte hi / 8-byte lo accesses, and the stores write-through (common.h CPT_ST_AUX).
     __syncthreads();                                  // every wave is done reading the W ring
-    constexpr int WCOLS = NJ * 32, CPW = WCOLS * 4 + 16, CH = WCOLS / 4, NSL = 2, P = 3;
+    constexpr int CPW = WCOLS * 4 + 16, CH = WCOLS / 4, NSL = 2, P = 3;
     static_assert(16 * CPW * NWV <= RING_BYTES, "per-wave slabs must fit in the ring");
     static_assert(C8 == WCOLS / 8 && NIT * 64 == 16 * C8 && (64 * P) % C8 == 0, "read-back fills whole waves; column chunk repeats with period P");
     unsigned char* slab = smem + wave * (16 * CPW);
@@ -353,9 +446,9 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
     };
     Aux aux_a, aux_b;
     if (CPT_PROD_AUX0) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax0h[0]), "+v"(ax0h[1]), "+v"(ax0h[2]), "+v"(ax0l[0]), "+v"(ax0l[1]), "+v"(ax0l[2]) : : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) { aux_a.h[it] = ax0h[it]; aux_a.l[it] = ax0l[it]; }
+        for (int it = 0; it < NIT; ++it) { asm volatile("" : "+v"(ax0h[it]), "+v"(ax0l[it])); aux_a.h[it] = ax0h[it]; aux_a.l[it] = ax0l[it]; }
     } else load_aux(0, aux_a);
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) {
@@ -398,19 +491,24 @@ __global__ __launch_bounds__(512, 2) void prod3_panel_kernel(
             __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{lq[0], lq[1]}, rsL, eo, 0, CPT_ST_AUX);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // partial row sums per 96-COLUMN block (one table slot each), whatever the wave's width: 4 lanes per row, 6 chunks each, then two
+        // shuffles -- the same additions in the same order for both wave shapes
         const int r16 = lane >> 2, part = lane & 3;
-        float sm = 0.f, sq = 0.f;
-#pragma unroll
-        for (int k = 0; k < CH / 4; ++k) {
-            const f32x4 f = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (part * (CH / 4) + k) * 16);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sm += f[e]; sq += f[e] * f[e]; }
-        }
-        sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
-        sm += __shfl_xor(sm, 2, 64); sq += __shfl_xor(sq, 2, 64);
         const int srow = wrow0 + sl * 16 + r16;
-        if (part == 0)
-            *reinterpret_cast<float2*>(st_out + 2 * ((size_t)srow * st_out_slots + wcol0 / WCOLS)) = float2{sm, sq};
+#pragma unroll
+        for (int hb = 0; hb < WCOLS / 96; ++hb) {
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const f32x4 f = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (hb * 24 + part * 6 + k) * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sm += f[e]; sq += f[e] * f[e]; }
+            }
+            sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
+            sm += __shfl_xor(sm, 2, 64); sq += __shfl_xor(sq, 2, 64);
+            if (part == 0)
+                *reinterpret_cast<float2*>(st_out + 2 * ((size_t)srow * st_out_slots + wcol0 / 96 + hb)) = float2{sm, sq};
+        }
     }
     if (trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -442,6 +540,8 @@ extern long long* g_gemm_trace;
 extern int g_trace_k, g_trace_epi;       // diagnostics: stamp only launches of this K (0: all) / this epilogue id (-1: all; the producers are 11)
 int g_prod_abl = 0;          // timing experiments (cpt_set_tuning key 13), see prod3_panel_kernel
 void set_prod_abl(int v) { g_prod_abl = v; }
+int g_prod_waves = 0;        // wave shape of the tile (cpt_set_tuning key 24): 8 = 4 x 2 waves of 32 x 96, 4 = 4 x 1 waves of 32 x 192, 0 = by K (4 from K = 1536 on); same bits
+void set_prod_waves(int v) { g_prod_waves = (v == 4 || v == 0) ? v : 8; }
 
 int panel_eligible(int M, int N, int K) { return M > 0 && M % TM == 0 && N > 0 && N % TN == 0 && K >= 512 && K % 256 == 0 && (size_t)M * K * 2 <= (size_t)0x7fffffff; }
 
@@ -470,8 +570,12 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     static bool attr_done_dev[CPT_MAX_DEV] = {};
     bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
-        for (const void* k : {(const void*)prod3_panel_kernel<0>, (const void*)prod3_panel_kernel<1>, (const void*)prod3_panel_kernel<2>, (const void*)prod3_panel_kernel<3>, (const void*)prod3_panel_kernel<4>}) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        for (const void* k : {(const void*)prod3_panel_kernel<0, 8>, (const void*)prod3_panel_kernel<1, 8>, (const void*)prod3_panel_kernel<2, 8>, (const void*)prod3_panel_kernel<3, 8>, (const void*)prod3_panel_kernel<4, 8>}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<8>::LDS_BYTES);
+            if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+        }
+        for (const void* k : {(const void*)prod3_panel_kernel<0, 4>, (const void*)prod3_panel_kernel<2, 4>, (const void*)prod3_panel_kernel<3, 4>}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<4>::LDS_BYTES);
             if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         }
         attr_done = true;
@@ -481,16 +585,23 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     const int npf = ((pf0 && pf0_bytes) || (pf1 && pf1_bytes)) ? (std::max(0, std::min(CPT_PREFETCH_WGS, 256 - ntile)) & ~7) : 0;
     if (!npf) { pf0 = nullptr; pf1 = nullptr; }
     const int nwg = ntile + npf;
-#define CPT_LAUNCH(ABL) prod3_panel_kernel<ABL><<<dim3(nwg), dim3(512), LDS_BYTES, s>>>(                                                         \
+#define CPT_LAUNCH(ABL, NWV) prod3_panel_kernel<ABL, NWV><<<dim3(nwg), dim3(NWV * 64), Shape<NWV>::LDS_BYTES, s>>>(                                  \
         (const bf16*)A_panel, (const bf16*)W, ldw, bias, (const bf16*)resid_hi, (const signed char*)resid_lo, ldr, st_in, ln_stat_parts(hidden), g_in, b_in, \
         eps, 1.0f / (float)hidden, (bf16*)out_hi, (signed char*)out_lo, ldo, st_out, ln_stat_slots(N), M, N, K, ((g_trace_epi < 0 || g_trace_epi == 11) && (g_trace_k == 0 || g_trace_k == K)) ? g_gemm_trace : nullptr, \
         pf0, pf0_bytes, pf1, pf1_bytes)
+    if (g_prod_waves == 4 || (g_prod_waves == 0 && K >= 1536)) {
+        switch (g_prod_abl) {
+            case 2: CPT_LAUNCH(2, 4); break;
+            case 3: CPT_LAUNCH(3, 4); break;
+            default: CPT_LAUNCH(0, 4); break;
+        }
+    } else
     switch (g_prod_abl) {
-        case 1: CPT_LAUNCH(1); break;
-        case 2: CPT_LAUNCH(2); break;
-        case 3: CPT_LAUNCH(3); break;
-        case 4: CPT_LAUNCH(4); break;
-        default: CPT_LAUNCH(0); break;
+        case 1: CPT_LAUNCH(1, 8); break;
+        case 2: CPT_LAUNCH(2, 8); break;
+        case 3: CPT_LAUNCH(3, 8); break;
+        case 4: CPT_LAUNCH(4, 8); break;
+        default: CPT_LAUNCH(0, 8); break;
     }
 #undef CPT_LAUNCH
     return CPT_OK;

@@ -179,6 +179,7 @@ int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const flo
                       const void* pf = nullptr, size_t pf_bytes = 0, int gelu = 1);     // gelu 0: plain LayerNorm-consumer GEMM (stand-alone QKV projection)
 void set_ffn_dma_late(int v);
 void set_prod_abl(int v);    // timing experiments of the panel producer (gemm_prod.hip)
+void set_prod_waves(int v);  // wave shape of the panel producer: 8 (4 x 2 waves of 32 x 96) or 4 (4 x 1 waves of 32 x 192)
 void set_gemm_trace(void* p);
 void set_gemm_trace_filter(int epi, int k);
 

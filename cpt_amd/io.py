@@ -55,6 +55,7 @@ class TSVFile(object):
         self.tsv_file = tsv_file
         self.lineidx = os.path.splitext(tsv_file)[0] + ".lineidx"
         self._offsets = None        # int64 [rows + 1]: row starts, then the file size
+        self._sequential = True     # the .lineidx lists every row in file order (offsets()): a row ends where the next one starts
         self._map = None
         self._map_owner = None      # the process that created the map (a forked child maps again)
         if generate_lineidx and not os.path.isfile(self.lineidx):
@@ -72,9 +73,36 @@ class TSVFile(object):
             table = np.empty(len(txt) + 1, dtype=np.int64)
             if txt:
                 table[:-1] = np.array(txt, dtype=np.int64)
-            table[-1] = os.path.getsize(self.tsv_file)
+            size = os.path.getsize(self.tsv_file)
+            table[-1] = size
+            starts = table[:-1]
+            if len(starts) and (starts.min() < 0 or starts.max() >= max(size, 1)):
+                raise ValueError("%s holds a row offset outside %s (%d bytes)" % (self.lineidx, self.tsv_file, size))
+            # A row ends where the next entry starts only when the table lists EVERY row in file order.  The reference reader
+            # (tsv_file.py:60-66: seek to the offset, readline) also serves subset / re-ordered .lineidx files; for those the
+            # row end is the next newline, found on demand.
+            self._sequential = bool(len(starts) == 0 or (starts[0] == 0 and (np.diff(table) > 0).all()))
             self._offsets = table
+            if self._sequential and len(starts):
+                self._sequential = self._lists_every_row(table, size)
         return self._offsets
+
+    def _lists_every_row(self, table, size):
+        """An ascending table that starts at 0 may still skip rows (a subset file): it lists every row iff no row span holds a
+        newline before its last byte.  Exact (one pass at memchr speed) up to 1 GiB; beyond that 64 evenly spaced rows are checked."""
+        buf = self.buffer()
+        n = len(table) - 1
+        if size <= (1 << 30):
+            arr = np.frombuffer(buf, dtype=np.uint8)
+            nl = 0
+            for lo in range(0, size, 1 << 26):
+                nl += int(np.count_nonzero(arr[lo:lo + (1 << 26)] == 10))
+            return nl == n or (nl == n - 1 and arr[-1] != 10)
+        for i in np.unique(np.linspace(0, n - 1, 64).astype(np.int64)):
+            lo, hi = int(table[i]), int(table[i + 1])
+            if buf.find(b"\n", lo, hi - 1) >= 0:
+                return False
+        return True
 
     def buffer(self):
         """The whole file as a read-only memory map (shared page cache; re-mapped in a forked worker)."""
@@ -92,7 +120,12 @@ class TSVFile(object):
         if not -n <= idx < n:
             raise IndexError("row %d of a %d-row TSV file" % (idx, n))
         idx %= n
-        return int(offs[idx]), int(offs[idx + 1])
+        lo = int(offs[idx])
+        if self._sequential:
+            return lo, int(offs[idx + 1])
+        buf = self.buffer()
+        nl = buf.find(b"\n", lo)
+        return lo, (nl + 1 if nl >= 0 else len(buf))
 
     # ---- the reference's surface ---------------------------------------------------------------------------------
     def num_rows(self):
@@ -113,7 +146,9 @@ class TSVFile(object):
         lo, hi = self.row_span(idx)
         buf = self.buffer()
         tab = buf.find(b"\t", lo, hi)
-        return buf[lo:(tab if tab >= 0 else hi)].decode("utf-8")
+        if tab < 0:                       # a one-column row: the column without its line terminator
+            return buf[lo:hi].decode("utf-8").rstrip("\r\n")
+        return buf[lo:tab].decode("utf-8")
 
 
 def b64_to_f32(s, dim=2054):

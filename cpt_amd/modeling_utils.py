@@ -67,7 +67,10 @@ class PreTrainedModel(nn.Module):
         (:843-851).  Returns (table, names of the model this checkpoint is expected to fill)."""
         table = {}
         for key, tensor in raw.items():
-            table[key.replace("gamma", "weight").replace("beta", "bias")] = tensor
+            # the reference's rule (:811-823): ONE substitution on the original key -- `beta` -> `bias` when the key holds "beta",
+            # else `gamma` -> `weight`
+            name = key.replace("beta", "bias") if "beta" in key else (key.replace("gamma", "weight") if "gamma" in key else key)
+            table[name] = tensor
         prefix = cls.base_model_prefix + "."
         prefixed = any(k.startswith(cls.base_model_prefix) for k in table)
         own = list(model.state_dict(keep_vars=True))
@@ -81,6 +84,10 @@ class PreTrainedModel(nn.Module):
     def adopt_state_dict(self, raw):
         """Copies a checkpoint's tensors into this model in place; returns {missing_keys, unexpected_keys, error_msgs}."""
         table, own = self._checkpoint_table(raw, self)
+        # Tied weights (cls.predictions.decoder.weight = bert.embeddings.word_embeddings.weight) appear under both names and alias one
+        # storage; names are visited in state-dict order, so when a checkpoint holds two different tensors for them the LATER name
+        # (the decoder) is what remains -- as in the reference, whose constructors tie before loading (modeling_bert.py:980,
+        # modeling_rec.py:109) and whose per-module loader visits `bert` before `cls`.
         mine = self.state_dict(keep_vars=True)
         missing, errors = [], []
         with torch.no_grad():

@@ -231,6 +231,12 @@ class _MLMLoss(torch.autograd.Function):
             raise errs[0]
         if accumulate:
             st.grad.add_(keep)
+            if st.sync is not None and not st.defer:
+                # the closing micro-step of an accumulation window: the sum is final now -- start every bucket's reduce-scatter here
+                # (it then runs under whatever the caller does before step(); nothing of this backward was left to hide it under)
+                sync = st.sync
+                for k in sync.order:
+                    sync.grads_ready(st.grad, k)
         for p, v in views:
             p.grad = v
         if sync is not None:
@@ -355,7 +361,9 @@ class FusedAdamW(object):
     def no_sync(self):
         """Context manager (DistributedDataParallel.no_sync): backward passes inside it do not start the gradient
         reduce-scatter -- for the leading micro-steps of a gradient-accumulation window, whose partial sums would be sent for
-        nothing.  The buckets are reduced by the backward that follows outside the context, or by step()."""
+        nothing.  The backward that closes the window (outside the context) adds its gradients to the kept partial sum and THEN starts
+        the buckets' reduce-scatters (they cannot overlap that backward: the sum is only final behind it); with ``defer_reduce`` they
+        run inside step()."""
         opt = self
 
         class _NoSync(object):
@@ -461,6 +469,7 @@ class FusedAdamW(object):
             self._adamw(eng.flat.data_ptr() + slo * 4, sync.gshard.data_ptr() + so * 4, self.m.data_ptr() + so * 4,
                         self.v.data_ptr() + so * 4, self.code.data_ptr() + so, None, shi - slo, lr, wd, self._clip / self.world)
         self._clip = 1.0
+        st.sent_version = None            # consumed: a later in-place edit of the (now stale) gradient views is the caller's business
         sync.all_gather_params(eng.flat)
         self._stale_shadow = set(sync.order)
         eng.pending = self

@@ -197,14 +197,14 @@ def tiny_case():
     return float((sc3 - scores.detach()).abs().max())
 
 
-def base_case(name, B, n_regions, seed_w=88, seed_b=88, with_grads=False, vary=False):
+def base_case(name, B, n_regions, seed_w=88, seed_b=88, with_grads=False, vary=False, Lt=70, Li=50):
     cfg = cfgmod.oscar_base()
     m, pre = build_ref(cfg, seed_w)
-    batch = synth.make_batch(B, cfg, seed=seed_b, n_regions=n_regions, vary_regions=vary)
+    batch = synth.make_batch(B, cfg, seed=seed_b, max_seq_len=Lt, img_seq_len=Li, n_regions=n_regions, vary_regions=vary)
     lab = labels_for(batch)
     ids_sub = sorted(set(list(synth.COLOR_IDS) + [synth.NONE_ID] +
                          [int(i) for i in np.random.Generator(np.random.PCG64(5)).integers(0, cfg.vocab_size, 64)]))
-    g = dict(B=B, n_regions=n_regions, seed_w=seed_w, seed_b=seed_b, vary=int(vary), ids_sub=np.array(ids_sub))
+    g = dict(B=B, n_regions=n_regions, seed_w=seed_w, seed_b=seed_b, vary=int(vary), ids_sub=np.array(ids_sub), Lt=Lt, Li=Li)
     if with_grads:
         out = m(batch["input_ids"], batch["segment_ids"], batch["attention_mask"],
                 img_feats=batch["img_feats"], masked_lm_labels=lab)
@@ -275,6 +275,42 @@ def vcr_nsp_case():
              grad_q0_weight=m.bert.encoder.layer[0].attention.self.query.weight.grad.numpy(),
              keys=np.array(sorted(m.state_dict().keys())))
     np.savez_compressed(os.path.join(OUT, "tiny_vcr_nsp.npz"), **g)
+
+
+def large_vcr_case(name="large_vcr_b2_l265", B=2, Lt=165, Li=100, seed_w=88, seed_b=21):
+    """BASELINE configs[4] shape: the reference's NSPCPT (modeling_vcr.py:79-129) on the Oscar-large config (24 layers, hidden 1024,
+    16 heads), L = 165 + 100, ragged region counts: relation scores, CE loss against the driver's labels
+    (fewshot/vcr_nsp_cpt.py:433-436), four gradient samples + every gradient norm under autograd (dropout off: eval mode)."""
+    from oscar.modeling.modeling_vcr import NSPCPT
+    cfg = cfgmod.oscar_large()
+    rc = to_ref_cfg(cfg)
+    pre = BertImgForPreTraining(rc)
+    sd = synth.init_state_dict(cfg, seed_w, head="pretrain")
+    pre.load_state_dict(sd, strict=True)
+    pre.tie_weights()
+    m = NSPCPT(rc)
+    m.copy_from_pretraining_model(pre)
+    m.eval()
+    del pre
+    batch = synth.make_batch(B, cfg, seed=seed_b, max_seq_len=Lt, img_seq_len=Li, n_regions=Li, vary_regions=True)
+    cls_labels = torch.tensor([(i * 2 + 1) % 3 for i in range(B)], dtype=torch.long)
+    loss, rel = m(batch["input_ids"], batch["segment_ids"], batch["attention_mask"], next_sentence_label=cls_labels,
+                  img_feats=batch["img_feats"])[:2]
+    m.zero_grad()
+    loss.backward()
+    gn = {k: (float(p.grad.double().norm()) if p.grad is not None else -1.0) for k, p in m.named_parameters()}
+    with torch.no_grad():
+        seq, pooled = m.bert(batch["input_ids"], batch["segment_ids"], batch["attention_mask"], img_feats=batch["img_feats"])[:2]
+    g = dict(B=B, Lt=Lt, Li=Li, seed_w=seed_w, seed_b=seed_b, rel=rel.detach().numpy(), loss=float(loss), cls_labels=cls_labels.numpy(),
+             choice_logits=(1 - rel.detach().softmax(-1)[:, 1]).numpy(),
+             seq_sample=seq[:, ::23, ::37].numpy(), pooled_sample=pooled[:, ::13].numpy(),
+             grad_names=np.array(list(gn.keys())), grad_norms=np.array(list(gn.values()), np.float64),
+             grad_cls_weight=m.cls.weight.grad.numpy().copy(),
+             grad_sample_pooler=m.bert.pooler.dense.weight.grad[:8, :16].numpy().copy(),
+             grad_sample_q23=m.bert.encoder.layer[23].attention.self.query.weight.grad[:8, :16].numpy().copy(),
+             grad_sample_ffn0=m.bert.encoder.layer[0].intermediate.dense.weight.grad[:8, :16].numpy().copy(),
+             grad_sample_img=m.bert.img_embedding.weight.grad[:8, 2040:2054].numpy().copy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **g)
 
 
 def tsv_rows_case():
@@ -429,6 +465,10 @@ def main():
     if "--only-tsv" in sys.argv:          # section 8(f).2 fixture
         tsv_rows_case()
         return
+    if "--only-cfg45" in sys.argv:        # round 4: BASELINE configs[3] / configs[4] shapes without rewriting the others
+        base_case("base_gqa_b2_l210", B=2, n_regions=45, seed_b=11, with_grads=True, vary=True, Lt=165, Li=45)
+        large_vcr_case()
+        return
     meta = {"reference": "thunlp/CPT @ /root/reference (v1)",
             "third_party_restated": "huggingface/transformers@067923d3267325f525f4e46f357360c191ba562e (pytorch_transformers)",
             "torch": torch.__version__}
@@ -443,6 +483,8 @@ def main():
     base_case("base_cfg1_b2_r36", B=2, n_regions=36)                       # BASELINE config 1 shape
     base_case("base_cfg2_b4_r50", B=4, n_regions=50, with_grads=True)      # config 2 shape (+ grads for config 3)
     base_case("base_ragged_b3", B=3, n_regions=50, seed_b=3, vary=True)
+    base_case("base_gqa_b2_l210", B=2, n_regions=45, seed_b=11, with_grads=True, vary=True, Lt=165, Li=45)   # configs[3] shape (Oscar/cmds/gqa/_cpt_fsl_base.sh:19,27)
+    large_vcr_case()                                                                                         # configs[4] shape (Oscar-large, 100 regions)
     with open(os.path.join(OUT, "META.json"), "w") as f:
         json.dump(meta, f, indent=2, sort_keys=True)
     print("wrote", OUT)

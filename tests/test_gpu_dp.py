@@ -156,6 +156,14 @@ def _nccl1_worker(rank, port, tmp):
             losses = l1 + _run(m, opt, b, slice(0, 4), steps=STEPS - 1)
             sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
             out[(mode, wire)] = {"losses": losses, "sd": sd, "sd1": sd1}
+        # comm profiling (bench.py --mode train prints this block): events around every collective and around every wait for one
+        m, opt = make("bf16")
+        _run(m, opt, b, slice(0, 4), steps=2)
+        opt.sync.profile = True
+        opt.sync.comm_report(1)                       # (clears)
+        _run(m, opt, b, slice(0, 4), steps=3)
+        out["comm"] = opt.sync.comm_report(3)
+        opt.sync.profile = False
         # stress: 50 steps back to back while a second stream thrashes HBM / MALL (tests/test_gpu_race.py's pressure)
         m, opt = make("bf16")
         side = torch.cuda.Stream(device=dev)
@@ -267,6 +275,13 @@ def test_rccl_path_on_one_gpu():
         again = fresh(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"])[0].cpu()
     assert torch.equal(again, r["stress"]["logits"])
     assert r["edit_raises"] is True
+    # the comm block of bench.py --mode train: one reduce-scatter and one all-gather per bucket per step, positive times, waits <= totals
+    c = r["comm"]
+    assert c["ranks"] == 1 and c["buckets"] == len(c["per_bucket"]) >= 3
+    assert c["reduce_scatter_ms_per_step"] > 0 and c["all_gather_ms_per_step"] > 0
+    assert c["reduce_scatter_bytes_per_rank_per_step"] == 4 * c["elements"] == c["all_gather_bytes_per_rank_per_step"]
+    assert all(v["rs_ms"] > 0 and v["ag_ms"] > 0 for v in c["per_bucket"].values())
+    assert c["fraction_hidden"]["reduce_scatter"] <= 1.0 and c["fraction_hidden"]["all_gather"] <= 1.0
     # defer_reduce: the halved local gradients reached the update -> equal to the plain step with the same edit
     m, opt = _make(cfgmod.tiny(), 1234, dev, "fp32")
     opt.zero_grad()

@@ -193,3 +193,100 @@ def test_bf16_colour_argmax_flip_count_1024_sequences(dev):
     assert st["bf16x3"]["few_shot_ratio_flips_outside_error_band"] == 0, st["bf16x3"]      # (bf16 mode: recorded, not asserted)
     assert st["bf16"]["max_abs_logit_error"] < BF16_TOL and st["bf16"]["zero_shot_flips"] <= 1024 // 50
     assert st["bf16x3"]["max_abs_logit_error"] < 1e-3 and st["bf16x3"]["zero_shot_flips"] == 0       # the parity bar of north_star
+
+
+def _rel_err(got, ref):
+    got, ref = got.double().cpu().flatten(), torch.as_tensor(ref).double().flatten()
+    return float((got - ref).norm() / (ref.norm() + 1e-30))
+
+
+def _check_norms(g, params, tol):
+    n = 0
+    for name, ref in zip(list(g["grad_names"]), g["grad_norms"]):
+        name = str(name)
+        if ref < 0:
+            continue
+        got = float(params[name].grad.double().norm())
+        if ".key.bias" in name:            # exactly zero in exact arithmetic: rounding noise on both sides
+            assert got < 1e-3 and ref < 1e-5, (name, got, ref)
+            continue
+        assert abs(got - ref) <= tol * max(ref, 1e-6), (name, got, ref)
+        n += 1
+    return n
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_config4_gqa_shape_reference_golden(dev, golden_dir, mode):
+    """BASELINE configs[3] shape (Oscar-base, L = 165 + 45, ragged regions) against the REFERENCE's own REC_MLM_CPT
+    (tests/golden/base_gqa_b2_l210.npz, oracle/make_golden.py): [MASK]-row logits on the colour + 64 random ids, loss, and the
+    gradient norms / samples of the reference's autograd through the HIP training step (dropout 0)."""
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    g = np.load(os.path.join(golden_dir, "base_gqa_b2_l210.npz"))
+    cfg = cfgmod.oscar_base()
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, int(g["seed_w"]), head="cpt"))
+    m.tie_weights()
+    m.to(dev).eval().set_compute_dtype(mode)
+    b = _dev(synth.make_batch(int(g["B"]), cfg, seed=int(g["seed_b"]), max_seq_len=int(g["Lt"]), img_seq_len=int(g["Li"]),
+                              n_regions=int(g["n_regions"]), vary_regions=True), dev)
+    ids = torch.from_numpy(g["ids_sub"])
+    with torch.no_grad():
+        loss, rows = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
+                       mask_token_pos=b["mask_token_pos"])
+    err = (rows.cpu()[:, ids] - torch.from_numpy(g["mask_logits_sub"])).abs().max().item()
+    print("config 4 shape vs reference golden (%s): max |d logit| %.3e, loss %.6f vs %.6f" % (mode, err, loss.item(), float(g["loss"])))
+    assert err < (1e-3 if mode == "fp32" else BF16_TOL)
+    assert abs(loss.item() - float(g["loss"])) < (1e-3 if mode == "fp32" else 5e-2)
+    if mode == "fp32":
+        assert (rows.argmax(-1).cpu().numpy() == g["mask_logits_argmax"]).all()
+    m.train()
+    loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
+                mask_token_pos=b["mask_token_pos"])
+    loss.backward()
+    params = dict(m.named_parameters())
+    assert _check_norms(g, params, 1e-3 if mode == "fp32" else 8e-2) > 190
+    stol = 1e-3 if mode == "fp32" else 0.15
+    assert _rel_err(params["bert.encoder.layer.11.attention.self.query.weight"].grad[:8, :16], g["grad_sample_qw"]) < stol
+    assert _rel_err(params["bert.img_embedding.weight"].grad[:8, 2040:2054], g["grad_sample_img"]) < stol
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_config5_oscar_large_reference_golden(dev, golden_dir, mode):
+    """BASELINE configs[4] shape against the REFERENCE's own NSPCPT on the Oscar-large config (24 layers, hidden 1024, 16 heads,
+    L = 165 + 100; tests/golden/large_vcr_b2_l265.npz): relation scores, choice logits, loss, four gradient samples and the
+    gradient norms of the reference's autograd through the HIP training step (dropout 0)."""
+    from cpt_amd.modeling_bert import BertImgForPreTraining
+    from cpt_amd.modeling_vcr import NSPCPT
+    g = np.load(os.path.join(golden_dir, "large_vcr_b2_l265.npz"))
+    cfg = cfgmod.oscar_large()
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0
+    pre = BertImgForPreTraining(cfg)
+    pre.load_state_dict(synth.init_state_dict(cfg, int(g["seed_w"]), head="pretrain"))
+    pre.tie_weights()
+    m = NSPCPT(cfg)
+    m.copy_from_pretraining_model(pre)
+    del pre
+    m.to(dev).eval().set_compute_dtype(mode)
+    b = _dev(synth.make_batch(int(g["B"]), cfg, seed=int(g["seed_b"]), max_seq_len=int(g["Lt"]), img_seq_len=int(g["Li"]),
+                              n_regions=int(g["Li"]), vary_regions=True), dev)
+    lab = torch.from_numpy(g["cls_labels"]).to(dev)
+    with torch.no_grad():
+        rel = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"])[0]
+    err = (rel.cpu() - torch.from_numpy(g["rel"])).abs().max().item()
+    choice = 1 - torch.softmax(rel.cpu(), -1)[:, 1]
+    print("config 5 shape vs reference golden (%s): max |d relation score| %.3e" % (mode, err))
+    assert err < (1e-3 if mode == "fp32" else BF16_TOL)
+    assert (choice - torch.from_numpy(g["choice_logits"])).abs().max().item() < (1e-3 if mode == "fp32" else BF16_TOL)
+    m.train()
+    loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], next_sentence_label=lab, img_feats=b["img_feats"])
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < (1e-3 if mode == "fp32" else 5e-2)
+    params = dict(m.named_parameters())
+    assert _check_norms(g, params, 1e-3 if mode == "fp32" else 8e-2) > 370
+    stol = 1e-3 if mode == "fp32" else 0.15
+    assert _rel_err(params["cls.weight"].grad, g["grad_cls_weight"]) < stol
+    assert _rel_err(params["bert.pooler.dense.weight"].grad[:8, :16], g["grad_sample_pooler"]) < stol
+    assert _rel_err(params["bert.encoder.layer.23.attention.self.query.weight"].grad[:8, :16], g["grad_sample_q23"]) < stol
+    assert _rel_err(params["bert.encoder.layer.0.intermediate.dense.weight"].grad[:8, :16], g["grad_sample_ffn0"]) < stol
+    assert _rel_err(params["bert.img_embedding.weight"].grad[:8, 2040:2054], g["grad_sample_img"]) < stol

@@ -485,12 +485,15 @@ def test_gemm_ln_prod3_matches_fp32_producer(dev, K):
             assert torch.equal(s_hi, o_hi[:Ms]) and torch.equal(s_lo, o_lo[:Ms]) and torch.equal(s_st, st3[:Ms])
 
 
+@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("K,H,M", [(768, 768, 640), (3072, 768, 640), (512, 384, 128), (1024, 192, 256)])
-def test_gemm_ln_prod3_panel_is_bit_identical(dev, K, H, M):
+def test_gemm_ln_prod3_panel_is_bit_identical(dev, K, H, M, waves):
     """Round 3: the producer that reads A from its fragment-major panel copy straight into registers (gemm_prod.hip) against the
     row-major producer on the same operands: hi, lo and the partial row sums bit for bit, with and without the on-the-fly residual
-    LayerNorm; the panel copy round-trips through cpt_panel_pack; 20 back-to-back launches give identical bits."""
-    from cpt_amd import ops
+    LayerNorm; the panel copy round-trips through cpt_panel_pack; 20 back-to-back launches give identical bits.  Both wave shapes of the
+    tile (round 4, cpt_set_tuning key 24: 4 x 2 waves of 32 x 96, 4 x 1 waves of 32 x 192) give the same bits."""
+    from cpt_amd import ops, _lib as L
+    L.check(L.lib().cpt_set_tuning(24, waves))
     rng = _rng(K + 5)          # (K = 512: the shortest K loop the kernel runs, 8 K-tiles; one row tile; 1, 2 and 4 column tiles)
     x = (_t(rng, M, H, scale=1.2) + 0.3).to(dev)
     hi, lo = ops.resid3_split(x)

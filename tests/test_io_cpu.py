@@ -157,3 +157,30 @@ def test_decode_pool_worker_processes_match_direct_decode(golden_dir):
             pool.next()
     finally:
         pool.close()
+
+
+def test_tsvfile_subset_and_reordered_lineidx(tmp_path):
+    """the reference reader (utils/tsv_file.py:60-66: seek to the offset, readline) also serves .lineidx files that list a
+    subset of the rows or list them out of order; a row then ends at its newline, not at the next table entry."""
+    from cpt_amd.io import TSVFile
+    rows = [("k%d" % i, "payload %d." % i + "x" * (3 * i)) for i in range(6)]
+    tsv = tmp_path / "t.tsv"
+    tsv.write_text("".join("%s\t%s\n" % r for r in rows) + "lonely\n")
+    full = TSVFile(str(tsv), generate_lineidx=True)
+    assert len(full) == 7 and full._sequential
+    assert [full.seek(i) for i in range(6)] == [list(r) for r in rows]
+    assert full.seek_first_column(6) == "lonely" and full.seek(6) == ["lonely"]
+    offs = [int(o) for o in (tmp_path / "t.lineidx").read_text().split()]
+    for name, pick in (("subset", [0, 2, 5]), ("reordered", [4, 1, 3, 0])):
+        sub = tmp_path / (name + ".tsv")
+        sub.write_bytes(tsv.read_bytes())
+        (tmp_path / (name + ".lineidx")).write_text("".join("%d\n" % offs[i] for i in pick))
+        t = TSVFile(str(sub))
+        assert len(t) == len(pick)
+        assert [t.seek(j) for j in range(len(pick))] == [list(rows[i]) for i in pick]
+        assert [t.seek_first_column(j) for j in range(len(pick))] == [rows[i][0] for i in pick]
+    bad = tmp_path / "bad.tsv"
+    bad.write_bytes(tsv.read_bytes())
+    (tmp_path / "bad.lineidx").write_text("0\n99999\n")
+    with pytest.raises(ValueError):
+        TSVFile(str(bad)).seek(0)

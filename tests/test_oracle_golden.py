@@ -70,13 +70,14 @@ def test_tiny_loss_and_grads(golden_dir):
     assert grads["bert.pooler.dense.weight"] is None
 
 
-@pytest.mark.parametrize("name", ["base_cfg1_b2_r36", "base_cfg2_b4_r50", "base_ragged_b3"])
+@pytest.mark.parametrize("name", ["base_cfg1_b2_r36", "base_cfg2_b4_r50", "base_ragged_b3", "base_gqa_b2_l210"])
 def test_base_mask_logits(golden_dir, name):
     g = _load(golden_dir, name + ".npz")
     cfg = cfgmod.oscar_base()
     sd = synth.init_state_dict(cfg, int(g["seed_w"]), head="pretrain")
     sd = {k.replace("cls.predictions.", "cls."): v for k, v in sd.items()}
-    b = synth.make_batch(int(g["B"]), cfg, seed=int(g["seed_b"]), n_regions=int(g["n_regions"]),
+    Lt, Li = (int(g["Lt"]), int(g["Li"])) if "Lt" in g.files else (70, 50)       # base_gqa_*: BASELINE configs[3], L = 165 + 45
+    b = synth.make_batch(int(g["B"]), cfg, seed=int(g["seed_b"]), max_seq_len=Lt, img_seq_len=Li, n_regions=int(g["n_regions"]),
                          vary_regions=bool(int(g["vary"])))
     B = int(g["B"])
     lab = torch.full(b["attention_mask"].shape, -1, dtype=torch.long)
@@ -98,6 +99,67 @@ def test_base_mask_logits(golden_dir, name):
     np.testing.assert_allclose(cls_rows[:, ids].numpy(), g["cls_row_logits_sub"], atol=2e-5, rtol=0)
     nsp = O.nsp_cpt_scores(sd, _cfg_dict(cfg), b["input_ids"], b["segment_ids"], b["attention_mask"], b["img_feats"])
     np.testing.assert_allclose(nsp.numpy(), g["nsp_scores"], atol=1e-5, rtol=0)
+
+
+def _check_grad_norms(g, grads, tol=2e-4):
+    n = 0
+    for name, ref in zip(list(g["grad_names"]), g["grad_norms"]):
+        name = str(name)
+        if ref < 0:
+            assert grads.get(name) is None, name
+            continue
+        got = float(grads[name].double().norm())
+        if ".key.bias" in name:            # exactly zero in exact arithmetic (softmax is shift-invariant): noise on both sides
+            assert got < 1e-5 and ref < 1e-5, (name, got, ref)
+            continue
+        assert abs(got - ref) <= tol * max(ref, 1e-7), (name, got, ref)
+        n += 1
+    return n
+
+
+def test_base_gqa_shape_gradients(golden_dir):
+    """BASELINE configs[3] shape (L = 165 + 45, ragged regions): loss and every gradient norm of the reference's REC_MLM_CPT under
+    autograd (oracle/make_golden.py base_case with_grads) reproduced by the oracle."""
+    g = _load(golden_dir, "base_gqa_b2_l210.npz")
+    cfg = cfgmod.oscar_base()
+    sd = synth.init_state_dict(cfg, int(g["seed_w"]), head="cpt")
+    b = synth.make_batch(int(g["B"]), cfg, seed=int(g["seed_b"]), max_seq_len=int(g["Lt"]), img_seq_len=int(g["Li"]),
+                         n_regions=int(g["n_regions"]), vary_regions=True)
+    loss, grads = O.train_step_grads(sd, _cfg_dict(cfg), b)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    assert _check_grad_norms(g, grads) > 190
+    np.testing.assert_allclose(grads["bert.encoder.layer.11.attention.self.query.weight"][:8, :16].numpy(), g["grad_sample_qw"], atol=1e-8, rtol=2e-3)
+    np.testing.assert_allclose(grads["bert.img_embedding.weight"][:8, 2040:2054].numpy(), g["grad_sample_img"], atol=1e-8, rtol=2e-3)
+
+
+def test_large_vcr_shape(golden_dir):
+    """BASELINE configs[4] shape: the reference's NSPCPT on the Oscar-large config (24 layers, hidden 1024, 16 heads, L = 165 + 100):
+    relation scores, loss, hidden-state / pooled samples, the four gradient samples and every gradient norm reproduced by the oracle."""
+    g = _load(golden_dir, "large_vcr_b2_l265.npz")
+    cfg = cfgmod.oscar_large()
+    sd0 = synth.init_state_dict(cfg, int(g["seed_w"]), head="pretrain")
+    b = synth.make_batch(int(g["B"]), cfg, seed=int(g["seed_b"]), max_seq_len=int(g["Lt"]), img_seq_len=int(g["Li"]),
+                         n_regions=int(g["Li"]), vary_regions=True)
+    keep = {k: v for k, v in sd0.items() if not k.startswith("cls.predictions")}
+    sd = {k: v.clone().requires_grad_(True) for k, v in keep.items()}
+    lab = torch.from_numpy(g["cls_labels"])
+    loss, rel = O.nsp_cpt_forward(sd, _cfg_dict(cfg), b["input_ids"], b["segment_ids"], b["attention_mask"], b["img_feats"],
+                                  next_sentence_label=lab)
+    np.testing.assert_allclose(rel.detach().numpy(), g["rel"], atol=2e-5, rtol=0)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5
+    loss.backward()
+    ren = {"cls.seq_relationship.weight": "cls.weight", "cls.seq_relationship.bias": "cls.bias"}       # NSPCPT's cls IS the relation Linear
+    grads = {ren.get(k, k): v.grad for k, v in sd.items()}
+    assert _check_grad_norms(g, grads) > 370
+    np.testing.assert_allclose(grads["cls.weight"].numpy(), g["grad_cls_weight"], atol=1e-7, rtol=2e-3)
+    np.testing.assert_allclose(grads["bert.pooler.dense.weight"][:8, :16].numpy(), g["grad_sample_pooler"], atol=1e-8, rtol=2e-3)
+    np.testing.assert_allclose(grads["bert.encoder.layer.23.attention.self.query.weight"][:8, :16].numpy(), g["grad_sample_q23"], atol=1e-8, rtol=2e-3)
+    np.testing.assert_allclose(grads["bert.encoder.layer.0.intermediate.dense.weight"][:8, :16].numpy(), g["grad_sample_ffn0"], atol=1e-8, rtol=2e-3)
+    np.testing.assert_allclose(grads["bert.img_embedding.weight"][:8, 2040:2054].numpy(), g["grad_sample_img"], atol=1e-8, rtol=2e-3)
+    with torch.no_grad():
+        seq, pooled = O.bert_img_forward(keep, _cfg_dict(cfg), b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"])
+    np.testing.assert_allclose(seq[:, ::23, ::37].numpy(), g["seq_sample"], atol=3e-5, rtol=0)
+    np.testing.assert_allclose(pooled[:, ::13].numpy(), g["pooled_sample"], atol=1e-5, rtol=0)
 
 
 def test_iou_and_lr_sched(golden_dir):

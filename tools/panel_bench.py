@@ -18,11 +18,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--n", type=int, default=768, help="output columns (192: one column tile per row tile, 60 workgroups -- no sibling tiles share A rows)")
     ap.add_argument("--no-cold", action="store_true")
+    ap.add_argument("--tune", default="", help="comma list of key=value for cpt_set_tuning (24=4: the 4-wave shape of the panel kernel)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, H, I = a.batch * 120, a.n, 3072
     torch.manual_seed(0)
     lib = L.lib()
+    for kv in [t for t in a.tune.split(",") if t]:
+        lib.cpt_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     for name, K in (("attn_out", 768), ("ffn_down", I)):
         x = torch.randn(M, H, device=dev) * 1.2 + 0.3
         hi, lo = ops.resid3_split(x)
@@ -55,7 +58,7 @@ def main():
                       % (name, M, H, K, rd, tag, us, 2.0 * M * H * K / us / 1e6, same), flush=True)
         # per-workgroup phase stamps of the panel kernel (prologue / K loop / epilogue, shader clocks)
         nwg = (M // 128) * (H // 192)
-        for abl in (0,):       # timing experiments (results garbage unless 0): 1 half the A loads, 2 no A loads, 3 no W DMA
+        for abl in ((0, 2, 3) if a.tune else (0,)):       # timing experiments (results garbage unless 0): 1 half the A loads, 2 no A loads, 3 no W DMA
             lib.cpt_set_tuning(13, abl)
             tr = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
             for _ in range(3):
