@@ -30,6 +30,7 @@ def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cpt_hip.h"))
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cpt_io.h"))
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cpt_hip_debug.h"))
     objs, jobs = [], []
     for f in _sources():
         src = os.path.join(CSRC, f)

@@ -1148,8 +1148,8 @@ int g_gemm_variant = 3;      // 0: generic register-staged kernel only; 3: pipel
 #define CPT_CFG_128x384 128, 384, 2, 4, 2, 2
 #define CPT_CFG_384x192 384, 192, 6, 2, 2, 6, 2
 #define CPT_CFG_128x192_OCC2 128, 192, 4, 2, 2, 1, 2, 2
-#define CPT_CFG_128x192_W4 128, 192, 2, 2, 2, 1, 2, 2     // 4 waves of 64x96, two workgroups per CU
-#define CPT_CFG_256x192 256, 192, 4, 2, 2, 1, 2, 1        // 8 waves of 64x96
+// (round 4: the 4-wave 64x96 form at two workgroups per CU and the 256x192 form, variants 16 / 17, lost every A/B of rounds 1-3
+// (profiles/r01_gemm_ladder.md, r03_gemm_variants_standalone.txt) and were removed)
 #define CPT_CFG_64x192 64, 192, 2, 2, 3                   // 4 waves of 32x96: twice the workgroups when M is small
 #define CPT_CFG_384x256 384, 256, 4, 2, 2, 1, 1, 1        // 8 waves of 96x128 (192 accumulator registers), the whole LDS as a 2-stage ring
 
@@ -1167,7 +1167,7 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         const Cand cand[9] = {{128, 192, 256, 320}, {192, 192, 256, 384}, {128, 384, 256, 512},
                               {384, 192, 256, 645 /* MFMA-bound */},
                               {128, 192, 512, 460 /* two co-resident workgroups per CU: epilogue under the other's K loop */},
-                              {0, 0, 1, 0}, {0, 0, 1, 0} /* 5, 6: experiment-only shapes */,
+                              {0, 0, 1, 0}, {0, 0, 1, 0} /* 5, 6: removed shapes */,
                               {64, 192, 256, 200 /* small M: fills the chip with half-height tiles */},
                               {big_ok ? 384 : 0, 256, 256, 860 /* MFMA-bound, 26 B of operands per MFMA cycle */}};
         long best_cost = -1;
@@ -1189,8 +1189,6 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
     else if (variant == 10) pick = 2;
     else if (variant == 14) pick = 3;
     else if (variant == 15) pick = 4;
-    else if (variant == 16) pick = 5;
-    else if (variant == 17) pick = 6;
     else if (variant == 18) pick = 7;
     else if (variant == 19) pick = 8;
     if constexpr (EPI == CPT_EPI_LNCONS_GELU) {
@@ -1202,8 +1200,6 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         case 2: launch_pipe<T, EPI, OT, CPT_CFG_128x384>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         case 3: launch_pipe<T, EPI, OT, CPT_CFG_384x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         case 4: launch_pipe<T, EPI, OT, CPT_CFG_128x192_OCC2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
-        case 5: launch_pipe<T, EPI, OT, CPT_CFG_128x192_W4>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
-        case 6: launch_pipe<T, EPI, OT, CPT_CFG_256x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         case 7: launch_pipe<T, EPI, OT, CPT_CFG_64x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         default: launch_pipe<T, EPI, OT, CPT_CFG_128x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
     }

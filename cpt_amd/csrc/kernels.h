@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/cpt_hip.h"
+#include "../../include/cpt_hip_debug.h"
 #include "dropout.h"
 
 namespace cpt {

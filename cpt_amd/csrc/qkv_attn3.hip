@@ -380,7 +380,9 @@ int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* 
     a.st_in = st_in; a.st_parts = ln_stat_parts(hidden); a.colc = colc; a.cold = cold; a.eps = eps; a.inv_h = 1.0f / (float)hidden;
     a.trace = (g_trace_epi < 0 || g_trace_epi == 10) ? g_q3_trace : nullptr;      // (diagnostics: trace filter by epilogue id, 10 = fused QKV + attention)
     a.mask = mask; a.ctx = (bf16*)ctx; a.ldo = ldo; a.M = B * L; a.K = K; a.L = L; a.heads = heads;
-    if (st_in) switch (g_q3_abl) {        // diagnostic instantiations (tools/abl_sweep.sh): cpt_set_tuning(1, bits)
+#ifdef CPT_ABLATION      // diagnostic builds only (tools/abl_sweep.sh, cpt_set_tuning(1, bits)): timing instantiations with GARBAGE results; row-major ctx only
+    if (st_in && g_q3_abl && ctx_panel) return CPT_ERR_SHAPE;
+    if (st_in) switch (g_q3_abl) {
         case 1: return q3_launch<true, 1>(a, B, s);
         case 2: return q3_launch<true, 2>(a, B, s);
         case 3: return q3_launch<true, 3>(a, B, s);
@@ -391,6 +393,7 @@ int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* 
         case 15: return q3_launch<true, 15>(a, B, s);
         default: break;
     }
+#endif
     if (ctx_panel) return st_in ? q3_launch<true, 0, true>(a, B, s) : q3_launch<false, 0, true>(a, B, s);
     return st_in ? q3_launch<true>(a, B, s) : q3_launch<false>(a, B, s);
 }

@@ -52,27 +52,43 @@ def val_queries(model, queries, none_id, device, few_shot=False, batch_queries=4
     return out
 
 
+def _label_grid(batch):
+    """(B, L) grid of -1 with each sequence's colour id at its [MASK] slot: what CrossEntropyLoss(ignore_index=-1) of
+    modeling_rec.py:147-150 wants (fewshot/refcoco_cpt.py:231-233)."""
+    grid = batch["attention_mask"].new_full(batch["attention_mask"].shape, -1, dtype=torch.long)
+    grid.scatter_(1, batch["mask_token_pos"].view(-1, 1), batch["colors"].view(-1, 1))
+    return grid
+
+
+def _apply_lr(optimizer, lr, head_multiplier):
+    """The reference's four parameter groups (fewshot/refcoco_cpt.py:318-343): groups 0-1 take lr x lr_mul, groups 2-3 the plain rate."""
+    groups = optimizer.param_groups
+    if len(groups) != 4:
+        raise ValueError("expected the four parameter groups of build_optimizer, got %d" % len(groups))
+    for g in groups[:2]:
+        g["lr"] = lr * head_multiplier
+    for g in groups[2:]:
+        g["lr"] = lr
+
+
 def train_batch(model, optimizer, batches, opts, device, global_step=0):
-    """One pass over ``batches`` (dicts with img_feats, input_ids, attention_mask, segment_ids,
-    mask_token_pos, colors), as fewshot/refcoco_cpt.py:225-255."""
+    """One pass over ``batches`` (dicts with img_feats, input_ids, attention_mask, segment_ids, mask_token_pos, colors): the few-shot
+    step of fewshot/refcoco_cpt.py:225-255 -- label grid, scheduled learning rate, zero_grad / forward / backward / step; a step that
+    raises RuntimeError is logged and skipped without advancing the schedule.  Returns (global_step, [loss tensors])."""
     model.train()
     losses = []
-    for step, b in enumerate(batches):
-        b = {k: v.to(device) for k, v in b.items()}
-        mlm_labels = torch.full(b["attention_mask"].size(), -1, dtype=torch.long, device=device)
-        mlm_labels[torch.arange(b["attention_mask"].size(0), device=device), b["mask_token_pos"]] = b["colors"]
-        lr_this_step = get_lr_sched(global_step, opts)
-        for i, group in enumerate(optimizer.param_groups):
-            group["lr"] = lr_this_step * getattr(opts, "lr_mul", 1.0) if i < 2 else lr_this_step
+    for index, host_batch in enumerate(batches):
+        batch = {name: t.to(device) for name, t in host_batch.items()}
+        _apply_lr(optimizer, get_lr_sched(global_step, opts), getattr(opts, "lr_mul", 1.0))
         try:
             optimizer.zero_grad()
-            loss, _ = model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
-                            masked_lm_labels=mlm_labels)
+            loss = model(batch["input_ids"], batch["segment_ids"], batch["attention_mask"], img_feats=batch["img_feats"],
+                         masked_lm_labels=_label_grid(batch))[0]
             loss.backward()
             optimizer.step()
-            global_step += 1
-            losses.append(loss.detach())
-        except RuntimeError as e:
-            logger.info("run time error at step %d, which is %s", step, str(e))
+        except RuntimeError as err:
+            logger.info("step %d of this pass skipped: %s", index, err)
             continue
+        global_step += 1
+        losses.append(loss.detach())
     return global_step, losses

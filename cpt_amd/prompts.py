@@ -121,20 +121,22 @@ def ground_truths(tokenizer, gt_bbox, colors, rects):
 
 
 def sample_train(gts, na_id, n_items, rng=_random):
-    """(:138-155) few-shot sampling: one positive proposal (all of them when the data set has <= 8 items), as many
-    negatives as positives.  Uses ``rng.shuffle`` exactly where the reference uses random.shuffle."""
-    tmp = [k != na_id for k in gts]
-    posids = [i for i, k in enumerate(tmp) if k]
-    negids = [i for i, k in enumerate(tmp) if not k]
-    if len(posids) == 0:
-        posids = [0]
-    if len(posids) > 1 and n_items > 8:
-        rng.shuffle(posids)
-        posids = posids[:1]
-    if len(posids) < len(negids):
-        rng.shuffle(negids)
-        negids = negids[:len(posids)]
-    return posids + negids
+    """Few-shot sampling of a row's proposals (the rule of refcoco_zsl_cpt_dataset.py:138-155): keep ONE proposal whose ground truth
+    is a colour (all of them when the data set has at most 8 rows; proposal 0 when there is none) and no more "none" proposals
+    than colour ones.  Consumes the generator exactly like the reference -- one ``shuffle`` of the colour list when it is cut,
+    then one of the "none" list when it is cut -- so a seeded run selects the same proposals (tests/golden/tiny_prompts.npz)."""
+    coloured, plain = [], []
+    for i, g in enumerate(gts):
+        (plain if g == na_id else coloured).append(i)
+    if not coloured:
+        coloured = [0]
+    elif len(coloured) > 1 and n_items > 8:
+        rng.shuffle(coloured)
+        del coloured[1:]
+    if len(plain) > len(coloured):
+        rng.shuffle(plain)
+        del plain[len(coloured):]
+    return coloured + plain
 
 
 class PromptBuilder(object):

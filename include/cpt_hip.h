@@ -212,9 +212,15 @@ size_t cpt_train_workspace_bytes_rows(const cpt_dims* d, int B, int Lt, int Li, 
  * CrossEntropyLoss(ignore_index=-1) over b->labels [B]; o->rel [B][n_rel] is written instead of o->logits, b->mask_pos is not used. */
 int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
                   size_t workspace_bytes, void* stream);
-/* backward of loss = loss_scale * mean over labelled rows; g's tensors must be zero on entry, or cleared by
- * cpt_train_zero_grads (vector gradients are accumulated with atomics, Linear weight gradients are written whole);
- * uses the workspace cpt_train_fwd filled. */
+/* backward of loss = loss_scale * mean over labelled rows; uses the workspace cpt_train_fwd filled.
+ * WRITE / ACCUMULATE contract of g's tensors (ABI 5):
+ *   WRITTEN whole by every call (previous contents ignored, never added to): every Linear weight gradient -- w_qkv, w_ao, w_in, w_out of each
+ *     layer, w_img, w_pool, w_tr, w_rel -- and, with the MLM head, the tied word-embedding / decoder table (decoder gradient written, lookup
+ *     gradients added behind it);
+ *   ACCUMULATED into with atomics (must hold zeros, or whatever the caller wants added to): every bias and LayerNorm gain / shift vector, the
+ *     position and token-type tables, and the word table when the model has no MLM head.
+ * cpt_train_zero_grads clears exactly the second group.  A caller that accumulates micro-batches must therefore ADD the written tensors
+ * itself between calls (cpt_amd/train.py keeps a copy and adds it); skipping the zero launch sums the vectors but OVERWRITES the matrices. */
 int cpt_train_bwd(const cpt_model* m, const cpt_batch* b, const cpt_model_grads* g, float loss_scale,
                   void* workspace, size_t workspace_bytes, void* stream);
 /* Clears what cpt_train_bwd ADDS into -- the bias / LayerNorm gradient vectors and the small embedding tables (atomic
@@ -398,58 +404,8 @@ int cpt_gather_rows(const void* src, int dtype, const int64_t* pos, void* out, i
 int cpt_ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V,
                 void* stream);
 
-/* ------------------------------------------------------------------------------------------
- * Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
- * ---------------------------------------------------------------------------------------- */
-enum { CPT_K_GEMM_QKV = 0, CPT_K_ATTN, CPT_K_GEMM_AO, CPT_K_LN, CPT_K_GEMM_FFN1, CPT_K_GEMM_FFN2,
-       CPT_K_EMBED, CPT_K_IMG, CPT_K_HEAD, CPT_K_OP /* any operator-level call */, CPT_K_COUNT };
-int cpt_prof_enable(int on);                          /* resets accumulators */
-int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchronises */
-
-/* Kernel-variant switches for A/B measurements; defaults are the shipped configuration.
- *   key 0  GEMM: 0 = generic register-staged kernel only; 3 (default) = pipelined LDS-DMA kernel, tile shape chosen
- *          per GEMM; fixed shapes 13 = 128x192 (3-stage), 11 = 192x192, 10 = 128x384, 14 = 384x192,
- *          15 = 128x192 two workgroups per CU, 16 = 128x192 with 4 waves of 64x96, 17 = 256x192,
- *          18 = 64x192 (small M)
- *   key 1  GEMM ablation bits: 1 no operand LDS-DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue,
- *          32 fused QKV + attention kernel without its attention phase
- *   key 2  attention backward: 0 = generic fp32-math kernel, 1 (default) = MFMA kernel for bf16, L <= 128
- *   key 3  split-K target for the generic path
- *   key 4  1 = bf16 residual stream in the kernel-per-op bf16 encoder (default 0: fp32 residual)
- *   key 5  0 = run the encoder LayerNorms as kernels even when cpt_model.fold is given (default 1: folded)
- *   key 6  QKV projection + attention: 0 = two kernels, 1 = fused, one workgroup per (sequence, head), two per CU,
- *          2 = the same, one per CU, 3 (default) = fused, one workgroup per (sequence, three heads) where heads % 3 == 0,
- *          else 1 (bf16, L <= 128 only; otherwise always two kernels)
- *   key 9  residual stream of the fused bf16 encoder: 1 (default) = 3-byte form (cpt_gemm_ln_prod3), 0 = fp32 + bf16 copies
- *   key 10 bf16 weight gradients of cpt_train_bwd: 1 (default) = TN GEMM (operands read as stored, split-K partials reduced in
- *          order), 0 = explicit operand transposes + NT GEMM
- *   key 11 fused QKV + attention, form 3: 1 (default) = read cpt_layer_fold.w_qkv_t when given, 0 = always the row-major weight
- *   key 12 FFN-up two-pass kernel: 1 (default) = refill DMA issued behind the first k-step after the barrier, 0 = right behind it
- *   key 13 timing experiments of the panel producer (gemm_prod.hip); 0 (default) = the shipped kernel
- *   key 14 panel mode of the fused bf16 encoder: 1 (default) = ctx / FFN activation in the fragment-major panel layout where shapes allow
- *          (cpt_gemm_ln_prod3_panel), 0 = row-major tensors (cpt_gemm_ln_prod3)
- *   key 15 panel mode: 1 (default) = launches that leave CUs idle carry 16 workgroups that read the next launch's weights into the
- *          Infinity Cache, 0 = no prefetch workgroups
- *   key 16 FFN-up two-pass kernel (and with it panel mode) from this many 384 x 256 tiles on (default 192; experiments with small batches)
- *   key 17 LayerNorm backward, two-stage column-sum form: rows per workgroup (default 0 = 8 from 2048 rows on, else 4; experiments)
- *   key 18 training backward, bias-gradient column sums inside their producers: bit 0 = b_in in the GELU-gradient epilogue, bit 1 = b_qkv
- *          in the attention backward kernel (default 2: bit 0 measured slower than the launch it replaces); a cleared bit runs the stand-alone column-sum launch
- *   key 19 training backward, a layer's weight gradients: 2 (default) = FFN down | FFN up | attention output in one launch + Q|K|V alone where the
- *          shapes fit one round (else as 1), 1 = two paired launches (the two FFN matrices; attention output + Q|K|V), 0 = four launches with
- *          their own split-K reductions
- *   key 20 stand-alone QKV projection with the LayerNorm folded (sequences longer than 128: attention runs as its own kernel): 1 (default) =
- *          the GELU-less form of the two-pass 384 x 256 kernel when its tiles fill the chip, 0 = the 384 x 192 pipelined kernel
- *   key 21 stand-alone attention kernel, sequences longer than 128: 1 (default) = the 128-query tiles of a (sequence, head) are neighbouring
- *          workgroups of one XCD (their shared K / V rows are fetched from memory once), 0 = the (pair, tile) grid
- *   key 22 training forward, FFN-down at 2048..6144 rows: 1 (default) = 128 x 192 tiles with K split over two workgroups, the two partial
- *          matrices added by the dropout + residual + LayerNorm pass behind it; 0 = 64 x 192 tiles over the whole K
- *   key 23 bf16x3 parity mode: 1 (default) = the FFN-up's GELU epilogue writes the split copy of its output that the FFN-down reads, 0 = an
- *          fp32 tensor and a stand-alone cpt_split3 pass
- *   key -1 restores the default of every key (value ignored) */
-int cpt_set_tuning(int key, int value);
-/* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
- * start / after prologue issue / after K loop / after staging / end, and the XCC id). */
-int cpt_debug_gemm_trace(void* buf);
+/* Per-kernel event timing, the A/B switches of the kernels (cpt_set_tuning) and the per-workgroup trace live in cpt_hip_debug.h: they are
+ * measurement and development entry points of the same library, not part of the interface a host binds for the hot path. */
 
 #ifdef __cplusplus
 }

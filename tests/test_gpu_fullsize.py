@@ -4,6 +4,8 @@
   * config 2's colour argmax over 1024 sequences: flip COUNT against the fp32 CPU oracle.
 Full-size checks use the size-independent property of the path -- sequences are independent, so rows of the big batch
 must reproduce the same sequences run in a small batch bit for bit -- plus the oracle on a B <= 4 subset."""
+import os
+
 import numpy as np
 import pytest
 import torch

@@ -174,7 +174,7 @@ def test_pad_cast_gather_ce(dev):
     assert _stats("ce grad", d.cpu(), lgr.grad) < 1e-6
 
 
-@pytest.mark.parametrize("variant", [0, 3, 10, 11, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [0, 3, 10, 11, 13, 14, 15, 18])
 def test_gemm_variants_agree(dev, variant):
     """Every GEMM kernel variant (tile shape / pipeline depth) gives the same answer, including
     ragged M/N edges and the unaligned-ldo decoder shape."""
