@@ -276,4 +276,218 @@ int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, v
     return CPT_ERR_DTYPE;
 }
 
+// ---- bf16x3 parity mode (round 4): attention on MFMA with split operands --------------------------------------------------------------
+// The parity mode ran its attention on the fp32 MFMA (1/16 of the bf16 rate: 52 us per layer at B = 64, 9 % of its step).  Here every
+// operand is split like the mode's GEMM operands, x = hi + lo with hi = bf16(x), lo = bf16(x - hi), and each product is the three-term
+// sum hi.hi + hi.lo + lo.hi in fp32 accumulators (error ~2^-16 relative per product, the dropped lo.lo term):
+//   S^T = K Q^T      from K hi / lo tiles in LDS and Q hi / lo fragments in registers (fp32 qkv rows split on load),
+//   softmax in fp32  (base 2, as the bf16 core), probabilities split in registers,
+//   O^T = V^T P^T    from V hi / lo tiles (row-major, transpose-read).
+// Output: ctx as fp32 [M][H], or (out_split) directly as the split copy [M][hi | hi | lo] (ld 3H) that the attention-output GEMM of the
+// mode reads -- the stand-alone cpt_split3 pass over ctx is gone.  2-D masks, L <= 224 (K + V hi / lo tiles: 112 KB at L = 224).
+__device__ __forceinline__ void split_chunk8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (bf16)a[e]; lo[e] = (bf16)(a[e] - (float)hi[e]);
+        hi[4 + e] = (bf16)b[e]; lo[4 + e] = (bf16)(b[e] - (float)hi[4 + e]);
+    }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attention_x3_kernel(
+    const float* __restrict__ qkv, const int64_t* __restrict__ attn_mask, float* __restrict__ ctx, bf16* __restrict__ ctx_split,
+    int B, int L, int heads) {
+    constexpr int LP = NKB * 32;
+    constexpr int K_BYTES = LP * 128, V_BYTES = LP * 128;       // V rows swizzled (att_voff_swz): 64.5 KB at L <= 128 = two workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sKh = smem;
+    unsigned char* sKl = sKh + K_BYTES;
+    unsigned char* sVh = sKl + K_BYTES;
+    unsigned char* sVl = sVh + V_BYTES;
+    float* sMask = reinterpret_cast<float*>(sVl + V_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, qt = blockIdx.y;
+    const int b = bh / heads, h = bh % heads;
+    const int q0 = qt * 128 + wave * 32;
+    const int H = heads * HD;
+    const size_t ldq = (size_t)3 * H;
+    const float* base = qkv + (size_t)b * L * ldq + h * HD;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int q = q0 + fr;
+
+    // Q fragments: lane = query row, chunk 2 ks + fh of its 64 head-dim columns (8 floats = two 16-byte loads), split in registers
+    bf16x8 fqh[4], fql[4];
+    {
+        f32x4 t[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            t[ks][0] = f32x4{0.f, 0.f, 0.f, 0.f}; t[ks][1] = t[ks][0];
+            if (q < L) {
+                const float* src = base + (size_t)q * ldq + (2 * ks + fh) * 8;
+                t[ks][0] = *reinterpret_cast<const f32x4*>(src);
+                t[ks][1] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) split_chunk8(t[ks][0], t[ks][1], fqh[ks], fql[ks]);
+    }
+    // K / V rows: 8 chunks of 8 floats per key; all loads of a thread first, then the split + LDS writes
+    constexpr int NLD = (LP * 8 + ATT_THREADS - 1) / ATT_THREADS;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {            // K, then V (keeps the register footprint at one operand's loads)
+        f32x4 r[NLD][2];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * ATT_THREADS, key = idx >> 3, c = idx & 7;
+            r[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; r[i][1] = r[i][0];
+            if (idx < LP * 8 && key < L) {
+                const float* src = base + (size_t)key * ldq + (half + 1) * H + c * 8;
+                r[i][0] = *reinterpret_cast<const f32x4*>(src);
+                r[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * ATT_THREADS, key = idx >> 3, c = idx & 7;
+            if (idx < LP * 8) {
+                bf16x8 hi, lo;
+                split_chunk8(r[i][0], r[i][1], hi, lo);
+                if (half == 0) {
+                    *reinterpret_cast<bf16x8*>(sKh + k_off<bf16>(key, c)) = hi;
+                    *reinterpret_cast<bf16x8*>(sKl + k_off<bf16>(key, c)) = lo;
+                } else {
+                    *reinterpret_cast<bf16x8*>(sVh + att_voff_swz(key, c)) = hi;
+                    *reinterpret_cast<bf16x8*>(sVl + att_voff_swz(key, c)) = lo;
+                }
+            }
+        }
+    }
+    for (int key = tid; key < LP; key += ATT_THREADS) {
+        float mv = -INFINITY;
+        if (key < L) mv = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
+        sMask[key] = mv * LOG2E;
+    }
+    __syncthreads();
+    if (q0 >= L) return;
+
+    // S^T = K . Q^T, three terms (small ones first)
+    f32x16 st[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 fkh = *reinterpret_cast<const bf16x8*>(sKh + k_off<bf16>(kb * 32 + fr, 2 * ks + fh));
+            const bf16x8 fkl = *reinterpret_cast<const bf16x8*>(sKl + k_off<bf16>(kb * 32 + fr, 2 * ks + fh));
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fkl, fqh[ks], st[kb], 0, 0, 0);
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fkh, fql[ks], st[kb], 0, 0, 0);
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fkh, fqh[ks], st[kb], 0, 0, 0);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sc = st[kb][r] * (0.125f * LOG2E) + sMask[kb * 32 + key_of(r, fh)];
+            st[kb][r] = sc;
+            mx = fmaxf(mx, sc);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(st[kb][r] - mx);      // v_exp_f32: 1 ulp, three decimal orders below the 2^-16 of the split products
+            st[kb][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] *= inv;
+
+    // O^T = V^T . P^T, three terms
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float p = st[kb][8 * s2 + j]; ph[j] = (bf16)p; pl[j] = (bf16)(p - (float)ph[j]); }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int vrow = kb * 32 + 16 * s2 + 4 * fh + ((lane & 15) >> 2), vcol = db * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                const int off = att_voff_swz(vrow, vcol >> 3) + (vcol & 7) * 2, off8 = att_voff_swz(vrow + 8, vcol >> 3) + (vcol & 7) * 2;
+                bf16x8 vh, vl;
+                {
+                    const bf16x4 a0 = lds_read_tr16(sVh + off), a1 = lds_read_tr16(sVh + off8);
+                    const bf16x4 b0 = lds_read_tr16(sVl + off), b1 = lds_read_tr16(sVl + off8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+                }
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[db], 0, 0, 0);
+            }
+        }
+    }
+    // O^T accumulators: register r <-> head-dim column db*32 + 8*(r>>2) + 4*fh + (r&3), lane&31 <-> query
+    if (q < L) {
+        const size_t row = (size_t)b * L + q;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = h * HD + 4 * fh + db * 32 + 8 * g;
+                const f32x4 v = {o[db][4 * g], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]};
+                if (ctx_split) {
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
+                    bf16* dst = ctx_split + row * 3 * H + col;
+                    *reinterpret_cast<bf16x4*>(dst) = hi;
+                    *reinterpret_cast<bf16x4*>(dst + H) = hi;
+                    *reinterpret_cast<bf16x4*>(dst + 2 * H) = lo;
+                } else {
+                    *reinterpret_cast<f32x4*>(ctx + row * H + col) = v;
+                }
+            }
+    }
+}
+
+template <int NKB>
+static int att_x3_launch(const float* qkv, const int64_t* mask, float* ctx, bf16* ctx_split, int B, int L, int heads, hipStream_t s) {
+    constexpr int LP = NKB * 32;
+    const size_t lds = (size_t)4 * LP * 128 + (size_t)LP * sizeof(float);
+    auto kern = attention_x3_kernel<NKB>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+    }
+    kern<<<dim3(B * heads, (L + 127) / 128), dim3(ATT_THREADS), lds, s>>>(qkv, mask, ctx, ctx_split, B, L, heads);
+    return CPT_OK;
+}
+
+int attention_x3_supported(int L) { return L > 0 && L <= 224; }
+
+int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* ctx_split, int B, int L, int heads, hipStream_t s) {
+    if (B <= 0 || heads <= 0 || !attention_x3_supported(L)) return CPT_ERR_SHAPE;
+    if (!qkv || (!ctx && !ctx_split)) return CPT_ERR_NULL;
+    if (((uintptr_t)qkv | (uintptr_t)ctx) & 15 || ((uintptr_t)ctx_split & 7)) return CPT_ERR_ALIGN;
+    if (L <= 32) return att_x3_launch<1>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
+    if (L <= 128) return att_x3_launch<4>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
+    return att_x3_launch<7>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
+}
+
 }  // namespace cpt

@@ -156,11 +156,14 @@ static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 on
 static int g_panel = 1;        // fused bf16 encoder: ctx and the FFN activation travel in the fragment-major panel layout and the LayerNorm producers read them straight into registers (gemm_prod.hip) where the shapes allow
 static int g_x3_fuse = 1;      // bf16x3 parity mode: split copies written by the producing kernels (FFN-up GELU epilogue, LayerNorm passes) instead of stand-alone split3 passes (cpt_set_tuning key 23)
 static int g_prefetch = 1;     // panel mode: the 240-tile launches carry 16 workgroups that read the next launch's weights into the Infinity Cache (common.h prefetch_region)
+static int g_x3_attn = 1;      // bf16x3 parity mode: attention on bf16 MFMA with split operands (0: the fp32 MFMA kernel + a split3 pass over ctx)
+static int g_dec_pf_pct = 40;   // percent of the decoder table prefetched by the head's first launch (the rest: by its reduce + GELU + LayerNorm launch)
+static int g_embed_pad = 1;    // bf16 fused encoder: text embedding + region-feature pad/cast in one launch (cpt_set_tuning key 25)
 static int g_resid3 = 1;       // fused bf16 encoder: residual stream in the 3-byte form (bf16 hi + int8 lo) instead of fp32 + bf16 copies
 
 int cpt_set_tuning(int key, int value) {
     if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
-        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1;
+        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1;
         cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
         cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_ffn_2pass_min_tiles(192); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0); cpt::set_lnb_rpb(0); cpt::set_bias_fuse(2); cpt::set_wgrad_pair(2); cpt::set_qkv_2pass(1); cpt::set_fwd_split2(1); g_x3_fuse = 1; cpt::set_attn_qt_all(1); cpt::set_prod_waves(0);
         return CPT_OK;
@@ -189,6 +192,9 @@ int cpt_set_tuning(int key, int value) {
     if (key == 22) { cpt::set_fwd_split2(value); return CPT_OK; }
     if (key == 23) { g_x3_fuse = value; return CPT_OK; }
     if (key == 24) { cpt::set_prod_waves(value); return CPT_OK; }
+    if (key == 25) { g_embed_pad = value; return CPT_OK; }
+    if (key == 27) { g_x3_attn = value; return CPT_OK; }
+    if (key == 26) { g_dec_pf_pct = value < 0 ? 0 : (value > 100 ? 100 : value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
 }
@@ -386,6 +392,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     // never materialised, and its region [M][I] fp32 holds the FFN-up's own split input [M][3H] bf16 (asplit).  (The LayerNorm passes writing
     // the split inputs of QKV / FFN-up themselves was built too: the two stand-alone passes it saves cost what its strided 8-byte stores
     // add to the LayerNorm launches -- 5.78-5.94 vs 5.84 ms -- so they stay.)
+    // round 4: the mode's attention on bf16 MFMA with split operands, writing ctx as the split copy the attention-output GEMM reads (key 27)
+    const bool x3a = x3 && g_x3_attn && !(flags & CPT_ATTN_MASK_3D) && cpt::attention_x3_supported(L) && H % 8 == 0;
     const bool x3f = x3 && g_x3_fuse && d.inter % 8 == 0 && (size_t)d.inter * 4 >= (size_t)3 * d.hidden * 2;
     auto gm = [&](int epi, const void* A, int lda, const void* W, int K, const float* bias, const float* resid, int ldr, void* out,
                   int out_dt, int ldo, int Mr, int N) -> int {
@@ -411,8 +419,14 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const bool r3 = fold && g_resid3;
     void* x_lo = x_f32;
     void* a_lo = a_f32;
-    // (a2) text embeddings -> rows b*L + t
-    {
+    // (a2) text embeddings -> rows b*L + t.  bf16 with the 3-byte stream: the same launch also converts the region features (rowops.hip embed_pad_kernel)
+    const bool embed_pad = r3 && Li > 0 && g_embed_pad && d.img_dim_pad % 8 == 0 && ((uintptr_t)b->img_feats % 8) == 0;
+    if (embed_pad) {
+        Scope p(CPT_K_EMBED, s);
+        TRY(cpt::embed_ln_pad_cast(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, d.ln_eps,
+                                   x_lp, x_lo, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, b->img_feats, ws + w.imgp, B * Li, d.img_dim, d.img_dim_pad, s),
+            "embed_ln + pad_cast(img_feats)");
+    } else {
         Scope p(CPT_K_EMBED, s);
         TRY(cpt::embed_ln(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb,
                           m->emb_ln_g, m->emb_ln_b, d.ln_eps, r3 ? nullptr : x_f32, lp ? x_lp : nullptr, dt, B, Lt, L, H,
@@ -422,7 +436,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     if (Li > 0) {
         Scope p(CPT_K_IMG, s);
         void* imgp = ws + w.imgp;
-        TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
+        if (!embed_pad) TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
         // bf16: K split over two workgroups per tile, the LayerNorm pass adds the two partial matrices (gemm_img_proj)
         const bool split2 = lp && d.img_dim_pad >= 128 && d.img_dim_pad % 64 == 0 && (size_t)2 * B * Li <= (size_t)M;
         if (split2) TRY(cpt::gemm_img_proj(imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, pre, H, B * Li, H, d.img_dim_pad, s), "gemm(img_embedding, split K)");
@@ -525,11 +539,14 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         { Scope p(CPT_K_GEMM_QKV, s);
           TRY(gm(CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H), "gemm(qkv)"); }
         { Scope p(CPT_K_ATTN, s);
-          TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s, nullptr, mask3), "attention"); }
+          if (x3a) TRY(cpt::attention_x3((const float*)qkv, b->attn_mask, nullptr, splitbuf, B, L, d.heads, s), "attention (split operands)");
+          else TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s, nullptr, mask3), "attention"); }
         }
         const bool lpr = lp && g_lp_resid;                       // residual operand read as bf16, fp32 copy not written
         const bool last = l + 1 == d.layers;
         { Scope p(CPT_K_GEMM_AO, s);
+          if (x3a) TRY(cpt::gemm(CPT_BF16, CPT_EPI_RESID, splitbuf, 3 * H, y.w_ao, 3 * H, y.b_ao, x_f32, H, pre, CPT_F32, H, M, H, 3 * H, s), "gemm(attn out, split ctx)");
+          else
           TRY(gm(lpr ? 5 : CPT_EPI_RESID, ctx, H, y.w_ao, H, y.b_ao, lpr ? (const float*)x_lp : x_f32, H, pre, CPT_F32, H, M, H), "gemm(attn out)"); }
         { Scope p(CPT_K_LN, s);
           TRY(cpt::layernorm_rows(pre, y.ln1_g, y.ln1_b, d.ln_eps, lpr ? nullptr : a_f32, lp ? a_lp : nullptr, dt, M, H, M, 0, 0, s), "layernorm(attn)"); }
@@ -589,13 +606,17 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         const bool all = flags & CPT_OUT_ALL_LOGITS;
         const int R = all ? M : B;
         const void* rows = x_lp;
+        // the decoder's weight table (47 MB at Oscar-base) is pulled into the Infinity Cache by spare workgroups of the head's two row launches:
+        // g_dec_pf_pct percent by the first (gather + LayerNorm), the rest by the reduce + GELU + LayerNorm launch (cpt_set_tuning key 26)
+        const size_t dec_bytes = (size_t)d.vocab * H * 2;
+        const size_t dec_pf0 = (dec_bytes / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023;
         if (!all) {
             void* g = ws + w.rows;
             if (pre_ln) {
                 const cpt_layer& yl = m->layers[d.layers - 1];
                 float* rf = (float*)(ws + w.rows_f32);
                 if (r3) TRY(cpt::head_rows_ln3(x_lp, x_lo, b->mask_pos, yl.ln2_g, yl.ln2_b, d.ln_eps, g, B, L, H, s,
-                                               g_prefetch ? m->w_dec : nullptr, (size_t)d.vocab * H * 2), "gather + merge + layernorm([MASK] rows)");
+                                               g_prefetch ? m->w_dec : nullptr, dec_pf0), "gather + merge + layernorm([MASK] rows)");
                 else {
                 TRY(cpt::gather_rows(x_f32, CPT_F32, b->mask_pos, rf, B, L, H, s), "gather([MASK] pre-LN)");
                 TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, g, dt, B, H, B, 0, 0, s), "layernorm([MASK] rows)");
@@ -607,12 +628,14 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         }
         float* t1 = (float*)(ws + w.t1);
         void* t2 = ws + w.t2;
+        const bool dec_pf_split = g_prefetch && r3 && pre_ln && !all;
         // bf16, [MASK] rows only: the transform GEMM splits K over workgroups (4 tiles of 12 K-tiles each would run on 4 CUs), the pass
         // behind it adds the partial matrices, applies GELU and the LayerNorm.  The split depends on H only: same bits for every batch.
         const int hs = cpt::head_transform_splits(H);
         if (lp && !all && H % 64 == 0 && hs > 1 && (size_t)hs * R <= (size_t)M) {
             TRY(cpt::gemm_head_transform(rows, H, m->w_tr, H, m->b_tr, pre, R, H, H, s), "gemm(head transform, split K)");
-            TRY(cpt::head_finish(pre, hs, m->tr_ln_g, m->tr_ln_b, d.ln_eps, t2, R, H, s), "reduce + gelu + layernorm(head)");
+            TRY(cpt::head_finish(pre, hs, m->tr_ln_g, m->tr_ln_b, d.ln_eps, t2, R, H, s,
+                                 dec_pf_split && dec_pf0 < dec_bytes ? (const unsigned char*)m->w_dec + dec_pf0 : nullptr, dec_bytes - dec_pf0), "reduce + gelu + layernorm(head)");
         } else {
         TRY(gm(CPT_EPI_GELU, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, t1, CPT_F32, H, R, H), "gemm(head transform)");
         TRY(cpt::layernorm_rows(t1, m->tr_ln_g, m->tr_ln_b, d.ln_eps, lp ? nullptr : (float*)t2, lp ? t2 : nullptr, dt, R, H, R, 0, 0, s), "layernorm(head)");

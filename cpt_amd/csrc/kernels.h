@@ -20,6 +20,11 @@ int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const fl
              float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
              int max_pos, int type_vocab, hipStream_t s, void* out_lo = nullptr);   // out_lo: rows leave in the 3-byte residual form (hi -> out_lp)
 
+// bf16 inference: embed_ln (3-byte or bf16 output rows) and pad_cast(bf16) of the region features in ONE launch (they touch disjoint data)
+int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
+                      const float* g, const float* bta, float eps, void* out_lp, void* out_lo, int B, int Lt, int L, int H, int vocab,
+                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s);
+
 int layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                    void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
                    hipStream_t s);
@@ -27,6 +32,11 @@ int layernorm_rows(const float* x, const float* g, const float* bta, float eps, 
 int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B,
               int L, int heads, hipStream_t s, const DropSpec* drop = nullptr, int mask_3d = 0,   // mask_3d: attn_mask is [B][L][L]
               int ctx_panel = 0);   // ctx_panel (bf16 inference): ctx leaves in the panel layout of the attn-out producer (gemm_prod.hip)
+
+// bf16x3 parity mode: attention on bf16 MFMA with split operands (three-term products); ctx fp32 [M][H] or, with ctx_split, the split copy
+// [M][hi | hi | lo] bf16 (ld 3H) for the attention-output GEMM; 2-D masks, L <= 224 (attention_x3_supported)
+int attention_x3_supported(int L);
+int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* ctx_split, int B, int L, int heads, hipStream_t s);
 
 int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s);
 int split3(const float* x, int ld, void* out_bf16, int R, int K, int weight_order, hipStream_t s);
@@ -113,7 +123,8 @@ int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const floa
                   const void* pf = nullptr, size_t pf_bytes = 0);     // pf: region (the decoder's weight table) that leading blocks of the launch read into the Infinity Cache
 int head_transform_splits(int K);
 int gemm_head_transform(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s);
-int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s);
+int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s,
+                const void* pf = nullptr, size_t pf_bytes = 0);     // pf: as head_rows_ln3 (the rest of the decoder table)
 int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s);
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,

@@ -170,14 +170,25 @@ int layernorm_rows(const float* x, const float* g, const float* bta, float eps, 
 }
 
 // ---- BertEmbeddings: gather 3 rows, add, LayerNorm -------------------------------------------
+struct EmbedArgs {
+    const int64_t *ids, *tt, *pos;
+    const float *word, *posw, *typew, *g, *bta;
+    float eps;
+    float* out_f32;
+    void* out_lp;
+    signed char* out_lo;
+    int B, Lt, L, H, vocab, max_pos, type_vocab;
+};
 template <typename LP>
-__global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(
-    const int64_t* __restrict__ ids, const int64_t* __restrict__ tt, const int64_t* __restrict__ pos,
-    const float* __restrict__ word, const float* __restrict__ posw, const float* __restrict__ typew,
-    const float* __restrict__ g, const float* __restrict__ bta, float eps, float* __restrict__ out_f32,
-    LP* __restrict__ out_lp, int B, int Lt, int L, int H, int vocab, int max_pos, int type_vocab, signed char* __restrict__ out_lo) {
+__device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
+    const int64_t* __restrict__ ids = a.ids; const int64_t* __restrict__ tt = a.tt; const int64_t* __restrict__ pos = a.pos;
+    const float* __restrict__ word = a.word; const float* __restrict__ posw = a.posw; const float* __restrict__ typew = a.typew;
+    const float* __restrict__ g = a.g; const float* __restrict__ bta = a.bta;
+    const float eps = a.eps;
+    float* __restrict__ out_f32 = a.out_f32; LP* __restrict__ out_lp = (LP*)a.out_lp; signed char* __restrict__ out_lo = a.out_lo;
+    const int B = a.B, Lt = a.Lt, L = a.L, H = a.H, vocab = a.vocab, max_pos = a.max_pos, type_vocab = a.type_vocab;
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+    const int r = block * (ROW_THREADS / 64) + (threadIdx.x >> 6);
     if (r >= B * Lt) return;
     const int b = r / Lt, t = r % Lt;
     long wid = ids[r];
@@ -206,6 +217,8 @@ __global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(
     ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
                  out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
 }
+template <typename LP>
+__global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(EmbedArgs a) { embed_ln_block<LP>(a, blockIdx.x); }
 
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
@@ -216,10 +229,9 @@ int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const fl
     if (!ids || !word || !posw || !typew || !g || !bta) return CPT_ERR_NULL;
     if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
     dim3 grid((B * Lt + 3) / 4), block(ROW_THREADS);
-    if (out_lp && lp_dtype == CPT_BF16)
-        embed_ln_kernel<bf16><<<grid, block, 0, s>>>(ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, (bf16*)out_lp, B, Lt, L, H, vocab, max_pos, type_vocab, (signed char*)out_lo);
-    else
-        embed_ln_kernel<float><<<grid, block, 0, s>>>(ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, (float*)out_lp, B, Lt, L, H, vocab, max_pos, type_vocab, nullptr);
+    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab};
+    if (out_lp && lp_dtype == CPT_BF16) embed_ln_kernel<bf16><<<grid, block, 0, s>>>(a);
+    else { a.out_lo = nullptr; embed_ln_kernel<float><<<grid, block, 0, s>>>(a); }
     return CPT_OK;
 }
 
@@ -231,10 +243,10 @@ int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const fl
 // pass is not bound by bytes in flight (its rows start on 8-byte boundaries: every 16-byte load straddles).
 constexpr int PC_UNR = 4;
 template <typename T>
-__global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__ x, T* __restrict__ out, int R, int K, int Kp) {
+__device__ __forceinline__ void pad_cast_block(const float* __restrict__ x, T* __restrict__ out, int R, int K, int Kp, int block, int nblocks) {
     const int cpr = Kp / 8;                                   // 8-element chunks per output row
-    const size_t total = (size_t)R * cpr, stride = (size_t)gridDim.x * 256;
-    const size_t idx0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)R * cpr, stride = (size_t)nblocks * 256;
+    const size_t idx0 = (size_t)block * 256 + threadIdx.x;
     float v[PC_UNR][8];
 #pragma unroll
     for (int u = 0; u < PC_UNR; ++u) {
@@ -270,6 +282,33 @@ __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__
             *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[u][4], v[u][5], v[u][6], v[u][7]};
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__ x, T* __restrict__ out, int R, int K, int Kp) {
+    pad_cast_block<T>(x, out, R, K, Kp, blockIdx.x, gridDim.x);
+}
+// Round 4: the text embedding and the region-feature pad + cast write disjoint rows of the model's input and depend on nothing: ONE launch
+// runs both (the first `npad` workgroups convert the regions, the rest gather + normalise the text rows), so that the embedding's gathers
+// ride under the HBM-bound conversion instead of a 10 us launch of their own in front of it.
+static_assert(ROW_THREADS == 256, "embed_pad_kernel: both bodies are written for 256 threads");
+__global__ __launch_bounds__(256) void embed_pad_kernel(EmbedArgs a, const float* __restrict__ x, bf16* __restrict__ xo, int R, int K, int Kp, int npad) {
+    if ((int)blockIdx.x < npad) pad_cast_block<bf16>(x, xo, R, K, Kp, blockIdx.x, npad);
+    else embed_ln_block<bf16>(a, blockIdx.x - npad);
+}
+
+int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
+                      const float* g, const float* bta, float eps, void* out_lp, void* out_lo, int B, int Lt, int L, int H, int vocab,
+                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s) {
+    if (B <= 0 || Lt <= 0 || L < Lt || H % 4 || H > 256 * MAXV || R <= 0 || K <= 0 || Kp < K || Kp % 8) return CPT_ERR_SHAPE;
+    if (!ids || !word || !posw || !typew || !g || !bta || !out_lp || !x || !xo) return CPT_ERR_NULL;
+    if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
+    if (((uintptr_t)xo % 16) || ((uintptr_t)x % 8)) return CPT_ERR_ALIGN;
+    const size_t n = (size_t)R * (Kp / 8);
+    const int npad = (int)((n + 256 * PC_UNR - 1) / (256 * PC_UNR));
+    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, nullptr, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab};
+    embed_pad_kernel<<<dim3(npad + (B * Lt + 3) / 4), dim3(256), 0, s>>>(a, x, (bf16*)xo, R, K, Kp, npad);
+    return CPT_OK;
 }
 
 // generic fallback (Kp not a multiple of 8 or unaligned output): one thread per pair of output elements
@@ -488,9 +527,17 @@ int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const floa
 // the reduction of the K-split transform GEMM, BertPredictionHeadTransform's GELU and its LayerNorm in one launch.  Partials are added
 // in split order (deterministic); GELU = the bf16 path's gelu_fast, as the GEMM epilogue it replaces.
 __global__ __launch_bounds__(ROW_THREADS) void head_finish_kernel(const f32x4* __restrict__ part, int S, const float* __restrict__ g, const float* __restrict__ bta,
-                                                                  float eps, bf16* __restrict__ out, int R, int H) {
+                                                                  float eps, bf16* __restrict__ out, int R, int H,
+                                                                  const void* __restrict__ pf, size_t pf_bytes, int pf_blocks) {
+    // round 4: this launch too has R / 4 blocks of real work: pf_blocks leading blocks stream the SECOND part of the decoder's weight table
+    // into the Infinity Cache (the first part rides on head_rows_ln3; the whole table there made that launch as long as its 47 MB take)
+    __shared__ __attribute__((aligned(16))) unsigned char pf_scratch[4 * 1024];
+    if ((int)blockIdx.x < pf_blocks) {
+        prefetch_region(pf, pf_bytes, blockIdx.x, pf_blocks, threadIdx.x, ROW_THREADS, pf_scratch);
+        return;
+    }
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+    const int r = (blockIdx.x - pf_blocks) * (ROW_THREADS / 64) + (threadIdx.x >> 6);
     if (r >= R) return;
     const int nv = (H + 255) / 256, q = H / 4;
     f32x4 v[MAXV];
@@ -516,10 +563,13 @@ __global__ __launch_bounds__(ROW_THREADS) void head_finish_kernel(const f32x4* _
     ln_stats(v, nv, lane, H, mean, rstd, eps);
     ln_write<bf16>(v, nv, lane, H, mean, rstd, g, bta, nullptr, out + (size_t)r * H);
 }
-int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s) {
+int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s,
+                const void* pf, size_t pf_bytes) {
     if (!partials || !g || !bta || !out_bf16) return CPT_ERR_NULL;
     if (R <= 0 || S <= 0 || H <= 0 || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
-    head_finish_kernel<<<dim3((R + 3) / 4), dim3(ROW_THREADS), 0, s>>>((const f32x4*)partials, S, g, bta, eps, (bf16*)out_bf16, R, H);
+    const int nb = (R + 3) / 4;
+    const int pfb = (pf && pf_bytes && !((uintptr_t)pf & 15) && nb < 224) ? 224 - (nb & ~7) : 0;
+    head_finish_kernel<<<dim3(nb + pfb), dim3(ROW_THREADS), 0, s>>>((const f32x4*)partials, S, g, bta, eps, (bf16*)out_bf16, R, H, pfb ? pf : nullptr, pf_bytes, pfb);
     return CPT_OK;
 }
 

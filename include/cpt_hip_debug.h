@@ -62,6 +62,11 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *          fp32 tensor and a stand-alone cpt_split3 pass
  *   key 24 wave shape of the panel LayerNorm producers' 128 x 192 tile (gemm_prod.hip; same bits either way): 0 (default) = by K -- 4 x 1 waves of
  *          32 x 192 with the operand stream interleaved between the MFMAs from K = 1536 on, else 4 x 2 waves of 32 x 96; 4 / 8 force one shape
+ *   key 25 fused bf16 encoder: 1 (default) = text embedding and region-feature pad + cast in ONE launch, 0 = two launches
+ *   key 26 MLM head on the [MASK] rows: percent of the decoder weight table prefetched by the gather + LayerNorm launch (default 40; the rest rides
+ *          on the reduce + GELU + LayerNorm launch; 100 = round 3's form)
+ *   key 27 bf16x3 parity mode: 1 (default) = attention on bf16 MFMA with split operands (three-term products), ctx written as the split copy the
+ *          attention-output GEMM reads; 0 = the fp32 MFMA attention kernel and a cpt_split3 pass over ctx
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
