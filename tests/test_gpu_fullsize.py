@@ -292,3 +292,98 @@ def test_config5_oscar_large_reference_golden(dev, golden_dir, mode):
     assert _rel_err(params["bert.encoder.layer.23.attention.self.query.weight"].grad[:8, :16], g["grad_sample_q23"]) < stol
     assert _rel_err(params["bert.encoder.layer.0.intermediate.dense.weight"].grad[:8, :16], g["grad_sample_ffn0"]) < stol
     assert _rel_err(params["bert.img_embedding.weight"].grad[:8, 2040:2054], g["grad_sample_img"]) < stol
+
+
+def _painted_batch(cfg, seed, B):
+    """A CPT-like synthetic task that a random-init model learns in a few dozen steps: the query's colour is "painted" into the region
+    features (a colour-specific block of 64 feature dims raised by 2 in 10 of the 50 regions); one sequence in six is left unpainted and
+    labelled with the "none" word.  Returns the batch with `colors` = the label ids."""
+    b = synth.make_batch(B, cfg, seed=seed, vary_regions=True)
+    g = torch.Generator().manual_seed(seed)
+    ids = list(synth.COLOR_IDS) + [synth.NONE_ID]
+    c = torch.randint(0, len(ids), (B,), generator=g)
+    for i in range(B):
+        if int(c[i]) < len(synth.COLOR_IDS):
+            rows = torch.randperm(25, generator=g)[:10]
+            b["img_feats"][i, rows, 64 * int(c[i]): 64 * int(c[i]) + 64] += 2.0
+    b["colors"] = torch.tensor(ids)[c]
+    return b
+
+
+def test_bf16_colour_argmax_with_trained_margins_1024_sequences(dev):
+    """north_star's "colour argmax identical" on weights with TRAINED-like margins.  The random-init Oscar-base model is
+    few-shot-trained with this build's own trainer (bf16, FusedAdamW, fewshot/refcoco_cpt.py:225-255) on a synthetic colour task until the
+    model labels >= 90 % of held-out sequences correctly AND the 5th percentile of the colour margin exceeds 0.5; then 1024 fresh sequences go through the bf16 throughput mode and the fp32 CPU oracle
+    (same trained weights): ZERO colour-argmax flips under both selection rules (zeroshot/refcoco_cpt.py:242, fewshot/refcoco_cpt.py:291)."""
+    import json
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    from cpt_amd.train import FusedAdamW
+    cfg = cfgmod.oscar_base()
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.1
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, 88, head="cpt"))
+    m.tie_weights()
+    m.to(dev).train().set_compute_dtype("bf16")
+    opt = FusedAdamW(m, lr=1e-4, betas=(0.9, 0.98), weight_decay=0.01)
+    cols = torch.tensor(list(synth.COLOR_IDS))
+    allid = torch.cat([cols, torch.tensor([synth.NONE_ID])])
+
+    def margins(logits):
+        t2 = logits[:, cols].topk(2, 1).values
+        return t2[:, 0] - t2[:, 1]
+    steps, p5, acc = 0, 0.0, 0.0
+    for steps in range(1, 801):
+        b = _dev(_painted_batch(cfg, 7000 + steps, 32), dev)
+        opt.zero_grad()
+        loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"],
+                    mask_token_pos=b["mask_token_pos"])
+        loss.backward()
+        opt.step()
+        if steps % 10 == 0:
+            m.eval()
+            e = _dev(_painted_batch(cfg, 90000 + steps, 64), dev)
+            with torch.no_grad():
+                lg = m(e["input_ids"], e["segment_ids"], e["attention_mask"], img_feats=e["img_feats"], mask_token_pos=e["mask_token_pos"])[0].float().cpu()
+            m.train()
+            p5 = float(margins(lg).kthvalue(4).values)            # 5th percentile of 64
+            acc = float((allid[lg[:, allid].argmax(1)] == e["colors"].cpu()).float().mean())
+            if p5 > 0.5 and acc >= 0.9:
+                break
+    assert p5 > 0.5 and acc >= 0.9, "the synthetic task was not learnt in 800 steps (held-out accuracy %.2f, 5th percentile of the margin %.3f)" % (acc, p5)
+    m.eval()
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    st = {"sequences": 0, "zero_shot_flips": 0, "few_shot_ratio_flips": 0, "max_abs_logit_error": 0.0, "label_accuracy_ref": 0.0}
+    ref_margins = []
+    for it in range(16):
+        b = _painted_batch(cfg, 1000 + it, 64)
+        with torch.no_grad():
+            ref = O.rec_mlm_cpt_forward(sd, cfg.to_dict(), b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                                        mask_rows_only=b["mask_token_pos"])[0]
+            d = _dev(b, dev)
+            got = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0].float().cpu()
+        rc, gc = ref[:, cols], got[:, cols]
+        rr, gr = rc / ref[:, synth.NONE_ID][:, None], gc / got[:, synth.NONE_ID][:, None]
+        st["sequences"] += 64
+        st["zero_shot_flips"] += int((gc.argmax(1) != rc.argmax(1)).sum())
+        st["few_shot_ratio_flips"] += int((gr.argmax(1) != rr.argmax(1)).sum())
+        st["max_abs_logit_error"] = max(st["max_abs_logit_error"], float((got - ref).abs().max()))
+        st["label_accuracy_ref"] += float((allid[ref[:, allid].argmax(1)] == b["colors"]).float().sum())
+        ref_margins.append(margins(ref))
+    rm = torch.cat(ref_margins)
+    st["label_accuracy_ref"] /= st["sequences"]
+    rec = {"workload": "Oscar-base, random init (seed 88) + %d few-shot steps of this build's bf16 trainer on the painted-region colour task "
+                       "(lr 1e-4, AdamW betas (0.9, 0.98), dropout 0.1, 32 sequences per step); 16 batches of 64 fresh sequences; reference = fp32 CPU "
+                       "oracle on the trained weights" % steps,
+           "training_steps": steps, "reference_colour_margin": {"median": float(rm.median()), "p5": float(rm.kthvalue(52).values), "min": float(rm.min())},
+           "bf16": st}
+    print(json.dumps(rec))
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "r04_trained_margin_flips.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+    except OSError:
+        pass
+    assert st["sequences"] == 1024 and float(rm.median()) > 0.5 and st["label_accuracy_ref"] > 0.85
+    assert st["zero_shot_flips"] == 0 and st["few_shot_ratio_flips"] == 0, st
+    assert st["max_abs_logit_error"] < 0.1
