@@ -61,6 +61,38 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     const f32x2 m = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
     return __builtin_elementwise_fma(-ax, r, m);
 }
+// The same arithmetic on NP independent pairs, written step by step across the pairs (round 4): a wave that runs alone on its SIMD
+// (gemm_ffn4.hip) cannot hide the latency of gelu_fast2's dependent chain behind another wave's work; NP chains side by side can.
+// Per pair bit-identical to gelu_fast2 (the same operations in the same order).
+template <int NP>
+__device__ __forceinline__ void gelu_fast2_n(f32x2 (&x)[NP]) {
+    f32x2 ax[NP], p[NP], r[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ax[i] = f32x2{fabsf(x[i][0]), fabsf(x[i][1])};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(ax[i], splat2(5.6212996640e-06f), splat2(5.1055209009e-05f));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], ax[i], splat2(3.9686137011e-05f));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], ax[i], splat2(3.4227392389e-03f));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], ax[i], splat2(2.2076998457e-02f));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], ax[i], splat2(5.2075163037e-02f));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], ax[i], splat2(1.0442737824e+00f));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) r[i] = f32x2{__builtin_amdgcn_rcpf(p[i][0]), __builtin_amdgcn_rcpf(p[i][1])};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) r[i] = r[i] * r[i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const f32x2 m = {fmaxf(x[i][0], 0.f), fmaxf(x[i][1], 0.f)};
+        x[i] = __builtin_elementwise_fma(-ax[i], r[i], m);
+    }
+}
 // Folded LayerNorm, shared by every kernel that applies it, with explicit fma for the same reason:
 //   (mean, rstd) from a row's sums;   x = rstd * (acc - mean * c) + d
 __device__ __forceinline__ void ln_mean_rstd(float sum, float sq, float inv_h, float eps, float& mu, float& rs) {

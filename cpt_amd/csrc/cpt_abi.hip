@@ -156,6 +156,7 @@ static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 on
 static int g_panel = 1;        // fused bf16 encoder: ctx and the FFN activation travel in the fragment-major panel layout and the LayerNorm producers read them straight into registers (gemm_prod.hip) where the shapes allow
 static int g_x3_fuse = 1;      // bf16x3 parity mode: split copies written by the producing kernels (FFN-up GELU epilogue, LayerNorm passes) instead of stand-alone split3 passes (cpt_set_tuning key 23)
 static int g_prefetch = 1;     // panel mode: the 240-tile launches carry 16 workgroups that read the next launch's weights into the Infinity Cache (common.h prefetch_region)
+static int g_panel_ffn_multi = 1;   // panel layout for the FFN activation also when the producers run several rounds of tiles (cpt_set_tuning key 28; experiments)
 static int g_x3_attn = 1;      // bf16x3 parity mode: attention on bf16 MFMA with split operands (0: the fp32 MFMA kernel + a split3 pass over ctx)
 static int g_dec_pf_pct = 40;   // percent of the decoder table prefetched by the head's first launch (the rest: by its reduce + GELU + LayerNorm launch)
 static int g_embed_pad = 1;    // bf16 fused encoder: text embedding + region-feature pad/cast in one launch (cpt_set_tuning key 25)
@@ -163,7 +164,7 @@ static int g_resid3 = 1;       // fused bf16 encoder: residual stream in the 3-b
 
 int cpt_set_tuning(int key, int value) {
     if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
-        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1;
+        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_panel_ffn_multi = 1; cpt::set_lncons4(1); g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1;
         cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
         cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_ffn_2pass_min_tiles(192); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0); cpt::set_lnb_rpb(0); cpt::set_bias_fuse(2); cpt::set_wgrad_pair(2); cpt::set_qkv_2pass(1); cpt::set_fwd_split2(1); g_x3_fuse = 1; cpt::set_attn_qt_all(1); cpt::set_prod_waves(0);
         return CPT_OK;
@@ -194,6 +195,8 @@ int cpt_set_tuning(int key, int value) {
     if (key == 24) { cpt::set_prod_waves(value); return CPT_OK; }
     if (key == 25) { g_embed_pad = value; return CPT_OK; }
     if (key == 27) { g_x3_attn = value; return CPT_OK; }
+    if (key == 28) { g_panel_ffn_multi = value; return CPT_OK; }
+    if (key == 29) { cpt::set_lncons4(value); return CPT_OK; }
     if (key == 26) { g_dec_pf_pct = value < 0 ? 0 : (value > 100 ? 100 : value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
@@ -457,10 +460,10 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const bool two_kernel = lp && !fuse_attn && !mask3;        // L > 128 (the GQA shape): QKV GEMM, then the stand-alone attention kernel writes the panel
     const bool panel = r3 && g_panel && (fused3 || two_kernel) && cpt::ffn_up_2pass_preferred(M, I, H) &&
                        cpt::panel_eligible(M, H, H) && cpt::panel_eligible(M, H, I);
-    // h (FFN-up -> FFN-down) in the panel layout only when the producers run as ONE round of tiles: over several rounds (GQA shape, 1680 tiles)
-    // the panel producer's longer pipeline fill is paid per tile and loses to the row-major kernel on the K = 3072 launch (4.05 vs 3.84 ms per
-    // step); ctx stays in the panel layout there -- the attention kernel's stores are what gains (2.20 -> 1.91 ms per step)
-    const bool panel_ffn = panel && (long)(M / 128) * (H / 192) <= 256;
+    // h (FFN-up -> FFN-down) in the panel layout.  Round 3 kept it row-major when the producers run several rounds of tiles (GQA shape, 1680 tiles:
+    // the 8-wave panel producer lost to the row-major kernel there, 4.05 vs 3.84 ms per step); with round 4's 4-wave producer the panel form wins
+    // there too (3.63 ms; cpt_set_tuning key 28 = 0 restores the row-major FFN activation for multi-round shapes)
+    const bool panel_ffn = panel && ((long)(M / 128) * (H / 192) <= 256 || g_panel_ffn_multi);
     const bool pfw = panel && g_prefetch;           // spare workgroups prefetch the next launch's weights (common.h prefetch_region)
     if (fold) {
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the

@@ -189,6 +189,11 @@ int ffn_up_2pass_preferred(int M, int N, int K);
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
                       float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s, int out_panel = 0,
                       const void* pf = nullptr, size_t pf_bytes = 0, int gelu = 1);     // gelu 0: plain LayerNorm-consumer GEMM (stand-alone QKV projection)
+// round 4: the same consumer GEMMs on one wave per SIMD (gemm_ffn4.hip); same shapes, same bits
+int gemm_lncons4(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
+                 float eps, int hidden, void* out, int ldo, int M, int N, int K, hipStream_t s, int out_panel, const void* pf, size_t pf_bytes, int gelu);
+int lncons4_enabled();
+void set_lncons4(int v);
 void set_ffn_dma_late(int v);
 void set_prod_abl(int v);    // timing experiments of the panel producer (gemm_prod.hip)
 void set_prod_waves(int v);  // wave shape of the panel producer: 8 (4 x 2 waves of 32 x 96) or 4 (4 x 1 waves of 32 x 192)

@@ -23,7 +23,7 @@ int cpt_prof_enable(int on);                          /* resets accumulators */
 int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchronises */
 
 /* Kernel-variant switches for A/B measurements; defaults are the shipped configuration.
- *   key 0  GEMM: 0 = generic register-staged kernel only; 3 (default) = pipelined LDS-DMA kernel, tile shape chosen
+ *   key 0  GEMM (20 / 21: force the two-pass / the 4-wave LayerNorm-consumer kernel where legal): 0 = generic register-staged kernel only; 3 (default) = pipelined LDS-DMA kernel, tile shape chosen
  *          per GEMM; fixed shapes 13 = 128x192 (3-stage), 11 = 192x192, 10 = 128x384, 14 = 384x192,
  *          15 = 128x192 two workgroups per CU, 18 = 64x192 (small M)
  *   key 1  GEMM ablation bits: 1 no operand LDS-DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue,
@@ -60,13 +60,18 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *          matrices added by the dropout + residual + LayerNorm pass behind it; 0 = 64 x 192 tiles over the whole K
  *   key 23 bf16x3 parity mode: 1 (default) = the FFN-up's GELU epilogue writes the split copy of its output that the FFN-down reads, 0 = an
  *          fp32 tensor and a stand-alone cpt_split3 pass
- *   key 24 wave shape of the panel LayerNorm producers' 128 x 192 tile (gemm_prod.hip; same bits either way): 0 (default) = by K -- 4 x 1 waves of
- *          32 x 192 with the operand stream interleaved between the MFMAs from K = 1536 on, else 4 x 2 waves of 32 x 96; 4 / 8 force one shape
+ *   key 24 wave shape of the panel LayerNorm producers' 128 x 192 tile (gemm_prod.hip; same bits either way): 0 (default) = by shape -- 4 x 1 waves of
+ *          32 x 192 with the operand stream interleaved between the MFMAs from K = 1536 on or when the tiles run several rounds, else 4 x 2 waves of
+ *          32 x 96; 4 / 8 force one shape
  *   key 25 fused bf16 encoder: 1 (default) = text embedding and region-feature pad + cast in ONE launch, 0 = two launches
  *   key 26 MLM head on the [MASK] rows: percent of the decoder weight table prefetched by the gather + LayerNorm launch (default 40; the rest rides
  *          on the reduce + GELU + LayerNorm launch; 100 = round 3's form)
  *   key 27 bf16x3 parity mode: 1 (default) = attention on bf16 MFMA with split operands (three-term products), ctx written as the split copy the
  *          attention-output GEMM reads; 0 = the fp32 MFMA attention kernel and a cpt_split3 pass over ctx
+ *   key 28 panel layout of the FFN activation when the producers run several rounds of tiles: 1 (default), 0 = row-major there (round 3)
+ *   key 29 the 4-wave 192 x 256 LayerNorm-consumer kernel with the operand stream between the MFMAs (gemm_ffn4.hip) in place of the two-pass
+ *          384 x 256 kernel (gemm_ffn.hip): 1 (default) = for the stand-alone QKV projection over several rounds of tiles, 2 = also for FFN-up,
+ *          0 = nowhere; same bits
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at

@@ -292,16 +292,16 @@ def test_ln_consumer_kernels_are_bit_identical(dev):
     cold = _t(rng, N, scale=0.1).to(dev)
     outs = {}
     try:
-        for v in (3, 15, 19, 20):
+        for v in (3, 15, 19, 20, 21):         # (3: the default choice = round 4's 4-wave kernel here; 20 / 21 force the two-pass / 4-wave kernels)
             L.check(L.lib().cpt_set_tuning(0, v))
             outs[v] = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, True)
             # the first 960 rows as their own (small) problem: other tile shape choices, ragged last tiles
             outs[(v, "small")] = ops.gemm_ln_cons(a[:960], wf, st[:960], colc, cold, 1e-12, K, True)
     finally:
         L.check(L.lib().cpt_set_tuning(0, 3))
-    for v in (15, 19, 20):
+    for v in (15, 19, 20, 21):
         assert torch.equal(outs[3], outs[v]), "variant %d differs from the default" % v
-    for v in (3, 15, 19, 20):
+    for v in (3, 15, 19, 20, 21):
         assert torch.equal(outs[3][:960], outs[(v, "small")]), "variant %d, 960-row problem" % v
 
 
@@ -321,6 +321,10 @@ def test_qkv_projection_two_pass_kernel_is_bit_identical(dev, M, N, K):
     cold = _t(rng, N, scale=0.1).to(dev)
     two = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, False)
     small = ops.gemm_ln_cons(a[:960], wf, st[:960], colc, cold, 1e-12, K, False)
+    for forced in (20, 21):           # the two-pass and the 4-wave consumer kernels, whatever the default chose
+        L.check(L.lib().cpt_set_tuning(0, forced))
+        assert torch.equal(ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, False), two), forced
+    L.check(L.lib().cpt_set_tuning(0, 3))
     L.check(L.lib().cpt_set_tuning(20, 0))
     pipe = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, False)
     assert torch.equal(two, pipe)
