@@ -540,7 +540,7 @@ extern long long* g_gemm_trace;
 extern int g_trace_k, g_trace_epi;       // diagnostics: stamp only launches of this K (0: all) / this epilogue id (-1: all; the producers are 11)
 int g_prod_abl = 0;          // timing experiments (cpt_set_tuning key 13), see prod3_panel_kernel
 void set_prod_abl(int v) { g_prod_abl = v; }
-int g_prod_waves = 0;        // wave shape of the tile (cpt_set_tuning key 24): 8 = 4 x 2 waves of 32 x 96, 4 = 4 x 1 waves of 32 x 192, 0 = by shape (4 from K = 1536 on or when the tiles run several rounds); same bits
+int g_prod_waves = 0;        // wave shape of the tile (cpt_set_tuning key 24): 8 = 4 x 2 waves of 32 x 96, 4 = 4 x 1 waves of 32 x 192, 0 = by shape (4 when the tiles run several rounds); same bits
 void set_prod_waves(int v) { g_prod_waves = (v == 4 || v == 0) ? v : 8; }
 
 int panel_eligible(int M, int N, int K) { return M > 0 && M % TM == 0 && N > 0 && N % TN == 0 && K >= 512 && K % 256 == 0 && (size_t)M * K * 2 <= (size_t)0x7fffffff; }
@@ -589,9 +589,11 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
         (const bf16*)A_panel, (const bf16*)W, ldw, bias, (const bf16*)resid_hi, (const signed char*)resid_lo, ldr, st_in, ln_stat_parts(hidden), g_in, b_in, \
         eps, 1.0f / (float)hidden, (bf16*)out_hi, (signed char*)out_lo, ldo, st_out, ln_stat_slots(N), M, N, K, ((g_trace_epi < 0 || g_trace_epi == 11) && (g_trace_k == 0 || g_trace_k == K)) ? g_gemm_trace : nullptr, \
         pf0, pf0_bytes, pf1, pf1_bytes)
-    // by default 4 waves where the K loop dominates the launch (K >= 1536) or the tiles run several rounds (GQA shape: 1680 tiles; measured
-    // attn-out 1.66 -> 1.56, FFN-down 3.79 -> 3.63 ms per step at B = 256, L = 210)
-    if (g_prod_waves == 4 || (g_prod_waves == 0 && (K >= 1536 || ntile > 256))) {
+    // by default 4 waves when the tiles run several rounds (GQA shape: 1680 tiles; measured attn-out 1.66 -> 1.56, FFN-down 3.79 -> 3.63 ms
+    // per step at B = 256, L = 210).  In one round (the bench shape, 240 tiles) the 4-wave FFN-down launch is 2.5 us shorter by its own
+    // brackets, but the step is not (1.706 vs 1.696 ms, 1.741 vs 1.739 on a second box): the chip sits at its power cap and the denser
+    // launch takes clock from its neighbours (profiles/r04_kloop_vs_hipblaslt.md), so the 8-wave shape stays there.
+    if (g_prod_waves == 4 || (g_prod_waves == 0 && ntile > 256)) {
         switch (g_prod_abl) {
             case 2: CPT_LAUNCH(2, 4); break;
             case 3: CPT_LAUNCH(3, 4); break;

@@ -61,8 +61,8 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 23 bf16x3 parity mode: 1 (default) = the FFN-up's GELU epilogue writes the split copy of its output that the FFN-down reads, 0 = an
  *          fp32 tensor and a stand-alone cpt_split3 pass
  *   key 24 wave shape of the panel LayerNorm producers' 128 x 192 tile (gemm_prod.hip; same bits either way): 0 (default) = by shape -- 4 x 1 waves of
- *          32 x 192 with the operand stream interleaved between the MFMAs from K = 1536 on or when the tiles run several rounds, else 4 x 2 waves of
- *          32 x 96; 4 / 8 force one shape
+ *          32 x 192 with the operand stream interleaved between the MFMAs when the tiles run several rounds, else 4 x 2 waves of 32 x 96 (in one
+ *          round the denser 4-wave launch takes clock from its neighbours under the power cap: no gain for the step); 4 / 8 force one shape
  *   key 25 fused bf16 encoder: 1 (default) = text embedding and region-feature pad + cast in ONE launch, 0 = two launches
  *   key 26 MLM head on the [MASK] rows: percent of the decoder weight table prefetched by the gather + LayerNorm launch (default 40; the rest rides
  *          on the reduce + GELU + LayerNorm launch; 100 = round 3's form)
