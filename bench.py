@@ -198,7 +198,9 @@ def hbm_kernels(cfg, B, dev, iters=20):
         tt = torch.zeros(Bs, 70, dtype=torch.long, device=dev)
         e32 = torch.empty(Bs, 120, H, device=dev)             # (preallocated: ops.embed_ln would add two fill kernels per call)
         e16 = torch.empty(Bs, 120, H, device=dev, dtype=torch.bfloat16)
-        entry("embed_ln (3 gathers, fp32 + bf16 out) [%s]" % tag, Bs * 70 * H * (3 * 4 + 4 + 2),
+        # unique-bytes model: every DISTINCT table row is read from memory once (repeats hit the caches), every output row is written
+        uniq = int(torch.unique(ids).numel())
+        entry("embed_ln (unique rows: %d word + 70 position + 1 type, fp32 + bf16 out) [%s]" % (uniq, tag), (uniq + 70 + 1) * H * 4 + Bs * 70 * H * (4 + 2),
               timeit(lambda: L.check(L.lib().cpt_embed_ln(ids.data_ptr(), tt.data_ptr(), None, word.data_ptr(), posw.data_ptr(), typw.data_ptr(),
                                                            g.data_ptr(), bt.data_ptr(), 1e-12, e32.data_ptr(), e16.data_ptr(), L.CPT_BF16, Bs, 70, 120, H,
                                                            cfg.vocab_size, 512, 2, L.stream_ptr()))))

@@ -51,6 +51,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CPT_FFN_PIPE
 #define CPT_FFN_PIPE 0
 #endif
+#ifndef CPT_FFN_EPI_PAIR
+#define CPT_FFN_EPI_PAIR 1          // round 4: exposed epilogues by quad PAIRS (epi_pair); 0 = one quad at a time (A/B builds)
+#endif
 // GELU = false (round 3): the same kernel as a plain LayerNorm-consumer GEMM -- the stand-alone QKV projection of the shapes whose attention
 // does not fuse (L > 128: GQA 165 + 45, VCR 165 + 100), which ran on the 384 x 192 pipe kernel at 2/3 of this kernel's rate per CU.
 template <int NT, bool LATE = true, bool PANEL = false, bool GELU = true, bool PIPE = (CPT_FFN_PIPE != 0)>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
@@ -250,6 +253,26 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
         bf16x4 p4 = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
         return __builtin_bit_cast(u32x2, p4);
     };
+    // round 4: both quads of a pair through the fold and the GELU side by side (four independent pairs per wave: the dependent chain of
+    // gelu_fast2 no longer waits on itself); same operations per element: same bits
+    auto epi_pair = [&](const f32x16& a, int pass, int p, u32x2& k0, u32x2& k1) {
+        const int i = p >> 2, j = (p >> 1) & 1;
+        const float2 ms = side_st[pass * HM + wm * 96 + i * 32 + fr];
+        f32x2 x[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int g = 2 * (p & 1) + h;
+            const int lc = wn * 64 + j * 32 + 8 * g + 4 * fh;
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(side_c + lc);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(side_d + lc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[2 * h + (e >> 1)][e & 1] = ln_fold(a[4 * g + e], ms.x, ms.y, c4[e], d4[e]);
+        }
+        if constexpr (GELU) gelu_fast2_n<4>(x);
+        const bf16x4 p0 = {(bf16)x[0][0], (bf16)x[0][1], (bf16)x[1][0], (bf16)x[1][1]};
+        const bf16x4 p1 = {(bf16)x[2][0], (bf16)x[2][1], (bf16)x[3][0], (bf16)x[3][1]};
+        k0 = __builtin_bit_cast(u32x2, p0); k1 = __builtin_bit_cast(u32x2, p1);
+    };
     auto epi_store = [&](int pass, int p, u32x2 k0, u32x2 k1) {
         const int i = p >> 2, j = (p >> 1) & 1, gp = p & 1;
         // half-wave exchange: lanes 0-31 get columns [16 gp, 16 gp + 8) of the block, lanes 32-63 the next 8 (guide T21)
@@ -373,12 +396,16 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
     // pairs of pass 0 that did not fit under pass 1 (NT < 12), then pass 1's own epilogue (exposed)
 #pragma unroll
     for (int p = PIPE ? NT : 0; p < MI * NJ * 2; ++p) {
-        const u32x2 k0 = epi_quad(acc0[p >> 2][(p >> 1) & 1], 0, p, 0), k1 = epi_quad(acc0[p >> 2][(p >> 1) & 1], 0, p, 1);
+        u32x2 k0, k1;
+        if (CPT_FFN_EPI_PAIR) epi_pair(acc0[p >> 2][(p >> 1) & 1], 0, p, k0, k1);
+        else { k0 = epi_quad(acc0[p >> 2][(p >> 1) & 1], 0, p, 0); k1 = epi_quad(acc0[p >> 2][(p >> 1) & 1], 0, p, 1); }
         epi_store(0, p, k0, k1);
     }
 #pragma unroll
     for (int p = 0; p < MI * NJ * 2; ++p) {
-        const u32x2 k0 = epi_quad(acc1[p >> 2][(p >> 1) & 1], 1, p, 0), k1 = epi_quad(acc1[p >> 2][(p >> 1) & 1], 1, p, 1);
+        u32x2 k0, k1;
+        if (CPT_FFN_EPI_PAIR) epi_pair(acc1[p >> 2][(p >> 1) & 1], 1, p, k0, k1);
+        else { k0 = epi_quad(acc1[p >> 2][(p >> 1) & 1], 1, p, 0); k1 = epi_quad(acc1[p >> 2][(p >> 1) & 1], 1, p, 1); }
         epi_store(1, p, k0, k1);
     }
 #undef CPT_SB
