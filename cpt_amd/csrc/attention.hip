@@ -32,10 +32,15 @@ template <> __device__ __forceinline__ int k_off<float>(int row, int chunk) { re
 // key index held by accumulator register r of half-wave h inside a 32-key block
 __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <typename T, int NKB>
+// LEAN (round 4): the inference instantiation -- no dropout, 2-D mask, no saved probabilities.  One kernel for everything carried the
+// Philox mask code and the per-score 3-D mask path behind run-time branches and spilled 72 / 168 / 234 SGPRs at NKB = 4 / 7 / 9.
+template <typename T, int NKB, int LEAN>      // 1: inference; 2: training without the rare extras (dropout on, 2-D mask, no saved probabilities); 0: everything
 __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kernel(
     const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
-    T* __restrict__ probs, int B, int L, int heads, DropSpec dr, int mask3, int ctx_panel, int remap) {
+    T* __restrict__ probs_arg, int B, int L, int heads, DropSpec dr_arg, int mask3_arg, int ctx_panel, int remap) {
+    const DropSpec dr = LEAN == 1 ? DropSpec{} : dr_arg;
+    const int mask3 = LEAN ? 0 : mask3_arg;
+    T* __restrict__ probs = LEAN ? nullptr : probs_arg;
     // remap (round 3, sequences of several 128-query tiles): a 1-D grid whose workgroups id, id + 8, .. (same XCD -- workgroups go to
     // the XCDs round robin -- dispatched back to back) are the query tiles of ONE (sequence, head), so the K / V rows the tiles share are
     // fetched from memory once and hit that XCD's L2 for the other tiles.  With the (pair, tile) grid the tiles of a pair ran 3072
@@ -244,7 +249,8 @@ static size_t att_lds_bytes() {
 template <typename T, int NKB>
 static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3, int ctx_panel) {
     const size_t lds = att_lds_bytes<T, NKB>();
-    auto kern = attention_kernel<T, NKB>;
+    const int lean = (!mask3 && !probs) ? (dr.thresh == 0 ? 1 : 2) : 0;
+    auto kern = lean == 1 ? attention_kernel<T, NKB, 1> : (lean == 2 ? attention_kernel<T, NKB, 2> : attention_kernel<T, NKB, 0>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;

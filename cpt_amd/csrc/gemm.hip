@@ -1661,14 +1661,17 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
         void* tr = ((g_trace_epi < 0 || g_trace_epi == CPT_EPI_LNCONS_GELU) && (g_trace_k == 0 || g_trace_k == K)) ? (void*)g_gemm_trace : nullptr;
         return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, tr, g_gemm_abl, s, 1, pf, pf_bytes);
     }
-    // round 4: the 4-wave consumer kernel (gemm_ffn4.hip, 192 x 256 tiles) takes the two-pass kernel's place for the stand-alone QKV projection
-    // over several rounds of tiles (GQA shape: 2.82 -> 2.69 ms per step; its GELU-less epilogue is light).  For FFN-up it measured slower
-    // (its K loop runs 1980 ticks per K-tile against the two-pass kernel's 2700-2900, but one wave per SIMD takes 13-15 k ticks for the GELU
-    // epilogue of a tile, 1.6x the two-pass kernel's per element): cpt_set_tuning key 29 = 2 turns it on there, 0 off everywhere; variant 21
-    // forces it (tests)
+    // round 4: the 4-wave consumer kernel (gemm_ffn4.hip, 192 x 256 tiles) where ITS tiles fill their rounds clearly better than the two-pass
+    // kernel's 384 x 256 ones: Oscar-large FFN-up, M = 8480, N = 4096: 720 tiles = 2.8 rounds (94 % of three) against 368 = 1.44 (72 % of two):
+    // 2.41 -> 2.13 ms per step (VCR shape).  At equal round efficiency the two-pass kernel stays: the 4-wave K loop is denser (1980 against
+    // 2700-2900 ticks per K-tile) but one wave per SIMD takes 13 k ticks for a tile's GELU epilogue, 1.6x the two-pass kernel's per element
+    // (bench shape 44 -> 49 us per launch; GQA-shape QKV projection equal).  cpt_set_tuning key 29: 0 never, 2 always (where legal);
+    // variant 21 forces it (tests).
     const long t4 = (long)((M + 191) / 192) * (N / 256), r4 = (t4 + 255) / 256;
+    const long t2 = (long)((M + 383) / 384) * (N / 256), r2 = (t2 + 255) / 256;
+    const bool fills_better = t4 * r2 * 10 >= t2 * r4 * 11;            // round efficiency t / (256 r): at least 10 % better
     if ((v == 21 && ffn_up_2pass_legal(M, N, K) && N % 256 == 0) ||
-        (v == 3 && ffn_up_2pass_preferred(M, N, K) && ((gelu && lncons4_enabled() >= 2) || (!gelu && lncons4_enabled() >= 1 && g_qkv_2pass && t4 > 512 && t4 * 5 >= r4 * 256 * 4))))
+        (v == 3 && ffn_up_2pass_preferred(M, N, K) && (gelu || (g_qkv_2pass && t4 * 5 >= r4 * 256 * 4)) && (lncons4_enabled() >= 2 || (lncons4_enabled() == 1 && fills_better))))
         return gemm_lncons4(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, s, 0, nullptr, 0, gelu);
     if (gelu && ((v == 3 && ffn_up_2pass_preferred(M, N, K)) || (v == 20 && ffn_up_2pass_legal(M, N, K)))) {     // variant 20: forced (tests)
         void* tr = ((g_trace_epi < 0 || g_trace_epi == CPT_EPI_LNCONS_GELU) && (g_trace_k == 0 || g_trace_k == K)) ? (void*)g_gemm_trace : nullptr;

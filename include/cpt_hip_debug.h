@@ -70,8 +70,8 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *          attention-output GEMM reads; 0 = the fp32 MFMA attention kernel and a cpt_split3 pass over ctx
  *   key 28 panel layout of the FFN activation when the producers run several rounds of tiles: 1 (default), 0 = row-major there (round 3)
  *   key 29 the 4-wave 192 x 256 LayerNorm-consumer kernel with the operand stream between the MFMAs (gemm_ffn4.hip) in place of the two-pass
- *          384 x 256 kernel (gemm_ffn.hip): 1 (default) = for the stand-alone QKV projection over several rounds of tiles, 2 = also for FFN-up,
- *          0 = nowhere; same bits
+ *          384 x 256 kernel (gemm_ffn.hip): 1 (default) = where its tiles fill their rounds at least 10 % better (Oscar-large FFN-up), 2 = wherever
+ *          legal, 0 = nowhere; same bits
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
