@@ -340,6 +340,9 @@ def main():
                          "default batch 256.  vcr: configs[4], Oscar-large 24 layers, NSP-CPT head, L=165+100, default batch 32")
     ap.add_argument("--print-launch", action="store_true", help="print the multi-rank launch command instead of running it")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="train mode: gradient dtype on the wire")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="debug, train mode at one rank: run the reduce-scatter / all-gather of the data-parallel step anyway (RCCL with one rank) so that the "
+                         "`comm` block of the line can be exercised on a 1-GPU box")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -366,10 +369,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rccl_ranks = 1
-    if world > 1:
+    if world > 1 or args.force_collectives:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29547")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                    # the ranks RCCL actually joined: every rank contributes 1 over the wire
         rccl_ranks = int(ones.item())
@@ -420,7 +427,7 @@ def main():
         from cpt_amd.train import FusedAdamW
         model.train()
         opt = FusedAdamW(model, lr=3e-5, betas=(0.9, 0.98), weight_decay=0.01,       # fewshot/refcoco_cpt.py:509-513
-                         grad_wire=args.grad_wire)
+                         grad_wire=args.grad_wire, force_collectives=args.force_collectives and world == 1)
     mpos = None if args.all_rows else b["mask_token_pos"]
     nsp_labels = (torch.arange(B, device=dev) % 3).to(torch.int64)       # VCR: relation label per (question, choice) sequence
 
@@ -591,9 +598,19 @@ def main():
         else:
             line["parity"] = None
         if extra is not None:
+            try:     # decode -> pinned ring -> H2D -> forward end to end (tools/io_pipeline_bench.py on the GPU box; a committed artefact, not run inside this line)
+                iop = json.load(open(_latest("io_pipeline.json")))
+                best = max(iop["configs"], key=lambda c: c["seq_per_s"])
+                extra["io_pipeline"] = {"source": "profiles/%s (tools/io_pipeline_bench.py: TSV rows -> C decoder worker processes -> shared pinned ring -> H2D on a side stream -> "
+                                                  "forward; 64 sequences x 50 regions per step) -- committed artefact, NOT measured inside this run" % os.path.basename(_latest("io_pipeline.json")),
+                                        "forward_only_seq_per_s": iop["forward_only_seq_per_s"], "end_to_end_seq_per_s": best["seq_per_s"],
+                                        "workers": best["workers"], "threads_per_worker": best["threads_per_worker"],
+                                        "fraction_of_forward_only": best["fraction_of_forward_only"]}
+            except Exception:
+                pass
             line["extra"] = extra
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 
 
