@@ -381,6 +381,11 @@ def main():
         dist.all_reduce(ones)                    # the ranks RCCL actually joined: every rank contributes 1 over the wire
         rccl_ranks = int(ones.item())
         assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
+        try:     # RCCL's version banner (C stdio, buffered on a pipe) leaves every rank's buffer NOW, long before rank 0 prints the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
     n_gpus = world
 
     from cpt_amd import config as cfgmod, synth, _lib, engine
@@ -609,9 +614,17 @@ def main():
             except Exception:
                 pass
             line["extra"] = extra
-        print(json.dumps(line), flush=True)
     if world > 1 or args.force_collectives:
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out LAST: RCCL writes its version banner through C stdio, which sits in the C library's buffer until it is flushed (or
+        # the process exits) when stdout is a pipe -- flushed here first, the banner can only precede the line, never follow it
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
