@@ -264,6 +264,47 @@ def test_bf16_forward_is_bit_reproducible(dev):
     assert torch.equal(outs[0][8:24], part)
 
 
+def test_round4_kernel_choices_are_bit_identical(dev):
+    """Round 4's switches between kernels that must produce the same BITS, at the bench shape (B = 64: one round of tiles) and at a shape whose
+    tiles run several rounds (B = 160): producer wave shape (key 24: 8 / 4 waves), merged embedding + pad/cast launch (key 25), decoder-table
+    prefetch split (key 26: a pure hint), panel FFN activation over several rounds (key 28), 4-wave LayerNorm-consumer kernel (key 29)."""
+    from cpt_amd import _lib as L
+    cfg = cfgmod.oscar_base()
+    m, _ = _model(cfg, 88, dev, "bf16")
+    for B in (64, 160):
+        b = _dev_batch(synth.make_batch(B, cfg, seed=6, vary_regions=True), dev)
+
+        def run():
+            with torch.no_grad():
+                return m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"])[0].clone()
+        ref = run()
+        for key, values in ((24, (8, 4)), (25, (0,)), (26, (100, 0)), (28, (0,)), (29, (0, 2))):
+            for v in values:
+                L.check(L.lib().cpt_set_tuning(key, v))
+                got = run()
+                L.check(L.lib().cpt_set_tuning(-1, 0))
+                assert torch.equal(got, ref), "B = %d: cpt_set_tuning(%d, %d) changes the logits" % (B, key, v)
+
+
+def test_bf16x3_attention_kernels_agree(dev):
+    """bf16x3 parity mode: the split-operand MFMA attention (round 4, key 27 = 1) against the fp32 MFMA attention kernel + cpt_split3 pass it replaces:
+    both within the mode's 1e-3 bar of each other on the [MASK] logits (observed ~1e-5), at L = 120 and at L = 210 (seven key blocks)."""
+    from cpt_amd import _lib as L
+    cfg = cfgmod.oscar_base()
+    m, _ = _model(cfg, 88, dev, "bf16x3")
+    for Lt, Li, B in ((70, 50, 8), (165, 45, 4)):
+        b = _dev_batch(synth.make_batch(B, cfg, seed=9, max_seq_len=Lt, img_seq_len=Li, vary_regions=True), dev)
+        outs = {}
+        for v in (1, 0):
+            L.check(L.lib().cpt_set_tuning(27, v))
+            with torch.no_grad():
+                outs[v] = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"])[0].float().cpu()
+        L.check(L.lib().cpt_set_tuning(-1, 0))
+        d = (outs[0] - outs[1]).abs().max().item()
+        print("bf16x3 attention kernels, L = %d: max |d logit| %.3e" % (Lt + Li, d))
+        assert d < 2e-4 and torch.isfinite(outs[1]).all()
+
+
 def test_bf16x3_parity_mode(dev, golden_dir):
     """'bf16x3' (VERDICT r1 item 7): the parity bar of north_star -- [MASK] logits within 1e-3 of the fp32 reference CPU path,
     colour argmax identical -- at bf16-MFMA rates: GEMM operands split into bf16 hi + lo, three MFMA terms."""
