@@ -63,7 +63,9 @@ __device__ __forceinline__ void a_load(u32x4& d, unsigned voff, const i32x4& rs,
 
 // ABL (timing experiments only, cpt_set_tuning key 13; results are garbage for 1-3): 1 = the wn = 1 waves skip their A loads (half the
 // A load instructions), 2 = no A loads, 3 = no W LDS-DMA, 4 = refill issued right behind the barrier (correct results)
-template <int ABL, int NWV>
+// SITE (round 4): 0 = short contraction (K <= 1024: the attention-output projection), 1 = long (FFN-down).  Not used by the code: it gives
+// the two launches of a layer DISTINCT kernel symbols, so that rocprofv3's per-kernel statistics separate them.
+template <int ABL, int NWV, int SITE>
 __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     const bf16* __restrict__ Ap, const bf16* __restrict__ W, int ldw, const float* __restrict__ bias,
     const bf16* __restrict__ resid_hi, const signed char* __restrict__ resid_lo, int ldr,
@@ -570,11 +572,11 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     static bool attr_done_dev[CPT_MAX_DEV] = {};
     bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
-        for (const void* k : {(const void*)prod3_panel_kernel<0, 8>, (const void*)prod3_panel_kernel<1, 8>, (const void*)prod3_panel_kernel<2, 8>, (const void*)prod3_panel_kernel<3, 8>, (const void*)prod3_panel_kernel<4, 8>}) {
+        for (const void* k : {(const void*)prod3_panel_kernel<0, 8, 0>, (const void*)prod3_panel_kernel<0, 8, 1>, (const void*)prod3_panel_kernel<1, 8, 1>, (const void*)prod3_panel_kernel<2, 8, 1>, (const void*)prod3_panel_kernel<3, 8, 1>, (const void*)prod3_panel_kernel<4, 8, 1>}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<8>::LDS_BYTES);
             if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         }
-        for (const void* k : {(const void*)prod3_panel_kernel<0, 4>, (const void*)prod3_panel_kernel<2, 4>, (const void*)prod3_panel_kernel<3, 4>}) {
+        for (const void* k : {(const void*)prod3_panel_kernel<0, 4, 0>, (const void*)prod3_panel_kernel<0, 4, 1>, (const void*)prod3_panel_kernel<2, 4, 1>, (const void*)prod3_panel_kernel<3, 4, 1>}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<4>::LDS_BYTES);
             if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         }
@@ -585,7 +587,8 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     const int npf = ((pf0 && pf0_bytes) || (pf1 && pf1_bytes)) ? (std::max(0, std::min(CPT_PREFETCH_WGS, 256 - ntile)) & ~7) : 0;
     if (!npf) { pf0 = nullptr; pf1 = nullptr; }
     const int nwg = ntile + npf;
-#define CPT_LAUNCH(ABL, NWV) prod3_panel_kernel<ABL, NWV><<<dim3(nwg), dim3(NWV * 64), Shape<NWV>::LDS_BYTES, s>>>(                                  \
+#define CPT_LAUNCH(ABL, NWV) CPT_LAUNCH3(ABL, NWV, 1)
+#define CPT_LAUNCH3(ABL, NWV, SITE) prod3_panel_kernel<ABL, NWV, SITE><<<dim3(nwg), dim3(NWV * 64), Shape<NWV>::LDS_BYTES, s>>>(                                  \
         (const bf16*)A_panel, (const bf16*)W, ldw, bias, (const bf16*)resid_hi, (const signed char*)resid_lo, ldr, st_in, ln_stat_parts(hidden), g_in, b_in, \
         eps, 1.0f / (float)hidden, (bf16*)out_hi, (signed char*)out_lo, ldo, st_out, ln_stat_slots(N), M, N, K, ((g_trace_epi < 0 || g_trace_epi == 11) && (g_trace_k == 0 || g_trace_k == K)) ? g_gemm_trace : nullptr, \
         pf0, pf0_bytes, pf1, pf1_bytes)
@@ -597,7 +600,7 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
         switch (g_prod_abl) {
             case 2: CPT_LAUNCH(2, 4); break;
             case 3: CPT_LAUNCH(3, 4); break;
-            default: CPT_LAUNCH(0, 4); break;
+            default: if (K <= 1024) CPT_LAUNCH3(0, 4, 0); else CPT_LAUNCH3(0, 4, 1); break;
         }
     } else
     switch (g_prod_abl) {
@@ -605,8 +608,9 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
         case 2: CPT_LAUNCH(2, 8); break;
         case 3: CPT_LAUNCH(3, 8); break;
         case 4: CPT_LAUNCH(4, 8); break;
-        default: CPT_LAUNCH(0, 8); break;
+        default: if (K <= 1024) CPT_LAUNCH3(0, 8, 0); else CPT_LAUNCH3(0, 8, 1); break;
     }
+#undef CPT_LAUNCH3
 #undef CPT_LAUNCH
     return CPT_OK;
 }

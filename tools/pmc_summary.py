@@ -4,6 +4,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 
@@ -13,6 +14,9 @@ def family(name, prev):
     if "qkv3_attn_kernel" in name:
         return "gemm_qkv_attn"                          # qkv_attn3.hip: QKV projection + attention, one workgroup per (sequence, three heads)
     if "prod3_panel_kernel" in name:                    # gemm_prod.hip: LayerNorm producers reading A from its panel copy
+        m = re.search(r"prod3_panel_kernelILi\d+ELi\d+ELi(\d)E", name)      # round 4: the SITE template argument names the launch (0 attn-out, 1 FFN-down)
+        if m:
+            return "gemm_attn_out" if m.group(1) == "0" else "gemm_ffn_down"
         return "gemm_attn_out" if prev in ("attention", "gemm_qkv_attn") else "gemm_ffn_down"
     if "gemm_pipe_kernel" in name:
         # template arguments: <T, EPI, OT, ...>; EPI 0 none, 1 gelu, 3 resid, 6 / 11 LN producer, 7/8 LN consumer (+gelu), 9/10 fused QKV + attention
