@@ -257,10 +257,10 @@ def extra_configs(dev, model, cfg, seed):
         def fn():
             with torch.no_grad():
                 return call(m, b)
-        dt = timed(fn, 2, 5)
+        dt = timed(fn, 2, 10)
         gf = fwd_gflop_per_seq(c, Lt, Li, mlm_head)
         fr, dom = gemm_fracs(fn, 3, B * (Lt + Li), c.hidden_size, c.intermediate_size)
-        return {"pairs/s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": B, "seq_len": "%d+%d" % (Lt, Li), "steps": 5,
+        return {"pairs/s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": B, "seq_len": "%d+%d" % (Lt, Li), "steps": 10,
                 "fwd_GFLOP_per_seq": round(gf, 2), "frac_of_bf16_peak_end_to_end": round(B * gf / dt / 1e3 / PEAK_TFLOPS["bf16"], 4),
                 "dominant_kernel": dom, "dominant_kernel_frac": fr.get(dom), "gemm_fracs": fr}
 
