@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <dlfcn.h>
 #include <vector>
 #include <algorithm>
 
@@ -61,9 +62,15 @@ struct Shape { const char* name; int M, N, K; };
 // --loop <shape 0..3> <iters> [seconds]: find the best algorithm of that shape, then launch it `iters` times back to back (for
 // rocprofv3 --pmc / --kernel-trace passes and power sampling: tools/kloop_diag.sh); with `seconds`, keep looping that long.
 static int loop_mode(int si, int iters, double seconds);
+// --chain <steps> [path of libcpt_hip.so]: the composite VERDICT r3 priced from stand-alone numbers ("vendor GEMM + row kernels"), measured as ONE
+// back-to-back chain under the same package power cap as the fused encoder: per layer hipBLASLt QKV (+bias) -> cpt_attention -> hipBLASLt
+// attention-output (+bias, + residual through beta = 1, fp32 out) -> cpt_layernorm_rows -> hipBLASLt FFN-up (+bias + GELU epilogue) ->
+// hipBLASLt FFN-down (+bias + residual, fp32 out) -> cpt_layernorm_rows; 12 layers = one encoder pass at BASELINE configs[1] (64 x 120 rows).
+static int chain_mode(int steps, const char* lib);
 
 int main(int argc, char** argv) {
     if (argc >= 4 && !strcmp(argv[1], "--loop")) return loop_mode(atoi(argv[2]), atoi(argv[3]), argc >= 5 ? atof(argv[4]) : 0.0);
+    if (argc >= 3 && !strcmp(argv[1], "--chain")) return chain_mode(atoi(argv[2]), argc >= 4 ? argv[3] : "cpt_amd/libcpt_hip.so");
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("{\"device\": \"%s\", \"cus\": %d, \"note\": \"tools-only ceiling probe; random [-1,1) bf16 operands; HIP-event time over back-to-back launches\",\n",
@@ -207,5 +214,125 @@ static int loop_mode(int si, int iters, double seconds) {
     }
     printf("{\"shape\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"algos\": %d, \"best_algo_index\": %d, \"loop_us\": %.2f, \"TFLOPs\": %.1f, \"sustained_launches\": %ld}\n",
            s.name, s.M, s.N, s.K, got, best_i, us, 2.0 * s.M * s.N * s.K / us * 1e-6, spins);
+    return 0;
+}
+
+// ---- --chain --------------------------------------------------------------------------------------------------------------------
+namespace {
+struct LtGemm {
+    hipblasLtMatmulDesc_t desc; hipblasLtMatrixLayout_t la, lb, lc; hipblasLtMatmulHeuristicResult_t algo; float beta; int M, N, K; double us; int algos;
+};
+// row-major D[M][N] (dtype dout) = A[M][K] . W[N][K]^T + bias[N] (+ C[M][N] when resid) with an optional GELU; bf16 operands
+static bool make_gemm(hipblasLtHandle_t h, LtGemm& g, int M, int N, int K, hipDataType dout, bool resid, bool gelu, void* ws, size_t ws_bytes,
+                      const void* A, const void* W, const void* bias, void* D) {
+    g.M = M; g.N = N; g.K = K; g.beta = resid ? 1.f : 0.f;
+    CB(hipblasLtMatmulDescCreate(&g.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+    hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+    CB(hipblasLtMatmulDescSetAttribute(g.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)));
+    CB(hipblasLtMatmulDescSetAttribute(g.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)));
+    hipblasLtEpilogue_t epi = gelu ? HIPBLASLT_EPILOGUE_GELU_BIAS : HIPBLASLT_EPILOGUE_BIAS;
+    CB(hipblasLtMatmulDescSetAttribute(g.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+    CB(hipblasLtMatmulDescSetAttribute(g.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+    hipDataType bt = HIP_R_32F;
+    CB(hipblasLtMatmulDescSetAttribute(g.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
+    CB(hipblasLtMatrixLayoutCreate(&g.la, HIP_R_16BF, K, N, K));
+    CB(hipblasLtMatrixLayoutCreate(&g.lb, HIP_R_16BF, K, M, K));
+    CB(hipblasLtMatrixLayoutCreate(&g.lc, dout, N, M, N));
+    hipblasLtMatmulPreference_t pref;
+    CB(hipblasLtMatmulPreferenceCreate(&pref));
+    CB(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes, sizeof(ws_bytes)));
+    std::vector<hipblasLtMatmulHeuristicResult_t> res(32);
+    int got = 0;
+    if (hipblasLtMatmulAlgoGetHeuristic(h, g.desc, g.la, g.lb, g.lc, g.lc, pref, 32, res.data(), &got) != HIPBLAS_STATUS_SUCCESS || got == 0) return false;
+    const float alpha = 1.f;
+    double best = 1e30; int bi = -1;
+    for (int i = 0; i < got; ++i) {
+        if (res[i].state != HIPBLAS_STATUS_SUCCESS) continue;
+        bool ok = true;
+        auto run = [&]() { if (hipblasLtMatmul(h, g.desc, &alpha, W, g.la, A, g.lb, &g.beta, D, g.lc, D, g.lc, &res[i].algo, ws, ws_bytes, 0) != HIPBLAS_STATUS_SUCCESS) ok = false; };
+        const double us = time_us(run, 3, 20);
+        if (ok && us < best) { best = us; bi = i; }
+    }
+    CB(hipblasLtMatmulPreferenceDestroy(pref));
+    if (bi < 0) return false;
+    g.algo = res[bi]; g.us = best; g.algos = got;
+    return true;
+}
+typedef int (*attn_fn)(int, const void*, const int64_t*, void*, void*, int, int, int, void*);
+typedef int (*ln_fn)(const float*, const float*, const float*, float, float*, void*, int, int, int, int, int, int, void*);
+__global__ void fill_i64(int64_t* p, size_t n, int64_t v) { for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v; }
+__global__ void fill_const(float* p, size_t n, float v) { for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v; }
+}  // namespace
+
+static int chain_mode(int steps, const char* libpath) {
+    void* lib = dlopen(libpath, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { fprintf(stderr, "dlopen %s: %s\n", libpath, dlerror()); return 2; }
+    attn_fn attention = (attn_fn)dlsym(lib, "cpt_attention");
+    ln_fn layernorm = (ln_fn)dlsym(lib, "cpt_layernorm_rows");
+    if (!attention || !layernorm) { fprintf(stderr, "cpt_attention / cpt_layernorm_rows not exported\n"); return 2; }
+    const int B = 64, L = 120, M = B * L, H = 768, I = 3072, heads = 12, layers = 12;
+    hipblasLtHandle_t h;
+    CB(hipblasLtCreate(&h));
+    const size_t ws_bytes = 256u << 20;
+    void* ws; CK(hipMalloc(&ws, ws_bytes));
+    // one layer's weights x 12 (distinct buffers, as in the model: 14 MB per layer streams from HBM / the Infinity Cache)
+    unsigned short *x_lp, *a_lp, *qkv, *ctx, *ffn;
+    float *x_f32, *a_f32, *pre, *bias, *gam, *bet;
+    int64_t* mask;
+    CK(hipMalloc(&x_lp, (size_t)M * H * 2)); CK(hipMalloc(&a_lp, (size_t)M * H * 2)); CK(hipMalloc(&qkv, (size_t)M * 3 * H * 2));
+    CK(hipMalloc(&ctx, (size_t)M * H * 2)); CK(hipMalloc(&ffn, (size_t)M * I * 2));
+    CK(hipMalloc(&x_f32, (size_t)M * H * 4)); CK(hipMalloc(&a_f32, (size_t)M * H * 4)); CK(hipMalloc(&pre, (size_t)M * H * 4));
+    CK(hipMalloc(&bias, (size_t)I * 4)); CK(hipMalloc(&gam, (size_t)H * 4)); CK(hipMalloc(&bet, (size_t)H * 4));
+    CK(hipMalloc(&mask, (size_t)B * L * 8));
+    fill_bf16<<<1024, 256>>>(x_lp, (size_t)M * H, 7u);
+    fill_const<<<64, 256>>>(bias, I, 0.01f); fill_const<<<8, 256>>>(gam, H, 1.0f); fill_const<<<8, 256>>>(bet, H, 0.0f);
+    fill_i64<<<64, 256>>>(mask, (size_t)B * L, 1);
+    fill_f32<<<1024, 256>>>(x_f32, (size_t)M * H);
+    std::vector<unsigned short*> wq(layers), wo(layers), wi(layers), wd(layers);
+    for (int l = 0; l < layers; ++l) {
+        CK(hipMalloc(&wq[l], (size_t)3 * H * H * 2)); CK(hipMalloc(&wo[l], (size_t)H * H * 2)); CK(hipMalloc(&wi[l], (size_t)I * H * 2)); CK(hipMalloc(&wd[l], (size_t)H * I * 2));
+        // (the LayerNorm behind every dense pair keeps the chain's activations finite whatever the weight scale)
+        fill_bf16<<<1024, 256>>>(wq[l], (size_t)3 * H * H, 11u + l); fill_bf16<<<1024, 256>>>(wo[l], (size_t)H * H, 31u + l);
+        fill_bf16<<<1024, 256>>>(wi[l], (size_t)I * H, 51u + l); fill_bf16<<<1024, 256>>>(wd[l], (size_t)H * I, 71u + l);
+    }
+    CK(hipDeviceSynchronize());
+    LtGemm gq, go, gi, gd;
+    hipDataType sum_dt = HIP_R_32F;
+    if (!make_gemm(h, gq, M, 3 * H, H, HIP_R_16BF, false, false, ws, ws_bytes, x_lp, wq[0], bias, qkv)) { fprintf(stderr, "no algorithm: qkv\n"); return 3; }
+    if (!make_gemm(h, go, M, H, H, sum_dt, true, false, ws, ws_bytes, ctx, wo[0], bias, pre)) { fprintf(stderr, "no algorithm: attn-out with fp32 C/D\n"); return 3; }
+    if (!make_gemm(h, gi, M, I, H, HIP_R_16BF, false, true, ws, ws_bytes, a_lp, wi[0], bias, ffn)) { fprintf(stderr, "no algorithm: ffn-up\n"); return 3; }
+    if (!make_gemm(h, gd, M, H, I, sum_dt, true, false, ws, ws_bytes, ffn, wd[0], bias, pre)) { fprintf(stderr, "no algorithm: ffn-down with fp32 C/D\n"); return 3; }
+    const float alpha = 1.f;
+    auto mm = [&](LtGemm& g, const void* A, const void* W, const void* C, void* D) {
+        CB(hipblasLtMatmul(h, g.desc, &alpha, W, g.la, A, g.lb, &g.beta, C, g.lc, D, g.lc, &g.algo.algo, ws, ws_bytes, 0));
+    };
+    int rc = 0;
+    auto encoder = [&]() {
+        for (int l = 0; l < layers; ++l) {
+            mm(gq, x_lp, wq[l], qkv, qkv);
+            rc |= attention(1 /* CPT_BF16 */, qkv, mask, ctx, nullptr, B, L, heads, nullptr);
+            mm(go, ctx, wo[l], x_f32, pre);                                     // pre = ctx.Wo^T + b + x
+            rc |= layernorm(pre, gam, bet, 1e-12f, a_f32, a_lp, 1, M, H, M, 0, 0, nullptr);
+            mm(gi, a_lp, wi[l], ffn, ffn);
+            mm(gd, ffn, wd[l], a_f32, pre);                                     // pre = h.Wd^T + b + a
+            rc |= layernorm(pre, gam, bet, 1e-12f, x_f32, x_lp, 1, M, H, M, 0, 0, nullptr);
+        }
+    };
+    // per-launch brackets of one warm pass (events between launches), then the chain timed as a whole
+    const double us_pass = time_us(encoder, 3, steps);
+    if (rc) { fprintf(stderr, "cpt_* returned %d\n", rc); return 4; }
+    double us_attn = time_us([&]() { attention(1, qkv, mask, ctx, nullptr, B, L, heads, nullptr); }, 3, 50);
+    double us_ln = time_us([&]() { layernorm(pre, gam, bet, 1e-12f, a_f32, a_lp, 1, M, H, M, 0, 0, nullptr); }, 3, 50);
+    // sustained: >= 2 s of back-to-back passes
+    const auto t0 = std::chrono::steady_clock::now();
+    long passes = 0;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0) { for (int i = 0; i < 50; ++i) encoder(); CK(hipDeviceSynchronize()); passes += 50; }
+    const double sus_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3 / passes;
+    printf("{\"what\": \"vendor GEMM + row kernels, one encoder pass (12 layers, 64 x 120 rows, bf16) as one back-to-back chain\",\n"
+           " \"standalone_best_us\": {\"qkv\": %.2f, \"attn_out_bias_resid_f32out\": %.2f, \"ffn_up_bias_gelu\": %.2f, \"ffn_down_bias_resid_f32out\": %.2f, \"cpt_attention\": %.2f, \"cpt_layernorm_rows\": %.2f},\n"
+           " \"standalone_sum_us_per_layer\": %.2f,\n \"chain_ms_per_encoder_pass\": %.4f, \"chain_us_per_layer\": %.2f, \"steps\": %d,\n"
+           " \"sustained_2s_ms_per_encoder_pass\": %.4f, \"sustained_passes\": %ld}\n",
+           gq.us, go.us, gi.us, gd.us, us_attn, us_ln, gq.us + go.us + gi.us + gd.us + us_attn + 2 * us_ln,
+           us_pass * 1e-3, us_pass / layers, steps, sus_ms, passes);
     return 0;
 }
