@@ -314,6 +314,21 @@ def extra_configs(dev, model, cfg, seed):
             "pairs/s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": B, "steps": 5,
             "fwd_bwd_GFLOP_per_seq": round(gf3, 2), "frac_of_bf16_peak_end_to_end": round(B * gf3 / dt / 1e3 / PEAK_TFLOPS["bf16"], 4),
             "note": "forward + backward + AdamW on one GPU, dropout 0.1" + ("; configs[2]'s per-GPU share at DP = 8" if B == 4 else "")}
+    # the same step in the parity-grade modes (the reference's few-shot loop is fp32, fewshot/refcoco_cpt.py:245-249): bf16x3 = every GEMM of the
+    # step as three bf16 MFMA terms over split fp32 operands, everything else as in fp32 mode
+    b = {k: v.to(dev) for k, v in synth.make_batch(32, cfg, seed=seed, max_seq_len=70, img_seq_len=50).items()}
+    for mode in ("bf16x3", "fp32"):
+        model.set_compute_dtype(mode)
+
+        def fn():
+            opt.zero_grad()
+            loss, _ = model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                            masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+            loss.backward()
+            opt.step()
+        dt = timed(fn, 1, 3)
+        out["config2_train_step_32seq_per_gpu_%s" % mode] = {"pairs/s": round(32 / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": 32, "steps": 3}
+    model.set_compute_dtype("bf16")
     model.eval()
     return out
 

@@ -1200,6 +1200,289 @@ static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void
     return CPT_OK;
 }
 
+// ---- bf16x3 training (round 4): the same two-phase MFMA backward on SPLIT fp32 operands ----------------------------------------------
+// qkv, dctx and dqkv are fp32.  Every tile lives in LDS twice -- bf16 hi and bf16 lo = bf16(x - hi) -- and every product a.b runs as
+// hi.hi + hi.lo + lo.hi (three bf16 MFMAs, fp32 accumulate: ~2^-16 per product); probabilities and dS, which exist only in registers,
+// are split there.  Row tiles only (8 x LP x 128 bytes), the operands of the products that contract over rows come through the LDS
+// transpose read as in the TR variant above; scores AND dP blocks are held in registers (one workgroup per CU: 512 registers per lane).
+// L <= 128.  Without it the mode's backward spent 1.2 ms per layer in the scalar fp32 kernel (44 % of the step).
+struct Frag2 { bf16x8 h, l; };
+__device__ __forceinline__ f32x16 mma3(const Frag2& a, const Frag2& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+    return c;
+}
+template <int NKB>
+__global__ __launch_bounds__(256, 1) void attn_bwd_x3_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
+                                                             const float* __restrict__ dctx, float* __restrict__ dqkv, int B, int L, int heads,
+                                                             DropSpec dr, float* __restrict__ dbias) {
+    constexpr int LP = NKB * 32;
+    constexpr int LO = 4 * LP * 128;                   // byte distance from a hi tile to its lo tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sQ = smem;                          // [LP][64] bf16, swizzled rows (kq_off_tr); hi tiles Q K V dO, then the four lo tiles
+    unsigned char* sK = sQ + LP * 128;
+    unsigned char* sV = sK + LP * 128;
+    unsigned char* sO = sV + LP * 128;
+    float* sMask = reinterpret_cast<float*>(smem + 2 * LO);
+    float* sM = sMask + LP;
+    float* sLi = sM + LP;
+    float* sD = sLi + LP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int H = heads * 64;
+    const size_t ldq = (size_t)3 * H;
+    const float* base = qkv + (size_t)b * L * ldq + h * 64;
+    float* dbase = dqkv + (size_t)b * L * ldq + h * 64;
+
+    auto put = [&](unsigned char* tile, int r, int c, const float* src) {      // 8 fp32 -> hi chunk + lo chunk
+        bf16x8 hi, lo;
+        if (src) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = j < 4 ? x0[j] : x1[j - 4];
+                const bf16 hh = (bf16)x;
+                hi[j] = hh; lo[j] = (bf16)(x - (float)hh);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = (bf16)0.f; lo[j] = (bf16)0.f; }
+        }
+        *reinterpret_cast<bf16x8*>(tile + kq_off_tr(r, c)) = hi;
+        *reinterpret_cast<bf16x8*>(tile + LO + kq_off_tr(r, c)) = lo;
+    };
+    for (int idx = tid; idx < LP * 8; idx += 256) {
+        const int r = idx >> 3, c = idx & 7;
+        const bool in = r < L;
+        put(sQ, r, c, in ? base + (size_t)r * ldq + c * 8 : nullptr);
+        put(sK, r, c, in ? base + (size_t)r * ldq + H + c * 8 : nullptr);
+        put(sV, r, c, in ? base + (size_t)r * ldq + 2 * H + c * 8 : nullptr);
+        put(sO, r, c, in ? dctx + ((size_t)b * L + r) * H + h * 64 + c * 8 : nullptr);
+    }
+    for (int key = tid; key < LP; key += 256) {
+        float mv = -INFINITY;
+        if (key < L) mv = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
+        sMask[key] = mv;
+    }
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    auto rowfrag = [&](const unsigned char* tile, int row, int ks) {
+        Frag2 f;
+        f.h = *reinterpret_cast<const bf16x8*>(tile + kq_off_tr(row, 2 * ks + fh));
+        f.l = *reinterpret_cast<const bf16x8*>(tile + LO + kq_off_tr(row, 2 * ks + fh));
+        return f;
+    };
+    auto pack8 = [&](const f32x16& x, int s2) {
+        Frag2 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = x[8 * s2 + j];
+            const bf16 hh = (bf16)v;
+            f.h[j] = hh; f.l[j] = (bf16)(v - (float)hh);
+        }
+        return f;
+    };
+    auto ldT1 = [&](const unsigned char* tile, int row, int e0) {
+        const int r0 = e0 + ((lane & 15) >> 2);
+        const int dcol = (row & ~31) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        const bf16x4 lo = lds_read_tr16(tile + kq_off_tr(r0, dcol >> 3) + (dcol & 7) * 2);
+        const bf16x4 hi = lds_read_tr16(tile + kq_off_tr(r0 + 8, dcol >> 3) + (dcol & 7) * 2);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = lo[j]; o[4 + j] = hi[j]; }
+        return o;
+    };
+    auto ldT = [&](const unsigned char* tile, int row, int e0) {
+        Frag2 f;
+        f.h = ldT1(tile, row, e0);
+        f.l = ldT1(tile + LO, row, e0);
+        return f;
+    };
+
+    // ================= phase A: query blocks (lane = query) =================
+    for (int qb = wave; qb < NKB; qb += 4) {
+        f32x16 st[NKB], dp[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                st[kb] = mma3(rowfrag(sK, kb * 32 + fr, ks), rowfrag(sQ, qb * 32 + fr, ks), st[kb]);
+                dp[kb] = mma3(rowfrag(sV, kb * 32 + fr, ks), rowfrag(sO, qb * 32 + fr, ks), dp[kb]);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = st[kb][r] * 0.125f + sMask[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+                st[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = expf(st[kb][r] - mx); st[kb][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (dr.thresh != 0) {
+            const int qd = min(qb * 32 + fr, L - 1);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bool keep[4];
+                    drop_attn_row4(dr, (uint32_t)blockIdx.x, qd, kb * 8 + 2 * g + fh, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dp[kb][4 * g + j] = keep[j] ? dp[kb][4 * g + j] * dr.scale : 0.f;
+                }
+        }
+        float dd = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] *= inv; dd += st[kb][r] * dp[kb][r]; }
+        dd += __shfl_xor(dd, 32, 64);
+        if (fh == 0) { sM[qb * 32 + fr] = mx; sLi[qb * 32 + fr] = inv; sD[qb * 32 + fr] = dd; }
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[kb][r] = st[kb][r] * (dp[kb][r] - dd);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Frag2 pa = pack8(dp[kb], s2);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) o[db] = mma3(pa, ldT(sK, db * 32 + fr, kb * 32 + 16 * s2 + 4 * fh), o[db]);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + acc_row(r, lane);
+                if (q < L) { dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = o[db][r] * 0.125f; cs += o[db][r] * 0.125f; }
+            }
+            if (dbias) {
+                cs += __shfl_xor(cs, 32, 64);
+                if (lane < 32) atomicAdd(&dbias[h * 64 + db * 32 + lane], cs);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================= phase B: key blocks (lane = key) =================
+    for (int kb = wave; kb < NKB; kb += 4) {
+        f32x16 aK[2], aV[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aK[db][r] = 0.f; aV[db][r] = 0.f; }
+        const float mk = sMask[kb * 32 + fr];
+#pragma unroll 1
+        for (int qb = 0; qb < NKB; ++qb) {
+            f32x16 sb, db_;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sb[r] = 0.f; db_[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sb = mma3(rowfrag(sQ, qb * 32 + fr, ks), rowfrag(sK, kb * 32 + fr, ks), sb);
+                db_ = mma3(rowfrag(sO, qb * 32 + fr, ks), rowfrag(sV, kb * 32 + fr, ks), db_);
+            }
+            float wgt[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wgt[r] = 1.f;
+            if (dr.thresh != 0) {
+                const int kd = min(kb * 32 + fr, L - 1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bool keep[4];
+                    drop_attn_col4(dr, (uint32_t)blockIdx.x, qb * 8 + 2 * g + fh, kd, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wgt[4 * g + j] = keep[j] ? dr.scale : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float p = expf(sb[r] * 0.125f + mk - sM[q]) * sLi[q];
+                sb[r] = p * wgt[r];
+                db_[r] = p * (db_[r] * wgt[r] - sD[q]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Frag2 pp = pack8(sb, s2), pd = pack8(db_, s2);
+                const int e0 = qb * 32 + 16 * s2 + 4 * fh;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    aV[db] = mma3(pp, ldT(sO, db * 32 + fr, e0), aV[db]);
+                    aK[db] = mma3(pd, ldT(sQ, db * 32 + fr, e0), aK[db]);
+                }
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            float ck = 0.f, cv = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + acc_row(r, lane);
+                if (key < L) {
+                    dbase[(size_t)key * ldq + H + db * 32 + acc_col(lane)] = aK[db][r] * 0.125f;
+                    dbase[(size_t)key * ldq + 2 * H + db * 32 + acc_col(lane)] = aV[db][r];
+                    ck += aK[db][r] * 0.125f; cv += aV[db][r];
+                }
+            }
+            if (dbias) {
+                ck += __shfl_xor(ck, 32, 64); cv += __shfl_xor(cv, 32, 64);
+                if (lane < 32) {
+                    atomicAdd(&dbias[H + h * 64 + db * 32 + lane], ck);
+                    atomicAdd(&dbias[2 * H + h * 64 + db * 32 + lane], cv);
+                }
+            }
+        }
+    }
+}
+
+template <int NKB>
+static int attn_bwd_x3_launch(const float* qkv, const int64_t* mask, const float* dctx, float* dqkv, int B, int L, int heads, const DropSpec& dr,
+                              hipStream_t s, float* dbias) {
+    constexpr int LP = NKB * 32;
+    const size_t lds = (size_t)8 * LP * 128 + (size_t)4 * LP * sizeof(float);
+    auto k = attn_bwd_x3_kernel<NKB>;
+    static bool done = false;
+    if (lds > 64 * 1024 && !done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+        done = true;
+    }
+    k<<<dim3(B * heads), dim3(256), lds, s>>>(qkv, mask, dctx, dqkv, B, L, heads, dr, dbias);
+    return CPT_OK;
+}
+int attention_bwd_x3_supported(int L, int mask_3d) { return !mask_3d && L > 0 && L <= 128; }
+int attention_bwd_x3(const float* qkv, const int64_t* attn_mask, const float* dctx, float* dqkv, int B, int L, int heads, hipStream_t s,
+                     const DropSpec* drop, float* dbias) {
+    if (B <= 0 || heads <= 0 || !attention_bwd_x3_supported(L, 0)) return CPT_ERR_SHAPE;
+    if (!qkv || !dctx || !dqkv) return CPT_ERR_NULL;
+    if ((((uintptr_t)qkv | (uintptr_t)dctx) & 15)) return CPT_ERR_ALIGN;
+    const DropSpec dr = drop ? *drop : DropSpec{};
+    if (L <= 32) return attn_bwd_x3_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+    if (L <= 64) return attn_bwd_x3_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+    if (L <= 96) return attn_bwd_x3_launch<3>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+    return attn_bwd_x3_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+}
+
 int g_attn_bwd_variant = 1;      // 1: transpose-read MFMA kernels for bf16 (L <= 288); 0: generic kernel always; 2: L <= 128 through the older MFMA kernel with transposed tile copies
 void set_attn_bwd_variant(int v) { g_attn_bwd_variant = v; }
 

@@ -40,6 +40,8 @@ int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* c
 
 int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s);
 int split3(const float* x, int ld, void* out_bf16, int R, int K, int weight_order, hipStream_t s);
+// [3][Rp][C] row-stacked split (blocks hi, hi, lo or hi, lo, hi; rows beyond R zero): operands of a product contracting over rows
+int split3_rows(const float* x, int ld, void* out_bf16, int R, int Rp, int C, int weight_order, hipStream_t s);
 
 int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H,
                 hipStream_t s, const int64_t* seq = nullptr, int n_seq = 0);      // seq: row b = position pos[b] of sequence seq[b] (of n_seq)
@@ -71,6 +73,10 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
                   const DropSpec* drop = nullptr, float* dbias = nullptr, int mask_3d = 0);     // dbias [3H]: += column sums of dqkv (the stacked Q|K|V bias gradient); mask_3d: attn_mask is [B][L][L]
 // y = dropout(x) (+ resid): x, y fp32 [R][H] (in place allowed), y_lp optional copy in lp_dtype; element index of the mask =
 // row * H + col.  Forward of the hidden dropouts and, with resid = NULL, their backward (the mask applied to a gradient).
+// bf16x3 training: the MFMA backward on split fp32 operands (bwd.hip attn_bwd_x3_kernel), L <= 128, per-key masks
+int attention_bwd_x3_supported(int L, int mask_3d);
+int attention_bwd_x3(const float* qkv, const int64_t* attn_mask, const float* dctx, float* dqkv, int B, int L, int heads, hipStream_t s,
+                     const DropSpec* drop, float* dbias);
 int attention_bwd_supported(int dtype, int L, int has_drop, int mask_3d = 0);
 int dropout_rows(const float* x, const float* resid, float* y, void* y_lp, int lp_dtype, int R, int H, const DropSpec& d, hipStream_t s);
 // keep-mask export (tests): kind 0 hidden [R][H]; kind 1 attention [BH][L][L]; out = 1 keep / 0 drop

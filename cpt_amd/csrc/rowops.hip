@@ -367,6 +367,37 @@ int split3(const float* x, int ld, void* out, int R, int K, int weight_order, hi
     return CPT_OK;
 }
 
+// The same split for a product that contracts over ROWS (bf16x3 training: a weight gradient dY^T . X over the M rows, read by the TN
+// kernel as stored): three row blocks of Rp rows each -- hi, hi, lo (dY) or hi, lo, hi (X) -- rows R..Rp-1 of every block zero.
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ x, int ld, bf16* __restrict__ out, int R, int Rp, int C, int worder) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int cc = C / 4;
+    if (i >= (size_t)Rp * cc) return;
+    const int r = (int)(i / cc), c = (int)(i % cc) * 4;
+    bf16x4 hi, lo;
+    if (r < R) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * ld + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = (bf16)0.f; lo[e] = (bf16)0.f; }
+    }
+    bf16* o = out + (size_t)r * C + c;
+    const size_t blk = (size_t)Rp * C;
+    *reinterpret_cast<bf16x4*>(o) = hi;
+    *reinterpret_cast<bf16x4*>(o + blk) = worder ? lo : hi;
+    *reinterpret_cast<bf16x4*>(o + 2 * blk) = worder ? hi : lo;
+}
+
+int split3_rows(const float* x, int ld, void* out, int R, int Rp, int C, int weight_order, hipStream_t s) {
+    if (R <= 0 || Rp < R || C <= 0 || C % 4 || ld % 4 || ld < C) return CPT_ERR_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 7)) return CPT_ERR_ALIGN;
+    const size_t n = (size_t)Rp * (C / 4);
+    split3_rows_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(x, ld, (bf16*)out, R, Rp, C, weight_order);
+    return CPT_OK;
+}
+
 // ---- fold a LayerNorm (gamma, beta) into the Linear that consumes its output ------------------------
 // Wf[n][k] = bf16(gamma[k] * W[n][k]);  colc[n] = sum_k float(Wf[n][k]) (what the MFMA will see);
 // cold[n] = sum_k beta[k] * W[n][k] + bias[n].  One wave per output row n.

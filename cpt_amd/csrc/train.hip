@@ -38,6 +38,7 @@ struct TrainLayout {
     size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2;     // offsets inside a layer block
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
     size_t dx, dpre, da, dpre_lp, dlp2, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
+    size_t sA, sW, sA_bytes, sW_bytes;      // bf16x3: split copies of a GEMM's two fp32 operands ([rows][hi | hi | lo] and [rows][hi | lo | hi])
     size_t total, tA_bytes, tB_bytes;
     int Mp, Bp, Vp, Rp;
 };
@@ -93,6 +94,16 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
     w.dimg_lp = take(R * H * es);
     w.dmask = take(M * H * 4);        // dropout: masked gradient of a dense output (the unmasked one feeds the residual path)
     w.dmask_lp = take(M * H * es);
+    w.sA = w.sW = 0; w.sA_bytes = w.sW_bytes = 0;
+    if (d.dtype == CPT_BF16X3) {
+        // A operands: activations [M][<= max(3H, I)], transposed gradients [<= max(3H, I)][Mp], the head's [Rh][Vp] / [V][Bp], region rows [R][Dp] / [H][Rp]
+        const size_t wide = std::max<size_t>(3 * H, I);
+        const size_t a_el = std::max<size_t>({wide * (size_t)w.Mp, (size_t)w.Vp * (size_t)w.Bp, (size_t)w.Rp * Dp, H * (size_t)w.Rp});
+        // W operands: weights [<= max(3H, I, V)][<= max(H, I)] and their transposes, transposed activations [<= max(I, Dp, H)][cols]
+        const size_t w_el = std::max<size_t>({3 * H * H, I * H, H * (size_t)w.Vp, H * Dp, std::max<size_t>({I, Dp, H}) * cols});
+        w.sA_bytes = 6 * a_el; w.sW_bytes = 6 * w_el;
+        w.sA = take(w.sA_bytes); w.sW = take(w.sW_bytes);
+    }
     w.total = o;
     return w;
 }
@@ -103,7 +114,7 @@ int check_common(const cpt_model* m, const cpt_batch* b, void* ws, size_t ws_byt
     if (b->n_rows < 0 || (long)b->n_rows > (long)b->B * (b->Lt + b->Li) || (b->n_rows > 0 && !b->row_seq))
         return abi_fail(CPT_ERR_SHAPE, "%s: n_rows %d needs row_seq and at most B * L = %ld rows", who, b->n_rows, (long)b->B * (b->Lt + b->Li));
     if (d.heads <= 0 || d.hidden != d.heads * 64) return abi_fail(CPT_ERR_SHAPE, "%s: head_dim must be 64", who);
-    if (d.dtype != CPT_F32 && d.dtype != CPT_BF16) return abi_fail(CPT_ERR_DTYPE, "%s: dtype %d", who, d.dtype);
+    if (d.dtype != CPT_F32 && d.dtype != CPT_BF16 && d.dtype != CPT_BF16X3) return abi_fail(CPT_ERR_DTYPE, "%s: dtype %d", who, d.dtype);
     if (d.img_dim_pad < d.img_dim || d.img_dim_pad % 64) return abi_fail(CPT_ERR_ALIGN, "%s: img_dim_pad must be a multiple of 64 for training", who);
     if (d.hidden % 64 || d.inter % 64) return abi_fail(CPT_ERR_ALIGN, "%s: hidden/intermediate sizes must be multiples of 64", who);
     const bool nsp = !m->w_tr && !m->w_dec && m->w_pool && m->w_rel && d.n_rel > 0;
@@ -142,6 +153,23 @@ int check_drop(const cpt_dropout* d, const char* who) {
 
 }  // namespace
 
+// One Linear-shaped product out[Mr][N] = A[Mr][K] . W[N][K]^T of the training step.  fp32 / bf16: the library GEMM of that type.  bf16x3 (the parity mode at
+// MFMA-bf16 rates, include/cpt_hip.h): both fp32 operands are split on the spot into [hi | hi | lo] / [hi | lo | hi] bf16 copies and the bf16 kernel runs
+// over K' = 3K -- a.w ~ hi.hi + hi.lo + lo.hi with fp32 accumulation; everything outside the GEMMs runs as in fp32 mode.  (The weights change every
+// step, so unlike inference there is no standing split copy of them.)
+#define CPT_TRAIN_GM                                                                                                                                    \
+    auto gm = [&](int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr, void* out, int out_dt,      \
+                  int ldo, int Mr, int N, int K, hipStream_t st) -> int {                                                                               \
+        if (!x3) return cpt::gemm(dt, epi, A, lda, W, ldw, bias, resid, ldr, out, out_dt, ldo, Mr, N, K, st);                                      \
+        if (out_dt != CPT_F32) return CPT_ERR_DTYPE;                                                                                                    \
+        if ((size_t)Mr * K * 6 > w.sA_bytes || (size_t)N * K * 6 > w.sW_bytes) return CPT_ERR_WORKSPACE;                                               \
+        int r3 = cpt::split3((const float*)A, lda, ws + w.sA, Mr, K, 0, st);                                                                           \
+        if (r3 != CPT_OK) return r3;                                                                                                                    \
+        r3 = cpt::split3((const float*)W, ldw, ws + w.sW, N, K, 1, st);                                                                                \
+        if (r3 != CPT_OK) return r3;                                                                                                                    \
+        return cpt::gemm(CPT_BF16, epi, ws + w.sA, 3 * K, ws + w.sW, 3 * K, bias, resid, ldr, out, CPT_F32, ldo, Mr, N, 3 * K, st);                   \
+    }
+
 #define TRY(expr, what)                        \
     do {                                       \
         int rc__ = abi_check((expr), what);    \
@@ -177,7 +205,8 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     if (nsp && b->n_rows > 0) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: label grids (n_rows) belong to the MLM head, not the NSP head");
     if (!o->loss || (nsp ? !o->rel : !o->logits)) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: loss and logits (NSP head: rel) outputs are required");
     hipStream_t s = (hipStream_t)stream;
-    const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, dt = d.dtype;
+    const bool x3 = d.dtype == CPT_BF16X3;
+    const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, dt = x3 ? CPT_F32 : d.dtype;
     if (L > 288) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: sequence length %d > 288", L);
     const int m3d = (b->mask_3d && b->attn_mask) ? 1 : 0;
     if (!cpt::attention_bwd_supported(dt, L, pa ? 1 : 0, m3d))       // reject here, not after the forward has run (the backward's attention kernel sets the limit)
@@ -188,6 +217,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
                         pa ? " with attention dropout" : "", lmax);
     }
     unsigned char* ws = (unsigned char*)workspace;
+    CPT_TRAIN_GM;
     float* x_f32 = (float*)(ws + w.x_f32);
     float* a_f32 = (float*)(ws + w.a_f32);
     auto LB = [&](int l, size_t off) { return (void*)(ws + w.layer0 + (size_t)l * w.layer_stride + off); };
@@ -202,7 +232,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         void* imgp = ws + w.imgp;
         float* imgpre = (float*)(ws + w.imgpre);
         TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
-        TRY(cpt::gemm(dt, CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, imgpre, CPT_F32, H,
+        TRY(gm(CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, imgpre, CPT_F32, H,
                       B * Li, H, d.img_dim_pad, s), "gemm(img_embedding)");
         const bool iln = d.use_img_ln && m->img_ln_g;       // use_img_layernorm = 0 (modeling_bert.py:263): the projection is used as is
         TRY(cpt::layernorm_rows(imgpre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, x_f32, LB(0, w.o_xin), dt, B * Li, H, Li, L, Lt, s),
@@ -217,14 +247,14 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
             if (rs == CPT_OK) return abi_check(CPT_OK, what);
             if (rs != CPT_ERR_SHAPE) return abi_check(rs, what);
         }
-        return abi_check(cpt::gemm(dt, resid ? CPT_EPI_RESID : CPT_EPI_NONE, A, lda, W, K, bias, resid, N, out, CPT_F32, N, M, N, K, s), what);
+        return abi_check(gm(resid ? CPT_EPI_RESID : CPT_EPI_NONE, A, lda, W, K, bias, resid, N, out, CPT_F32, N, M, N, K, s), what);
     };
     for (int l = 0; l < d.layers; ++l) {
         const cpt_layer& y = m->layers[l];
         need(1 + l);
         void* xin = LB(l, w.o_xin);
         void* xnext = l + 1 < d.layers ? LB(l + 1, w.o_xin) : (void*)(ws + w.xout);
-        TRY(cpt::gemm(dt, CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
+        TRY(gm(CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
         TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr, m3d), "attention");
         // round 3: where the dense layer's K is split over workgroups (few rows; or 2048..6144 rows with a long K), its partial matrices go
@@ -257,7 +287,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         if (dt == CPT_BF16 && H % 64 == 0 && I % 8 == 0) {
             TRY(cpt::gemm_gelu2(LB(l, w.o_a), H, y.w_in, H, y.b_in, LB(l, w.o_u), LB(l, w.o_h), I, M, I, H, s), "gemm(ffn up)+gelu");
         } else {
-        TRY(cpt::gemm(dt, CPT_EPI_NONE, LB(l, w.o_a), H, y.w_in, H, y.b_in, nullptr, 0, LB(l, w.o_u), dt, I, M, I, H, s), "gemm(ffn up)");
+        TRY(gm(CPT_EPI_NONE, LB(l, w.o_a), H, y.w_in, H, y.b_in, nullptr, 0, LB(l, w.o_u), dt, I, M, I, H, s), "gemm(ffn up)");
         TRY(cpt::gelu_fwd(LB(l, w.o_u), LB(l, w.o_h), dt, (size_t)M * I, s), "gelu");
         }
         // (FFN-down the same way: at M = 3840 two 128 x 192 half-K workgroups per tile, 240 workgroups at twice the arithmetic intensity of the
@@ -286,13 +316,13 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     if (nsp) {
         // NSPCPT: pooled = tanh([CLS] W_pool^T + b_pool) (kept in `uh`), rel = pooled W_rel^T + b_rel, CE over n_rel classes
         TRY(cpt::gather_rows(ws + w.xout, dt, nullptr, rows, B, L, H, s), "gather([CLS])");
-        TRY(cpt::gemm(dt, CPT_EPI_TANH, rows, H, m->w_pool, H, m->b_pool, nullptr, 0, uh, CPT_F32, H, B, H, H, s), "gemm(pooler)");
+        TRY(gm(CPT_EPI_TANH, rows, H, m->w_pool, H, m->b_pool, nullptr, 0, uh, CPT_F32, H, B, H, H, s), "gemm(pooler)");
         const void* pin = uh;
         if (dt == CPT_BF16) {
             TRY(cpt::layernorm_rows(uh, nullptr, nullptr, 0.f, nullptr, t2, dt, B, H, B, 0, 0, s), "cast(pooled)");
             pin = t2;
         }
-        TRY(cpt::gemm(dt, CPT_EPI_NONE, pin, H, m->w_rel, H, m->b_rel, nullptr, 0, o->rel, CPT_F32, d.n_rel, B, d.n_rel, H, s), "gemm(seq_relationship)");
+        TRY(gm(CPT_EPI_NONE, pin, H, m->w_rel, H, m->b_rel, nullptr, 0, o->rel, CPT_F32, d.n_rel, B, d.n_rel, H, s), "gemm(seq_relationship)");
         hipError_t e2 = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);
         if (e2 != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e2, "zero loss: %s", hipGetErrorString(e2));
         TRY(cpt::ce_rows(o->rel, b->labels, o->loss, (float*)(ws + w.dlogits), B, d.n_rel, s), "ce_rows(rel)");
@@ -303,10 +333,10 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     // Rh head rows: the [MASK] position of every sequence, or the n_rows labelled positions of a label grid (row_seq, mask_pos)
     const int Rh = b->n_rows > 0 ? b->n_rows : B;
     TRY(cpt::gather_rows(ws + w.xout, dt, b->mask_pos, rows, Rh, L, H, s, b->n_rows > 0 ? b->row_seq : nullptr, B), "gather([MASK])");
-    TRY(cpt::gemm(dt, CPT_EPI_NONE, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, uh, CPT_F32, H, Rh, H, H, s), "gemm(head transform)");
+    TRY(gm(CPT_EPI_NONE, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, uh, CPT_F32, H, Rh, H, H, s), "gemm(head transform)");
     TRY(cpt::layernorm_rows_ex(uh, m->tr_ln_g, m->tr_ln_b, d.ln_eps, dt == CPT_F32 ? (float*)t2 : nullptr,
                                dt == CPT_F32 ? nullptr : t2, dt, Rh, H, Rh, 0, 0, 1, s), "gelu+layernorm(head)");
-    TRY(cpt::gemm(dt, CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, Rh, d.vocab, H, s), "gemm(decoder)");
+    TRY(gm(CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, Rh, d.vocab, H, s), "gemm(decoder)");
     hipError_t e = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);
     if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero loss: %s", hipGetErrorString(e));
     TRY(cpt::ce_rows(o->logits, b->labels, o->loss, (float*)(ws + w.dlogits), Rh, d.vocab, s), "ce_rows");
@@ -330,9 +360,11 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     int rc = check_common(m, b, workspace, workspace_bytes, w, "cpt_train_bwd");
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, V = d.vocab, dt = d.dtype;
+    const bool x3 = d.dtype == CPT_BF16X3;
+    const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, V = d.vocab, dt = x3 ? CPT_F32 : d.dtype;
     const int Mp = w.Mp, Bp = w.Bp, Vp = w.Vp, Rp = w.Rp, Dp = d.img_dim_pad;
     unsigned char* ws = (unsigned char*)workspace;
+    CPT_TRAIN_GM;
     auto LB = [&](int l, size_t off) { return (void*)(ws + w.layer0 + (size_t)l * w.layer_stride + off); };
     float* dx = (float*)(ws + w.dx);
     float* dpre = (float*)(ws + w.dpre);
@@ -353,10 +385,18 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             TRY(cpt::gemm_tn(dY, ldy, X, ldx, out, ldo, Nout, Kout, rows_p, tA, w.tA_bytes, s, rows), what);
             return CPT_OK;
         }
+        // bf16x3: the same TN kernel over row-stacked split copies of the two fp32 operands (contraction 3 rows_p: hi.hi + hi.lo + lo.hi)
+        if (x3 && g_wgrad_tn && dY_dt == CPT_F32 && cpt::gemm_tn_eligible(Nout, Kout, 3 * rows_p, Nout, Kout, ldo) &&
+            (size_t)6 * rows_p * Nout <= w.sA_bytes && (size_t)6 * rows_p * Kout <= w.sW_bytes) {
+            TRY(cpt::split3_rows((const float*)dY, ldy, ws + w.sA, rows, rows_p, Nout, 0, s), what);
+            TRY(cpt::split3_rows((const float*)X, ldx, ws + w.sW, rows, rows_p, Kout, 1, s), what);
+            TRY(cpt::gemm_tn(ws + w.sA, Nout, ws + w.sW, Kout, out, ldo, Nout, Kout, 3 * rows_p, tA, w.tA_bytes, s, 3 * rows_p), what);
+            return CPT_OK;
+        }
         TRY(cpt::transpose_cast(dY, dY_dt, ldy, tA, dt, rows_p, rows, Nout, s), what);
         TRY(cpt::transpose_cast(X, dt, ldx, tB, dt, rows_p, rows, Kout, s), what);
         // (split-K with fp32 atomics was measured slower at B=32: 11.7-16.6 ms/step vs 10.4 -- see DESIGN.md)
-        TRY(cpt::gemm(dt, CPT_EPI_NONE, tA, rows_p, tB, rows_p, nullptr, nullptr, 0, out, CPT_F32, ldo, Nout, Kout, rows_p, s), what);
+        TRY(gm(CPT_EPI_NONE, tA, rows_p, tB, rows_p, nullptr, nullptr, 0, out, CPT_F32, ldo, Nout, Kout, rows_p, s), what);
         return CPT_OK;
     };
     // two weight gradients over the same rows in one launch (bf16, tile-aligned shapes); false = not applicable, the caller runs two wgrad
@@ -381,7 +421,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         }
         if (gelu_u) return NOT_FUSED;   // caller runs the unfused pair (dgrad, then gelu_bwd)
         TRY(cpt::transpose_cast(Wt, dt, ldw, wT, dt, Nout_p, Nout, Kout, s), what);
-        TRY(cpt::gemm(dt, resid ? CPT_EPI_RESID : CPT_EPI_NONE, dY, ldy, wT, Nout_p, nullptr, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s), what);
+        TRY(gm(resid ? CPT_EPI_RESID : CPT_EPI_NONE, dY, ldy, wT, Nout_p, nullptr, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s), what);
         return CPT_OK;
     };
 
@@ -505,6 +545,10 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         rc = dgrad(dao_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
         if (rc) return rc;
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
+        if (x3 && cpt::attention_bwd_x3_supported(L, (b->mask_3d && b->attn_mask) ? 1 : 0))
+            TRY(cpt::attention_bwd_x3((const float*)LB(l, w.o_qkv), b->attn_mask, (const float*)dctx, (float*)dbig, B, L, d.heads, s, pa ? &da_spec : nullptr,
+                                      (g_bias_fuse & 2) ? gy.b_qkv : nullptr), "attention_bwd (split operands)");
+        else
         TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr, (g_bias_fuse & 2) ? gy.b_qkv : nullptr, (b->mask_3d && b->attn_mask) ? 1 : 0), "attention_bwd+bias");
         if (!(g_bias_fuse & 2)) TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
         if (triple) {

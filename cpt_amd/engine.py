@@ -136,15 +136,20 @@ class PackedModel(object):
     def _versions(self):
         return sum(p._version for p in self._plist)
 
-    def refresh_shadow(self, force=False):
+    def refresh_shadow(self, force=False, train=False):
         """bf16 copy of the flat buffer + zero-padded img weight; redone whenever a parameter
-        was written in place (load_state_dict, an optimizer step done outside this engine)."""
+        was written in place (load_state_dict, an optimizer step done outside this engine).
+        train (bf16x3 mode): the training step splits its operands itself, so the standing split copies of the weights
+        are only marked stale here and rebuilt by the next inference forward."""
         if self.pending is not None:
             self.complete_pending()
         sig = self._versions()
         if self._sig is None:
             self._sig = {}
         if not force and self._sig.get(self.dtype) == sig:
+            if self.dtype == "bf16x3" and not train and getattr(self, "_x3_stale", False):
+                self._build_x3(L.stream_ptr())
+                self._x3_stale = False
             return
         self._sig[self.dtype] = sig
         self._fold_stale = True
@@ -170,7 +175,11 @@ class PackedModel(object):
             L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_f32.data_ptr(), L.CPT_F32, H, D, Dp, st),
                     "cpt_pad_cast(w_img)")
             if self.dtype == "bf16x3":
-                self._build_x3(st)
+                if train:
+                    self._x3_stale = True
+                else:
+                    self._build_x3(st)
+                    self._x3_stale = False
 
     def _x3_matrices(self):
         """(key, first parameter name, rows, cols) of every matrix the forward multiplies by (Q|K|V stacked as one)."""
@@ -246,6 +255,8 @@ class PackedModel(object):
                 L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_lp.data_ptr(), L.CPT_BF16, H, D, Dp, st), "cpt_pad_cast(w_img)")
             elif self.dtype != "bf16" and getattr(self, "img_pad_f32", None) is not None:
                 L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_f32.data_ptr(), L.CPT_F32, H, D, Dp, st), "cpt_pad_cast(w_img)")
+        if self.dtype == "bf16x3":
+            self._x3_stale = True
         self._fold_stale = True
 
     def weights_updated(self, shadow_fresh=False):
@@ -266,7 +277,7 @@ class PackedModel(object):
             L.check(L.lib().cpt_pad_cast(w_img.data_ptr(), self.img_pad_lp.data_ptr(), L.CPT_BF16, H, D, Dp, st),
                     "cpt_pad_cast(w_img)")
         else:
-            self.refresh_shadow(force=True)
+            self.refresh_shadow(force=True, train=True)      # (bf16x3: the split copies wait for the next inference forward)
             return
         self._sig[self.dtype] = self._versions()
 
@@ -321,13 +332,17 @@ class PackedModel(object):
         self._fold_stale = False
 
     # ---- descriptor ----------------------------------------------------------------------
-    def descriptor(self):
-        key = (self.dtype, bool(self.fold_ln))
+    def descriptor(self, train=False):
+        """cpt_model of the current compute mode.  train: the descriptor cpt_train_fwd / cpt_train_bwd take -- in bf16x3 mode the
+        fp32 master weights (split per GEMM by the step itself) instead of the standing split copies inference reads."""
+        x3 = self.dtype == "bf16x3"
+        x3_train = x3 and bool(train)
+        key = (self.dtype, bool(self.fold_ln), x3_train)
         if key in self._desc:
             return self._desc[key]
         cfg = self.cfg
         lp = self.dtype == "bf16"
-        x3 = self.dtype == "bf16x3"
+        x3 = x3 and not x3_train
         esz = 2 if lp else 4
         mat_base = (self.flat_lp if lp else self.flat).data_ptr()
         vec_base = self.flat.data_ptr()
@@ -350,7 +365,7 @@ class PackedModel(object):
                    max_pos=cfg.max_position_embeddings, type_vocab=cfg.type_vocab_size,
                    use_img_ln=1 if getattr(cfg, "use_img_layernorm", None) else 0,
                    n_rel=getattr(cfg, "num_contrast_classes", 2) if self.head in ("pretrain", "nsp") else 0,
-                   dtype=L.CPT_BF16 if lp else (L.CPT_BF16X3 if x3 else L.CPT_F32), ln_eps=cfg.layer_norm_eps,
+                   dtype=L.CPT_BF16 if lp else (L.CPT_BF16X3 if (x3 or x3_train) else L.CPT_F32), ln_eps=cfg.layer_norm_eps,
                    img_ln_eps=getattr(cfg, "img_layer_norm_eps", cfg.layer_norm_eps))
         layers = (L.Layer * cfg.num_hidden_layers)()
         for i in range(cfg.num_hidden_layers):

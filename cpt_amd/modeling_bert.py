@@ -116,7 +116,7 @@ class _EngineMixin(object):
 
     def set_compute_dtype(self, dtype):
         """'fp32' (exact-fp32 MFMA, parity mode; default), 'bf16' (bf16 MFMA operands, fp32 accumulate / residual /
-        LayerNorm / softmax; throughput mode) or 'bf16x3' (inference only: parity mode at bf16-MFMA rates -- every GEMM
+        LayerNorm / softmax; throughput mode) or 'bf16x3' (parity mode at bf16-MFMA rates, inference and training -- every GEMM
         operand split into bf16 hi + lo, three MFMA terms, everything else as in fp32 mode)."""
         if dtype not in ("fp32", "bf16", "bf16x3"):
             raise ValueError("compute dtype must be 'fp32', 'bf16' or 'bf16x3'")

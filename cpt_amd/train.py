@@ -114,7 +114,7 @@ class _TrainState(object):
 
     def workspace(self, B, Lt, Li, n_rows=0):
         eng = self.eng
-        m, _ = eng.descriptor()
+        m, _ = eng.descriptor(train=True)
         need = L.lib().cpt_train_workspace_bytes_rows(C.byref(m.dims), B, Lt, Li, n_rows)
         if need == 0:
             raise RuntimeError("cpt_amd: cpt_train_workspace_bytes rejected the batch shape")
@@ -153,7 +153,7 @@ class _MLMLoss(torch.autograd.Function):
         B, Lt = ids.shape
         R = int(rseq.numel()) if rseq is not None else 0        # label grid: R labelled rows (else one per sequence)
         Li = feats.size(1) if feats is not None else 0
-        m, _ = eng.descriptor()
+        m, _ = eng.descriptor(train=True)
         dev = eng.flat.device
         loss_acc = torch.empty(2, device=dev, dtype=torch.float32)
         if eng.head == "nsp":       # relation scores of the pooled [CLS] instead of vocabulary logits of the [MASK] row
@@ -203,7 +203,7 @@ class _MLMLoss(torch.autograd.Function):
                                "training forward only (one workspace per model); call backward() before the next "
                                "training forward of the same model")
         st.ensure()
-        m, _ = eng.descriptor()
+        m, _ = eng.descriptor(train=True)
         views = _named_grad_views(eng, st)
         accumulate = any(p.grad is not None for p, v in views if v is not None)
         if st.sync is not None:
@@ -260,11 +260,11 @@ def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels,
     if mask_token_pos is None and eng.head != "nsp":
         raise NotImplementedError("cpt_amd: training needs mask_token_pos (the (B, L) label grid of the reference has "
                                   "exactly one labelled position per row: pass it as mask_token_pos)")
-    if eng.dtype not in ("fp32", "bf16"):
-        raise NotImplementedError("cpt_amd: training runs in 'fp32' or 'bf16' compute mode ('%s' is an inference mode)" % eng.dtype)
+    if eng.dtype not in ("fp32", "bf16", "bf16x3"):
+        raise NotImplementedError("cpt_amd: training runs in 'fp32', 'bf16x3' or 'bf16' compute mode (not '%s')" % eng.dtype)
     eng.ensure_packed()
     if eng.pending is None:          # (data parallel: a pending parameter all-gather is awaited bucket by bucket in the forward)
-        eng.refresh_shadow()
+        eng.refresh_shadow(train=True)
     st = _state(eng)
     st.ensure()
 

@@ -21,11 +21,13 @@
  *   - dtype: CPT_F32 runs every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32; parity mode, matches
  *     the reference CPU path to ~1e-5); CPT_BF16 feeds bf16 operands to v_mfma_f32_32x32x16_bf16
  *     with fp32 accumulation and keeps the residual stream, LayerNorm, softmax, GELU and all
- *     reductions in fp32 (throughput mode); CPT_BF16X3 (cpt_model_fwd only) is the parity mode at MFMA-bf16 rates:
+ *     reductions in fp32 (throughput mode); CPT_BF16X3 is the parity mode at MFMA-bf16 rates:
  *     every GEMM operand is split into bf16 hi + lo parts and the product a.w is computed as hi.hi + hi.lo + lo.hi
  *     (three bf16 MFMA terms, fp32 accumulate; relative error ~2^-16 per product instead of 2^-8), laid out as ONE bf16
  *     GEMM over a tripled K: activations [M][hi | hi | lo], weights [N][hi | lo | hi] (cpt_split3).  Everything
- *     outside the GEMMs runs as in CPT_F32 mode.
+ *     outside the GEMMs runs as in CPT_F32 mode.  cpt_model_fwd takes the weight matrices of a CPT_BF16X3 model as
+ *     standing split copies; cpt_train_fwd / cpt_train_bwd take them as plain fp32 (as in CPT_F32 mode: they change every
+ *     step) and split both operands of every GEMM -- forward, input gradient, weight gradient -- on the spot.
  */
 #ifndef CPT_HIP_H
 #define CPT_HIP_H
