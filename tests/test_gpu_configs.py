@@ -139,7 +139,7 @@ def test_train_batch_driver_runs_and_learns(dev):
     assert float(losses[-1]) < float(losses[0]) - 0.3
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16x3"])
 def test_vcr_nspcpt_golden(dev, golden_dir, mode):
     """Section 8(f).1: NSPCPT (modeling_vcr.py:79-129) through the HIP path against the fixture produced by the
     reference's own class: relation scores, CE loss (fewshot/vcr_nsp_cpt.py:433-436 labels) and the driver's
@@ -197,9 +197,9 @@ def test_vcr_nspcpt_finetune_gradients(dev, golden_dir, mode):
     lab = scoring.nsp_choice_labels([2, 0], int(g["interval"]), 8, device=dev)
     loss, rel = m(b["input_ids"], b["segment_ids"], b["attention_mask"], next_sentence_label=lab, img_feats=b["img_feats"])
     loss.backward()
-    ltol, gtol = (1e-5, 2e-4) if mode == "fp32" else (5e-3, 8e-2)
+    ltol, gtol = {"fp32": (1e-5, 2e-4), "bf16x3": (2e-5, 5e-4), "bf16": (5e-3, 8e-2)}[mode]
     assert abs(loss.item() - float(g["loss"])) < ltol
-    assert (rel.detach().cpu() - torch.from_numpy(g["rel"])).abs().max().item() < (2e-5 if mode == "fp32" else 5e-3)
+    assert (rel.detach().cpu() - torch.from_numpy(g["rel"])).abs().max().item() < {"fp32": 2e-5, "bf16x3": 1e-4, "bf16": 5e-3}[mode]
     named = dict(m.named_parameters())
 
     def rel_err(name, ref):
@@ -222,7 +222,7 @@ def test_vcr_nspcpt_finetune_gradients(dev, golden_dir, mode):
         if ref is None or prm.grad is None:
             assert ref is None or float(ref.abs().max()) == 0.0, name
             continue
-        if float(ref.abs().max()) < 1e-6 and float(prm.grad.abs().max()) < (1e-5 if mode == "fp32" else 1e-3):
+        if float(ref.abs().max()) < 1e-6 and float(prm.grad.abs().max()) < (1e-3 if mode == "bf16" else 1e-5):
             continue                     # key bias: true gradient 0 (softmax is shift-invariant), rounding noise on both sides
         e = rel_err(name, ref)
         worst = max(worst, e)
