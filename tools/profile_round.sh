@@ -11,6 +11,8 @@ python bench.py --steps 10 --warmup 3 --dtype bf16x3 --no-cpu > $O/${T}_bench_b6
 python bench.py --steps 10 --warmup 3 --workload gqa > $O/${T}_bench_gqa_b256_bf16.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --workload vcr > $O/${T}_bench_vcr_large_b32_bf16.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --mode train > $O/${T}_bench_train_b32_bf16.json 2>/dev/null
+python bench.py --steps 5 --warmup 2 --mode train --dtype bf16x3 --no-cpu > $O/${T}_bench_train_b32_bf16x3.json 2>/dev/null
+python bench.py --steps 3 --warmup 1 --mode train --dtype fp32 --no-cpu > $O/${T}_bench_train_b32_fp32.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --mode train --workload gqa > $O/${T}_bench_train_gqa_b32_bf16.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --mode train --workload vcr > $O/${T}_bench_train_vcr_large_b8_bf16.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --all-rows --no-cpu > $O/${T}_bench_b64_bf16_allrows.json 2>/dev/null
