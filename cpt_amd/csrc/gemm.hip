@@ -1158,6 +1158,17 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
                         const float* resid, int ldr, OT* out, int ldo, int M, int N, int K, hipStream_t s,
                         const EpiX* ex = nullptr) {
     int pick = 0;
+#ifndef CPT_DECODER_64x128
+#define CPT_DECODER_64x128 1
+#endif
+    // A few rows against a long table (the MLM decoder: <= 64 [MASK] rows x 30522 x 768, 47 MB of weights streamed once): 64 x 128 tiles = 239
+    // workgroups pull the table through 239 CUs instead of the 159 of 64 x 192 tiles; same K order, same bits.
+    if constexpr (EPI == CPT_EPI_NONE && sizeof(T) == 2 && CPT_DECODER_64x128) {
+        if (variant == 3 && M <= 64 && N >= 8192) {
+            launch_pipe<T, EPI, OT, 64, 128, 2, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex);
+            return;
+        }
+    }
     if (variant == 3) {
         // Tile shape by a two-term model measured on MI355X (tools/ubench.hip): the K loop is
         // bound by LDS port time (LDS-DMA writes + fragment reads) unless the tile does >= 3.6 MFMA per KiB of
