@@ -76,7 +76,7 @@ def _worker(rank, world, port, tmp, mode, wire):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,wire", [("fp32", None), ("bf16", None), ("fp32", "bf16")])
+@pytest.mark.parametrize("mode,wire", [("fp32", None), ("bf16", None), ("fp32", "bf16"), ("bf16x3", None)])
 def test_product_dp_step_world2_matches_single_process(mode, wire):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -94,7 +94,8 @@ def test_product_dp_step_world2_matches_single_process(mode, wire):
         logits = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
                    mask_token_pos=b["mask_token_pos"])[0].cpu()
     exact = mode == "fp32" and wire is None
-    ptol, ltol = (2e-6, 1e-5) if exact else (4e-3, 5e-2)
+    x3 = mode == "bf16x3"          # split-operand GEMMs: two half batches against one whole batch differ by ~1e-5 of the gradient scale
+    ptol, ltol = (2e-6, 1e-5) if exact else ((5e-5, 1e-4) if x3 else (4e-3, 5e-2))
     # replicas identical to each other bit for bit, and equal to the single-process run on the concatenated batch
     for k, v in m.state_dict().items():
         assert torch.equal(r[0]["sd"][k], r[1]["sd"][k]), k
@@ -103,14 +104,14 @@ def test_product_dp_step_world2_matches_single_process(mode, wire):
         err = (r[0]["sd"][k] - v.cpu()).abs().max().item()
         assert err < ptol, (k, err)
     assert torch.equal(r[0]["logits"], r[1]["logits"])
-    assert (r[0]["logits"] - logits).abs().max().item() < (1e-4 if exact else 0.15)
+    assert (r[0]["logits"] - logits).abs().max().item() < (1e-4 if exact else (1e-3 if x3 else 0.15))
     for s in range(STEPS):
         mean = 0.5 * (r[0]["losses"][s] + r[1]["losses"][s])        # equal labelled-row counts per rank
         assert abs(mean - losses[s]) < ltol, (s, mean, losses[s])
     ref = opt.state_dict()
     for k in ref["state"]:
         e = (r[0]["opt"]["state"][k]["exp_avg"] - ref["state"][k]["exp_avg"]).abs().max().item()
-        assert e < (1e-6 if exact else 1e-2), (k, e)
+        assert e < (1e-6 if exact else (1e-4 if x3 else 1e-2)), (k, e)
     assert r[0]["opt"]["step_count"] == STEPS
 
 

@@ -499,7 +499,8 @@ def test_label_grid_with_several_labelled_positions_per_sequence(dev, mode):
     assert n > 30
 
 
-@pytest.mark.parametrize("mode,Lt,Li,p", [("fp32", 20, 6, 0.0), ("bf16", 20, 6, 0.0), ("fp32", 100, 45, 0.0), ("bf16", 165, 45, 0.0), ("fp32", 20, 6, 0.1)])
+@pytest.mark.parametrize("mode,Lt,Li,p", [("fp32", 20, 6, 0.0), ("bf16", 20, 6, 0.0), ("fp32", 100, 45, 0.0), ("bf16", 165, 45, 0.0), ("fp32", 20, 6, 0.1),
+                                            ("bf16x3", 20, 6, 0.1)])     # bf16x3: per-query masks go through the fp32 attention kernels, the GEMMs stay split
 def test_training_with_a_three_dimensional_attention_mask(dev, mode, Lt, Li, p):
     """Round 3: attention_mask (B, L, L), one mask row per query (modeling_bert.py:215-216), in the TRAINING step:
     the forward attention kernel reads it per query, the backward runs the generic kernels (they read the mask per score; the MFMA
@@ -534,7 +535,7 @@ def test_training_with_a_three_dimensional_attention_mask(dev, mode, Lt, Li, p):
     ref_loss, _ = O.rec_mlm_cpt_forward(work, cfg.to_dict(), b["input_ids"], b["segment_ids"], per_q, masked_lm_labels=grid,
                                         img_feats=b["img_feats"], mask_rows_only=b["mask_token_pos"], drop=drop)
     ref_loss.backward()
-    ltol, gtol = (2e-4, 2e-4) if mode == "fp32" else (4e-2, 8e-2)
+    ltol, gtol = {"fp32": (2e-4, 2e-4), "bf16x3": (2e-4, 5e-4), "bf16": (4e-2, 8e-2)}[mode]
     assert abs(loss.item() - float(ref_loss.detach())) < ltol, (loss.item(), float(ref_loss.detach()))
     two = O.rec_mlm_cpt_forward(sd | {"cls.decoder.weight": sd["bert.embeddings.word_embeddings.weight"]}, cfg.to_dict(), b["input_ids"],
                                 b["segment_ids"], b["attention_mask"], masked_lm_labels=grid, img_feats=b["img_feats"],
@@ -547,7 +548,7 @@ def test_training_with_a_three_dimensional_attention_mask(dev, mode, Lt, Li, p):
         if rg is None or float(rg.abs().max()) == 0.0:
             continue
         rel, mx = _rel(prm.grad, rg)
-        assert rel < gtol or mx < (1e-9 if mode == "fp32" else 2e-6), (name, rel, mx)
+        assert rel < gtol or mx < {"fp32": 1e-9, "bf16x3": 1e-8, "bf16": 2e-6}[mode], (name, rel, mx)
         n += 1
     assert n > 30
 
