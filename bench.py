@@ -556,8 +556,8 @@ def main():
                 "traffic": pmc_traffic_bytes(dom) if (B == 64 and args.dtype == "bf16" and args.workload == "refcoco") else None,
                 "traffic_source": "profiles/%s: rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled, see MI355X_MICROARCH.md), committed "
                                   "with the round's artefacts -- NOT measured inside this run" % os.path.basename(PMC_FILE),
-                "peak_note": "2.5 PF/s is the 2.4 GHz spec figure; on this workload the chip sits at its 1400 W package power cap and these launches run at "
-                             "1.5-2.1 GHz (DESIGN.md 5i, profiles/r03_power_samples.txt)",
+                "peak_note": "2.5 PF/s is the 2.4 GHz spec figure; on this workload the package power limiter (PPT) is active for 43-47 % of the step's time and the "
+                             "shader clock averages 1.95 GHz (DESIGN.md 5j, profiles/r04_throttle_step_vs_chain.txt, r04_power_step_vs_chain.txt)",
                 "avg_launch_ms": round(avg_ms, 5),
                 "flop_per_launch": gemm_flops(dom, M, H, I),
                 # every encoder GEMM against the same peak (gemm_qkv: projection flops only; its launches also run the attention)
