@@ -1455,6 +1455,287 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_x3_kernel(const float* __rest
     }
 }
 
+// Long sequences (128 < L <= 288: the GQA / VCR few-shot lengths): eight split tiles do not fit, so each phase keeps only the two tensors it
+// reads ACROSS blocks in LDS (hi + lo: LP x 512 bytes = 147 KB at 288) -- K, V in phase A, then Q, dO in phase B -- and takes its OWN 32-row block of
+// the other two straight from global memory into registers (a row fragment is 32 contiguous bytes of fp32 per lane and k-step).  dP blocks are
+// computed twice as in the bf16 transpose-read variant (scores of all key blocks stay in registers: 16 NKB).
+template <int NKB>
+__global__ __launch_bounds__(256, 1) void attn_bwd_x3_long_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
+                                                                  const float* __restrict__ dctx, float* __restrict__ dqkv, int B, int L, int heads,
+                                                                  DropSpec dr, float* __restrict__ dbias) {
+    constexpr int LP = NKB * 32;
+    constexpr int LO = 2 * LP * 128;                   // byte distance from a hi tile to its lo tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;                          // phase A: K, phase B: Q    ([LP][64] bf16 rows, kq_off_tr swizzle; lo copy at + LO)
+    unsigned char* sY = sX + LP * 128;                 // phase A: V, phase B: dO
+    float* sMask = reinterpret_cast<float*>(smem + 2 * LO);
+    float* sM = sMask + LP;
+    float* sLi = sM + LP;
+    float* sD = sLi + LP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int H = heads * 64;
+    const size_t ldq = (size_t)3 * H;
+    const float* base = qkv + (size_t)b * L * ldq + h * 64;
+    const float* obase = dctx + (size_t)b * L * H + h * 64;
+    float* dbase = dqkv + (size_t)b * L * ldq + h * 64;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    auto split8 = [&](const float* src, bf16x8& hi, bf16x8& lo) {          // src == nullptr: zeros (rows beyond L)
+        if (src) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = j < 4 ? x0[j] : x1[j - 4];
+                const bf16 hh = (bf16)x;
+                hi[j] = hh; lo[j] = (bf16)(x - (float)hh);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = (bf16)0.f; lo[j] = (bf16)0.f; }
+        }
+    };
+    auto fill = [&](const float* x, size_t ldx, const float* y, size_t ldy) {    // rows of two tensors -> sX / sY (hi + lo)
+        for (int idx = tid; idx < LP * 8; idx += 256) {
+            const int r = idx >> 3, c = idx & 7;
+            bf16x8 hi, lo;
+            split8(r < L ? x + (size_t)r * ldx + c * 8 : nullptr, hi, lo);
+            *reinterpret_cast<bf16x8*>(sX + kq_off_tr(r, c)) = hi;
+            *reinterpret_cast<bf16x8*>(sX + LO + kq_off_tr(r, c)) = lo;
+            split8(r < L ? y + (size_t)r * ldy + c * 8 : nullptr, hi, lo);
+            *reinterpret_cast<bf16x8*>(sY + kq_off_tr(r, c)) = hi;
+            *reinterpret_cast<bf16x8*>(sY + LO + kq_off_tr(r, c)) = lo;
+        }
+    };
+    // this lane's fragments of row `row` of a global tensor: what rowfrag would read from a tile holding it
+    auto ownfrag = [&](const float* x, size_t ldx, int row, Frag2 (&f)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) split8(row < L ? x + (size_t)row * ldx + (2 * ks + fh) * 8 : nullptr, f[ks].h, f[ks].l);
+    };
+    auto rowfrag = [&](const unsigned char* tile, int row, int ks) {
+        Frag2 f;
+        f.h = *reinterpret_cast<const bf16x8*>(tile + kq_off_tr(row, 2 * ks + fh));
+        f.l = *reinterpret_cast<const bf16x8*>(tile + LO + kq_off_tr(row, 2 * ks + fh));
+        return f;
+    };
+    auto pack8 = [&](const f32x16& x, int s2) {
+        Frag2 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = x[8 * s2 + j];
+            const bf16 hh = (bf16)v;
+            f.h[j] = hh; f.l[j] = (bf16)(v - (float)hh);
+        }
+        return f;
+    };
+    auto ldT1 = [&](const unsigned char* tile, int row, int e0) {
+        const int r0 = e0 + ((lane & 15) >> 2);
+        const int dcol = (row & ~31) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        const bf16x4 lo = lds_read_tr16(tile + kq_off_tr(r0, dcol >> 3) + (dcol & 7) * 2);
+        const bf16x4 hi = lds_read_tr16(tile + kq_off_tr(r0 + 8, dcol >> 3) + (dcol & 7) * 2);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = lo[j]; o[4 + j] = hi[j]; }
+        return o;
+    };
+    auto ldT = [&](const unsigned char* tile, int row, int e0) {
+        Frag2 f;
+        f.h = ldT1(tile, row, e0);
+        f.l = ldT1(tile + LO, row, e0);
+        return f;
+    };
+
+    // ================= phase A: K, V in LDS; query blocks (lane = query), Q and dO rows from global =================
+    fill(base + H, ldq, base + 2 * H, ldq);
+    for (int key = tid; key < LP; key += 256) {
+        float mv = -INFINITY;
+        if (key < L) mv = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
+        sMask[key] = mv;
+    }
+    __syncthreads();
+    for (int qb = wave; qb < NKB; qb += 4) {
+        Frag2 fq[4], fo[4];
+        ownfrag(base, ldq, qb * 32 + fr, fq);
+        ownfrag(obase, (size_t)H, qb * 32 + fr, fo);
+        f32x16 st[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) st[kb] = mma3(rowfrag(sX, kb * 32 + fr, ks), fq[ks], st[kb]);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = st[kb][r] * 0.125f + sMask[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+                st[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = expf(st[kb][r] - mx); st[kb][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        const int qd = min(qb * 32 + fr, L - 1);
+        auto dp_block = [&](int kb) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) d = mma3(rowfrag(sY, kb * 32 + fr, ks), fo[ks], d);
+            if (dr.thresh != 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bool keep[4];
+                    drop_attn_row4(dr, (uint32_t)blockIdx.x, qd, kb * 8 + 2 * g + fh, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[4 * g + j] = keep[j] ? d[4 * g + j] * dr.scale : 0.f;
+                }
+            }
+            return d;
+        };
+        float dd = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f32x16 d = dp_block(kb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] *= inv; dd += st[kb][r] * d[r]; }
+        }
+        dd += __shfl_xor(dd, 32, 64);
+        if (fh == 0) { sM[qb * 32 + fr] = mx; sLi[qb * 32 + fr] = inv; sD[qb * 32 + fr] = dd; }
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 d = dp_block(kb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = st[kb][r] * (d[r] - dd);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Frag2 pa = pack8(d, s2);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) o[db] = mma3(pa, ldT(sX, db * 32 + fr, kb * 32 + 16 * s2 + 4 * fh), o[db]);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + acc_row(r, lane);
+                if (q < L) { dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = o[db][r] * 0.125f; cs += o[db][r] * 0.125f; }
+            }
+            if (dbias) {
+                cs += __shfl_xor(cs, 32, 64);
+                if (lane < 32) atomicAdd(&dbias[h * 64 + db * 32 + lane], cs);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================= phase B: Q, dO in LDS; key blocks (lane = key), K and V rows from global =================
+    fill(base, ldq, obase, (size_t)H);
+    __syncthreads();
+    for (int kb = wave; kb < NKB; kb += 4) {
+        Frag2 fk[4], fv[4];
+        ownfrag(base + H, ldq, kb * 32 + fr, fk);
+        ownfrag(base + 2 * H, ldq, kb * 32 + fr, fv);
+        f32x16 aK[2], aV[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aK[db][r] = 0.f; aV[db][r] = 0.f; }
+        const float mk = sMask[kb * 32 + fr];
+#pragma unroll 1
+        for (int qb = 0; qb < NKB; ++qb) {
+            f32x16 sb, db_;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sb[r] = 0.f; db_[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sb = mma3(rowfrag(sX, qb * 32 + fr, ks), fk[ks], sb);
+                db_ = mma3(rowfrag(sY, qb * 32 + fr, ks), fv[ks], db_);
+            }
+            float wgt[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wgt[r] = 1.f;
+            if (dr.thresh != 0) {
+                const int kd = min(kb * 32 + fr, L - 1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bool keep[4];
+                    drop_attn_col4(dr, (uint32_t)blockIdx.x, qb * 8 + 2 * g + fh, kd, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wgt[4 * g + j] = keep[j] ? dr.scale : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float p = expf(sb[r] * 0.125f + mk - sM[q]) * sLi[q];
+                sb[r] = p * wgt[r];
+                db_[r] = p * (db_[r] * wgt[r] - sD[q]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Frag2 pp = pack8(sb, s2), pd = pack8(db_, s2);
+                const int e0 = qb * 32 + 16 * s2 + 4 * fh;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    aV[db] = mma3(pp, ldT(sY, db * 32 + fr, e0), aV[db]);
+                    aK[db] = mma3(pd, ldT(sX, db * 32 + fr, e0), aK[db]);
+                }
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            float ck = 0.f, cv = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + acc_row(r, lane);
+                if (key < L) {
+                    dbase[(size_t)key * ldq + H + db * 32 + acc_col(lane)] = aK[db][r] * 0.125f;
+                    dbase[(size_t)key * ldq + 2 * H + db * 32 + acc_col(lane)] = aV[db][r];
+                    ck += aK[db][r] * 0.125f; cv += aV[db][r];
+                }
+            }
+            if (dbias) {
+                ck += __shfl_xor(ck, 32, 64); cv += __shfl_xor(cv, 32, 64);
+                if (lane < 32) {
+                    atomicAdd(&dbias[H + h * 64 + db * 32 + lane], ck);
+                    atomicAdd(&dbias[2 * H + h * 64 + db * 32 + lane], cv);
+                }
+            }
+        }
+    }
+}
+
+template <int NKB>
+static int attn_bwd_x3_long_launch(const float* qkv, const int64_t* mask, const float* dctx, float* dqkv, int B, int L, int heads, const DropSpec& dr,
+                                   hipStream_t s, float* dbias) {
+    constexpr int LP = NKB * 32;
+    const size_t lds = (size_t)4 * LP * 128 + (size_t)4 * LP * sizeof(float);
+    auto k = attn_bwd_x3_long_kernel<NKB>;
+    static bool done = false;
+    if (lds > 64 * 1024 && !done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
+        done = true;
+    }
+    k<<<dim3(B * heads), dim3(256), lds, s>>>(qkv, mask, dctx, dqkv, B, L, heads, dr, dbias);
+    return CPT_OK;
+}
+
 template <int NKB>
 static int attn_bwd_x3_launch(const float* qkv, const int64_t* mask, const float* dctx, float* dqkv, int B, int L, int heads, const DropSpec& dr,
                               hipStream_t s, float* dbias) {
@@ -1470,7 +1751,7 @@ static int attn_bwd_x3_launch(const float* qkv, const int64_t* mask, const float
     k<<<dim3(B * heads), dim3(256), lds, s>>>(qkv, mask, dctx, dqkv, B, L, heads, dr, dbias);
     return CPT_OK;
 }
-int attention_bwd_x3_supported(int L, int mask_3d) { return !mask_3d && L > 0 && L <= 128; }
+int attention_bwd_x3_supported(int L, int mask_3d) { return !mask_3d && L > 0 && L <= 288; }
 int attention_bwd_x3(const float* qkv, const int64_t* attn_mask, const float* dctx, float* dqkv, int B, int L, int heads, hipStream_t s,
                      const DropSpec* drop, float* dbias) {
     if (B <= 0 || heads <= 0 || !attention_bwd_x3_supported(L, 0)) return CPT_ERR_SHAPE;
@@ -1480,7 +1761,10 @@ int attention_bwd_x3(const float* qkv, const int64_t* attn_mask, const float* dc
     if (L <= 32) return attn_bwd_x3_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
     if (L <= 64) return attn_bwd_x3_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
     if (L <= 96) return attn_bwd_x3_launch<3>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
-    return attn_bwd_x3_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+    if (L <= 128) return attn_bwd_x3_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+    if (L <= 160) return attn_bwd_x3_long_launch<5>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+    if (L <= 224) return attn_bwd_x3_long_launch<7>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+    return attn_bwd_x3_long_launch<9>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
 }
 
 int g_attn_bwd_variant = 1;      // 1: transpose-read MFMA kernels for bf16 (L <= 288); 0: generic kernel always; 2: L <= 128 through the older MFMA kernel with transposed tile copies

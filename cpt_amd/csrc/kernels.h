@@ -73,7 +73,7 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
                   const DropSpec* drop = nullptr, float* dbias = nullptr, int mask_3d = 0);     // dbias [3H]: += column sums of dqkv (the stacked Q|K|V bias gradient); mask_3d: attn_mask is [B][L][L]
 // y = dropout(x) (+ resid): x, y fp32 [R][H] (in place allowed), y_lp optional copy in lp_dtype; element index of the mask =
 // row * H + col.  Forward of the hidden dropouts and, with resid = NULL, their backward (the mask applied to a gradient).
-// bf16x3 training: the MFMA backward on split fp32 operands (bwd.hip attn_bwd_x3_kernel), L <= 128, per-key masks
+// bf16x3 training: the MFMA backward on split fp32 operands (bwd.hip attn_bwd_x3_kernel / attn_bwd_x3_long_kernel), L <= 288, per-key masks
 int attention_bwd_x3_supported(int L, int mask_3d);
 int attention_bwd_x3(const float* qkv, const int64_t* attn_mask, const float* dctx, float* dqkv, int B, int L, int heads, hipStream_t s,
                      const DropSpec* drop, float* dbias);

@@ -92,8 +92,9 @@ def test_exported_masks_match_cpu_restatement_and_rate(dev):
 @pytest.mark.parametrize("mode,Lt,Li", [("fp32", 20, 6), ("bf16", 20, 6), ("fp32", 60, 40), ("bf16", 60, 40),
                                         ("fp32", 100, 45), ("bf16", 100, 45), ("bf16", 165, 45), ("bf16", 165, 100),
                                         ("fp32", 165, 45), ("fp32", 165, 100),      # fp32 beyond L = 176: V read from global memory (round 3)
-                                        # bf16x3 training (round 4): the split-operand MFMA attention backward at L <= 128, the fp32 kernel beyond
-                                        ("bf16x3", 20, 6), ("bf16x3", 60, 40), ("bf16x3", 100, 45)])
+                                        # bf16x3 training (round 4): the split-operand MFMA attention backward -- all eight tiles in LDS at L <= 128,
+                                        # the two-phase form that keeps two tensors per phase in LDS at L = 145 / 210 / 265
+                                        ("bf16x3", 20, 6), ("bf16x3", 60, 40), ("bf16x3", 100, 45), ("bf16x3", 165, 45), ("bf16x3", 165, 100)])
 def test_loss_and_gradients_match_oracle_with_the_same_masks(dev, mode, Lt, Li):
     p = 0.1
     cfg = cfgmod.tiny(max_position_embeddings=max(96, Lt))
