@@ -1186,7 +1186,13 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         // scratch spills, and a spilling instance runs 3-5x slower: those shapes are not candidates for them
         constexpr bool heavy_epi = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || EPI == CPT_EPI_LNPROD || EPI == CPT_EPI_LNPROD3;
         for (int i = 0; i < 9; ++i) {
-            if (cand[i].bm == 0 || (heavy_epi && (i == 3 || i == 4))) continue;
+            // (round 4: the two-per-CU form of the 3-byte LayerNorm producer spills 29 registers, all of them in its epilogue: behind a long
+            // contraction it still wins where 128 x 192 tiles would run two rounds -- Oscar-large FFN-down, 402 tiles: 2.65 -> 2.45 ms per step)
+#ifndef CPT_OCC2_PROD
+#define CPT_OCC2_PROD 1
+#endif
+            const bool occ2_ok = CPT_OCC2_PROD && EPI == CPT_EPI_LNPROD3 && K >= 2048;
+            if (cand[i].bm == 0 || (heavy_epi && (i == 3 || (i == 4 && !occ2_ok)))) continue;
             const long wgs = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn);
             long rc = cand[i].round_cost;
             // round 3 (measured on the Oscar-large shapes, M = 8480, N = 1024): with a residual-type epilogue the 128 x 384 shape (8 waves of
