@@ -1697,7 +1697,14 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
     // round 3: the stand-alone QKV projection (attention not fused: L > 128) through the GELU-less two-pass kernel when its 384 x 256 tiles
     // fill the chip (key 20 = 0: the 384 x 192 pipe kernel as before); same accumulation order, same bits
     // (only when its tiles fill their rounds: M = 8480, N = 3072 makes 23 x 12 = 276 tiles = 1.08 rounds, where 192 x 192 tiles take 1.70 vs 1.97 ms per step)
+    // (round 4: not where 128 x 192 tiles run many rounds -- there the two-per-CU form of the pipe kernel is ahead of both LayerNorm-consumer
+    // kernels: GQA shape, 5040 tiles: 2.74 against 2.87 (two-pass) and 2.81 ms per step (4-wave); the tile model would take 384 x 192: 3.98)
     const long t2p = (long)((M + 383) / 384) * (N / 256), r2p = (t2p + 255) / 256;
+    const long t128 = (long)((M + 127) / 128) * ((N + 191) / 192);
+    if (!gelu && v == 3 && g_qkv_2pass && t128 >= 2048) {
+        launch_pipe<bf16, CPT_EPI_LNCONS, bf16, CPT_CFG_128x192_OCC2>((const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, 1, &ex);
+        return CPT_OK;
+    }
     if (!gelu && g_qkv_2pass && ((v == 3 && ffn_up_2pass_preferred(M, N, K) && t2p * 5 >= r2p * 256 * 4) || (v == 20 && ffn_up_2pass_legal(M, N, K))))
         return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, nullptr, g_gemm_abl, s, 0, nullptr, 0, 0);
     if (gelu) launch_fast<bf16, CPT_EPI_LNCONS_GELU, bf16>(v, (const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, &ex);
