@@ -1701,7 +1701,10 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
     // kernels: GQA shape, 5040 tiles: 2.74 against 2.87 (two-pass) and 2.81 ms per step (4-wave); the tile model would take 384 x 192: 3.98)
     const long t2p = (long)((M + 383) / 384) * (N / 256), r2p = (t2p + 255) / 256;
     const long t128 = (long)((M + 127) / 128) * ((N + 191) / 192);
-    if (!gelu && v == 3 && g_qkv_2pass && t128 >= 2048) {
+#ifndef CPT_QKV_OCC2_MIN
+#define CPT_QKV_OCC2_MIN 1024
+#endif
+    if (!gelu && v == 3 && g_qkv_2pass && t128 >= CPT_QKV_OCC2_MIN) {
         launch_pipe<bf16, CPT_EPI_LNCONS, bf16, CPT_CFG_128x192_OCC2>((const bf16*)A, lda, (const bf16*)Wf, ldw, nullptr, nullptr, 0, (bf16*)out_lp, ldo, M, N, K, s, 1, &ex);
         return CPT_OK;
     }
