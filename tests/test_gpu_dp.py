@@ -95,7 +95,7 @@ def test_product_dp_step_world2_matches_single_process(mode, wire):
                    mask_token_pos=b["mask_token_pos"])[0].cpu()
     exact = mode == "fp32" and wire is None
     x3 = mode == "bf16x3"          # split-operand GEMMs: two half batches against one whole batch differ by ~1e-5 of the gradient scale
-    ptol, ltol = (2e-6, 1e-5) if exact else ((5e-5, 1e-4) if x3 else (4e-3, 5e-2))
+    ptol, ltol = (2e-6, 1e-5) if exact else ((2e-4, 2e-4) if x3 else (4e-3, 5e-2))
     # replicas identical to each other bit for bit, and equal to the single-process run on the concatenated batch
     for k, v in m.state_dict().items():
         assert torch.equal(r[0]["sd"][k], r[1]["sd"][k]), k
