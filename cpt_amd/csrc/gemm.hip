@@ -1212,11 +1212,19 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
         if (pick == 8) { launch_pipe<T, EPI, OT, CPT_CFG_384x256>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); return; }
     }
     if (pick == 8) pick = 0;
+    // (round 4: the shapes whose register caps the residual-type epilogues overflow -- 384 x 192 at 114-254 spilled registers, the two-per-CU form
+    // except for the 3-byte producer -- are not instantiated for them any more: a forced variant 14 / 15 runs the 128 x 192 kernel there)
+    constexpr bool spills = EPI == CPT_EPI_RESID || EPI == CPT_EPI_RESID_LP || EPI == CPT_EPI_LNPROD || EPI == CPT_EPI_LNPROD3;
+    if constexpr (spills) { if (pick == 3 || (pick == 4 && EPI != CPT_EPI_LNPROD3)) pick = 0; }
+    if constexpr (!spills) {
+        if (pick == 3) { launch_pipe<T, EPI, OT, CPT_CFG_384x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); return; }
+    }
+    if constexpr (!spills || EPI == CPT_EPI_LNPROD3) {
+        if (pick == 4) { launch_pipe<T, EPI, OT, CPT_CFG_128x192_OCC2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); return; }
+    }
     switch (pick) {
         case 1: launch_pipe<T, EPI, OT, CPT_CFG_192x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         case 2: launch_pipe<T, EPI, OT, CPT_CFG_128x384>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
-        case 3: launch_pipe<T, EPI, OT, CPT_CFG_384x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
-        case 4: launch_pipe<T, EPI, OT, CPT_CFG_128x192_OCC2>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         case 7: launch_pipe<T, EPI, OT, CPT_CFG_64x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
         default: launch_pipe<T, EPI, OT, CPT_CFG_128x192>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex); break;
     }
