@@ -420,6 +420,16 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             return CPT_OK;
         }
         if (gelu_u) return NOT_FUSED;   // caller runs the unfused pair (dgrad, then gelu_bwd)
+        // bf16x3: the same NN kernel on split operands -- dY as [rows][hi | hi | lo], the weight AS STORED split into three row blocks
+        // (hi; lo; hi): contraction 3 Nout_p, no transposed weight copy
+        if (x3 && g_wgrad_tn && out_dt == CPT_F32 && Nout_p % 4 == 0 && cpt::gemm_nn_eligible(rows, Kout, 3 * Nout_p, 3 * Nout_p, Kout) &&
+            (size_t)6 * rows * Nout_p <= w.sA_bytes && (size_t)6 * Nout_p * Kout <= w.sW_bytes) {
+            TRY(cpt::split3((const float*)dY, ldy, ws + w.sA, rows, Nout_p, 0, s), what);
+            TRY(cpt::split3_rows((const float*)Wt, ldw, ws + w.sW, Nout, Nout_p, Kout, 1, s), what);
+            TRY(cpt::gemm_nn(ws + w.sA, 3 * Nout_p, ws + w.sW, Kout, resid, Kout, out, CPT_F32, Kout, rows, Kout, 3 * Nout_p, s, 3 * Nout_p, tA, w.tA_bytes,
+                             nullptr, 0, nullptr), what);
+            return CPT_OK;
+        }
         TRY(cpt::transpose_cast(Wt, dt, ldw, wT, dt, Nout_p, Nout, Kout, s), what);
         TRY(gm(resid ? CPT_EPI_RESID : CPT_EPI_NONE, dY, ldy, wT, Nout_p, nullptr, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s), what);
         return CPT_OK;
