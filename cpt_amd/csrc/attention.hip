@@ -485,7 +485,7 @@ static int att_x3_launch(const float* qkv, const int64_t* mask, float* ctx, bf16
     return CPT_OK;
 }
 
-int attention_x3_supported(int L) { return L > 0 && L <= 224; }
+int attention_x3_supported(int L) { return L > 0 && L <= 288; }
 
 int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* ctx_split, int B, int L, int heads, hipStream_t s) {
     if (B <= 0 || heads <= 0 || !attention_x3_supported(L)) return CPT_ERR_SHAPE;
@@ -493,7 +493,8 @@ int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* c
     if (((uintptr_t)qkv | (uintptr_t)ctx) & 15 || ((uintptr_t)ctx_split & 7)) return CPT_ERR_ALIGN;
     if (L <= 32) return att_x3_launch<1>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
     if (L <= 128) return att_x3_launch<4>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
-    return att_x3_launch<7>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
+    if (L <= 224) return att_x3_launch<7>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
+    return att_x3_launch<9>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);      // Oscar-large VCR, L = 265: 148.6 KB of LDS
 }
 
 }  // namespace cpt

@@ -34,7 +34,7 @@ int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, v
               int ctx_panel = 0);   // ctx_panel (bf16 inference): ctx leaves in the panel layout of the attn-out producer (gemm_prod.hip)
 
 // bf16x3 parity mode: attention on bf16 MFMA with split operands (three-term products); ctx fp32 [M][H] or, with ctx_split, the split copy
-// [M][hi | hi | lo] bf16 (ld 3H) for the attention-output GEMM; 2-D masks, L <= 224 (attention_x3_supported)
+// [M][hi | hi | lo] bf16 (ld 3H) for the attention-output GEMM; 2-D masks, L <= 288 (attention_x3_supported)
 int attention_x3_supported(int L);
 int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* ctx_split, int B, int L, int heads, hipStream_t s);
 

@@ -288,11 +288,12 @@ def test_round4_kernel_choices_are_bit_identical(dev):
 
 def test_bf16x3_attention_kernels_agree(dev):
     """bf16x3 parity mode: the split-operand MFMA attention (round 4, key 27 = 1) against the fp32 MFMA attention kernel + cpt_split3 pass it replaces:
-    both within the mode's 1e-3 bar of each other on the [MASK] logits (observed ~1e-5), at L = 120 and at L = 210 (seven key blocks)."""
+    both within the mode's 1e-3 bar of each other on the [MASK] logits (observed ~1e-5), at L = 120, L = 210 (seven key blocks) and L = 265 (nine: the
+    Oscar-large VCR length)."""
     from cpt_amd import _lib as L
     cfg = cfgmod.oscar_base()
     m, _ = _model(cfg, 88, dev, "bf16x3")
-    for Lt, Li, B in ((70, 50, 8), (165, 45, 4)):
+    for Lt, Li, B in ((70, 50, 8), (165, 45, 4), (165, 100, 3)):
         b = _dev_batch(synth.make_batch(B, cfg, seed=9, max_seq_len=Lt, img_seq_len=Li, vary_regions=True), dev)
         outs = {}
         for v in (1, 0):
