@@ -302,7 +302,7 @@ __device__ __forceinline__ void split_chunk8(const f32x4& a, const f32x4& b, bf1
 template <int NKB>
 __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attention_x3_kernel(
     const float* __restrict__ qkv, const int64_t* __restrict__ attn_mask, float* __restrict__ ctx, bf16* __restrict__ ctx_split,
-    int B, int L, int heads) {
+    int B, int L, int heads, DropSpec dr) {
     constexpr int LP = NKB * 32;
     constexpr int K_BYTES = LP * 128, V_BYTES = LP * 128;       // V rows swizzled (att_voff_swz): 64.5 KB at L <= 128 = two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -417,6 +417,18 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attention_x3_ke
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[kb][r] *= inv;
+    // training (bf16x3 mode's forward): dropout on the probabilities, the same stream the backward kernels regenerate (attn_core.h)
+    if (dr.thresh != 0) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bool keep[4];
+                drop_attn_row4(dr, (uint32_t)bh, q, kb * 8 + 2 * g + fh, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st[kb][4 * g + j] = keep[j] ? st[kb][4 * g + j] * dr.scale : 0.f;
+            }
+    }
 
     // O^T = V^T . P^T, three terms
     f32x16 o[2];
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attention_x3_ke
 }
 
 template <int NKB>
-static int att_x3_launch(const float* qkv, const int64_t* mask, float* ctx, bf16* ctx_split, int B, int L, int heads, hipStream_t s) {
+static int att_x3_launch(const float* qkv, const int64_t* mask, float* ctx, bf16* ctx_split, int B, int L, int heads, hipStream_t s, const DropSpec& dr) {
     constexpr int LP = NKB * 32;
     const size_t lds = (size_t)4 * LP * 128 + (size_t)LP * sizeof(float);
     auto kern = attention_x3_kernel<NKB>;
@@ -481,20 +493,21 @@ static int att_x3_launch(const float* qkv, const int64_t* mask, float* ctx, bf16
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
     }
-    kern<<<dim3(B * heads, (L + 127) / 128), dim3(ATT_THREADS), lds, s>>>(qkv, mask, ctx, ctx_split, B, L, heads);
+    kern<<<dim3(B * heads, (L + 127) / 128), dim3(ATT_THREADS), lds, s>>>(qkv, mask, ctx, ctx_split, B, L, heads, dr);
     return CPT_OK;
 }
 
 int attention_x3_supported(int L) { return L > 0 && L <= 288; }
 
-int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* ctx_split, int B, int L, int heads, hipStream_t s) {
+int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* ctx_split, int B, int L, int heads, hipStream_t s, const DropSpec* drop) {
+    const DropSpec dr = drop ? *drop : DropSpec{};
     if (B <= 0 || heads <= 0 || !attention_x3_supported(L)) return CPT_ERR_SHAPE;
     if (!qkv || (!ctx && !ctx_split)) return CPT_ERR_NULL;
     if (((uintptr_t)qkv | (uintptr_t)ctx) & 15 || ((uintptr_t)ctx_split & 7)) return CPT_ERR_ALIGN;
-    if (L <= 32) return att_x3_launch<1>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
-    if (L <= 128) return att_x3_launch<4>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
-    if (L <= 224) return att_x3_launch<7>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);
-    return att_x3_launch<9>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s);      // Oscar-large VCR, L = 265: 148.6 KB of LDS
+    if (L <= 32) return att_x3_launch<1>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s, dr);
+    if (L <= 128) return att_x3_launch<4>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s, dr);
+    if (L <= 224) return att_x3_launch<7>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s, dr);
+    return att_x3_launch<9>(qkv, attn_mask, ctx, (bf16*)ctx_split, B, L, heads, s, dr);      // Oscar-large VCR, L = 265: 148.6 KB of LDS
 }
 
 }  // namespace cpt

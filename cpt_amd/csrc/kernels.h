@@ -36,7 +36,8 @@ int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, v
 // bf16x3 parity mode: attention on bf16 MFMA with split operands (three-term products); ctx fp32 [M][H] or, with ctx_split, the split copy
 // [M][hi | hi | lo] bf16 (ld 3H) for the attention-output GEMM; 2-D masks, L <= 288 (attention_x3_supported)
 int attention_x3_supported(int L);
-int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* ctx_split, int B, int L, int heads, hipStream_t s);
+int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* ctx_split, int B, int L, int heads, hipStream_t s,
+                 const DropSpec* drop = nullptr);      // drop: dropout on the probabilities (the training forward of the mode)
 
 int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s);
 int split3(const float* x, int ld, void* out_bf16, int R, int K, int weight_order, hipStream_t s);

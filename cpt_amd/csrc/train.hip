@@ -256,6 +256,12 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         void* xnext = l + 1 < d.layers ? LB(l + 1, w.o_xin) : (void*)(ws + w.xout);
         TRY(gm(CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
+#ifndef CPT_X3_TRAIN_ATTN
+#define CPT_X3_TRAIN_ATTN 1
+#endif
+        if (CPT_X3_TRAIN_ATTN && x3 && !m3d && cpt::attention_x3_supported(L))      // bf16x3: the mode's split-operand MFMA attention (fp32 ctx out), same dropout stream
+            TRY(cpt::attention_x3((const float*)LB(l, w.o_qkv), b->attn_mask, (float*)LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention (split operands)");
+        else
         TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr, m3d), "attention");
         // round 3: where the dense layer's K is split over workgroups (few rows; or 2048..6144 rows with a long K), its partial matrices go
         // straight to the row pass behind it, which adds them in split order -- no reduction launch in between (cpt_set_tuning key 22)
