@@ -318,16 +318,19 @@ def extra_configs(dev, model, cfg, seed):
     # step as three bf16 MFMA terms over split fp32 operands, everything else as in fp32 mode
     b = {k: v.to(dev) for k, v in synth.make_batch(32, cfg, seed=seed, max_seq_len=70, img_seq_len=50).items()}
     for mode in ("bf16x3", "fp32"):
-        model.set_compute_dtype(mode)
+        try:      # (a side figure: it must never take the line down with it)
+            model.set_compute_dtype(mode)
 
-        def fn():
-            opt.zero_grad()
-            loss, _ = model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
-                            masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
-            loss.backward()
-            opt.step()
-        dt = timed(fn, 1, 3)
-        out["config2_train_step_32seq_per_gpu_%s" % mode] = {"pairs/s": round(32 / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": 32, "steps": 3}
+            def fn():
+                opt.zero_grad()
+                loss, _ = model(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
+                                masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+                loss.backward()
+                opt.step()
+            dt = timed(fn, 1, 3)
+            out["config2_train_step_32seq_per_gpu_%s" % mode] = {"pairs/s": round(32 / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": 32, "steps": 3}
+        except Exception as e:
+            out["config2_train_step_32seq_per_gpu_%s" % mode] = {"error": repr(e)[:200]}
     model.set_compute_dtype("bf16")
     model.eval()
     return out
