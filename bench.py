@@ -605,7 +605,12 @@ def main():
         # to its clocks -- a 5-step measurement right behind it read 16.3 ms for a 14.0 ms step)
         extra = None
         if n_gpus == 1 and not args.no_extra and not train and args.workload == "refcoco" and args.dtype == "bf16" and not args.tune:
-            extra = extra_configs(dev, model, cfg, seed)
+            try:
+                extra = extra_configs(dev, model, cfg, seed)
+            except Exception as e:      # side figures: a failure there is reported, the headline line still goes out
+                extra = {"error": repr(e)[:300]}
+                model.set_compute_dtype(args.dtype)
+                model.eval()
         ref_logits = None
         if n_gpus == 1 and not args.no_cpu and not train and args.workload == "refcoco":
             ref_logits, line["cpu_baseline"] = cpu_baseline(cfg, seed, min(usable_cores(), 64))
