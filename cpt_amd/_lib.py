@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPT_LIB_PATH") or os.path.join(HERE, "libcpt_hip.so")     # (CPT_LIB_PATH: developer A/B builds, tools/ only)
 
-CPT_F32, CPT_BF16, CPT_BF16X3 = 0, 1, 2
+CPT_F32, CPT_BF16, CPT_BF16X3, CPT_BF16X3_MASTERS = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID = 0, 1, 2, 3
 OUT_SEQ, OUT_POOLED, OUT_MASK_LOGITS, OUT_ALL_LOGITS, OUT_LOSS, OUT_REL = 1, 2, 4, 8, 16, 32
 ATTN_MASK_3D = 256        # input flag: attention mask is (B, L, L)
@@ -160,8 +160,8 @@ def lib():
             fn = getattr(l, name)        # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if l.cpt_version() != 5:
-            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 5" % l.cpt_version())
+        if l.cpt_version() != 6:
+            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 6" % l.cpt_version())
         _lib = l
     return _lib
 

@@ -370,6 +370,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     if (B <= 0 || Lt <= 0 || Li < 0) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: bad batch shape B=%d Lt=%d Li=%d", B, Lt, Li);
     if (d.heads <= 0 || H != d.heads * 64) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: hidden %d / heads %d: head_dim must be 64", H, d.heads);
     if (L > 288) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: sequence length %d > 288 not supported", L);
+    if (d.dtype == CPT_BF16X3_MASTERS)
+        return fail(CPT_ERR_DTYPE, "cpt_model_fwd: CPT_BF16X3_MASTERS (fp32 master weights) is the training step's tag; inference reads the split copies under CPT_BF16X3");
     if (d.dtype != CPT_F32 && d.dtype != CPT_BF16 && d.dtype != CPT_BF16X3) return fail(CPT_ERR_DTYPE, "cpt_model_fwd: dtype %d", d.dtype);
     if (d.img_dim_pad < d.img_dim || d.img_dim_pad % 8) return fail(CPT_ERR_ALIGN, "cpt_model_fwd: img_dim_pad %d must be >= img_dim and a multiple of 8", d.img_dim_pad);
     if (Li > 0 && !b->img_feats) return fail(CPT_ERR_NULL, "cpt_model_fwd: img_feats is NULL with Li=%d", Li);

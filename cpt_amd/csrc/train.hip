@@ -95,7 +95,7 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
     w.dmask = take(M * H * 4);        // dropout: masked gradient of a dense output (the unmasked one feeds the residual path)
     w.dmask_lp = take(M * H * es);
     w.sA = w.sW = 0; w.sA_bytes = w.sW_bytes = 0;
-    if (d.dtype == CPT_BF16X3) {
+    if (d.dtype == CPT_BF16X3_MASTERS) {
         // A operands: activations [M][<= max(3H, I)], transposed gradients [<= max(3H, I)][Mp], the head's [Rh][Vp] / [V][Bp], region rows [R][Dp] / [H][Rp]
         const size_t wide = std::max<size_t>(3 * H, I);
         const size_t a_el = std::max<size_t>({wide * (size_t)w.Mp, (size_t)w.Vp * (size_t)w.Bp, (size_t)w.Rp * Dp, H * (size_t)w.Rp});
@@ -114,7 +114,10 @@ int check_common(const cpt_model* m, const cpt_batch* b, void* ws, size_t ws_byt
     if (b->n_rows < 0 || (long)b->n_rows > (long)b->B * (b->Lt + b->Li) || (b->n_rows > 0 && !b->row_seq))
         return abi_fail(CPT_ERR_SHAPE, "%s: n_rows %d needs row_seq and at most B * L = %ld rows", who, b->n_rows, (long)b->B * (b->Lt + b->Li));
     if (d.heads <= 0 || d.hidden != d.heads * 64) return abi_fail(CPT_ERR_SHAPE, "%s: head_dim must be 64", who);
-    if (d.dtype != CPT_F32 && d.dtype != CPT_BF16 && d.dtype != CPT_BF16X3) return abi_fail(CPT_ERR_DTYPE, "%s: dtype %d", who, d.dtype);
+    if (d.dtype == CPT_BF16X3)
+        return abi_fail(CPT_ERR_DTYPE, "%s: CPT_BF16X3 describes the standing split weight copies cpt_model_fwd reads; the training step takes the fp32 "
+                        "master weights under CPT_BF16X3_MASTERS (ABI 6)", who);
+    if (d.dtype != CPT_F32 && d.dtype != CPT_BF16 && d.dtype != CPT_BF16X3_MASTERS) return abi_fail(CPT_ERR_DTYPE, "%s: dtype %d", who, d.dtype);
     if (d.img_dim_pad < d.img_dim || d.img_dim_pad % 64) return abi_fail(CPT_ERR_ALIGN, "%s: img_dim_pad must be a multiple of 64 for training", who);
     if (d.hidden % 64 || d.inter % 64) return abi_fail(CPT_ERR_ALIGN, "%s: hidden/intermediate sizes must be multiples of 64", who);
     const bool nsp = !m->w_tr && !m->w_dec && m->w_pool && m->w_rel && d.n_rel > 0;
@@ -192,6 +195,12 @@ int cpt_train_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     return cpt_train_fwd_ex(m, b, o, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr);
 }
 
+// bf16x3 training: ONE predicate decides whether a step's attention runs on the mode's split-operand MFMA kernels -- forward AND backward
+// (the forward used to pick by a macro and the backward on its own, and the shape gate asked the fp32 kernel either way).
+static inline bool train_x3_attention(const cpt_dims& d, int L, int m3d) {
+    return d.dtype == CPT_BF16X3_MASTERS && !m3d && cpt::attention_x3_supported(L) && cpt::attention_bwd_x3_supported(L, m3d);
+}
+
 int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, void* workspace,
                      size_t workspace_bytes, void* stream, cpt_bucket_fn before_bucket, void* user, const cpt_dropout* drop) {
     if (!m || !b || !o || !workspace) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: null argument");
@@ -205,14 +214,15 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     if (nsp && b->n_rows > 0) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: label grids (n_rows) belong to the MLM head, not the NSP head");
     if (!o->loss || (nsp ? !o->rel : !o->logits)) return abi_fail(CPT_ERR_NULL, "cpt_train_fwd: loss and logits (NSP head: rel) outputs are required");
     hipStream_t s = (hipStream_t)stream;
-    const bool x3 = d.dtype == CPT_BF16X3;
+    const bool x3 = d.dtype == CPT_BF16X3_MASTERS;
     const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, dt = x3 ? CPT_F32 : d.dtype;
     if (L > 288) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: sequence length %d > 288", L);
     const int m3d = (b->mask_3d && b->attn_mask) ? 1 : 0;
-    if (!cpt::attention_bwd_supported(dt, L, pa ? 1 : 0, m3d))       // reject here, not after the forward has run (the backward's attention kernel sets the limit)
+    const bool x3_attn = train_x3_attention(d, L, m3d);
+    if (!x3_attn && !cpt::attention_bwd_supported(dt, L, pa ? 1 : 0, m3d))       // reject here, not after the forward has run (the backward's attention kernel sets the limit)
     {
         int lmax = L;
-        while (lmax > 0 && !cpt::attention_bwd_supported(dt, lmax, pa ? 1 : 0, m3d)) --lmax;
+        while (lmax > 0 && !train_x3_attention(d, lmax, m3d) && !cpt::attention_bwd_supported(dt, lmax, pa ? 1 : 0, m3d)) --lmax;
         return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: no attention backward for dtype %d at sequence length %d%s (longest supported: %d)", dt, L,
                         pa ? " with attention dropout" : "", lmax);
     }
@@ -256,10 +266,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         void* xnext = l + 1 < d.layers ? LB(l + 1, w.o_xin) : (void*)(ws + w.xout);
         TRY(gm(CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
-#ifndef CPT_X3_TRAIN_ATTN
-#define CPT_X3_TRAIN_ATTN 1
-#endif
-        if (CPT_X3_TRAIN_ATTN && x3 && !m3d && cpt::attention_x3_supported(L))      // bf16x3: the mode's split-operand MFMA attention (fp32 ctx out), same dropout stream
+        if (x3_attn)      // bf16x3: the mode's split-operand MFMA attention (fp32 ctx out), same dropout stream
             TRY(cpt::attention_x3((const float*)LB(l, w.o_qkv), b->attn_mask, (float*)LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention (split operands)");
         else
         TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr, m3d), "attention");
@@ -366,7 +373,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     int rc = check_common(m, b, workspace, workspace_bytes, w, "cpt_train_bwd");
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const bool x3 = d.dtype == CPT_BF16X3;
+    const bool x3 = d.dtype == CPT_BF16X3_MASTERS;
     const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter, V = d.vocab, dt = x3 ? CPT_F32 : d.dtype;
     const int Mp = w.Mp, Bp = w.Bp, Vp = w.Vp, Rp = w.Rp, Dp = d.img_dim_pad;
     unsigned char* ws = (unsigned char*)workspace;
@@ -561,7 +568,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         rc = dgrad(dao_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
         if (rc) return rc;
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
-        if (x3 && cpt::attention_bwd_x3_supported(L, (b->mask_3d && b->attn_mask) ? 1 : 0))
+        if (train_x3_attention(d, L, (b->mask_3d && b->attn_mask) ? 1 : 0))
             TRY(cpt::attention_bwd_x3((const float*)LB(l, w.o_qkv), b->attn_mask, (const float*)dctx, (float*)dbig, B, L, d.heads, s, pa ? &da_spec : nullptr,
                                       (g_bias_fuse & 2) ? gy.b_qkv : nullptr), "attention_bwd (split operands)");
         else

@@ -56,15 +56,17 @@ def _label_grid(batch):
     """(B, L) grid of -1 with each sequence's colour id at its [MASK] slot: what CrossEntropyLoss(ignore_index=-1) of
     modeling_rec.py:147-150 wants (fewshot/refcoco_cpt.py:231-233)."""
     grid = batch["attention_mask"].new_full(batch["attention_mask"].shape, -1, dtype=torch.long)
-    grid.scatter_(1, batch["mask_token_pos"].view(-1, 1), batch["colors"].view(-1, 1))
+    # index assignment as the reference writes it: any integer dtype and negative (from-the-end) positions are accepted
+    grid[torch.arange(grid.size(0), device=grid.device), batch["mask_token_pos"].long().view(-1)] = batch["colors"].long().view(-1)
     return grid
 
 
 def _apply_lr(optimizer, lr, head_multiplier):
-    """The reference's four parameter groups (fewshot/refcoco_cpt.py:318-343): groups 0-1 take lr x lr_mul, groups 2-3 the plain rate."""
+    """The reference's parameter groups (fewshot/refcoco_cpt.py:236-243, 318-343): groups 0-1 take lr x lr_mul, groups 2-3 the plain
+    rate; like the reference, an optimizer with fewer groups trains and only a fifth group raises."""
     groups = optimizer.param_groups
-    if len(groups) != 4:
-        raise ValueError("expected the four parameter groups of build_optimizer, got %d" % len(groups))
+    if len(groups) > 4:
+        raise ValueError("at most the four parameter groups of build_optimizer are scheduled, got %d" % len(groups))
     for g in groups[:2]:
         g["lr"] = lr * head_multiplier
     for g in groups[2:]:

@@ -348,8 +348,8 @@ class PackedModel(object):
         vec_base = self.flat.data_ptr()
         x3_key = {}
         if x3:
-            for key, pname, _, _ in self._x3_matrices():
-                x3_key.setdefault(pname, key)
+            for xkey, pname, _, _ in self._x3_matrices():
+                x3_key.setdefault(pname, xkey)
 
         def mat(n):
             if x3:
@@ -365,7 +365,7 @@ class PackedModel(object):
                    max_pos=cfg.max_position_embeddings, type_vocab=cfg.type_vocab_size,
                    use_img_ln=1 if getattr(cfg, "use_img_layernorm", None) else 0,
                    n_rel=getattr(cfg, "num_contrast_classes", 2) if self.head in ("pretrain", "nsp") else 0,
-                   dtype=L.CPT_BF16 if lp else (L.CPT_BF16X3 if (x3 or x3_train) else L.CPT_F32), ln_eps=cfg.layer_norm_eps,
+                   dtype=L.CPT_BF16 if lp else (L.CPT_BF16X3_MASTERS if x3_train else (L.CPT_BF16X3 if x3 else L.CPT_F32)), ln_eps=cfg.layer_norm_eps,
                    img_ln_eps=getattr(cfg, "img_layer_norm_eps", cfg.layer_norm_eps))
         layers = (L.Layer * cfg.num_hidden_layers)()
         for i in range(cfg.num_hidden_layers):

@@ -55,7 +55,7 @@ class TSVFile(object):
         self.tsv_file = tsv_file
         self.lineidx = os.path.splitext(tsv_file)[0] + ".lineidx"
         self._offsets = None        # int64 [rows + 1]: row starts, then the file size
-        self._sequential = True     # the .lineidx lists every row in file order (offsets()): a row ends where the next one starts
+        self._ascending = True      # the .lineidx offsets increase (offsets()): the next entry bounds a row's newline search
         self._map = None
         self._map_owner = None      # the process that created the map (a forked child maps again)
         if generate_lineidx and not os.path.isfile(self.lineidx):
@@ -78,31 +78,12 @@ class TSVFile(object):
             starts = table[:-1]
             if len(starts) and (starts.min() < 0 or starts.max() >= max(size, 1)):
                 raise ValueError("%s holds a row offset outside %s (%d bytes)" % (self.lineidx, self.tsv_file, size))
-            # A row ends where the next entry starts only when the table lists EVERY row in file order.  The reference reader
-            # (tsv_file.py:60-66: seek to the offset, readline) also serves subset / re-ordered .lineidx files; for those the
-            # row end is the next newline, found on demand.
-            self._sequential = bool(len(starts) == 0 or (starts[0] == 0 and (np.diff(table) > 0).all()))
+            # The reference reader (tsv_file.py:60-66: seek to the offset, readline) also serves .lineidx files that list a
+            # subset of the rows or list them out of order, so a row ends at ITS newline, found on demand (row_span); an
+            # ascending table only bounds that search by the next entry.
+            self._ascending = bool(len(starts) == 0 or (np.diff(table) > 0).all())
             self._offsets = table
-            if self._sequential and len(starts):
-                self._sequential = self._lists_every_row(table, size)
         return self._offsets
-
-    def _lists_every_row(self, table, size):
-        """An ascending table that starts at 0 may still skip rows (a subset file): it lists every row iff no row span holds a
-        newline before its last byte.  Exact (one pass at memchr speed) up to 1 GiB; beyond that 64 evenly spaced rows are checked."""
-        buf = self.buffer()
-        n = len(table) - 1
-        if size <= (1 << 30):
-            arr = np.frombuffer(buf, dtype=np.uint8)
-            nl = 0
-            for lo in range(0, size, 1 << 26):
-                nl += int(np.count_nonzero(arr[lo:lo + (1 << 26)] == 10))
-            return nl == n or (nl == n - 1 and arr[-1] != 10)
-        for i in np.unique(np.linspace(0, n - 1, 64).astype(np.int64)):
-            lo, hi = int(table[i]), int(table[i + 1])
-            if buf.find(b"\n", lo, hi - 1) >= 0:
-                return False
-        return True
 
     def buffer(self):
         """The whole file as a read-only memory map (shared page cache; re-mapped in a forked worker)."""
@@ -121,11 +102,11 @@ class TSVFile(object):
             raise IndexError("row %d of a %d-row TSV file" % (idx, n))
         idx %= n
         lo = int(offs[idx])
-        if self._sequential:
-            return lo, int(offs[idx + 1])
         buf = self.buffer()
-        nl = buf.find(b"\n", lo)
-        return lo, (nl + 1 if nl >= 0 else len(buf))
+        # exact for any file size and any table: memchr over one row is negligible next to its base64 decode
+        hi = int(offs[idx + 1]) if self._ascending else len(buf)
+        nl = buf.find(b"\n", lo, hi)
+        return lo, (nl + 1 if nl >= 0 else hi)
 
     # ---- the reference's surface ---------------------------------------------------------------------------------
     def num_rows(self):

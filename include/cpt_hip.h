@@ -27,7 +27,7 @@
  *     GEMM over a tripled K: activations [M][hi | hi | lo], weights [N][hi | lo | hi] (cpt_split3).  Everything
  *     outside the GEMMs runs as in CPT_F32 mode.  cpt_model_fwd takes the weight matrices of a CPT_BF16X3 model as
  *     standing split copies; cpt_train_fwd / cpt_train_bwd take them as plain fp32 (as in CPT_F32 mode: they change every
- *     step) and split both operands of every GEMM -- forward, input gradient, weight gradient -- on the spot.
+ *     step) under the tag CPT_BF16X3_MASTERS -- a descriptor of the other kind is refused, not misread -- and split both operands of every GEMM -- forward, input gradient, weight gradient -- on the spot.
  */
 #ifndef CPT_HIP_H
 #define CPT_HIP_H
@@ -38,9 +38,12 @@
 extern "C" {
 #endif
 
-#define CPT_ABI_VERSION 5     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads, cpt_batch.n_rows / mask_3d / row_seq */
+#define CPT_ABI_VERSION 6     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads, cpt_batch.n_rows / mask_3d / row_seq;
+                               * 6: CPT_BF16X3 in cpt_train_* (fp32 master weights there, NOT the split copies cpt_model_fwd reads under the same tag: the training step's own tag is CPT_BF16X3_MASTERS),
+                               *    cpt_set_tuning / cpt_prof_* / cpt_debug_gemm_trace declared in cpt_hip_debug.h, operator-level backward entry points, cpt_comm_* */
 
-enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2 };
+enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2,
+       CPT_BF16X3_MASTERS = 3 /* ABI 6, cpt_dims.dtype for cpt_train_* only: CPT_BF16X3 arithmetic on plain fp32 weight matrices (split per GEMM) */ };
 enum { CPT_EPI_NONE = 0, CPT_EPI_GELU = 1, CPT_EPI_TANH = 2, CPT_EPI_RESID = 3 };
 enum {
     CPT_OK = 0,
@@ -77,7 +80,7 @@ typedef struct {
     int32_t type_vocab;    /* config.type_vocab_size */
     int32_t use_img_ln;    /* config.use_img_layernorm */
     int32_t n_rel;         /* rows of cls.seq_relationship (num_contrast_classes), 0 if absent */
-    int32_t dtype;         /* CPT_F32 | CPT_BF16 | CPT_BF16X3 (matrices then are [N][3K] bf16 split copies, cpt_split3) */
+    int32_t dtype;         /* CPT_F32 | CPT_BF16 | CPT_BF16X3 (matrices then are [N][3K] bf16 split copies, cpt_split3) | CPT_BF16X3_MASTERS (cpt_train_*) */
     float ln_eps;          /* config.layer_norm_eps */
     float img_ln_eps;      /* config.img_layer_norm_eps */
 } cpt_dims;

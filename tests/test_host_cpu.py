@@ -228,3 +228,22 @@ def test_nspcpt_surface_and_choice_rule(golden_dir):
         with torch.no_grad():
             m(torch.from_numpy(g["in_input_ids"]), torch.from_numpy(g["in_segment_ids"]),
               torch.from_numpy(g["in_attention_mask"]), img_feats=torch.from_numpy(g["in_img_feats"]))
+
+
+def test_train_batch_helpers_accept_what_the_reference_accepts():
+    """ADVICE r4 (fewshot/refcoco_cpt.py:231-243): the label grid is built by index assignment -- int32 and negative [MASK] positions,
+    any integer colour dtype -- and only a FIFTH parameter group raises; an optimizer with one to three groups trains."""
+    from cpt_amd import drivers
+    mask = torch.ones(3, 7, dtype=torch.long)
+    batch = {"attention_mask": mask, "mask_token_pos": torch.tensor([2, -1, 0], dtype=torch.int32), "colors": torch.tensor([5, 6, 7], dtype=torch.int32)}
+    grid = drivers._label_grid(batch)
+    want = torch.full((3, 7), -1, dtype=torch.long)
+    want[0, 2], want[1, 6], want[2, 0] = 5, 6, 7
+    assert grid.dtype == torch.long and torch.equal(grid, want)
+    ps = [torch.nn.Parameter(torch.zeros(2)) for _ in range(5)]
+    for n in (1, 2, 3, 4):
+        opt = torch.optim.AdamW([{"params": [p]} for p in ps[:n]], lr=1.0)
+        drivers._apply_lr(opt, 0.5, 10.0)
+        assert [g["lr"] for g in opt.param_groups] == ([5.0, 5.0, 0.5, 0.5])[:n]
+    with pytest.raises(ValueError):
+        drivers._apply_lr(torch.optim.AdamW([{"params": [p]} for p in ps], lr=1.0), 0.5, 10.0)

@@ -167,7 +167,7 @@ def test_tsvfile_subset_and_reordered_lineidx(tmp_path):
     tsv = tmp_path / "t.tsv"
     tsv.write_text("".join("%s\t%s\n" % r for r in rows) + "lonely\n")
     full = TSVFile(str(tsv), generate_lineidx=True)
-    assert len(full) == 7 and full._sequential
+    assert len(full) == 7 and full._ascending
     assert [full.seek(i) for i in range(6)] == [list(r) for r in rows]
     assert full.seek_first_column(6) == "lonely" and full.seek(6) == ["lonely"]
     offs = [int(o) for o in (tmp_path / "t.lineidx").read_text().split()]
@@ -179,6 +179,14 @@ def test_tsvfile_subset_and_reordered_lineidx(tmp_path):
         assert len(t) == len(pick)
         assert [t.seek(j) for j in range(len(pick))] == [list(rows[i]) for i in pick]
         assert [t.seek_first_column(j) for j in range(len(pick))] == [rows[i][0] for i in pick]
+    # an ascending subset that starts at row 0 and skips rows in between (what a sampled check of a tens-of-GB file
+    # would have classified as "every row listed"): the skipped lines must not be merged into the row in front of them
+    sub = tmp_path / "skips.tsv"
+    sub.write_bytes(tsv.read_bytes())
+    (tmp_path / "skips.lineidx").write_text("".join("%d\n" % offs[i] for i in [0, 1, 4, 6]))
+    t = TSVFile(str(sub))
+    assert [t.seek(j) for j in range(3)] == [list(rows[i]) for i in [0, 1, 4]] and t.seek(3) == ["lonely"]
+    assert [t.row_span(j)[1] - t.row_span(j)[0] for j in range(3)] == [len("%s\t%s\n" % rows[i]) for i in [0, 1, 4]]
     bad = tmp_path / "bad.tsv"
     bad.write_bytes(tsv.read_bytes())
     (tmp_path / "bad.lineidx").write_text("0\n99999\n")
