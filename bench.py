@@ -24,6 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+BF16_DLOGIT_LIMIT = 0.03       # bf16 throughput mode against the fp32 oracle on the bench batch: beyond this the run exits non-zero
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}      # MI355X_MICROARCH.md: dense MFMA peaks
 def _latest(name):
     """newest committed round artefact profiles/rNN_<name>"""
@@ -154,6 +155,97 @@ def parity_block(mode, got, ref):
             "vocab_argmax_flips": int((got.argmax(1) != ref.argmax(1)).sum()),
             "median_colour_margin_of_reference": float((top2[:, 0] - top2[:, 1]).median()),
             "bar": "north_star: 1e-3 and identical argmax (met by the fp32 and bf16x3 modes; bf16 is the throughput mode, see extra.parity_modes)"}
+
+
+def io_pipeline_leg(dev, model, b, seconds=2.0, workers=None, threads=2):
+    """The input side of the hot path INSIDE this run (zeroshot/refcoco_cpt.py:213-218, utils/tsv_file.py:20-85,
+    refcoco_zsl_cpt_dataset.py:161-180): generated predictions.tsv rows -> cpt_decode_tsv_rows in worker processes -> shared pinned ring ->
+    H2D on a side stream -> forward, every step on freshly decoded and freshly copied region features, timed for `seconds` of steady state
+    beside `seconds / 2` of the forward alone on a resident batch."""
+    import tempfile
+    from cpt_amd import io, synth
+    B, rows_per_batch, n_rows = 64, 8, 48
+    tsv_path = os.path.join(tempfile.gettempdir(), "cpt_bench_predictions_%d.tsv" % os.getuid())
+    if not (os.path.exists(tsv_path) and os.path.exists(os.path.splitext(tsv_path)[0] + ".lineidx")
+            and io.TSVFile(tsv_path).num_rows() == n_rows):
+        synth.write_predictions_tsv(tsv_path, n_rows, rows_per_batch, 50, seed=88)
+    workers = workers or max(2, min(8, usable_cores() // 2))
+
+    def fwd(feats, mask):
+        with torch.no_grad():
+            return model(b["input_ids"], b["segment_ids"], mask, img_feats=feats, mask_token_pos=b["mask_token_pos"])[0]
+    pool = io.DecodePool(tsv_path, max_seqs=B, workers=workers, slots=2 * workers, threads=threads)
+    try:
+        side = torch.cuda.Stream(dev)
+        dfe = [torch.empty((B, 50, 2054), device=dev) for _ in range(2)]
+        dma = [b["attention_mask"].clone() for _ in range(2)]
+        consumed = [None, None]
+        state = {"next": 0, "wait": 0.0}
+
+        def pump():
+            while pool.can_submit():
+                i = state["next"]
+                pool.submit([(rows_per_batch * i + j) % n_rows for j in range(rows_per_batch)])
+                state["next"] += 1
+
+        def step(k):
+            tw = time.perf_counter()
+            slot, names, infos, spr, regions = pool.next()
+            state["wait"] += time.perf_counter() - tw
+            S = sum(spr)
+            with torch.cuda.stream(side):
+                if consumed[k] is not None:
+                    side.wait_event(consumed[k])            # the forward that read this device buffer is done
+                dfe[k][:S].copy_(pool.feats[slot][:S], non_blocking=True)
+                dma[k][:S, 70:].copy_(pool.masks[slot][:S], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            torch.cuda.current_stream().wait_event(ev)
+            out = fwd(dfe[k][:S], dma[k][:S])
+            consumed[k] = torch.cuda.Event()
+            consumed[k].record()
+            ev.synchronize()                                # the copy out of the pinned slot is done: the slot is free
+            pool.release(slot)
+            pump()
+            return out
+        pump()
+        step(0)
+        torch.cuda.synchronize()
+        # what reached the device in step 0 is bit for bit what a plain host decode of the same rows gives (rows 0..7 of the file)
+        tsv = io.TSVFile(tsv_path)
+        _, hf, hm, _, _ = io.decode_rows([tsv.seek_raw(i)[1].strip() for i in range(rows_per_batch)], 50, max_seqs=B)
+        check = bool(torch.equal(dfe[0].cpu(), hf) and torch.equal(dma[0][:, 70:].cpu(), hm))
+        for i in range(2 * workers + 8):                    # workers started, every slot touched, ring in steady state
+            step((i + 1) & 1)
+        torch.cuda.synchronize()
+        # the forward alone on the resident batch, same clocks
+        n_f, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / 2:
+            for _ in range(20):
+                fwd(b["img_feats"], b["attention_mask"])
+            torch.cuda.synchronize()
+            n_f += 20
+        fwd_only = B * n_f / (time.perf_counter() - t0)
+        for i in range(8):
+            step(i & 1)
+        torch.cuda.synchronize()
+        state["wait"] = 0.0
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            step(n & 1)
+            n += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        pool.close()
+    rate = B * n / dt
+    return {"measured_in_this_run": True, "end_to_end_pairs_per_s": round(rate, 1), "forward_only_pairs_per_s": round(fwd_only, 1),
+            "fraction_of_forward_only": round(rate / fwd_only, 4), "workers": workers, "threads_per_worker": threads, "steps": n,
+            "ms_per_step": round(dt / n * 1e3, 4), "ms_waiting_for_decode_per_step": round(state["wait"] / n * 1e3, 4),
+            "h2d_MB_per_step": round(B * 50 * 2054 * 4 / 1e6, 1), "distinct_batches_in_file": n_rows // rows_per_batch, "host_cores": usable_cores(),
+            "device_batch_equals_host_decode": check,
+            "path": "generated predictions.tsv (48 rows x 8 proposals x 50 boxes, base64 float32[2054]) -> cpt_amd.io.DecodePool (C decoder in worker processes, "
+                    "shared pinned ring) -> hipMemcpyAsync on a side stream -> REC_MLM_CPT forward; 64 sequences per step, fresh features every step"}
 
 
 def hbm_kernels(cfg, B, dev, iters=20):
@@ -349,6 +441,7 @@ def main():
                          "(configs[2]: forward+backward+grad all-reduce+AdamW, 32 sequences per GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-io", action="store_true", help="skip the measured input-pipeline leg (extra.io_pipeline_measured)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (the `extra` object of the line)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained run behind the K timed steps")
     ap.add_argument("--tune", default="", help="debug: comma list of key=value passed to cpt_set_tuning")
@@ -611,6 +704,12 @@ def main():
                 extra = {"error": repr(e)[:300]}
                 model.set_compute_dtype(args.dtype)
                 model.eval()
+            if not args.no_io and B == 64:
+                # the input side measured in THIS run (default-on, about 3 s timed): decode workers -> pinned ring -> side-stream H2D -> forward
+                try:
+                    extra["io_pipeline_measured"] = io_pipeline_leg(dev, model, b)
+                except Exception as e:
+                    extra["io_pipeline_measured"] = {"error": repr(e)[:300]}
         ref_logits = None
         if n_gpus == 1 and not args.no_cpu and not train and args.workload == "refcoco":
             ref_logits, line["cpu_baseline"] = cpu_baseline(cfg, seed, min(usable_cores(), 64))
@@ -626,16 +725,6 @@ def main():
         else:
             line["parity"] = None
         if extra is not None:
-            try:     # decode -> pinned ring -> H2D -> forward end to end (tools/io_pipeline_bench.py on the GPU box; a committed artefact, not run inside this line)
-                iop = json.load(open(_latest("io_pipeline.json")))
-                best = max(iop["configs"], key=lambda c: c["seq_per_s"])
-                extra["io_pipeline"] = {"source": "profiles/%s (tools/io_pipeline_bench.py: TSV rows -> C decoder worker processes -> shared pinned ring -> H2D on a side stream -> "
-                                                  "forward; 64 sequences x 50 regions per step) -- committed artefact, NOT measured inside this run" % os.path.basename(_latest("io_pipeline.json")),
-                                        "forward_only_seq_per_s": iop["forward_only_seq_per_s"], "end_to_end_seq_per_s": best["seq_per_s"],
-                                        "workers": best["workers"], "threads_per_worker": best["threads_per_worker"],
-                                        "fraction_of_forward_only": best["fraction_of_forward_only"]}
-            except Exception:
-                pass
             line["extra"] = extra
     if world > 1 or args.force_collectives:
         dist.destroy_process_group()
@@ -648,6 +737,12 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+        par = line.get("parity")
+        if par and par["mode"] == "bf16" and not par["max_abs_dlogit"] <= BF16_DLOGIT_LIMIT:
+            # loud: the throughput mode drifted out of its band against the oracle (observed 1.0-1.9e-2; tests/test_gpu_model.py BF16_TOL 0.025)
+            sys.stderr.write("bench.py: PARITY FAILURE: bf16 max |d logit| %.4g against the oracle exceeds %.3g -- the rate above is not a valid measurement\n"
+                             % (par["max_abs_dlogit"], BF16_DLOGIT_LIMIT))
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -150,3 +150,31 @@ def make_batch(B, cfg, seed=88, max_seq_len=70, img_seq_len=50, n_regions=None,
     return dict(img_feats=torch.from_numpy(img), input_ids=torch.from_numpy(ids),
                 segment_ids=torch.from_numpy(seg), attention_mask=torch.from_numpy(att),
                 mask_token_pos=torch.from_numpy(mpos), colors=torch.from_numpy(colors))
+
+
+def make_prediction_rows(n_rows, proposals=8, boxes=50, seed=0, dim=2054):
+    """Synthetic rows of a RefCOCO ``predictions.tsv`` in the reference's wire format (written by
+    ``inference_ref.py:157-191``, read by ``refcoco_zsl_cpt_dataset.py:161-180``): per row ``proposals`` painted copies of an image, each
+    a list of ``boxes`` detections whose ``feature`` is the base64 text of float32[dim] (non-negative like post-ReLU pooled CNN features).
+    Returns the rows' JSON payloads as bytes (about 4.4 MB each at 8 x 50); every row carries different features."""
+    import base64
+    import json
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(n_rows):
+        feats = np.maximum(rng.standard_normal((proposals, boxes, dim), dtype=np.float32), 0)
+        objs = [[{"rect": [1.0, 2.0, 30.0, 40.0], "bbox_id": j, "class": "dog", "conf": 0.9, "feature": base64.b64encode(feats[p, j].tobytes()).decode()}
+                 for j in range(boxes)] for p in range(proposals)]
+        rows.append(json.dumps({"objects": [objs, "a dog on the left", [["red"]] * proposals, [[[1, 2, 30, 40]]] * proposals]}).encode())
+    return rows
+
+
+def write_predictions_tsv(path, n_rows, proposals=8, boxes=50, seed=0):
+    """``make_prediction_rows`` as ``key \\t json`` lines plus the ``.lineidx`` companion the readers seek through."""
+    import os
+    from cpt_amd import io
+    with open(path, "wb") as f:
+        for i, r in enumerate(make_prediction_rows(n_rows, proposals, boxes, seed)):
+            f.write(b"img_%d\t" % i + r + b"\n")
+    io.generate_lineidx_file(path, os.path.splitext(path)[0] + ".lineidx")
+    return path

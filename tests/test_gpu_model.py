@@ -13,7 +13,7 @@ from cpt_amd import synth
 
 pytestmark = pytest.mark.gpu
 FP32_TOL = 1e-3          # north_star: [MASK] colour-token logits within 1e-3 of the fp32 reference CPU path
-BF16_TOL = 0.04          # bf16 throughput mode: max |d logit| observed 1.0-1.6e-2 on logits of range +-2.2 (<= 0.04)
+BF16_TOL = 0.025         # bf16 throughput mode: max |d logit| observed 1.0-1.9e-2 on logits of range +-2.2 (0.025; bench.py exits non-zero beyond 0.03)
 
 
 @pytest.fixture(scope="module")
