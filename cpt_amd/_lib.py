@@ -105,6 +105,8 @@ _SIGS = {
     "cpt_panel_pack": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_gemm_ln_prod3_panel": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int,
                                           C.c_int, C.c_int, vp]),
+    "cpt_panel_pack_bytes": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_gemm_ln_prod3_rpanel": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_resid3_split": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "cpt_resid3_merge": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_gemm_nn": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),

@@ -244,6 +244,23 @@ __device__ __forceinline__ void sum_parts(const float* __restrict__ st, int part
     }
 }
 
+// ---- the ONE summation order of a LayerNorm producer's partial row sums (round 5) -----------------------------------------------
+// A row's 96-column block (one slot of the [M][slots][2] table) is summed the same way by every epilogue, whatever its register layout,
+// so that a row's statistics -- and with them every later bit -- do not depend on the kernel that served it:
+//   the block's 24 four-column chunks c = 8 j + 2 q + h  (j = 32-column MFMA block 0..2, q = register quad 0..3, h = half-wave 0 / 1: the
+//   accumulator layout of the swapped-operand MFMA, lane = row) form 12 chunk pairs (j, qq, h) = chunks (j, 2 qq, h) and (j, 2 qq + 1, h);
+//   P(j, qq, h) = the pair's 8 values added one by one (rowsum_chunk_pair; squares by fma);
+//   T(qq, h) = (P(0, qq, h) + P(1, qq, h)) + P(2, qq, h);   S(h) = T(0, h) + T(1, h);   S = S(0) + S(1).
+// Register-direct epilogues (lane = row, half-wave h) keep T in registers and add the two half-waves; slab epilogues give the four
+// lanes of a row the roles (h, qq) = (part & 1, part >> 1) and add across qq, then across h.
+__device__ __forceinline__ void rowsum_chunk_pair(const f32x4& a, const f32x4& b, float& sm, float& sq) {
+    sm = a[0]; sq = a[0] * a[0];
+#pragma unroll
+    for (int e = 1; e < 4; ++e) { sm += a[e]; sq = fmaf(a[e], a[e], sq); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sm += b[e]; sq = fmaf(b[e], b[e], sq); }
+}
+
 // ---- round 3: fragment-major "panel" layout of a GEMM A operand + write-through output stores ------------------------------
 // panel[M / 32][K / 16][64][8] bf16 (gemm_prod.hip): the 16-byte unit holding columns [8 c8, 8 c8 + 8) of `row`; k16 = K / 16
 __device__ __forceinline__ unsigned panel_unit(int row, int c8, int k16) {

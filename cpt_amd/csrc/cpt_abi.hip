@@ -124,15 +124,15 @@ FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
 static int g_qkv_tiled = 1;    // form 3: read the K-tile-major weight copy (cpt_layer_fold.w_qkv_t) when the model carries one
 static int qkv_attn(int config, const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
                     const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads, int K,
-                    hipStream_t s, const void* W_tiled, int ctx_panel = 0) {
+                    hipStream_t s, const void* W_tiled, int ctx_panel = 0, int a_panel = 0) {
     if (config == 3) {
         if (cpt::qkv_attn3_eligible(L, heads, K)) {
             const bool tl = W_tiled && g_qkv_tiled;
-            return cpt::gemm_qkv_attn3(A, lda, tl ? W_tiled : W, ldw, bias, st_in, colc, cold, eps, hidden, mask, ctx, ldo, B, L, heads, K, s, tl ? 1 : 0, ctx_panel);
+            return cpt::gemm_qkv_attn3(A, lda, tl ? W_tiled : W, ldw, bias, st_in, colc, cold, eps, hidden, mask, ctx, ldo, B, L, heads, K, s, tl ? 1 : 0, ctx_panel, a_panel);
         }
         config = 1;
     }
-    if (ctx_panel) return CPT_ERR_SHAPE;
+    if (ctx_panel || a_panel) return CPT_ERR_SHAPE;
     return cpt::gemm_qkv_attn(A, lda, W, ldw, bias, st_in, colc, cold, eps, hidden, mask, ctx, ldo, B, L, heads, K, config, s);
 }
 
@@ -155,6 +155,7 @@ static int g_fuse_attn = 3;    // bf16, L <= 128: QKV projection + attention in 
 static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
 static int g_panel = 1;        // fused bf16 encoder: ctx and the FFN activation travel in the fragment-major panel layout and the LayerNorm producers read them straight into registers (gemm_prod.hip) where the shapes allow
 static int g_x3_fuse = 1;      // bf16x3 parity mode: split copies written by the producing kernels (FFN-up GELU epilogue, LayerNorm passes) instead of stand-alone split3 passes (cpt_set_tuning key 23)
+static int g_rpanel = 1;       // round 5: the residual stream itself travels in the panel layout and the LayerNorm producers run their register-direct epilogue (gemm_prod.hip RP; cpt_set_tuning key 30)
 static int g_prefetch = 1;     // panel mode: the 240-tile launches carry 16 workgroups that read the next launch's weights into the Infinity Cache (common.h prefetch_region)
 static int g_panel_ffn_multi = 1;   // panel layout for the FFN activation also when the producers run several rounds of tiles (cpt_set_tuning key 28; experiments)
 static int g_x3_attn = 1;      // bf16x3 parity mode: attention on bf16 MFMA with split operands (0: the fp32 MFMA kernel + a split3 pass over ctx)
@@ -164,7 +165,7 @@ static int g_resid3 = 1;       // fused bf16 encoder: residual stream in the 3-b
 
 int cpt_set_tuning(int key, int value) {
     if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
-        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_panel_ffn_multi = 1; cpt::set_lncons4(1); g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1;
+        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_panel_ffn_multi = 1; cpt::set_lncons4(1); g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1; g_rpanel = 1;
         cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
         cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_ffn_2pass_min_tiles(192); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0); cpt::set_lnb_rpb(0); cpt::set_bias_fuse(2); cpt::set_wgrad_pair(2); cpt::set_qkv_2pass(1); cpt::set_fwd_split2(1); g_x3_fuse = 1; cpt::set_attn_qt_all(1); cpt::set_prod_waves(0);
         return CPT_OK;
@@ -196,6 +197,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 25) { g_embed_pad = value; return CPT_OK; }
     if (key == 27) { g_x3_attn = value; return CPT_OK; }
     if (key == 28) { g_panel_ffn_multi = value; return CPT_OK; }
+    if (key == 30) { g_rpanel = value; return CPT_OK; }
     if (key == 29) { cpt::set_lncons4(value); return CPT_OK; }
     if (key == 26) { g_dec_pf_pct = value < 0 ? 0 : (value > 100 ? 100 : value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
@@ -288,6 +290,17 @@ int cpt_gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const floa
 int cpt_panel_pack(const void* src_bf16, int ld, void* dst_bf16, int M, int K, int to_panel, void* stream) {
     return check_launch(cpt::panel_pack(src_bf16, ld, dst_bf16, M, K, to_panel, (hipStream_t)stream), "cpt_panel_pack");
 }
+int cpt_panel_pack_bytes(const void* src_i8, int ld, void* dst_i8, int M, int K, int to_panel, void* stream) {
+    return check_launch(cpt::panel_pack(src_i8, ld, dst_i8, M, K, to_panel, (hipStream_t)stream, 1), "cpt_panel_pack_bytes");
+}
+int cpt_gemm_ln_prod3_rpanel(const void* A_panel, const void* W, int ldw, const float* bias, const void* resid_hi_panel, const void* resid_lo_panel,
+                             const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi_panel, void* out_lo_panel,
+                             float* st_out, int M, int N, int K, void* stream) {
+    if (!cpt::panel_eligible(M, N, K))
+        return fail(CPT_ERR_SHAPE, "cpt_gemm_ln_prod3_rpanel: needs M %% 128 == 0, N %% 192 == 0, K %% 256 == 0, K >= 512 (got M=%d N=%d K=%d)", M, N, K);
+    return check_launch(cpt::gemm_ln_prod3_panel(A_panel, W, ldw, bias, resid_hi_panel, resid_lo_panel, N, st_in, g_in, b_in, eps, hidden, out_hi_panel, out_lo_panel,
+                                                 st_out, N, M, N, K, (hipStream_t)stream, nullptr, 0, nullptr, 0, 1), "cpt_gemm_ln_prod3_rpanel");
+}
 
 int cpt_gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
                             const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi, void* out_lo,
@@ -361,6 +374,18 @@ size_t cpt_fwd_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li, int fla
         if (rc__ != CPT_OK) return rc__;         \
     } while (0)
 
+// Shapes / switches at which cpt_model_fwd keeps the residual stream in the panel layout (round 5): the full panel mode of the fused bf16 encoder --
+// 3-byte stream, (sequence, three heads) QKV + attention, two-pass FFN-up with panel output, both LayerNorm producers on the panel kernel.
+static bool rpanel_mode(const cpt_dims& d, int B, int Lt, int Li, int flags, bool has_fold) {
+    const int L = Lt + Li, M = B * L, H = d.hidden, I = d.inter;
+    if (d.dtype != CPT_BF16 || !has_fold || !g_fold_ln || g_lp_resid || !g_resid3 || !g_panel || !g_rpanel) return false;
+    if (flags & CPT_ATTN_MASK_3D) return false;
+    if (!(g_fuse_attn == 3 && L <= 128 && H % 64 == 0 && cpt::qkv_attn3_eligible(L, d.heads, H))) return false;
+    if (!cpt::ffn_up_2pass_preferred(M, I, H) || !cpt::panel_eligible(M, H, H) || !cpt::panel_eligible(M, H, I)) return false;
+    if (!((long)(M / 128) * (H / 192) <= 256 || g_panel_ffn_multi)) return false;
+    return cpt::lncons4_enabled() < 2;
+}
+
 int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, int flags,
                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || !b || !o || !workspace) return fail(CPT_ERR_NULL, "cpt_model_fwd: null argument");
@@ -424,18 +449,24 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const bool r3 = fold && g_resid3;
     void* x_lo = x_f32;
     void* a_lo = a_f32;
+    // Round 5: at the shapes of the full panel mode (below) the residual stream itself travels in the panel layout [M / 32][H / 16][64][8]
+    // (hi as bf16, lo as bytes): the LayerNorm producers run a register-direct epilogue and the two consumers gather their A tiles out of it.
+    // The embedding and region LayerNorm launches write their rows at their panel positions, the heads gather their rows out of it.
+    const bool rpanel = rpanel_mode(d, B, Lt, Li, flags, m->fold != nullptr);
+    void* e_lp = x_lp;
+    void* e_lo = x_lo;
     // (a2) text embeddings -> rows b*L + t.  bf16 with the 3-byte stream: the same launch also converts the region features (rowops.hip embed_pad_kernel)
     const bool embed_pad = r3 && Li > 0 && g_embed_pad && d.img_dim_pad % 8 == 0 && ((uintptr_t)b->img_feats % 8) == 0;
     if (embed_pad) {
         Scope p(CPT_K_EMBED, s);
         TRY(cpt::embed_ln_pad_cast(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, d.ln_eps,
-                                   x_lp, x_lo, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, b->img_feats, ws + w.imgp, B * Li, d.img_dim, d.img_dim_pad, s),
+                                   e_lp, e_lo, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, b->img_feats, ws + w.imgp, B * Li, d.img_dim, d.img_dim_pad, s, rpanel),
             "embed_ln + pad_cast(img_feats)");
     } else {
         Scope p(CPT_K_EMBED, s);
         TRY(cpt::embed_ln(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb,
-                          m->emb_ln_g, m->emb_ln_b, d.ln_eps, r3 ? nullptr : x_f32, lp ? x_lp : nullptr, dt, B, Lt, L, H,
-                          d.vocab, d.max_pos, d.type_vocab, s, r3 ? x_lo : nullptr), "embed_ln");
+                          m->emb_ln_g, m->emb_ln_b, d.ln_eps, r3 ? nullptr : x_f32, lp ? e_lp : nullptr, dt, B, Lt, L, H,
+                          d.vocab, d.max_pos, d.type_vocab, s, r3 ? e_lo : nullptr, rpanel), "embed_ln");
     }
     // (a3,a4) region projection -> rows b*L + Lt + i
     if (Li > 0) {
@@ -448,8 +479,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         else TRY(gm(CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, pre, CPT_F32, H, B * Li, H), "gemm(img_embedding)");
         const bool iln = d.use_img_ln && m->img_ln_g;
         TRY(cpt::layernorm_rows_ex(pre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, r3 ? nullptr : x_f32,
-                                   lp ? x_lp : nullptr, dt, B * Li, H, Li, L, Lt, 0, s, split2 ? pre + (size_t)B * Li * H : nullptr, nullptr, nullptr,
-                                   r3 ? x_lo : nullptr), "layernorm(img)");
+                                   lp ? e_lp : nullptr, dt, B * Li, H, Li, L, Lt, 0, s, split2 ? pre + (size_t)B * Li * H : nullptr, nullptr, nullptr,
+                                   r3 ? e_lo : nullptr, 1, 0, rpanel), "layernorm(img)");
     }
     // (a5-a9) encoder
     const int mask3 = (flags & CPT_ATTN_MASK_3D) ? 1 : 0;
@@ -462,10 +493,12 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const bool two_kernel = lp && !fuse_attn && !mask3;        // L > 128 (the GQA shape): QKV GEMM, then the stand-alone attention kernel writes the panel
     const bool panel = r3 && g_panel && (fused3 || two_kernel) && cpt::ffn_up_2pass_preferred(M, I, H) &&
                        cpt::panel_eligible(M, H, H) && cpt::panel_eligible(M, H, I);
+    if (rpanel && !(panel && fused3)) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: panel residual mode outside the full panel mode");
     // h (FFN-up -> FFN-down) in the panel layout.  Round 3 kept it row-major when the producers run several rounds of tiles (GQA shape, 1680 tiles:
     // the 8-wave panel producer lost to the row-major kernel there, 4.05 vs 3.84 ms per step); with round 4's 4-wave producer the panel form wins
     // there too (3.63 ms; cpt_set_tuning key 28 = 0 restores the row-major FFN activation for multi-round shapes)
     const bool panel_ffn = panel && ((long)(M / 128) * (H / 192) <= 256 || g_panel_ffn_multi);
+    if (rpanel && !panel_ffn) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: panel residual mode without the panel FFN activation");
     const bool pfw = panel && g_prefetch;           // spare workgroups prefetch the next launch's weights (common.h prefetch_region)
     if (fold) {
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
@@ -482,9 +515,9 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
             if (fuse_attn) {
               Scope p(CPT_K_GEMM_QKV, s);      // QKV projection + attention, one kernel; q/k/v never reach HBM
               if (l == 0) TRY(qkv_attn(g_fuse_attn, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, nullptr, nullptr, d.ln_eps, H, b->attn_mask, ctx, H,
-                                                 B, L, d.heads, H, s, f.w_qkv_t, panel), "gemm(qkv)+attention");
+                                                 B, L, d.heads, H, s, f.w_qkv_t, panel, rpanel), "gemm(qkv)+attention");
               else TRY(qkv_attn(g_fuse_attn, x_lp, H, f.w_qkv_f, H, nullptr, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, b->attn_mask, ctx, H,
-                                          B, L, d.heads, H, s, f.w_qkv_t, panel), "gemm(qkv, folded LN)+attention");
+                                          B, L, d.heads, H, s, f.w_qkv_t, panel, rpanel), "gemm(qkv, folded LN)+attention");
             } else {
             { Scope p(CPT_K_GEMM_QKV, s);
               if (l == 0) TRY(cpt::gemm(dt, CPT_EPI_NONE, x_lp, H, y.w_qkv, H, y.b_qkv, nullptr, 0, qkv, dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
@@ -494,7 +527,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
             }
             { Scope p(CPT_K_GEMM_AO, s);
               if (panel) TRY(cpt::gemm_ln_prod3_panel(ctx, y.w_ao, H, y.b_ao, x_lp, x_lo, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
-                                                      a_lp, a_lo, st1, H, M, H, H, s, pfw ? f.w_in_f : nullptr, (size_t)I * H * 2), "gemm(attn out, LN producer, panel A)");
+                                                      a_lp, a_lo, st1, H, M, H, H, s, pfw ? f.w_in_f : nullptr, (size_t)I * H * 2, nullptr, 0, rpanel), "gemm(attn out, LN producer, panel A)");
               else
               if (r3) TRY(cpt::gemm_ln_prod3(ctx, H, y.w_ao, H, y.b_ao, x_lp, x_lo, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
                                              a_lp, a_lo, st1, H, M, H, H, s), "gemm(attn out, LN producer, 3-byte residual)");
@@ -502,7 +535,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
               TRY(cpt::gemm_ln_prod(ctx, H, y.w_ao, H, y.b_ao, x_f32, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
                                     a_f32, a_lp, st1, H, M, H, H, s), "gemm(attn out, LN producer)"); }
             { Scope p(CPT_K_GEMM_FFN1, s);
-              TRY(cpt::gemm_ln_cons(a_lp, H, f.w_in_f, H, st1, f.c_in, f.d_in, d.ln_eps, H, 1, ffn, I, M, I, H, s, panel_ffn, pfw ? y.w_out : nullptr, (size_t)H * I * 2), "gemm(ffn up, folded LN)"); }
+              TRY(cpt::gemm_ln_cons(a_lp, H, f.w_in_f, H, st1, f.c_in, f.d_in, d.ln_eps, H, 1, ffn, I, M, I, H, s, panel_ffn, pfw ? y.w_out : nullptr, (size_t)H * I * 2, rpanel), "gemm(ffn up, folded LN)"); }
             { Scope p(CPT_K_GEMM_FFN2, s);
               if (panel_ffn) {
                   // next layer's QKV weight (the copy its launch will read) and attention-output weight
@@ -518,7 +551,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                       na = nullptr; nab = 0;
                   }
                   TRY(cpt::gemm_ln_prod3_panel(ffn, y.w_out, I, y.b_out, a_lp, a_lo, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_lp, x_lo, st2, H, M, H, I, s,
-                                               nq, nqb, na, nab), "gemm(ffn down, LN producer, panel A)");
+                                               nq, nqb, na, nab, rpanel), "gemm(ffn down, LN producer, panel A)");
               } else
               if (r3) TRY(cpt::gemm_ln_prod3(ffn, I, y.w_out, I, y.b_out, a_lp, a_lo, H, st1, y.ln1_g, y.ln1_b, d.ln_eps, H, x_lp, x_lo, st2, H, M, H, I, s),
                           "gemm(ffn down, LN producer, 3-byte residual)");
@@ -530,7 +563,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         const cpt_layer& yl = m->layers[d.layers - 1];
         if (flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) {
             Scope p(CPT_K_LN, s);
-            if (r3) TRY(cpt::r3_merge(x_lp, x_lo, nullptr, pre, M, L, H, 0, s), "resid3_merge(all rows)");   // (x_lo lives in the x_f32 region)
+            if (r3) TRY(cpt::r3_merge(x_lp, x_lo, nullptr, pre, M, L, H, 0, s, rpanel), "resid3_merge(all rows)");   // (x_lo lives in the x_f32 region)
             TRY(cpt::layernorm_rows(r3 ? pre : x_f32, yl.ln2_g, yl.ln2_b, d.ln_eps, x_f32, x_lp, dt, M, H, M, 0, 0, s), "layernorm(final)");
         }
     } else
@@ -587,7 +620,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         if (pre_ln) {
             const cpt_layer& yl = m->layers[d.layers - 1];
             float* rf = (float*)(ws + w.rows_f32);
-            if (r3) TRY(cpt::r3_merge(x_lp, x_lo, nullptr, rf, B, L, H, 1, s), "resid3_merge([CLS] pre-LN)");
+            if (r3) TRY(cpt::r3_merge(x_lp, x_lo, nullptr, rf, B, L, H, 1, s, rpanel), "resid3_merge([CLS] pre-LN)");
             else TRY(cpt::gather_rows(x_f32, CPT_F32, nullptr, rf, B, L, H, s), "gather([CLS] pre-LN)");
             TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, rows, dt, B, H, B, 0, 0, s), "layernorm([CLS] rows)");
         } else
@@ -621,7 +654,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                 const cpt_layer& yl = m->layers[d.layers - 1];
                 float* rf = (float*)(ws + w.rows_f32);
                 if (r3) TRY(cpt::head_rows_ln3(x_lp, x_lo, b->mask_pos, yl.ln2_g, yl.ln2_b, d.ln_eps, g, B, L, H, s,
-                                               g_prefetch ? m->w_dec : nullptr, dec_pf0), "gather + merge + layernorm([MASK] rows)");
+                                               g_prefetch ? m->w_dec : nullptr, dec_pf0, rpanel), "gather + merge + layernorm([MASK] rows)");
                 else {
                 TRY(cpt::gather_rows(x_f32, CPT_F32, b->mask_pos, rf, B, L, H, s), "gather([MASK] pre-LN)");
                 TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, g, dt, B, H, B, 0, 0, s), "layernorm([MASK] rows)");

@@ -618,6 +618,7 @@ __device__ __forceinline__ void gemm_pipe_body(
                     }
                 }
                 float sm = 0.f, sq = 0.f;
+                float tsm[2] = {0.f, 0.f}, tsq[2] = {0.f, 0.f};      // row sums in the library's one order (common.h rowsum_chunk_pair)
                 float m_i = mu0, r_i = rs0;
                 if (i > 0) row_stats(i, m_i, r_i);
 #pragma unroll
@@ -625,6 +626,7 @@ __device__ __forceinline__ void gemm_pipe_body(
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
                         u32x2 pk[2];
+                        f32x4 xs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int g = 2 * gp + h;
@@ -640,7 +642,7 @@ __device__ __forceinline__ void gemm_pipe_body(
                                     x[e] = acc[i][j][4 * g + e] + b4[e] + ln_apply(rq[j * 4 + g][e], m_i, r_i, g4[e], t4[e]);
                                 if (rok && cok && !(abl & 64)) *reinterpret_cast<f32x4*>(out + (size_t)row * ldo + c) = x;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) { sm += cok ? x[e] : 0.f; sq += cok ? x[e] * x[e] : 0.f; }
+                                for (int e = 0; e < 4; ++e) xs[h][e] = cok ? x[e] : 0.f;
                             } else {
                                 const f32x4 c4 = *reinterpret_cast<const f32x4*>(sd + lc);
                                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + WC + lc);
@@ -664,8 +666,14 @@ __device__ __forceinline__ void gemm_pipe_body(
                         const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
                         const int c8 = wcol0 + j * 32 + 16 * gp + 8 * fh;
                         if (rok && (FULL || c8 < N) && !(abl & 64)) *reinterpret_cast<u32x4*>(out_lp + (size_t)row * ldo + c8) = w;
+                        if constexpr (LNPROD) {
+                            float ps, pq;
+                            rowsum_chunk_pair(xs[0], xs[1], ps, pq);
+                            if (j == 0) { tsm[gp] = ps; tsq[gp] = pq; } else { tsm[gp] += ps; tsq[gp] += pq; }
+                        }
                     }
                 if constexpr (LNPROD) {
+                    sm = tsm[0] + tsm[1]; sq = tsq[0] + tsq[1];
                     sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
                     static_assert(!LNPROD || WC == 96, "statistics slots are 96 columns wide");
                     if (fh == 0 && rok)
@@ -1028,16 +1036,19 @@ __device__ __forceinline__ void gemm_pipe_body(
                 // into this wave's own slot (column block wcol0 / 96) of the partial-sum table
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const int r16 = lane >> 2, part = lane & 3;
+                static_assert(!LNPROD || WCOLS == 96, "statistics slots are 96 columns wide");
+                // the library's ONE order of a row's partial sums over a 96-column block (common.h rowsum_chunk_pair): lane `part` = (h, qq)
                 float sm = 0.f, sq = 0.f;
 #pragma unroll
-                for (int k = 0; k < CH / 4; ++k) {
-                    const f32x4 f = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (part * (CH / 4) + k) * 16);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { sm += f[e]; sq += f[e] * f[e]; }
+                for (int j = 0; j < 3; ++j) {
+                    const f32x4 f0 = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (j * 8 + 4 * (part >> 1) + (part & 1)) * 16);
+                    const f32x4 f1 = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (j * 8 + 4 * (part >> 1) + 2 + (part & 1)) * 16);
+                    float ps, pq;
+                    rowsum_chunk_pair(f0, f1, ps, pq);
+                    if (j == 0) { sm = ps; sq = pq; } else { sm += ps; sq += pq; }
                 }
-                sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
                 sm += __shfl_xor(sm, 2, 64); sq += __shfl_xor(sq, 2, 64);
-                static_assert(!LNPROD || WCOLS == 96, "statistics slots are 96 columns wide");
+                sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
                 const int srow = wrow0 + sl * 16 + r16;
                 if (part == 0 && srow < M)
                     *reinterpret_cast<float2*>(ex.st_out + 2 * ((size_t)srow * ex.st_out_slots + wcol0 / WCOLS)) = float2{sm, sq};
@@ -1673,8 +1684,9 @@ int g_qkv_2pass = 1;
 void set_qkv_2pass(int v) { g_qkv_2pass = v; }
 
 int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
-                 float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s, int out_panel, const void* pf, size_t pf_bytes) {
+                 float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s, int out_panel, const void* pf, size_t pf_bytes, int a_panel) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || ldw % 8) return CPT_ERR_SHAPE;
+    if (a_panel && (!out_panel || lncons4_enabled() >= 2)) return CPT_ERR_SHAPE;      // A from the panel residual stream: the two-pass kernel with panel output only (ln_cons_takes_panel_a)
     if (!A || !Wf || !st_in || !colc || !cold || !out_lp) return CPT_ERR_NULL;
     if (N % 8 || ldo % 8 || (((uintptr_t)out_lp | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
     EpiX ex = {};
@@ -1684,7 +1696,7 @@ int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* s
         if (!gelu || !ffn_up_2pass_legal(M, N, K)) return CPT_ERR_SHAPE;
         if (lncons4_enabled() >= 2) return gemm_lncons4(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, s, 1, pf, pf_bytes, 1);
         void* tr = ((g_trace_epi < 0 || g_trace_epi == CPT_EPI_LNCONS_GELU) && (g_trace_k == 0 || g_trace_k == K)) ? (void*)g_gemm_trace : nullptr;
-        return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, tr, g_gemm_abl, s, 1, pf, pf_bytes);
+        return gemm_ffn_up_2pass(A, lda, Wf, ldw, st_in, ln_stat_parts(hidden), colc, cold, eps, hidden, out_lp, ldo, M, N, K, tr, g_gemm_abl, s, 1, pf, pf_bytes, 1, a_panel);
     }
     // round 4: the 4-wave consumer kernel (gemm_ffn4.hip, 192 x 256 tiles) where ITS tiles fill their rounds clearly better than the two-pass
     // kernel's 384 x 256 ones: Oscar-large FFN-up, M = 8480, N = 4096: 720 tiles = 2.8 rounds (94 % of three) against 368 = 1.44 (72 % of two):

@@ -56,7 +56,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #endif
 // GELU = false (round 3): the same kernel as a plain LayerNorm-consumer GEMM -- the stand-alone QKV projection of the shapes whose attention
 // does not fuse (L > 128: GQA 165 + 45, VCR 165 + 100), which ran on the 384 x 192 pipe kernel at 2/3 of this kernel's rate per CU.
-template <int NT, bool LATE = true, bool PANEL = false, bool GELU = true, bool PIPE = (CPT_FFN_PIPE != 0)>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
+// APANEL (round 5): A is the residual stream's hi part in the panel layout [M / 32][K / 16][64][8] (gemm_prod.hip RP; lda ignored, M % 32 == 0): every
+// LDS-DMA piece is one contiguous KiB unit of the panel and keeps that layout in LDS, so the A fragment reads are lane-linear (no swizzle).
+// (First version: the row-major LDS image gathered from the panel -- eight 128-byte runs per piece, sixteen cache lines per 16 lanes: +2.8 us per launch.)
+template <int NT, bool LATE = true, bool PANEL = false, bool GELU = true, bool PIPE = (CPT_FFN_PIPE != 0), bool APANEL = false>       // K-tiles per pass: K = 64 NT; LATE: the refill DMA is issued behind the first k-step after the barrier
 __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                                                               bf16* __restrict__ out, int ldo, int M, int N,
                                                               const float* __restrict__ st_in, int st_parts, const float* __restrict__ colc,
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
         n0 = (in_g / gsz) * TN;
     }
 
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)(APANEL ? ((M + 31) & ~31) : M) * (APANEL ? 64 * NT : lda) * 2, (size_t)0x7fffffff), 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)min((size_t)((M + 31) & ~31) * (PANEL ? N : ldo) * 2, (size_t)0x7fffffff), 0x00020000);
     const int rbase = wave * 8 + (lane >> 3);
@@ -110,12 +113,21 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
     auto stage_a = [&](int sa, int it) {
         if (abl & 1) return;
         const int pass = it >= NT ? 1 : 0;
-        const int soff = (it - pass * NT) * 64 * 2;
+        const int soff = (it - pass * NT) * (APANEL ? 4096 : 64 * 2);
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
             auto lds = (__attribute__((address_space(3))) void*)(smem + sa * A_SLOT + (i * NWV + wave) * 1024);
+            if constexpr (APANEL) {
+                // piece p = i NWV + wave IS one 1 KiB unit of the panel: row block p / 4 of the half-tile, k16 unit p % 4 of the K-tile; the LDS image keeps
+                // the unit as it is (lane l = row l % 32, k half l / 32: the MFMA operand order), so the fragment reads below are lane-linear
+                const int p = i * NWV + wave;
+                const unsigned rb = (unsigned)min((m0 + pass * HM) / 32 + (p >> 2), (M >> 5) - 1);
+                const unsigned vo = (rb * (unsigned)(NT * 4) + (unsigned)(p & 3)) * 1024u + (unsigned)lane * 16u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lds, 16, vo, soff, 0, 0);
+            } else {
             const unsigned vo = (unsigned)min(m0 + pass * HM + rbase + i * NWV * 8, M - 1) * (unsigned)(lda * 2) + c16;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lds, 16, vo, soff, 0, 0);
+            }
         }
     };
     auto stage_w = [&](int sw, int it) {
@@ -173,7 +185,11 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
     const unsigned abase = (unsigned)(wm * 96 + fr) * RB, wbase = (unsigned)W_RING + (unsigned)(wn * 64 + fr) * RB;
     const unsigned sx = (unsigned)((fr >> 1) & 7);
     auto coff = [&](int ks) { return (((unsigned)(ks * 2 + fh)) ^ sx) << 4; };
-    auto rd_a = [&](int i, int sa, int ks) { if (abl & 2) return; fa[i] = *reinterpret_cast<const bf16x8*>(smem + abase + coff(ks) + (unsigned)(sa * A_SLOT) + i * 32 * RB); };
+    auto rd_a = [&](int i, int sa, int ks) {
+        if (abl & 2) return;
+        if constexpr (APANEL) fa[i] = *reinterpret_cast<const bf16x8*>(smem + (unsigned)(sa * A_SLOT) + (unsigned)(((wm * 3 + i) * 4 + ks) * 1024) + (unsigned)lane * 16u);
+        else fa[i] = *reinterpret_cast<const bf16x8*>(smem + abase + coff(ks) + (unsigned)(sa * A_SLOT) + i * 32 * RB);
+    };
     auto rd_b = [&](int b, int sw, int ks) {
         if (abl & 2) return;
 #pragma unroll
@@ -421,11 +437,11 @@ __global__ __launch_bounds__(512, 2) void ffn_up_2pass_kernel(const bf16* __rest
 #endif
 }
 
-template <int NT, bool LATE = true, bool PANEL = false, bool GELU = true>
+template <int NT, bool LATE = true, bool PANEL = false, bool GELU = true, bool APANEL = false>
 int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int ldo, int M, int N, const float* st_in, int st_parts,
                  const float* colc, const float* cold, float eps, float inv_h, long long* trace, int abl, hipStream_t s,
                  const void* pf = nullptr, size_t pf_bytes = 0) {
-    auto kern = ffn_up_2pass_kernel<NT, LATE, PANEL, GELU>;
+    auto kern = ffn_up_2pass_kernel<NT, LATE, PANEL, GELU, (CPT_FFN_PIPE != 0), APANEL>;
     static bool attr_done_dev[CPT_MAX_DEV] = {};
     bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
@@ -458,8 +474,9 @@ int ffn_up_2pass_preferred(int M, int N, int K) {
 
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
                       float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s, int out_panel,
-                      const void* pf, size_t pf_bytes, int gelu) {
+                      const void* pf, size_t pf_bytes, int gelu, int a_panel) {
     if (!ffn_up_2pass_legal(M, N, K)) return CPT_ERR_SHAPE;
+    if (a_panel && (!gelu || !out_panel || M % 32)) return CPT_ERR_SHAPE;          // the panel-in form exists for the fused encoder's FFN-up only
     if (!gelu) {        // plain LayerNorm-consumer form (QKV projection): row-major output only
         if (out_panel) return CPT_ERR_SHAPE;
         if (lda % 8 || ldw % 8 || ldo % 8 || (((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)out | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
@@ -470,6 +487,10 @@ int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const flo
     if (out_panel) {
         if (N % 16) return CPT_ERR_SHAPE;
         if ((uintptr_t)pf & 15) pf = nullptr;          // (a prefetch region is a hint: dropped when the 16-byte loads cannot take it)
+        if (a_panel) {
+            if (K == 768) return launch_2pass<12, true, true, true, true>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s, pf, pf_bytes);
+            return launch_2pass<16, true, true, true, true>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s, pf, pf_bytes);
+        }
         if (K == 768) return launch_2pass<12, true, true>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s, pf, pf_bytes);
         return launch_2pass<16, true, true>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, 1.0f / (float)hidden, (long long*)trace, abl, s, pf, pf_bytes);
     }

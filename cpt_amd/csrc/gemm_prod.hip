@@ -65,7 +65,14 @@ __device__ __forceinline__ void a_load(u32x4& d, unsigned voff, const i32x4& rs,
 // A load instructions), 2 = no A loads, 3 = no W LDS-DMA, 4 = refill issued right behind the barrier (correct results)
 // SITE (round 4): 0 = short contraction (K <= 1024: the attention-output projection), 1 = long (FFN-down).  Not used by the code: it gives
 // the two launches of a layer DISTINCT kernel symbols, so that rocprofv3's per-kernel statistics separate them.
-template <int ABL, int NWV, int SITE>
+// RP (round 5): the RESIDUAL STREAM travels in the panel layout too -- resid_hi / out_hi as [M / 32][N / 16][64][8] bf16 (exactly the A operand
+// panel the next GEMM reads), resid_lo / out_lo as [M / 32][N / 16][64][8] bytes -- and the MFMA operands are swapped (lane = output row,
+// register quad = 4 consecutive columns), so the epilogue needs NO LDS slab: a lane's residual columns arrive as one 16-byte + one 8-byte
+// load from a contiguous KiB per wave instruction, two v_permlane32_swap put them in the accumulator's quad order, per-row statistics are
+// per-lane scalars, the row sums are in-lane chains + one cross-half add, and the stores leave the same way.  No barrier between the K loop
+// and the epilogue (nothing reuses the ring).  Same arithmetic per element and the same order in the row sums as the slab epilogue:
+// bit-identical results (tests/test_gpu_ops.py).
+template <int ABL, int NWV, int SITE, bool RP = false>
 __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     const bf16* __restrict__ Ap, const bf16* __restrict__ W, int ldw, const float* __restrict__ bias,
     const bf16* __restrict__ resid_hi, const signed char* __restrict__ resid_lo, int ldr,
@@ -164,6 +171,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     const bool fold_resid = g_in != nullptr;
     constexpr int NSIDE = 7;
     f32x4 sd_b, sd_g, sd_t, sd_s[4];
+    float2 ms_reg = {0.f, 1.f};        // RP: (mean, rstd) of this lane's row of the residual's LayerNorm
 #define CPT_SIDE_LOADS()                                                                                                        \
     do {                                                                                                                        \
         const int c4 = wcol0 + min(lane, WCOLS / 4 - 1) * 4;                                                                              \
@@ -205,7 +213,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     do {                                                                                                           \
         const bf16x8 a_ = __builtin_bit_cast(bf16x8, afr[BUF][KS]);                                                 \
         _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_)                                                           \
-            acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][j_], acc[j_], 0, 0, 0);                    \
+            acc[j_] = RP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[KS][j_], a_, acc[j_], 0, 0, 0)                \
+                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][j_], acc[j_], 0, 0, 0);               \
     } while (0)
 
     wait_vm<(CPT_PROD_SIDE == 2 ? NSIDE : 0) + 2 * GA + 3 * GW>();            // tile 0 landed: younger than W(0) are the side data, A(1) A(2), W(1) W(2) W(3)
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     do {                                                                                                                        \
         asm volatile("" : "+v"(sd_b), "+v"(sd_g), "+v"(sd_t), "+v"(sd_s[0]), "+v"(sd_s[1]), "+v"(sd_s[2]), "+v"(sd_s[3]));       \
         unsigned char* side_ = smem + RING_BYTES + wave * SIDE;                                                                  \
-        if (lane < 32) {                                                                                                         \
+        if (RP || lane < 32) {                                                                                                   \
             float2 ms = {0.f, 1.f};                                                                                              \
             if (fold_resid) {     /* the arithmetic of sum_parts_n<4> (slot order, unused slots skipped by select) */           \
                 float sum = 0.f, sq = 0.f;                                                                                       \
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
                 }                                                                                                                \
                 ln_mean_rstd(sum, sq, inv_h, eps, ms.x, ms.y);                                                                   \
             }                                                                                                                    \
-            reinterpret_cast<float2*>(side_)[lane] = ms;                                                                         \
+            if (RP) ms_reg = ms; else reinterpret_cast<float2*>(side_)[lane] = ms;                                                \
         }                                                                                                                        \
         if (lane < WCOLS / 4) {                                                                                                  \
             *reinterpret_cast<f32x4*>(side_ + 256 + lane * 16) = fold_resid ? sd_g : f32x4{1.f, 1.f, 1.f, 1.f};                  \
@@ -243,8 +252,21 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     // residual rows of the first epilogue slice (16 rows x 96 columns per wave: 16-byte hi + 8-byte lo per lane, three per lane), by asm loads
     constexpr int C8 = WCOLS / 8, NIT = 16 * C8 / 64;
     u32x4 ax0h[NIT]; u32x2_t ax0l[NIT];
+    // RP: the wave tile's residual = KB consecutive KiB (hi) / half-KiB (lo) units of the panel, one unit per 16 columns; lane l takes bytes 16 l / 8 l
+    constexpr int KB = WCOLS / 16;
+    u32x4 rph[RP ? KB : 1]; u32x2_t rpl[RP ? KB : 1];
+    const size_t rp_unit0 = (size_t)(wrow0 >> 5) * (size_t)(N >> 4) + (size_t)(wcol0 >> 4);        // first unit of this wave's tile (same for resid and out)
 #define CPT_AUX0()                                                                                                              \
     do {                                                                                                                        \
+        if constexpr (RP) {                                                                                                     \
+            const unsigned char* ph_ = reinterpret_cast<const unsigned char*>(resid_hi) + rp_unit0 * 1024 + lane * 16;           \
+            const unsigned char* pl_ = reinterpret_cast<const unsigned char*>(resid_lo) + rp_unit0 * 512 + lane * 8;             \
+            _Pragma("unroll") for (int kb = 0; kb < KB; ++kb) {                                                                  \
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rph[kb]) : "v"(ph_ + kb * 1024));                          \
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rpl[kb]) : "v"(pl_ + kb * 512));                           \
+            }                                                                                                                   \
+            break;                                                                                                              \
+        }                                                                                                                       \
         _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                                    \
             const int idx = it * 64 + lane, rr = idx / C8, c8 = idx % C8;                                                         \
             const size_t off = (size_t)(wrow0 + rr) * ldr + wcol0 + c8 * 8;                                                       \
@@ -296,7 +318,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     // Issue order per wave: A(0) W(0) side A(1) A(2) W(1) W(2) W(3) | iteration t: A(t+3) ... W(t+4).  "Tile t+1 landed" leaves in flight what is
     // younger than A(t+1): W(t+2) A(t+2) W(t+3) A(t+3) = 2 GW + 2 GA (t = 0: younger than W(1): W(2) W(3) A(3) = 2 GW + GA);
     // t = nt-3: W(nt-1) A(nt-1) = GW + GA; t = nt-2: nothing.
-#define CPT_MF1(BUF, KS, J) acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[BUF][KS]), fb[KS][J], acc[J], 0, 0, 0)
+#define CPT_MF1(BUF, KS, J) acc[J] = RP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[KS][J], __builtin_bit_cast(bf16x8, afr[BUF][KS]), acc[J], 0, 0, 0) \
+                                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[BUF][KS]), fb[KS][J], acc[J], 0, 0, 0)
 #define CPT_RD1(SLOT, KS, J) fb[KS][J] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * W_SLOT + ldsoff((J) * 32 + fr, (KS) * 2 + fh))
 #define CPT_AL1(BUF, T, KS) do { if (ABL != 2) a_load<(KS) * 1024>(afr[BUF][KS], voffa, rsA, a_base + (T) * 4096); } while (0)
 #define CPT_SW1(SLOT, T, I)                                                                                                      \
@@ -401,6 +424,92 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     // ---- epilogue: gemm.hip's per-wave slab epilogue (CPT_EPI_LNPROD3, interior-tile instance): the same arithmetic per element and the
     // same order in the row sums (bit-identical outputs), but EIGHT columns per lane in the read-back instead of four: half the
     // vector-memory instructions, 16-byte hi / 8-byte lo accesses, and the stores write-through (common.h CPT_ST_AUX).
+    if constexpr (RP) {
+        // ---- register-direct epilogue on the panel residual stream (see the kernel's head comment) ----
+        unsigned char* side = smem + RING_BYTES + wave * SIDE;
+        const float* side_g = reinterpret_cast<const float*>(side + 256);
+        const float* side_t = side_g + WCOLS;
+        const float* side_b = side_t + WCOLS;
+        if (CPT_PROD_SIDE == 0) {     // A/B: side data fetched here
+            float2 ms = {0.f, 1.f};
+            if (fold_resid) {
+                float sum, sq;
+                sum_parts(st_in, st_in_parts, wrow0 + fr, sum, sq);
+                ln_mean_rstd(sum, sq, inv_h, eps, ms.x, ms.y);
+            }
+            ms_reg = ms;
+            if (lane < WCOLS / 4) {
+                float* sg = reinterpret_cast<float*>(side + 256);
+                *reinterpret_cast<f32x4*>(sg + lane * 4) = fold_resid ? *reinterpret_cast<const f32x4*>(g_in + wcol0 + lane * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+                *reinterpret_cast<f32x4*>(sg + WCOLS + lane * 4) = fold_resid ? *reinterpret_cast<const f32x4*>(b_in + wcol0 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(sg + 2 * WCOLS + lane * 4) = bias ? *reinterpret_cast<const f32x4*>(bias + wcol0 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!CPT_PROD_AUX0) {
+            const unsigned char* ph = reinterpret_cast<const unsigned char*>(resid_hi) + rp_unit0 * 1024 + lane * 16;
+            const unsigned char* pl = reinterpret_cast<const unsigned char*>(resid_lo) + rp_unit0 * 512 + lane * 8;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                rph[kb] = *reinterpret_cast<const u32x4*>(ph + kb * 1024);
+                rpl[kb] = *reinterpret_cast<const u32x2_t*>(pl + kb * 512);
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(rph[kb]), "+v"(rpl[kb]));
+        }
+        const auto rsH = __builtin_amdgcn_make_buffer_rsrc((void*)out_hi, 0, (int)min((size_t)M * N * 2, (size_t)0x7fffffff), 0x00020000);
+        const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)out_lo, 0, (int)min((size_t)M * N, (size_t)0x7fffffff), 0x00020000);
+        const unsigned so_h = (unsigned)__builtin_amdgcn_readfirstlane((int)(rp_unit0 * 1024)), so_l = (unsigned)__builtin_amdgcn_readfirstlane((int)(rp_unit0 * 512));
+        const float mu = ms_reg.x, rs = ms_reg.y;
+#pragma unroll
+        for (int hb = 0; hb < WCOLS / 96; ++hb) {
+            float tsm[2], tsq[2];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const int j = hb * 3 + jj;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int kb = j * 2 + kk;
+                    // panel unit -> the two accumulator quads of this lane: q = 2 kk (columns 16 kk + 4 h ..) and q = 2 kk + 1 (+ 8)
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(rph[kb][0], rph[kb][2], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(rph[kb][1], rph[kb][3], false, false);
+                    const auto sl = __builtin_amdgcn_permlane32_swap(rpl[kb][0], rpl[kb][1], false, false);
+                    const f32x4 rA = r3_decode(u32x2_t{s0[0], s1[0]}, sl[0]);
+                    const f32x4 rB = r3_decode(u32x2_t{s0[1], s1[1]}, sl[1]);
+                    const int lcA = j * 32 + 16 * kk + 4 * fh, lcB = lcA + 8;
+                    const f32x4 bA = *reinterpret_cast<const f32x4*>(side_b + lcA), bB = *reinterpret_cast<const f32x4*>(side_b + lcB);
+                    const f32x4 gA = *reinterpret_cast<const f32x4*>(side_g + lcA), gB = *reinterpret_cast<const f32x4*>(side_g + lcB);
+                    const f32x4 tA = *reinterpret_cast<const f32x4*>(side_t + lcA), tB = *reinterpret_cast<const f32x4*>(side_t + lcB);
+                    f32x4 xA, xB;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = acc[j][8 * kk + e] + bA[e];
+                        a += ln_apply(rA[e], mu, rs, gA[e], tA[e]);
+                        xA[e] = a;
+                        float b2 = acc[j][8 * kk + 4 + e] + bB[e];
+                        b2 += ln_apply(rB[e], mu, rs, gB[e], tB[e]);
+                        xB[e] = b2;
+                    }
+                    float ps, pq;
+                    rowsum_chunk_pair(xA, xB, ps, pq);
+                    if (jj == 0) { tsm[kk] = ps; tsq[kk] = pq; } else { tsm[kk] += ps; tsq[kk] += pq; }
+                    u32x2_t hA, hB; unsigned lA, lB;
+                    r3_encode(xA, hA, lA);
+                    r3_encode(xB, hB, lB);
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(hA[0], hB[0], false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(hA[1], hB[1], false, false);
+                    const auto tl = __builtin_amdgcn_permlane32_swap(lA, lB, false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{t0[0], t1[0], t0[1], t1[1]}, rsH, (unsigned)lane * 16u + kb * 1024u, so_h, CPT_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{tl[0], tl[1]}, rsL, (unsigned)lane * 8u + kb * 512u, so_l, CPT_ST_AUX);
+                }
+            }
+            float sm = tsm[0] + tsm[1], sq = tsq[0] + tsq[1];
+            sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+            if (fh == 0)
+                *reinterpret_cast<float2*>(st_out + 2 * ((size_t)(wrow0 + fr) * st_out_slots + wcol0 / 96 + hb)) = float2{sm, sq};
+        }
+    } else {
     __syncthreads();                                  // every wave is done reading the W ring
     constexpr int CPW = WCOLS * 4 + 16, CH = WCOLS / 4, NSL = 2, P = 3;
     static_assert(16 * CPW * NWV <= RING_BYTES, "per-wave slabs must fit in the ring");
@@ -501,16 +610,19 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
         for (int hb = 0; hb < WCOLS / 96; ++hb) {
             float sm = 0.f, sq = 0.f;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const f32x4 f = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (hb * 24 + part * 6 + k) * 16);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { sm += f[e]; sq += f[e] * f[e]; }
+            for (int j = 0; j < 3; ++j) {          // the library's one order of a row's partial sums (common.h rowsum_chunk_pair): lane `part` = (h, qq)
+                const f32x4 f0 = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (hb * 24 + j * 8 + 4 * (part >> 1) + (part & 1)) * 16);
+                const f32x4 f1 = *reinterpret_cast<const f32x4*>(slab + r16 * CPW + (hb * 24 + j * 8 + 4 * (part >> 1) + 2 + (part & 1)) * 16);
+                float ps, pq;
+                rowsum_chunk_pair(f0, f1, ps, pq);
+                if (j == 0) { sm = ps; sq = pq; } else { sm += ps; sq += pq; }
             }
-            sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
             sm += __shfl_xor(sm, 2, 64); sq += __shfl_xor(sq, 2, 64);
+            sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
             if (part == 0)
                 *reinterpret_cast<float2*>(st_out + 2 * ((size_t)srow * st_out_slots + wcol0 / 96 + hb)) = float2{sm, sq};
         }
+    }
     }
     if (trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -523,8 +635,9 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
 #endif
 }
 
-// row-major [M][ld] <-> panel
-__global__ __launch_bounds__(256) void panel_pack_kernel(const uint4* __restrict__ src, int ld8, uint4* __restrict__ dst, int M, int K16, int to_panel) {
+// row-major [M][ld] <-> panel; one unit = 8 consecutive elements of a row (16 bytes of bf16, 8 bytes of int8)
+template <typename U>
+__global__ __launch_bounds__(256) void panel_pack_kernel(const U* __restrict__ src, int ld8, U* __restrict__ dst, int M, int K16, int to_panel) {
     const size_t n = (size_t)(M / 32) * K16 * 64;
     for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < n; u += (size_t)gridDim.x * 256) {
         const int l = (int)(u & 63);
@@ -547,20 +660,21 @@ void set_prod_waves(int v) { g_prod_waves = (v == 4 || v == 0) ? v : 8; }
 
 int panel_eligible(int M, int N, int K) { return M > 0 && M % TM == 0 && N > 0 && N % TN == 0 && K >= 512 && K % 256 == 0 && (size_t)M * K * 2 <= (size_t)0x7fffffff; }
 
-int panel_pack(const void* src, int ld, void* dst, int M, int K, int to_panel, hipStream_t s) {
-    if (M <= 0 || K <= 0 || M % 32 || K % 16 || ld % 8) return CPT_ERR_SHAPE;
+int panel_pack(const void* src, int ld, void* dst, int M, int K, int to_panel, hipStream_t s, int elem_bytes) {
+    if (M <= 0 || K <= 0 || M % 32 || K % 16 || ld % 8 || (elem_bytes != 2 && elem_bytes != 1)) return CPT_ERR_SHAPE;
     if (!src || !dst) return CPT_ERR_NULL;
-    if (((uintptr_t)src | (uintptr_t)dst) & 15) return CPT_ERR_ALIGN;
+    if (((uintptr_t)src | (uintptr_t)dst) & (elem_bytes == 2 ? 15 : 7)) return CPT_ERR_ALIGN;
     const size_t n = (size_t)M * K / 8;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-    panel_pack_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const uint4*)src, ld / 8, (uint4*)dst, M, K / 16, to_panel);
+    if (elem_bytes == 2) panel_pack_kernel<uint4><<<dim3(blocks), dim3(256), 0, s>>>((const uint4*)src, ld / 8, (uint4*)dst, M, K / 16, to_panel);
+    else panel_pack_kernel<uint2><<<dim3(blocks), dim3(256), 0, s>>>((const uint2*)src, ld / 8, (uint2*)dst, M, K / 16, to_panel);
     return CPT_OK;
 }
 
 int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
                         const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
                         void* out_hi, void* out_lo, float* st_out, int ldo, int M, int N, int K, hipStream_t s,
-                        const void* pf0, size_t pf0_bytes, const void* pf1, size_t pf1_bytes) {
+                        const void* pf0, size_t pf0_bytes, const void* pf1, size_t pf1_bytes, int resid_panel) {
     if (!panel_eligible(M, N, K) || ldw % 8 || (st_in && ln_stat_parts(hidden) > 8)) return CPT_ERR_SHAPE;     // (the prologue fetches 8 slots of partial row sums)
     if ((uintptr_t)pf0 & 15) pf0 = nullptr;          // (a prefetch region is a hint: one the 16-byte loads cannot take is dropped, not an error)
     if ((uintptr_t)pf1 & 15) pf1 = nullptr;
@@ -572,11 +686,11 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     static bool attr_done_dev[CPT_MAX_DEV] = {};
     bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
-        for (const void* k : {(const void*)prod3_panel_kernel<0, 8, 0>, (const void*)prod3_panel_kernel<0, 8, 1>, (const void*)prod3_panel_kernel<1, 8, 1>, (const void*)prod3_panel_kernel<2, 8, 1>, (const void*)prod3_panel_kernel<3, 8, 1>, (const void*)prod3_panel_kernel<4, 8, 1>}) {
+        for (const void* k : {(const void*)prod3_panel_kernel<0, 8, 0, true>, (const void*)prod3_panel_kernel<0, 8, 1, true>, (const void*)prod3_panel_kernel<0, 8, 0>, (const void*)prod3_panel_kernel<0, 8, 1>, (const void*)prod3_panel_kernel<1, 8, 1>, (const void*)prod3_panel_kernel<2, 8, 1>, (const void*)prod3_panel_kernel<3, 8, 1>, (const void*)prod3_panel_kernel<4, 8, 1>}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<8>::LDS_BYTES);
             if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         }
-        for (const void* k : {(const void*)prod3_panel_kernel<0, 4, 0>, (const void*)prod3_panel_kernel<0, 4, 1>, (const void*)prod3_panel_kernel<2, 4, 1>, (const void*)prod3_panel_kernel<3, 4, 1>}) {
+        for (const void* k : {(const void*)prod3_panel_kernel<0, 4, 0, true>, (const void*)prod3_panel_kernel<0, 4, 1, true>, (const void*)prod3_panel_kernel<0, 4, 0>, (const void*)prod3_panel_kernel<0, 4, 1>, (const void*)prod3_panel_kernel<2, 4, 1>, (const void*)prod3_panel_kernel<3, 4, 1>}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<4>::LDS_BYTES);
             if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         }
@@ -588,7 +702,8 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     if (!npf) { pf0 = nullptr; pf1 = nullptr; }
     const int nwg = ntile + npf;
 #define CPT_LAUNCH(ABL, NWV) CPT_LAUNCH3(ABL, NWV, 1)
-#define CPT_LAUNCH3(ABL, NWV, SITE) prod3_panel_kernel<ABL, NWV, SITE><<<dim3(nwg), dim3(NWV * 64), Shape<NWV>::LDS_BYTES, s>>>(                                  \
+#define CPT_LAUNCH3(ABL, NWV, SITE) CPT_LAUNCH4(ABL, NWV, SITE, false)
+#define CPT_LAUNCH4(ABL, NWV, SITE, RP) prod3_panel_kernel<ABL, NWV, SITE, RP><<<dim3(nwg), dim3(NWV * 64), Shape<NWV>::LDS_BYTES, s>>>(                                  \
         (const bf16*)A_panel, (const bf16*)W, ldw, bias, (const bf16*)resid_hi, (const signed char*)resid_lo, ldr, st_in, ln_stat_parts(hidden), g_in, b_in, \
         eps, 1.0f / (float)hidden, (bf16*)out_hi, (signed char*)out_lo, ldo, st_out, ln_stat_slots(N), M, N, K, ((g_trace_epi < 0 || g_trace_epi == 11) && (g_trace_k == 0 || g_trace_k == K)) ? g_gemm_trace : nullptr, \
         pf0, pf0_bytes, pf1, pf1_bytes)
@@ -596,6 +711,12 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     // per step at B = 256, L = 210).  In one round (the bench shape, 240 tiles) the 4-wave FFN-down launch is 2.5 us shorter by its own
     // brackets, but the step is not (1.706 vs 1.696 ms, 1.741 vs 1.739 on a second box): the chip sits at its power cap and the denser
     // launch takes clock from its neighbours (profiles/r04_kloop_vs_hipblaslt.md), so the 8-wave shape stays there.
+    if (resid_panel) {      // residual stream in the panel layout, register-direct epilogue (round 5)
+        if ((size_t)M * N * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;
+        const bool w4 = g_prod_waves == 4 || (g_prod_waves == 0 && ntile > 256);
+        if (w4) { if (K <= 1024) CPT_LAUNCH4(0, 4, 0, true); else CPT_LAUNCH4(0, 4, 1, true); }
+        else { if (K <= 1024) CPT_LAUNCH4(0, 8, 0, true); else CPT_LAUNCH4(0, 8, 1, true); }
+    } else
     if (g_prod_waves == 4 || (g_prod_waves == 0 && ntile > 256)) {
         switch (g_prod_abl) {
             case 2: CPT_LAUNCH(2, 4); break;
@@ -610,6 +731,7 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
         case 4: CPT_LAUNCH(4, 8); break;
         default: if (K <= 1024) CPT_LAUNCH3(0, 8, 0); else CPT_LAUNCH3(0, 8, 1); break;
     }
+#undef CPT_LAUNCH4
 #undef CPT_LAUNCH3
 #undef CPT_LAUNCH
     return CPT_OK;

@@ -18,12 +18,12 @@ int gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, con
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
              float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
-             int max_pos, int type_vocab, hipStream_t s, void* out_lo = nullptr);   // out_lo: rows leave in the 3-byte residual form (hi -> out_lp)
+             int max_pos, int type_vocab, hipStream_t s, void* out_lo = nullptr, int out_panel = 0);   // out_lo: rows leave in the 3-byte residual form (hi -> out_lp); out_panel: at their panel positions
 
 // bf16 inference: embed_ln (3-byte or bf16 output rows) and pad_cast(bf16) of the region features in ONE launch (they touch disjoint data)
 int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
                       const float* g, const float* bta, float eps, void* out_lp, void* out_lo, int B, int Lt, int L, int H, int vocab,
-                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s);
+                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s, int out_panel = 0);     // out_panel (round 5): out_lp / out_lo = the panel-layout residual stream
 
 int layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                    void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
@@ -87,7 +87,7 @@ int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
                       const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr,
-                      int x_parts = 1, size_t x_stride = 0);     // x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
+                      int x_parts = 1, size_t x_stride = 0, int out_panel = 0);     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
 // resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients
@@ -127,7 +127,7 @@ int gemm_img_proj(const void* A, int lda, const void* W, int ldw, const float* b
 // MLM head on the [MASK] rows, bf16 path (round 3): gather + 3-byte merge + LayerNorm in one launch; transform GEMM with K split over
 // workgroups (partials[S][M][N], S = head_transform_splits(K)); reduction + GELU + LayerNorm in one launch
 int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, void* out_bf16, int R, int L, int H, hipStream_t s,
-                  const void* pf = nullptr, size_t pf_bytes = 0);     // pf: region (the decoder's weight table) that leading blocks of the launch read into the Infinity Cache
+                  const void* pf = nullptr, size_t pf_bytes = 0, int src_panel = 0);     // src_panel (round 5): hi / lo in the panel layout; pf: region (the decoder's weight table) that leading blocks of the launch read into the Infinity Cache
 int head_transform_splits(int K);
 int gemm_head_transform(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s);
 int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s,
@@ -143,19 +143,20 @@ int gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const float* b
 // round 3: the same producer with A read from its fragment-major ("panel") copy straight into registers (gemm_prod.hip);
 // panel[M / 32][K / 16][64][8] bf16, see panel_pack; needs panel_eligible(M, N, K)
 int panel_eligible(int M, int N, int K);
-int panel_pack(const void* src, int ld, void* dst, int M, int K, int to_panel, hipStream_t s);     // to_panel 0: the inverse
+int panel_pack(const void* src, int ld, void* dst, int M, int K, int to_panel, hipStream_t s, int elem_bytes = 2);     // to_panel 0: the inverse; elem_bytes 1: the residual stream's lo bytes (units of 8 bytes)
 int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
                         const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,
                         void* out_hi, void* out_lo, float* st_out, int ldo, int M, int N, int K, hipStream_t s,
-                        const void* pf0 = nullptr, size_t pf0_bytes = 0, const void* pf1 = nullptr, size_t pf1_bytes = 0);
+                        const void* pf0 = nullptr, size_t pf0_bytes = 0, const void* pf1 = nullptr, size_t pf1_bytes = 0, int resid_panel = 0);
+// resid_panel (round 5): resid_hi / resid_lo / out_hi / out_lo are in the panel layout [M / 32][N / 16][64][8] (ldr, ldo ignored); register-direct epilogue
 // pf0 / pf1: regions (the NEXT launches' weight matrices) that the launch's spare workgroups read into the Infinity Cache (common.h prefetch_region)
 int r3_split(const float* x, void* hi_bf16, void* lo_i8, size_t n, hipStream_t s);
-int r3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, hipStream_t s);
+int r3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, hipStream_t s, int src_panel = 0);
 int ln_stat_parts(int n_cols);      // 96-column blocks of a gemm_ln_prod of n_cols columns
 int ln_stat_slots(int n_cols);      // slots per row of the partial row-sum table [M][slots][2] it fills
 int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
                  float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s, int out_panel = 0,
-                 const void* pf = nullptr, size_t pf_bytes = 0);      // pf: prefetch region of the panel form (as gemm_ln_prod3_panel)
+                 const void* pf = nullptr, size_t pf_bytes = 0, int a_panel = 0);      // pf: prefetch region of the panel form (as gemm_ln_prod3_panel)
 // out_panel (gelu form, ffn_up_2pass_legal shapes): out_lp leaves in the fragment-major panel layout (gemm_prod.hip) instead of row-major
 // fused QKV projection + self-attention (bf16, L <= 128); st_in NULL: plain bias, else LayerNorm folded (colc/cold);
 // config 1: two workgroups per CU (2-stage ring), 2: one workgroup per CU (3-stage ring)
@@ -168,7 +169,7 @@ void set_q3_trace(void* p);  // cpt_debug_gemm_trace: per-workgroup phase stamps
 void set_q3_abl(int v);     // diagnostic builds (-DCPT_ABLATION): ablation bits of the kernel, see qkv_attn3.hip
 int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
                    const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads,
-                   int K, hipStream_t s, int w_tiled = 0, int ctx_panel = 0);     // w_tiled: W is the K-tile-major copy made by retile_k32; ctx_panel: ctx leaves in the panel layout (gemm_prod.hip), rows padded to a multiple of 32
+                   int K, hipStream_t s, int w_tiled = 0, int ctx_panel = 0, int a_panel = 0);     // a_panel (round 5): A = the residual stream's hi part in the panel layout     // w_tiled: W is the K-tile-major copy made by retile_k32; ctx_panel: ctx leaves in the panel layout (gemm_prod.hip), rows padded to a multiple of 32
 // dst[K / 32][N][32] = src[N][K] (bf16): every K-tile of 32 of all rows contiguous (64 bytes per row, rows adjacent)
 int retile_k32(const void* src, void* dst, int N, int K, hipStream_t s);
 int select_regions(const float* logits, int V, const int64_t* color_ids, int C, const int* query_first, int Q,
@@ -195,7 +196,7 @@ int ffn_up_2pass_legal(int M, int N, int K);
 int ffn_up_2pass_preferred(int M, int N, int K);
 int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
                       float eps, int hidden, void* out, int ldo, int M, int N, int K, void* trace, int abl, hipStream_t s, int out_panel = 0,
-                      const void* pf = nullptr, size_t pf_bytes = 0, int gelu = 1);     // gelu 0: plain LayerNorm-consumer GEMM (stand-alone QKV projection)
+                      const void* pf = nullptr, size_t pf_bytes = 0, int gelu = 1, int a_panel = 0);     // gelu 0: plain LayerNorm-consumer GEMM (stand-alone QKV projection); a_panel: A = the panel residual stream (round 5)
 // round 4: the same consumer GEMMs on one wave per SIMD (gemm_ffn4.hip); same shapes, same bits
 int gemm_lncons4(const void* A, int lda, const void* Wf, int ldw, const float* st_in, int st_parts, const float* colc, const float* cold,
                  float eps, int hidden, void* out, int ldo, int M, int N, int K, hipStream_t s, int out_panel, const void* pf, size_t pf_bytes, int gelu);

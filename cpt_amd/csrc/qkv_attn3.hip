@@ -47,6 +47,7 @@ __device__ __forceinline__ int q3_off(int row, int chunk) { return row * Q3_RB +
 
 struct Q3Args {
     const bf16* A; int lda;                // activations [M][K] (bf16 hi part of the residual stream)
+    int a_panel;                           // round 5: A is the residual stream's hi part in the panel layout [M rounded up to 32 / 32][K / 16][64][8] (gemm_prod.hip RP), lda ignored
     const bf16* W; int ldw;                // fused [3 * heads * 64][K] weight (LayerNorm gain folded in when st_in != NULL)
     int w_tiled;                           // 1: W is the K-tile-major copy [K / 32][3 * heads * 64][32] (cpt_retile_k32): a piece's 16 rows are 1 KiB contiguous
     const float* bias;                     // [3 * heads * 64] (plain form) or NULL
@@ -90,21 +91,26 @@ __global__ __launch_bounds__(Q3_NW * 64, 3) void qkv3_attn_kernel(Q3Args a) {
     // w + 24 and w + 36; pieces 44..47 (waves 8..11) do not exist: those waves re-read their first piece into a dummy area,
     // so that every wave has the same four loads per stage in flight (one counted vmcnt for all).
     const int n3 = 3 * hd64;
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)min((size_t)M * a.lda * 2, (size_t)0x7fffffff), 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)min((size_t)(a.a_panel ? ((M + 31) & ~31) : M) * (a.a_panel ? a.K : a.lda) * 2, (size_t)0x7fffffff), 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)min((size_t)n3 * a.ldw * 2, (size_t)0x7fffffff), 0x00020000);
     const bool big = wave < 8;             // wave-uniform: has a real fourth piece; its first piece is an activation piece
     const auto rs0 = big ? rsA : rsW;      // (scalar select: the main loop stays one basic block)
     // row-major weight: row stride ldw, K-tile t at byte offset 64 t;  K-tile-major copy: row stride 64 B, K-tile t at n3 * 64 t
     const unsigned w_row = a.w_tiled ? (unsigned)Q3_RB : (unsigned)a.ldw * 2u;
     const int w_kstep = a.w_tiled ? n3 * Q3_RB : Q3_RB;
-    const int k0step = big ? Q3_RB : w_kstep;       // first piece: activations (waves 0..7) or weights
+    // (A from the panel copy: a K-tile of 32 is two 1 KiB units of the row block further on; a piece's 16 rows x 64 B become 256-byte runs of one unit half)
+    const int k0step = big ? (a.a_panel ? 2048 : Q3_RB) : w_kstep;       // first piece: activations (waves 0..7) or weights
     unsigned voff[Q3_G];
 #pragma unroll
     for (int i = 0; i < Q3_G; ++i) {
         const int p = (i == 3 && !big) ? wave : wave + 12 * i;
         const int row = p * 16 + (lane >> 2);
         const int sc = (lane & 3) ^ ((row >> 2) & 3);
-        if (p < 8) voff[i] = (unsigned)(((size_t)min(m0 + row, M - 1) * a.lda) * 2 + sc * 16);
+        if (p < 8) {
+            const int rg = min(m0 + row, M - 1);
+            voff[i] = a.a_panel ? (unsigned)((((rg >> 5) * (a.K >> 4) + (sc >> 1)) * 64 + (sc & 1) * 32 + (rg & 31)) * 16)
+                                : (unsigned)(((size_t)rg * a.lda) * 2 + sc * 16);
+        }
         else {
             const int rw = row - Q3_TM;                        // 0..575: head rw / 192, (q | k | v) block, row in head
             const int hh = rw / 192, r2 = rw - hh * 192;
@@ -369,13 +375,14 @@ int qkv_attn3_eligible(int L, int heads, int K) { return L > 0 && L <= 128 && he
 // Same contract as gemm_qkv_attn (gemm.hip): st_in == NULL -> x W^T + bias, else the LayerNorm-folded form.
 int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
                    const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads,
-                   int K, hipStream_t s, int w_tiled, int ctx_panel) {
+                   int K, hipStream_t s, int w_tiled, int ctx_panel, int a_panel) {
+    if (a_panel && K % 16) return CPT_ERR_SHAPE;
     if (B <= 0 || !qkv_attn3_eligible(L, heads, K) || lda % 8 || ldw % 8 || ldo % 4 || (st_in && ln_stat_slots(hidden) > 8)) return CPT_ERR_SHAPE;
     if (!A || !W || !ctx || (st_in && (!colc || !cold))) return CPT_ERR_NULL;
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)bias | (uintptr_t)colc | (uintptr_t)cold) & 15) || ((uintptr_t)ctx & (ctx_panel ? 15 : 7))) return CPT_ERR_ALIGN;
     if (ctx_panel && (heads * 64) % 16) return CPT_ERR_SHAPE;
     Q3Args a;
-    a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias; a.w_tiled = w_tiled ? 1 : 0;
+    a.A = (const bf16*)A; a.lda = lda; a.a_panel = a_panel ? 1 : 0; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias; a.w_tiled = w_tiled ? 1 : 0;
     if (w_tiled && ldw != K) return CPT_ERR_SHAPE;
     a.st_in = st_in; a.st_parts = ln_stat_parts(hidden); a.colc = colc; a.cold = cold; a.eps = eps; a.inv_h = 1.0f / (float)hidden;
     a.trace = (g_trace_epi < 0 || g_trace_epi == 10) ? g_q3_trace : nullptr;      // (diagnostics: trace filter by epilogue id, 10 = fused QKV + attention)

@@ -28,10 +28,16 @@ __device__ __forceinline__ void ln_stats(const f32x4 (&v)[MAXV], int nv, int lan
     rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
 }
 
+// index (in 4-element quads) of columns [c, c + 4) of `row` in a tensor kept in the panel layout [rows / 32][H / 16][64][8] (gemm_prod.hip)
+__device__ __forceinline__ size_t panel_quad(size_t row, int c, int H) {
+    return ((size_t)panel_unit((int)row, c >> 3, H >> 4) << 1) + ((c >> 2) & 1);
+}
+
 template <typename LP>
 __device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lane, int H, float mean, float rstd,
-                                         const float* g, const float* b, float* of, LP* ol, signed char* olo = nullptr) {
+                                         const float* g, const float* b, float* of, LP* ol, signed char* olo = nullptr, long long panel_row = -1) {
     // olo != NULL (bf16 LP only): the row leaves in the 3-byte residual form (common.h r3_encode): hi -> ol, lo -> olo
+    // panel_row >= 0 (round 5, with olo): ol / olo are the BASES of the panel-layout residual stream and the row lands at its quads there
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = (lane + 64 * i) * 4;
@@ -50,6 +56,12 @@ __device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lan
                 if (olo) {
                     u32x2_t hq; unsigned lq;
                     r3_encode(y, hq, lq);
+                    if (panel_row >= 0) {
+                        const size_t qd = panel_quad((size_t)panel_row, c, H);
+                        reinterpret_cast<u32x2_t*>(ol)[qd] = hq;
+                        reinterpret_cast<unsigned*>(olo)[qd] = lq;
+                        continue;
+                    }
                     *reinterpret_cast<u32x2_t*>(ol + c) = hq;
                     *reinterpret_cast<unsigned*>(olo + c) = lq;
                     continue;
@@ -78,7 +90,7 @@ template <typename LP, bool GELU_IN, int LN_RPW>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
-    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride) {      // x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
+    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride, int out_panel) {      // x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
     // x_parts / x_stride (round 3): x is x_parts split-K partial matrices of the dense layer in front, x_stride elements apart; the row that is
     // processed is their sum in split order (training forward: no reduction launch between the GEMM and this pass)
     // resid / dr / pre_out (training forward of LN(dropout(dense) + residual), modeling_bert.py:85-86,145 with the third-party
@@ -135,6 +147,8 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
         float mean = 0.f, rstd = 1.f;
         if (g) ln_stats(v[u], nv, lane, H, mean, rstd, eps);
         const size_t orow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
+        if (out_panel) ln_write<LP>(v[u], nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
+        else
         ln_write<LP>(v[u], nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
                      out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
     }
@@ -142,8 +156,9 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
 
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
-                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride) {
+                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride, int out_panel) {
     if (x_parts < 1 || x_parts > 64) return CPT_ERR_SHAPE;
+    if (out_panel && (!out_lo || out_f32 || H % 16)) return CPT_ERR_SHAPE;      // panel output: the 3-byte residual stream only (rows rounded up to 32 by the caller's buffer)
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
     if (R <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
@@ -154,8 +169,8 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
 #define LNK(LPT, GI)                                                                                                                              \
     do {                                                                                                                                          \
-        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride); \
-        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride);          \
+        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel); \
+        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel);          \
     } while (0)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
     else      { if (gelu_in) LNK(float, true); else LNK(float, false); }
@@ -178,6 +193,7 @@ struct EmbedArgs {
     void* out_lp;
     signed char* out_lo;
     int B, Lt, L, H, vocab, max_pos, type_vocab;
+    int out_panel;      // round 5: out_lp / out_lo are the panel-layout residual stream (3-byte form)
 };
 template <typename LP>
 __device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
@@ -214,6 +230,8 @@ __device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
     float mean, rstd;
     ln_stats(v, nv, lane, H, mean, rstd, eps);
     const size_t orow = (size_t)b * L + t;
+    if (a.out_panel) ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
+    else
     ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
                  out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
 }
@@ -223,13 +241,14 @@ __global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(EmbedArgs a) { em
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
              float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
-             int max_pos, int type_vocab, hipStream_t s, void* out_lo) {
+             int max_pos, int type_vocab, hipStream_t s, void* out_lo, int out_panel) {
     if (B <= 0 || Lt <= 0 || L < Lt || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
+    if (out_panel && (!out_lo || out_f32 || H % 16)) return CPT_ERR_SHAPE;
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
     if (!ids || !word || !posw || !typew || !g || !bta) return CPT_ERR_NULL;
     if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
     dim3 grid((B * Lt + 3) / 4), block(ROW_THREADS);
-    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab};
+    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0};
     if (out_lp && lp_dtype == CPT_BF16) embed_ln_kernel<bf16><<<grid, block, 0, s>>>(a);
     else { a.out_lo = nullptr; embed_ln_kernel<float><<<grid, block, 0, s>>>(a); }
     return CPT_OK;
@@ -299,14 +318,15 @@ __global__ __launch_bounds__(256) void embed_pad_kernel(EmbedArgs a, const float
 
 int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
                       const float* g, const float* bta, float eps, void* out_lp, void* out_lo, int B, int Lt, int L, int H, int vocab,
-                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s) {
+                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s, int out_panel) {
+    if (out_panel && (!out_lo || H % 16)) return CPT_ERR_SHAPE;
     if (B <= 0 || Lt <= 0 || L < Lt || H % 4 || H > 256 * MAXV || R <= 0 || K <= 0 || Kp < K || Kp % 8) return CPT_ERR_SHAPE;
     if (!ids || !word || !posw || !typew || !g || !bta || !out_lp || !x || !xo) return CPT_ERR_NULL;
     if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
     if (((uintptr_t)xo % 16) || ((uintptr_t)x % 8)) return CPT_ERR_ALIGN;
     const size_t n = (size_t)R * (Kp / 8);
     const int npad = (int)((n + 256 * PC_UNR - 1) / (256 * PC_UNR));
-    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, nullptr, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab};
+    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, nullptr, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0};
     embed_pad_kernel<<<dim3(npad + (B * Lt + 3) / 4), dim3(256), 0, s>>>(a, x, (bf16*)xo, R, K, Kp, npad);
     return CPT_OK;
 }
@@ -495,8 +515,9 @@ int r3_split(const float* x, void* hi, void* lo, size_t n, hipStream_t s) {
     return CPT_OK;
 }
 __global__ __launch_bounds__(256) void r3_merge_kernel(const u32x2_t* __restrict__ hi, const unsigned* __restrict__ lo, const int64_t* __restrict__ pos,
-                                                       f32x4* __restrict__ out, int R, int L, int gather, int q) {
+                                                       f32x4* __restrict__ out, int R, int L, int gather, int q, int src_panel) {
     // one block per output row; gather: row r reads source row r * L + clamp(pos[r]) (pos NULL: 0), else source row r
+    // src_panel (round 5): hi / lo are the panel-layout residual stream
     const int r = blockIdx.x;
     size_t src = r;
     if (gather) {
@@ -504,12 +525,15 @@ __global__ __launch_bounds__(256) void r3_merge_kernel(const u32x2_t* __restrict
         p = p < 0 ? 0 : (p >= L ? L - 1 : p);
         src = (size_t)r * L + p;
     }
-    for (int c = threadIdx.x; c < q; c += 256) out[(size_t)r * q + c] = r3_decode(hi[src * q + c], lo[src * q + c]);
+    for (int c = threadIdx.x; c < q; c += 256) {
+        const size_t qd = src_panel ? panel_quad(src, c * 4, q * 4) : src * q + c;
+        out[(size_t)r * q + c] = r3_decode(hi[qd], lo[qd]);
+    }
 }
-int r3_merge(const void* hi, const void* lo, const int64_t* pos, float* out, int R, int L, int H, int gather, hipStream_t s) {
+int r3_merge(const void* hi, const void* lo, const int64_t* pos, float* out, int R, int L, int H, int gather, hipStream_t s, int src_panel) {
     if (!hi || !lo || !out) return CPT_ERR_NULL;
-    if (R <= 0 || H % 4 || (gather && L <= 0)) return CPT_ERR_SHAPE;
-    r3_merge_kernel<<<dim3(R), dim3(256), 0, s>>>((const u32x2_t*)hi, (const unsigned*)lo, pos, (f32x4*)out, R, L, gather, H / 4);
+    if (R <= 0 || H % 4 || (gather && L <= 0) || (src_panel && H % 16)) return CPT_ERR_SHAPE;
+    r3_merge_kernel<<<dim3(R), dim3(256), 0, s>>>((const u32x2_t*)hi, (const unsigned*)lo, pos, (f32x4*)out, R, L, gather, H / 4, src_panel);
     return CPT_OK;
 }
 
@@ -519,7 +543,7 @@ int r3_merge(const void* hi, const void* lo, const int64_t* pos, float* out, int
 __global__ __launch_bounds__(ROW_THREADS) void head_rows_ln3_kernel(const u32x2_t* __restrict__ hi, const unsigned* __restrict__ lo, const int64_t* __restrict__ pos,
                                                                     const float* __restrict__ g, const float* __restrict__ bta, float eps,
                                                                     bf16* __restrict__ out, int R, int L, int H,
-                                                                    const void* __restrict__ pf, size_t pf_bytes, int pf_blocks) {
+                                                                    const void* __restrict__ pf, size_t pf_bytes, int pf_blocks, int src_panel) {
     // The launch has R / 4 blocks of real work (16 at B = 64) on a 256-CU chip: pf_blocks LEADING blocks stream the vocabulary decoder's
     // weight table (47 MB, read once by the GEMM three launches later) into the Infinity Cache meanwhile (common.h prefetch_region)
     __shared__ __attribute__((aligned(16))) unsigned char pf_scratch[4 * 1024];
@@ -538,20 +562,23 @@ __global__ __launch_bounds__(ROW_THREADS) void head_rows_ln3_kernel(const u32x2_
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
-        if (i < nv && c * 4 < H) v[i] = r3_decode(hi[src + c], lo[src + c]);
+        if (i < nv && c * 4 < H) {
+            const size_t qd = src_panel ? panel_quad((size_t)r * L + p, c * 4, H) : src + c;
+            v[i] = r3_decode(hi[qd], lo[qd]);
+        }
     }
     float mean, rstd;
     ln_stats(v, nv, lane, H, mean, rstd, eps);
     ln_write<bf16>(v, nv, lane, H, mean, rstd, g, bta, nullptr, out + (size_t)r * H);
 }
 int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, void* out_bf16, int R, int L, int H, hipStream_t s,
-                  const void* pf, size_t pf_bytes) {
+                  const void* pf, size_t pf_bytes, int src_panel) {
     if (!hi || !lo || !g || !bta || !out_bf16) return CPT_ERR_NULL;
-    if (R <= 0 || L <= 0 || H <= 0 || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
+    if (R <= 0 || L <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || (src_panel && H % 16)) return CPT_ERR_SHAPE;
     const int nb = (R + 3) / 4;
     const int pfb = (pf && pf_bytes && !((uintptr_t)pf & 15) && nb < 224) ? 224 - (nb & ~7) : 0;      // (a hint: dropped when misaligned or when the rows fill the chip)
     head_rows_ln3_kernel<<<dim3(nb + pfb), dim3(ROW_THREADS), 0, s>>>((const u32x2_t*)hi, (const unsigned*)lo, pos, g, bta, eps, (bf16*)out_bf16, R, L, H,
-                                                                       pfb ? pf : nullptr, pf_bytes, pfb);
+                                                                       pfb ? pf : nullptr, pf_bytes, pfb, src_panel);
     return CPT_OK;
 }
 // head_finish: row r of the output = LayerNorm(gelu(sum over the S split-K partial matrices of row r)) as bf16 (the bias rides in partial 0):

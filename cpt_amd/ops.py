@@ -221,6 +221,36 @@ def gemm_ln_prod3_panel(a_panel, K, w, bias, resid_hi, resid_lo, st_in=None, g_i
     return out_hi, out_lo, st_out
 
 
+def panel_pack_bytes(a, to_panel=True, K=None):
+    """panel_pack for one-byte elements (the residual stream's lo bytes): int8 [M, K] <-> [M/32][K/16][64][8] bytes (flat)."""
+    _need_cuda(a)
+    if to_panel:
+        M, K = a.shape
+        out = torch.empty(M * K, device=a.device, dtype=torch.int8)
+        L.check(L.lib().cpt_panel_pack_bytes(a.data_ptr(), a.stride(0), out.data_ptr(), M, K, 1, L.stream_ptr()), "cpt_panel_pack_bytes")
+        return out
+    M = a.numel() // K
+    out = torch.empty((M, K), device=a.device, dtype=torch.int8)
+    L.check(L.lib().cpt_panel_pack_bytes(a.data_ptr(), K, out.data_ptr(), M, K, 0, L.stream_ptr()), "cpt_panel_pack_bytes")
+    return out
+
+
+def gemm_ln_prod3_rpanel(a_panel, K, w, bias, resid_hi_panel, resid_lo_panel, st_in=None, g_in=None, b_in=None, eps=1e-12, hidden=None):
+    """gemm_ln_prod3_panel with the residual stream (input and output) in the panel layout too (round 5): returns the PANEL copies
+    (out_hi bf16 flat, out_lo int8 flat) and st_out."""
+    _need_cuda(a_panel, w, bias, resid_hi_panel, resid_lo_panel)
+    M = a_panel.numel() // K
+    N = w.size(0)
+    hidden = hidden or N
+    out_hi = torch.empty(M * N, device=w.device, dtype=torch.bfloat16)
+    out_lo = torch.empty(M * N, device=w.device, dtype=torch.int8)
+    st_out = torch.zeros((M, ln_stat_slots(N), 2), device=w.device, dtype=torch.float32)
+    L.check(L.lib().cpt_gemm_ln_prod3_rpanel(a_panel.data_ptr(), w.data_ptr(), w.stride(0), L.ptr(bias), resid_hi_panel.data_ptr(), resid_lo_panel.data_ptr(),
+                                             L.ptr(st_in), L.ptr(g_in), L.ptr(b_in), float(eps), hidden, out_hi.data_ptr(), out_lo.data_ptr(),
+                                             st_out.data_ptr(), M, N, K, L.stream_ptr()), "cpt_gemm_ln_prod3_rpanel")
+    return out_hi, out_lo, st_out
+
+
 def gemm_ln_cons(a, wf, st_in, colc, cold, eps, hidden, gelu):
     """[gelu]( rstd * (a @ wf.T - mean * colc) + cold ): bf16 a[M,K], wf[N,K]; st_in from row_stats_table / gemm_ln_prod."""
     _need_cuda(a, wf, st_in, colc, cold)

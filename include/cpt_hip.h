@@ -376,6 +376,15 @@ int cpt_gemm_ln_prod3_panel(const void* A_panel, const void* W_bf16, int ldw, co
                             int ldr, const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi, void* out_lo,
                             float* st_out, int ldo, int M, int N, int K, void* stream);
 int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos, float* out, int R, int L, int H, int gather, void* stream);
+/* Round 5 (ABI 6): the producer with the RESIDUAL STREAM in the panel layout as well -- resid_hi / out_hi as [M / 32][N / 16][64][8] bf16 (the very
+ * A-operand panel the next GEMM reads), resid_lo / out_lo as [M / 32][N / 16][64][8] bytes (cpt_panel_pack_bytes: the same index arithmetic on
+ * one-byte elements) -- with a register-direct epilogue (swapped MFMA operands, lane = output row; no LDS slab, no barrier behind the K loop).
+ * Element for element and slot for slot the same bits as cpt_gemm_ln_prod3_panel / cpt_gemm_ln_prod3 on the row-major tensors.  Inside
+ * cpt_model_fwd it is what the fused bf16 encoder runs at panel-eligible shapes (BertSelfOutput / BertOutput, modeling_bert.py:85-86, :145). */
+int cpt_panel_pack_bytes(const void* src_i8, int ld, void* dst_i8, int M, int K, int to_panel, void* stream);
+int cpt_gemm_ln_prod3_rpanel(const void* A_panel, const void* W_bf16, int ldw, const float* bias, const void* resid_hi_panel, const void* resid_lo_panel,
+                             const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi_panel, void* out_lo_panel,
+                             float* st_out, int M, int N, int K, void* stream);
 
 /* Weight-gradient GEMM in the TN form (what cpt_train_bwd runs for dW = dY^T . X, fewshot/refcoco_cpt.py:248's autograd of
  * every nn.Linear): out[M][N] fp32 = sum over k < K of A[k][m] * W[k][n], A bf16 [K][lda], W bf16 [K][ldw] -- both operands

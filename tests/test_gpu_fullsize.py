@@ -55,6 +55,22 @@ def test_config2_panel_mode_is_bit_identical(dev):
     assert torch.isfinite(on).all()
     assert torch.equal(on, again)
     assert torch.equal(on, off)
+    # round 5: by default the residual stream itself travels in the panel layout and the LayerNorm producers run their register-direct
+    # epilogue (cpt_set_tuning key 30); the round-3 form (row-major 3-byte stream, slab epilogue) gives the same bits, with both wave
+    # shapes of the producer tile, and so do the pooled output and the all-row sequence output
+    for waves in (8, 4):
+        L.check(L.lib().cpt_set_tuning(24, waves))
+        assert torch.equal(run(), on), "producer tile as %d waves" % waves
+    L.check(L.lib().cpt_set_tuning(24, 0))
+    with torch.no_grad():
+        seq_on, pooled_on = m.bert(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])[:2]
+        seq_on, pooled_on = seq_on.clone(), pooled_on.clone()
+    L.check(L.lib().cpt_set_tuning(30, 0))
+    rowmajor = run()
+    with torch.no_grad():
+        seq_off, pooled_off = m.bert(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])[:2]
+    L.check(L.lib().cpt_set_tuning(30, 1))
+    assert torch.equal(on, rowmajor) and torch.equal(seq_on, seq_off) and torch.equal(pooled_on, pooled_off)
     # and the rows of the big batch reproduce a 4-sequence batch (which runs the row-major kernels: below the panel shapes)
     ds = {k: v[:4].contiguous() for k, v in d.items()}
     with torch.no_grad():

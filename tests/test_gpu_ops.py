@@ -522,6 +522,37 @@ def test_gemm_ln_prod3_panel_is_bit_identical(dev, K, H, M, waves):
             assert torch.equal(q_hi, r_hi) and torch.equal(q_lo, r_lo) and torch.equal(q_st, r_st)
 
 
+@pytest.mark.parametrize("waves", [8, 4])
+@pytest.mark.parametrize("K,H,M", [(768, 768, 640), (3072, 768, 640), (512, 384, 128), (1024, 192, 256)])
+def test_gemm_ln_prod3_rpanel_is_bit_identical(dev, K, H, M, waves):
+    """Round 5: the producer with the RESIDUAL STREAM in the panel layout as well and a register-direct epilogue (swapped MFMA operands, no
+    LDS slab) against the row-major producer: hi, lo (unpacked from their panels) and the partial row sums bit for bit, with and without
+    the on-the-fly residual LayerNorm, both wave shapes; the byte panel round-trips; 20 back-to-back launches give identical bits."""
+    from cpt_amd import ops, _lib as L
+    L.check(L.lib().cpt_set_tuning(24, waves))
+    rng = _rng(K + 11)
+    x = (_t(rng, M, H, scale=1.2) + 0.3).to(dev)
+    hi, lo = ops.resid3_split(x)
+    hi, lo = hi.view(M, H), lo.view(M, H)
+    st = ops.row_stats_table(x)
+    a = _t(rng, M, K).to(torch.bfloat16).to(dev)
+    w = _t(rng, H, K, scale=0.03).to(torch.bfloat16).to(dev)
+    bias, g, bt = _t(rng, H, scale=0.1).to(dev), (1 + _t(rng, H, scale=0.1)).to(dev), _t(rng, H, scale=0.1).to(dev)
+    ap, hp, lp = ops.panel_pack(a), ops.panel_pack(hi), ops.panel_pack_bytes(lo)
+    assert torch.equal(ops.panel_pack_bytes(lp, to_panel=False, K=H), lo)
+    rows = torch.arange(M, device=dev)[:, None]
+    ks = torch.arange(H, device=dev)[None, :]
+    idx = (((rows // 32) * (H // 16) + ks // 16) * 64 + ((ks % 16) // 8) * 32 + rows % 32) * 8 + ks % 8
+    assert torch.equal(lp[idx.reshape(-1)].view(M, H), lo)
+    for fold in (True, False):
+        gi, bi, si = (g, bt, st) if fold else (None, None, None)
+        r_hi, r_lo, r_st = ops.gemm_ln_prod3(a, w, bias, hi, lo, si, gi, bi, 1e-12, H)
+        for rep in range(21):
+            q_hi, q_lo, q_st = ops.gemm_ln_prod3_rpanel(ap, K, w, bias, hp, lp, si, gi, bi, 1e-12, H)
+            assert torch.equal(q_st, r_st), "row sums (fold %s, launch %d)" % (fold, rep)
+            assert torch.equal(ops.panel_pack(q_hi, to_panel=False, K=H), r_hi) and torch.equal(ops.panel_pack_bytes(q_lo, to_panel=False, K=H), r_lo)
+
+
 @pytest.mark.parametrize("Mbig,Msmall", [(7680, 840), (7680, 120), (1000, 77)])
 def test_operators_are_batch_invariant(dev, Mbig, Msmall):
     """Rows [0, Msmall) of a big problem equal the same rows run as their own problem, bit for bit, for the four GEMM forms of
