@@ -86,6 +86,9 @@ _SIGS = {
                                    BUCKET_CB, vp, C.POINTER(Dropout)]),
     "cpt_train_zero_grads": (C.c_int, [C.POINTER(Model), C.POINTER(ModelGrads), C.c_int, vp]),
     "cpt_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_attention_bwd": (C.c_int, [C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Dropout), C.c_int, vp]),
+    "cpt_layernorm_bwd": (C.c_int, [vp, vp, vp, C.c_float, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.POINTER(Dropout), C.c_int, vp, vp, C.c_size_t, vp]),
+    "cpt_embed_ln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_adamw": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                             C.c_int, C.c_float, vp]),
     "cpt_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int,

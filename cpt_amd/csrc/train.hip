@@ -666,6 +666,48 @@ int cpt_dropout_mask(const cpt_dropout* drop, int site, int is_attn, unsigned ch
     return abi_check(cpt::dropout_mask(is_attn ? 1 : 0, out, n0, n1, n2, sp, (hipStream_t)stream), "cpt_dropout_mask");
 }
 
+// ---- operator-level backward entry points (ABI 6): thin wrappers over the kernels cpt_train_bwd launches, for per-operator parity tests ----
+int cpt_attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, int mask_3d, const void* dctx, void* dqkv, float* dbias_qkv,
+                      int B, int L, int heads, const cpt_dropout* drop, int site, void* stream) {
+    if (!qkv || !dctx || !dqkv) return abi_fail(CPT_ERR_NULL, "cpt_attention_bwd: null argument");
+    if (B <= 0 || L <= 0 || heads <= 0) return abi_fail(CPT_ERR_SHAPE, "cpt_attention_bwd: bad shape B=%d L=%d heads=%d", B, L, heads);
+    if (int rcd = check_drop(drop, "cpt_attention_bwd")) return rcd;
+    const bool pa = drop && drop->p_attn > 0.f;
+    const cpt::DropSpec sp = drop_spec(drop, site, true);
+    const int m3 = (mask_3d && attn_mask) ? 1 : 0;
+    if (dtype == CPT_BF16X3 || dtype == CPT_BF16X3_MASTERS) {
+        if (!cpt::attention_bwd_x3_supported(L, m3))
+            return abi_fail(CPT_ERR_SHAPE, "cpt_attention_bwd: no split-operand attention backward at L = %d%s", L, m3 ? " with a 3-D mask" : "");
+        return abi_check(cpt::attention_bwd_x3((const float*)qkv, attn_mask, (const float*)dctx, (float*)dqkv, B, L, heads, (hipStream_t)stream,
+                                               pa ? &sp : nullptr, dbias_qkv), "cpt_attention_bwd (split operands)");
+    }
+    if (dtype != CPT_F32 && dtype != CPT_BF16) return abi_fail(CPT_ERR_DTYPE, "cpt_attention_bwd: dtype %d", dtype);
+    if (!cpt::attention_bwd_supported(dtype, L, pa ? 1 : 0, m3))
+        return abi_fail(CPT_ERR_SHAPE, "cpt_attention_bwd: no attention backward for dtype %d at L = %d%s", dtype, L, pa ? " with attention dropout" : "");
+    return abi_check(cpt::attention_bwd(dtype, qkv, attn_mask, dctx, dqkv, B, L, heads, (hipStream_t)stream, pa ? &sp : nullptr, dbias_qkv, m3), "cpt_attention_bwd");
+}
+
+int cpt_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype, float* dg, float* db,
+                      int R, int H, const cpt_dropout* drop, int site, float* dbias, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!dy || !x || !g || !dx || !dg || !db) return abi_fail(CPT_ERR_NULL, "cpt_layernorm_bwd: null argument");
+    if (R <= 0 || H <= 0 || H % 4) return abi_fail(CPT_ERR_SHAPE, "cpt_layernorm_bwd: bad shape R=%d H=%d", R, H);
+    if (dx_lp && lp_dtype != CPT_BF16 && lp_dtype != CPT_F32) return abi_fail(CPT_ERR_DTYPE, "cpt_layernorm_bwd: lp_dtype %d", lp_dtype);
+    if (int rcd = check_drop(drop, "cpt_layernorm_bwd")) return rcd;
+    const bool ph = drop && drop->p_hidden > 0.f;
+    const cpt::DropSpec sp = drop_spec(drop, site, false);
+    return abi_check(cpt::ln_bwd(dy, x, g, eps, dx, dx_lp, lp_dtype, dg, db, R, H, R, 0, 0, 0, (hipStream_t)stream, (float*)scratch, scratch_bytes,
+                                 ph ? &sp : nullptr, dbias), "cpt_layernorm_bwd");
+}
+
+int cpt_embed_ln_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
+                     const float* g, float eps, float* dword, float* dposw, float* dtypew, float* dg, float* db, int B, int Lt, int L, int H,
+                     int vocab, int max_pos, int type_vocab, void* stream) {
+    if (!dy || !ids || !word || !posw || !typew || !g || !dword || !dposw || !dtypew || !dg || !db) return abi_fail(CPT_ERR_NULL, "cpt_embed_ln_bwd: null argument");
+    if (B <= 0 || Lt <= 0 || L < Lt || H <= 0 || H % 4) return abi_fail(CPT_ERR_SHAPE, "cpt_embed_ln_bwd: bad shape B=%d Lt=%d L=%d H=%d", B, Lt, L, H);
+    return abi_check(cpt::embed_bwd(dy, ids, tt, pos, word, posw, typew, g, eps, dword, dposw, dtypew, dg, db, B, Lt, L, H, vocab, max_pos, type_vocab,
+                                    (hipStream_t)stream), "cpt_embed_ln_bwd");
+}
+
 int cpt_adamw(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16,
               size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
               float grad_scale, void* stream) {

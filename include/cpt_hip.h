@@ -418,6 +418,30 @@ int cpt_gather_rows(const void* src, int dtype, const int64_t* pos, void* out, i
 int cpt_ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V,
                 void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Operator-level BACKWARD entry points (ABI 6; SURVEY 8(b): attention_bwd, bias_residual_ln_bwd, embed_ln_bwd): the kernels cpt_train_bwd
+ * launches, one by one -- what autograd runs under loss.backward() (Oscar/oscar/fewshot/refcoco_cpt.py:248) for the blocks of
+ * Oscar/oscar/modeling/modeling_bert.py:30-70 (self-attention), :85-86 / :145 (BertSelfOutput / BertOutput LayerNorm) and :244-245 (BertEmbeddings).
+ * `drop` / `site` as in cpt_train_*_ex (NULL or p = 0: no dropout): masks are regenerated from (seed, step, site), never stored.
+ *
+ * cpt_attention_bwd: qkv [B*L][3H] and dctx [B*L][H] -> dqkv [B*L][3H] (written) for ctx = dropout(softmax(q k^T / 8 + mask)) v per head, the probabilities
+ *   recomputed.  dtype CPT_F32: fp32 tensors; CPT_BF16: bf16 tensors (MFMA kernel, L <= 288); CPT_BF16X3: fp32 tensors through the split-operand
+ *   MFMA kernel.  dbias_qkv (optional, [3H] fp32): += column sums of dqkv (the stacked Q | K | V bias gradient).  mask_3d: attn_mask is [B][L][L].
+ * cpt_layernorm_bwd: y = LayerNorm(x; g, b) over rows of x [R][H] fp32 (x = the stored pre-LayerNorm sum): dx [R][H] fp32 written; dg, db += their sums
+ *   (atomics: zero them first); dx_lp (optional): the copy of dx in lp_dtype THROUGH the hidden-site dropout mask of `site` when drop is given
+ *   (the gradient entering the dense layer in front of the residual add), dbias (optional, [H]) += its column sums.  scratch (optional,
+ *   >= (R / 4) * 3 * H * 4 bytes): two-stage column sums instead of per-block atomics.
+ * cpt_embed_ln_bwd: backward of cpt_embed_ln for dy = rows b * L + t of a [B*L][H] fp32 gradient: LayerNorm backward, then scatter-add into dword
+ *   (rows of padding_idx 0 skipped, as nn.Embedding), dposw, dtypew; dg, db += (zero everything first).
+ * ---------------------------------------------------------------------------------------- */
+int cpt_attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, int mask_3d, const void* dctx, void* dqkv, float* dbias_qkv,
+                      int B, int L, int heads, const cpt_dropout* drop, int site, void* stream);
+int cpt_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype, float* dg, float* db,
+                      int R, int H, const cpt_dropout* drop, int site, float* dbias, void* scratch, size_t scratch_bytes, void* stream);
+int cpt_embed_ln_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
+                     const float* g, float eps, float* dword, float* dposw, float* dtypew, float* dg, float* db, int B, int Lt, int L, int H,
+                     int vocab, int max_pos, int type_vocab, void* stream);
+
 /* Per-kernel event timing, the A/B switches of the kernels (cpt_set_tuning) and the per-workgroup trace live in cpt_hip_debug.h: they are
  * measurement and development entry points of the same library, not part of the interface a host binds for the hot path. */
 
