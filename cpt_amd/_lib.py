@@ -89,6 +89,13 @@ _SIGS = {
     "cpt_attention_bwd": (C.c_int, [C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Dropout), C.c_int, vp]),
     "cpt_layernorm_bwd": (C.c_int, [vp, vp, vp, C.c_float, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.POINTER(Dropout), C.c_int, vp, vp, C.c_size_t, vp]),
     "cpt_embed_ln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_comm_unique_id": (C.c_int, [vp]),
+    "cpt_comm_init": (C.c_int, [C.c_int, C.c_int, vp]),
+    "cpt_comm_rank": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "cpt_allreduce_grads": (C.c_int, [vp, C.c_size_t, C.c_int, vp]),
+    "cpt_reduce_scatter": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp]),
+    "cpt_allgather": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp]),
+    "cpt_comm_destroy": (C.c_int, []),
     "cpt_adamw": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                             C.c_int, C.c_float, vp]),
     "cpt_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int,

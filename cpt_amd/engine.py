@@ -48,6 +48,28 @@ def pack_order(cfg, head):
     return sorted(final, key=lambda n: bucket_of(n, nl))     # stable: registration order inside a bucket
 
 
+def bucket_table(cfg, head, numel=None):
+    """(offsets, buckets, total) of the flat parameter / gradient / moment buffers WITHOUT allocating them: offsets[name] = (first
+    element, elements), buckets[k] = [lo, hi) of data-parallel bucket k (every bucket starts on a BUCKET_ALIGN boundary: it splits evenly
+    over 1, 2, 4 or 8 ranks).  numel(name) -> elements (default: from synth.param_specs).  The layout PackedModel.ensure_packed builds."""
+    if numel is None:
+        shapes = {n: shape for n, shape, kind in param_specs(cfg, head) if kind != "tied"}
+        numel = lambda n: int(torch.Size(shapes[n]).numel())
+    total, offsets, starts = 0, {}, {}
+    nl = cfg.num_hidden_layers
+    for n in pack_order(cfg, head):
+        k = bucket_of(n, nl)
+        if k not in starts:                       # a new bucket starts on a BUCKET_ALIGN boundary
+            total = (total + BUCKET_ALIGN - 1) // BUCKET_ALIGN * BUCKET_ALIGN
+            starts[k] = total
+        offsets[n] = (total, numel(n))
+        total += (numel(n) + ALIGN - 1) // ALIGN * ALIGN
+    total = (total + BUCKET_ALIGN - 1) // BUCKET_ALIGN * BUCKET_ALIGN
+    ks = sorted(starts)
+    buckets = {k: (starts[k], starts[ks[i + 1]] if i + 1 < len(ks) else total) for i, k in enumerate(ks)}
+    return offsets, buckets, total
+
+
 class PackedModel(object):
     """Flat parameter storage + C descriptor for one nn.Module (BertImgModel or a head wrapper)."""
 
@@ -100,21 +122,8 @@ class PackedModel(object):
         for n, p in named.items():
             if p.dtype != torch.float32:
                 raise RuntimeError("cpt_amd: parameter %s is %s; master weights must be fp32" % (n, p.dtype))
-        total = 0
-        self.offsets = {}
-        nl = self.cfg.num_hidden_layers
-        starts = {}
-        for n, p in named.items():
-            k = bucket_of(n, nl)
-            if k not in starts:                       # a new bucket starts on a BUCKET_ALIGN boundary
-                total = (total + BUCKET_ALIGN - 1) // BUCKET_ALIGN * BUCKET_ALIGN
-                starts[k] = total
-            self.offsets[n] = (total, p.numel())
-            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-        total = (total + BUCKET_ALIGN - 1) // BUCKET_ALIGN * BUCKET_ALIGN
         # [lo, hi) element range of bucket k in the flat parameter / gradient / moment buffers (gaps hold zeros)
-        ks = sorted(starts)
-        self.buckets = {k: (starts[k], starts[ks[i + 1]] if i + 1 < len(ks) else total) for i, k in enumerate(ks)}
+        self.offsets, self.buckets, total = bucket_table(self.cfg, self.head, numel=lambda n: named[n].numel())
         flat = torch.zeros(total, device=dev, dtype=torch.float32)
         for n, p in named.items():
             off, num = self.offsets[n]

@@ -442,6 +442,25 @@ int cpt_embed_ln_bwd(const float* dy, const int64_t* ids, const int64_t* tt, con
                      const float* g, float eps, float* dword, float* dposw, float* dtypew, float* dg, float* db, int B, int Lt, int L, int H,
                      int vocab, int max_pos, int type_vocab, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Communicator block (ABI 6) for hosts that are NOT PyTorch.  cpt_amd itself keeps its collectives in torch.distributed
+ * (backend "nccl" = RCCL over xGMI) and starts them from the bucket callbacks of cpt_train_fwd_ex / cpt_train_bwd_ex; a host without
+ * torch.distributed drives the same data-parallel step through these calls instead: sum the flat gradient (cpt_allreduce_grads, or
+ * cpt_reduce_scatter + cpt_allgather around a sharded cpt_adamw) where the reference's DistributedDataParallel all-reduces it
+ * (Oscar/oscar/fewshot/refcoco_cpt.py:516-522), and gather the per-rank result arrays where the reference all_gathers pickled dicts
+ * (Oscar/oscar/utils/comm.py:102-142).  RCCL is bound at run time (dlopen of librccl.so.1: no link-time dependency; inside a PyTorch
+ * process the soname resolves to the copy torch loaded).  ONE communicator per process, on the device current at cpt_comm_init; rank 0
+ * creates the 128-byte id with cpt_comm_unique_id and the host ships it to the other ranks out of band (a file, a socket, MPI).
+ * All collectives are asynchronous on `stream`; dtype CPT_F32 or CPT_BF16; counts in elements; in-place allowed where RCCL allows it.
+ * ---------------------------------------------------------------------------------------- */
+int cpt_comm_unique_id(void* id128);                              /* host buffer of 128 bytes */
+int cpt_comm_init(int rank, int nranks, const void* id128);
+int cpt_comm_rank(int* rank, int* nranks);
+int cpt_allreduce_grads(void* buf, size_t count, int dtype, void* stream);                                     /* in-place sum over ranks */
+int cpt_reduce_scatter(const void* send, void* recv, size_t recv_count, int dtype, void* stream);              /* send holds nranks * recv_count elements */
+int cpt_allgather(const void* send, void* recv, size_t send_count, int dtype, void* stream);                   /* recv holds nranks * send_count elements */
+int cpt_comm_destroy(void);
+
 /* Per-kernel event timing, the A/B switches of the kernels (cpt_set_tuning) and the per-workgroup trace live in cpt_hip_debug.h: they are
  * measurement and development entry points of the same library, not part of the interface a host binds for the hot path. */
 

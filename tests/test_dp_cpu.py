@@ -122,3 +122,81 @@ def test_bench_spawns_one_rank_per_gpu():
     line = out.stdout.strip().splitlines()[-1]
     assert "torch.distributed.run" in line and "--nproc-per-node 4" in line and "--master-addr 127.0.0.1" in line
     assert line.rstrip().endswith("--gpus 4 --steps 3 --warmup 1")
+
+
+# ---- world 4 and world 8 (readiness for the 8-GPU node without one) -------------------------------------------------
+# The REAL Oscar-base bucket table (engine.bucket_table: 14 buckets, 111.69 M elements = 447 MB of fp32 gradients per rank) through
+# ShardedGradSync's reduce-scatter -> sharded update -> all-gather, with integer-valued gradients so that every sum is exact in fp32 and
+# each rank can check its shards and the gathered parameters bit for bit; gather_fixed with query counts that do not divide by the world
+# size (some ranks even hold no query).  Replaces DistributedDataParallel (fewshot/refcoco_cpt.py:516-522) and the pickled all_gather of
+# utils/comm.py:102-142.
+
+def _pattern(n, mul, mod, off):
+    return ((torch.arange(n, dtype=torch.int64) * mul) % mod - off).to(torch.float32)
+
+
+def _world_n_worker(rank, world, port, tmp, real_table):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpt_amd import config as cfgmod
+        from cpt_amd.engine import bucket_table
+        cfg = cfgmod.oscar_base() if real_table else cfgmod.tiny()
+        _, buckets, total = bucket_table(cfg, "cpt")
+        assert all((hi - lo) % world == 0 for lo, hi in buckets.values())
+        flat = _pattern(total, 7, 127, 0) if rank == 0 else torch.zeros(total)
+        cdist.broadcast_(flat, 0)
+        f = _pattern(total, 3, 251, 125)                         # small integers: (rank + 1) * f and every partial sum are exact
+        grad = f * float(rank + 1)
+        sync = cdist.ShardedGradSync(buckets, "cpu")
+        sync.wait_params()
+        sync.begin_backward()
+        for k in sorted(buckets, reverse=True)[:-1]:             # backward order: head, layers N-1 .. 0; the embedding bucket is left to finish_reduce
+            sync.grads_ready(grad, k)
+        sync.finish_reduce(grad)
+        tri = world * (world + 1) // 2
+        for k in sync.order:
+            slo, shi = sync.shard_range(k)
+            got = sync.shard_view(sync.gshard, k)
+            assert torch.equal(got, f[slo:shi] * float(tri)), "rank %d bucket %d: reduce-scatter shard" % (rank, k)
+            flat[slo:shi] -= got * (8.0 / world / 16.0)          # "optimizer": p -= sum / world * 0.5, a power-of-two scale
+        sync.all_gather_params(flat)
+        sync.wait_params()
+        want = _pattern(total, 7, 127, 0) - f * (tri * 8.0 / world / 16.0)
+        assert torch.equal(flat, want), "rank %d: gathered parameters" % rank
+        # result gather with uneven query counts (the val loop's chosen indices)
+        for n_total in (37, 5, world, 1):
+            lo, hi = cdist.shard_range(n_total, rank, world)
+            local = torch.arange(lo, hi, dtype=torch.int64) * 3 - 1
+            allc = cdist.gather_fixed(local, n_total, fill=-7)
+            assert torch.equal(allc, torch.arange(n_total, dtype=torch.int64) * 3 - 1), (rank, n_total)
+            two = cdist.gather_fixed(torch.stack([local.float(), -local.float()], 1), n_total)
+            assert two.shape == (n_total, 2) and torch.equal(two[:, 0], -two[:, 1])
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,real_table", [(4, True), (8, True), (8, False)])
+def test_sharded_grad_sync_and_result_gather_world4_world8(world, real_table):
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_world_n_worker, args=(world, _free_port(), tmp, real_table), nprocs=world, join=True)
+        assert all(os.path.exists(os.path.join(tmp, "ok%d" % r)) for r in range(world))
+
+
+def test_real_bucket_table_shape():
+    """The flat layout the 8-GPU job would shard: 14 buckets (embeddings + region projection | 12 layers | pooler + head), each a multiple of
+    512 elements, together the 111.68 M parameters of Oscar-base + alignment gaps; the largest message is the embedding bucket."""
+    from cpt_amd import config as cfgmod
+    from cpt_amd.engine import bucket_table, BUCKET_ALIGN
+    offsets, buckets, total = bucket_table(cfgmod.oscar_base(), "cpt")
+    assert len(buckets) == 14 and sorted(buckets) == list(range(14))
+    assert all(lo % BUCKET_ALIGN == 0 and hi % BUCKET_ALIGN == 0 for lo, hi in buckets.values())
+    assert buckets[0][0] == 0 and buckets[13][1] == total and all(buckets[k][1] == buckets[k + 1][0] for k in range(13))
+    n_params = sum(n for _, n in offsets.values())
+    assert n_params == 111684410 or abs(n_params - 111.68e6) < 0.02e6
+    assert total - n_params < 14 * BUCKET_ALIGN + 64 * len(offsets)
+    sizes = {k: hi - lo for k, (lo, hi) in buckets.items()}
+    assert max(sizes, key=sizes.get) == 0 and len({sizes[k] for k in range(1, 13)}) == 1

@@ -367,3 +367,134 @@ def test_stale_training_forward_raises():
     with pytest.raises(RuntimeError, match="stale training forward"):
         la.backward()
     lb.backward()                                                   # the latest forward still has its activations
+
+
+# ---- inference: the val loop sharded over two ranks ---------------------------------------------------------
+# Whole queries are sharded (cdist.shard_range), no collective runs inside the model, ONE fixed-shape gather of the chosen indices closes the
+# loop (replaces the pickled-dict all_gather of utils/comm.py:102-142 called from zeroshot/refcoco_cpt.py:256).  Both ranks share cuda:0
+# over gloo; 7 queries do not divide by 2, so the shards differ in size.
+
+def _val_queries(cfg, n, seed):
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    qs = []
+    for i in range(n):
+        P = int(rng.integers(1, 5))
+        b = synth.make_batch(P, cfg, seed=seed * 100 + i, vary_regions=True)
+        colors = [[int(c) for c in rng.choice(synth.COLOR_IDS, size=int(rng.integers(1, 4)), replace=False)] for _ in range(P)]
+        rects = [[[10 * j, 5 * k, 10 * j + 30, 5 * k + 40] for k in range(len(colors[j]))] for j in range(P)]
+        q = {k: b[k] for k in ("img_feats", "input_ids", "segment_ids", "attention_mask", "mask_token_pos")}
+        q["colors"], q["rects"] = colors, rects
+        qs.append(q)
+    return qs
+
+
+def _val_model(cfg, dev, mode):
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, 21, head="cpt"))
+    m.tie_weights()
+    m.to(dev).eval()
+    m.set_compute_dtype(mode)
+    return m
+
+
+def _val_worker(rank, world, port, tmp, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpt_amd import drivers
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        cfg = cfgmod.oscar_base(num_hidden_layers=2)
+        m = _val_model(cfg, dev, mode)
+        qs = _val_queries(cfg, 7, 3)
+        out = {fs: drivers.val_queries(m, qs, synth.NONE_ID, dev, few_shot=fs, batch_queries=3) for fs in (False, True)}
+        torch.save(out, os.path.join(tmp, "v%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_val_queries_two_ranks_equal_single_process(mode):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cpt_amd import drivers
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_val_worker, args=(world, _free_port(), tmp, mode), nprocs=world, join=True)
+        r = [torch.load(os.path.join(tmp, "v%d.pt" % i)) for i in range(world)]
+    dev = torch.device("cuda:0")
+    cfg = cfgmod.oscar_base(num_hidden_layers=2)
+    m = _val_model(cfg, dev, mode)
+    qs = _val_queries(cfg, 7, 3)
+    for fs in (False, True):
+        single = drivers.val_queries(m, qs, synth.NONE_ID, dev, few_shot=fs, batch_queries=3)
+        assert r[0][fs] == r[1][fs], "every rank holds the whole result"
+        # sequences are independent and every kernel is batch-invariant: the sharded loop scores each query with the same bits
+        assert r[0][fs] == single, (fs, r[0][fs], single)
+        assert sorted(single) == list(range(7)) and all(v[0] >= 0 and v[1] is not None for v in single.values())
+
+
+# ---- the C ABI's own communicator block (cpt_comm_*, include/cpt_hip.h): RCCL bound at run time, for hosts without torch.distributed ----
+
+def _comm_worker(rank, world, tmp):
+    import ctypes as C
+    import time
+    from cpt_amd import _lib as L
+    lib = L.lib()
+    dev = torch.device("cuda:%d" % rank)
+    torch.cuda.set_device(dev)
+    idf = os.path.join(tmp, "id.bin")
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        L.check(lib.cpt_comm_unique_id(buf), "cpt_comm_unique_id")
+        open(idf + ".tmp", "wb").write(buf.raw)
+        os.replace(idf + ".tmp", idf)                       # the id travels out of band: here a file
+    else:
+        for _ in range(600):
+            if os.path.exists(idf):
+                break
+            time.sleep(0.05)
+        buf.raw = open(idf, "rb").read()
+    assert lib.cpt_allreduce_grads(torch.zeros(4, device=dev).data_ptr(), 4, L.CPT_F32, L.stream_ptr()) != 0      # no communicator yet
+    assert b"cpt_comm_init" in lib.cpt_last_error()
+    L.check(lib.cpt_comm_init(rank, world, buf), "cpt_comm_init")
+    assert lib.cpt_comm_init(rank, world, buf) != 0                                                                # one communicator per process
+    r, n = C.c_int(-1), C.c_int(-1)
+    L.check(lib.cpt_comm_rank(C.byref(r), C.byref(n)), "cpt_comm_rank")
+    assert (r.value, n.value) == (rank, world)
+    N = 1 << 20
+    g = torch.arange(N, device=dev, dtype=torch.float32) % 97 + rank
+    L.check(lib.cpt_allreduce_grads(g.data_ptr(), N, L.CPT_F32, L.stream_ptr()), "cpt_allreduce_grads")
+    want = (torch.arange(N, device=dev, dtype=torch.float32) % 97) * world + world * (world - 1) / 2
+    assert torch.equal(g, want)
+    gb = ((torch.arange(N, device=dev) % 13).float() + rank).to(torch.bfloat16)
+    L.check(lib.cpt_allreduce_grads(gb.data_ptr(), N, L.CPT_BF16, L.stream_ptr()), "cpt_allreduce_grads(bf16)")
+    assert torch.equal(gb.float(), (torch.arange(N, device=dev) % 13).float() * world + world * (world - 1) / 2)
+    # reduce-scatter -> "update" -> all-gather: the sharded form of the same step
+    src = torch.arange(N, device=dev, dtype=torch.float32) % 31 - rank
+    shard = torch.empty(N // world, device=dev)
+    L.check(lib.cpt_reduce_scatter(src.data_ptr(), shard.data_ptr(), N // world, L.CPT_F32, L.stream_ptr()), "cpt_reduce_scatter")
+    full = (torch.arange(N, device=dev, dtype=torch.float32) % 31) * world - world * (world - 1) / 2
+    assert torch.equal(shard, full[rank * (N // world):(rank + 1) * (N // world)])
+    out = torch.empty(N, device=dev)
+    L.check(lib.cpt_allgather(shard.data_ptr(), out.data_ptr(), N // world, L.CPT_F32, L.stream_ptr()), "cpt_allgather")
+    assert torch.equal(out, full)
+    assert lib.cpt_allgather(shard.data_ptr(), out.data_ptr(), N // world, 5, L.stream_ptr()) != 0                  # bad dtype
+    torch.cuda.synchronize(dev)
+    L.check(lib.cpt_comm_destroy(), "cpt_comm_destroy")
+    L.check(lib.cpt_comm_destroy(), "cpt_comm_destroy (idempotent)")
+    open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_c_abi_communicator_block(world):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs" % world)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_comm_worker, args=(world, tmp), nprocs=world, join=True)
+        assert all(os.path.exists(os.path.join(tmp, "ok%d" % r)) for r in range(world))
