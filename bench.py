@@ -444,7 +444,7 @@ def main():
     ap.add_argument("--no-io", action="store_true", help="skip the measured input-pipeline leg (extra.io_pipeline_measured)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (the `extra` object of the line)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained run behind the K timed steps")
-    ap.add_argument("--tune", default="", help="debug: comma list of key=value passed to cpt_set_tuning")
+    ap.add_argument("--tune", default="", help="debug: comma list of key=value passed to cpt_set_tuning (loads the CPT_ABLATION development build of the library)")
     ap.add_argument("--no-check", action="store_true", help="debug: skip the finite-output check (ablation runs)")
     ap.add_argument("--workload", default="refcoco", choices=["refcoco", "gqa", "vcr"],
                     help="refcoco: BASELINE configs[1] (default; the headline metric).  gqa: configs[3] shape, Oscar-base L=165+45, "
@@ -499,6 +499,8 @@ def main():
             pass
     n_gpus = world
 
+    if args.tune:
+        os.environ.setdefault("CPT_AMD_ABLATION", "1")      # A/B switches exist in the development build of the library only (cpt_amd/libcpt_hip_abl.so)
     from cpt_amd import config as cfgmod, synth, _lib, engine
     from cpt_amd.modeling_rec import REC_MLM_CPT
     _lib.check(_lib.lib().cpt_check_device(local), "cpt_check_device")

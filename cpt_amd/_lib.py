@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CPT_LIB_PATH") or os.path.join(HERE, "libcpt_hip.so")     # (CPT_LIB_PATH: developer A/B builds, tools/ only)
+# CPT_AMD_ABLATION=1: the development build with live kernel-variant switches (include/cpt_hip_debug.h; `python -m cpt_amd.build --ablation`);
+# CPT_LIB_PATH: developer A/B builds (tools/ only)
+LIB_PATH = os.environ.get("CPT_LIB_PATH") or os.path.join(HERE, "libcpt_hip_abl.so" if os.environ.get("CPT_AMD_ABLATION", "0") not in ("", "0") else "libcpt_hip.so")
 
 CPT_F32, CPT_BF16, CPT_BF16X3, CPT_BF16X3_MASTERS = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID = 0, 1, 2, 3
@@ -116,7 +118,11 @@ _SIGS = {
     "cpt_gemm_ln_prod3_panel": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int,
                                           C.c_int, C.c_int, vp]),
     "cpt_panel_pack_bytes": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
-    "cpt_gemm_ln_prod3_rpanel": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_gemm_ln_prod3_rpanel": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_gemm_tile": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_gemm_ln_cons_tile": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "cpt_gemm_ln_prod3_panel_waves": (C.c_int, [C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int,
+                                                C.c_int, C.c_int, vp]),
     "cpt_resid3_split": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "cpt_resid3_merge": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "cpt_gemm_nn": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
@@ -128,6 +134,7 @@ _SIGS = {
     "cpt_ce_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "cpt_retile_k32": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "cpt_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "cpt_build_info": (C.c_int, []),
     "cpt_debug_gemm_trace": (C.c_int, [vp]),
     "cpt_prof_enable": (C.c_int, [C.c_int]),
     "cpt_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -156,6 +163,11 @@ def _bind_torch_hip_runtime():
 
 def exported_symbols():
     return sorted(_SIGS)
+
+
+def ablation_build():
+    """True when the loaded library is the CPT_ABLATION development build (cpt_set_tuning works)."""
+    return bool(lib().cpt_build_info() & 1)
 
 
 def lib():

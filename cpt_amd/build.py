@@ -8,11 +8,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcpt_hip.so")
+LIB_ABL = os.path.join(HERE, "libcpt_hip_abl.so")      # development build (-DCPT_ABLATION): kernel-variant switches live (include/cpt_hip_debug.h)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result", "-I" + os.path.join(os.path.dirname(HERE), "include")]
-if os.environ.get("CPT_ABLATION"):          # diagnostic build: GEMM ablation bits live (tools/abl_sweep.sh)
-    FLAGS.append("-DCPT_ABLATION")
 
 
 def _sources():
@@ -26,18 +25,23 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, ablation=False):
+    """Product library (default) or, with ablation=True, the development library libcpt_hip_abl.so (-DCPT_ABLATION; objects under csrc/abl/)."""
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cpt_hip.h"))
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cpt_io.h"))
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cpt_hip_debug.h"))
+    odir = os.path.join(CSRC, "abl") if ablation else CSRC
+    os.makedirs(odir, exist_ok=True)
+    lib = LIB_ABL if ablation else LIB
+    flags = FLAGS + (["-DCPT_ABLATION"] if ablation else [])
     objs, jobs = [], []
     for f in _sources():
         src = os.path.join(CSRC, f)
-        obj = os.path.join(CSRC, f[:-4] + ".o")
+        obj = os.path.join(odir, f[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -49,10 +53,10 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-ldl"])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", lib] + objs + ["-ldl"])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, ablation="--ablation" in sys.argv))

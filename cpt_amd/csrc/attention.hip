@@ -236,8 +236,8 @@ __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kerne
         }
 }
 
-int g_attn_remap = 1;       // cpt_set_tuning(21, v): 0 = the (pair, tile) grid of rounds 1-2 (A/B)
-void set_attn_qt_all(int v) { g_attn_remap = v; }
+CPT_SWITCH(int g_attn_remap, 1);       // cpt_set_tuning(21, v): 0 = the (pair, tile) grid of rounds 1-2 (A/B)
+void set_attn_qt_all(int v) { CPT_SWITCH_SET(g_attn_remap = v); (void)v; }
 
 template <typename T, int NKB>
 static size_t att_lds_bytes() {

@@ -391,8 +391,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     atomicAdd(c < H ? &dg[c] : (c < 2 * H ? &db[c - H] : &dbias[c - 2 * H]), a);
 }
 
-int g_lnb_rpb = 0;       // cpt_set_tuning(17, rows): rows per workgroup of the two-stage form (0: 8 from 2048 rows on, else 4 = one row per wave)
-void set_lnb_rpb(int v) { g_lnb_rpb = v > 0 ? v : 0; }
+CPT_SWITCH(int g_lnb_rpb, 0);       // cpt_set_tuning(17, rows): rows per workgroup of the two-stage form (0: 8 from 2048 rows on, else 4 = one row per wave)
+void set_lnb_rpb(int v) { CPT_SWITCH_SET(g_lnb_rpb = v > 0 ? v : 0); (void)v; }
 
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
@@ -1767,8 +1767,8 @@ int attention_bwd_x3(const float* qkv, const int64_t* attn_mask, const float* dc
     return attn_bwd_x3_long_launch<9>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
 }
 
-int g_attn_bwd_variant = 1;      // 1: transpose-read MFMA kernels for bf16 (L <= 288); 0: generic kernel always; 2: L <= 128 through the older MFMA kernel with transposed tile copies
-void set_attn_bwd_variant(int v) { g_attn_bwd_variant = v; }
+CPT_SWITCH(int g_attn_bwd_variant, 1);      // 1: transpose-read MFMA kernels for bf16 (L <= 288); 0: generic kernel always; 2: L <= 128 through the older MFMA kernel with transposed tile copies
+void set_attn_bwd_variant(int v) { CPT_SWITCH_SET(g_attn_bwd_variant = v); (void)v; }
 
 static size_t attn_bwd_vg_lds(int L, int has_drop) { return ((size_t)L * 65 + 2 * 16 * 65 + (has_drop ? 3 : 2) * 16 * (L + 1) + L) * sizeof(float); }
 // Whether attention_bwd has a kernel for (dtype, L, dropout on the probabilities): asked by cpt_train_fwd so that an unsupported

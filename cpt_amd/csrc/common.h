@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "switches.h"
+
 namespace cpt {
 
 typedef __bf16 bf16;

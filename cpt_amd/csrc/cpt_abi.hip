@@ -121,7 +121,7 @@ FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
 }  // namespace
 
 // fused QKV projection + attention: form chosen by cpt_set_tuning(6, .)
-static int g_qkv_tiled = 1;    // form 3: read the K-tile-major weight copy (cpt_layer_fold.w_qkv_t) when the model carries one
+CPT_SWITCH(static int g_qkv_tiled, 1);    // form 3: read the K-tile-major weight copy (cpt_layer_fold.w_qkv_t) when the model carries one
 static int qkv_attn(int config, const void* A, int lda, const void* W, int ldw, const float* bias, const float* st_in, const float* colc,
                     const float* cold, float eps, int hidden, const int64_t* mask, void* ctx, int ldo, int B, int L, int heads, int K,
                     hipStream_t s, const void* W_tiled, int ctx_panel = 0, int a_panel = 0) {
@@ -150,20 +150,35 @@ int cpt_check_device(int dev) {
     return CPT_OK;
 }
 
-static int g_fold_ln = 1;      // bf16 mode with cpt_model.fold: fold the encoder LayerNorms into the GEMMs (0 = run them as kernels)
-static int g_fuse_attn = 3;    // bf16, L <= 128: QKV projection + attention in one kernel (0 = two kernels; 1 = one workgroup per (sequence, head), two per CU; 2 = same, one per CU; 3 = one workgroup per (sequence, three heads) where heads % 3 == 0, else 1)
-static int g_lp_resid = 0;     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
-static int g_panel = 1;        // fused bf16 encoder: ctx and the FFN activation travel in the fragment-major panel layout and the LayerNorm producers read them straight into registers (gemm_prod.hip) where the shapes allow
-static int g_x3_fuse = 1;      // bf16x3 parity mode: split copies written by the producing kernels (FFN-up GELU epilogue, LayerNorm passes) instead of stand-alone split3 passes (cpt_set_tuning key 23)
-static int g_rpanel = 1;       // round 5: the residual stream itself travels in the panel layout and the LayerNorm producers run their register-direct epilogue (gemm_prod.hip RP; cpt_set_tuning key 30)
-static int g_prefetch = 1;     // panel mode: the 240-tile launches carry 16 workgroups that read the next launch's weights into the Infinity Cache (common.h prefetch_region)
-static int g_panel_ffn_multi = 1;   // panel layout for the FFN activation also when the producers run several rounds of tiles (cpt_set_tuning key 28; experiments)
-static int g_x3_attn = 1;      // bf16x3 parity mode: attention on bf16 MFMA with split operands (0: the fp32 MFMA kernel + a split3 pass over ctx)
-static int g_dec_pf_pct = 40;   // percent of the decoder table prefetched by the head's first launch (the rest: by its reduce + GELU + LayerNorm launch)
-static int g_embed_pad = 1;    // bf16 fused encoder: text embedding + region-feature pad/cast in one launch (cpt_set_tuning key 25)
-static int g_resid3 = 1;       // fused bf16 encoder: residual stream in the 3-byte form (bf16 hi + int8 lo) instead of fp32 + bf16 copies
+CPT_SWITCH(static int g_fold_ln, 1);      // bf16 mode with cpt_model.fold: fold the encoder LayerNorms into the GEMMs (0 = run them as kernels)
+CPT_SWITCH(static int g_fuse_attn, 3);    // bf16, L <= 128: QKV projection + attention in one kernel (0 = two kernels; 1 = one workgroup per (sequence, head), two per CU; 2 = same, one per CU; 3 = one workgroup per (sequence, three heads) where heads % 3 == 0, else 1)
+CPT_SWITCH(static int g_lp_resid, 0);     // bf16 mode: keep the residual stream in bf16 only (A/B switch)
+CPT_SWITCH(static int g_panel, 1);        // fused bf16 encoder: ctx and the FFN activation travel in the fragment-major panel layout and the LayerNorm producers read them straight into registers (gemm_prod.hip) where the shapes allow
+CPT_SWITCH(static int g_x3_fuse, 1);      // bf16x3 parity mode: split copies written by the producing kernels (FFN-up GELU epilogue, LayerNorm passes) instead of stand-alone split3 passes (cpt_set_tuning key 23)
+CPT_SWITCH(static int g_rpanel, 1);       // round 5: the residual stream itself travels in the panel layout and the LayerNorm producers run their register-direct epilogue (gemm_prod.hip RP; cpt_set_tuning key 30)
+CPT_SWITCH(static int g_prefetch, 1);     // panel mode: the 240-tile launches carry 16 workgroups that read the next launch's weights into the Infinity Cache (common.h prefetch_region)
+CPT_SWITCH(static int g_panel_ffn_multi, 1);   // panel layout for the FFN activation also when the producers run several rounds of tiles (cpt_set_tuning key 28; experiments)
+CPT_SWITCH(static int g_x3_attn, 1);      // bf16x3 parity mode: attention on bf16 MFMA with split operands (0: the fp32 MFMA kernel + a split3 pass over ctx)
+CPT_SWITCH(static int g_dec_pf_pct, 40);   // percent of the decoder table prefetched by the head's first launch (the rest: by its reduce + GELU + LayerNorm launch)
+CPT_SWITCH(static int g_embed_pad, 1);    // bf16 fused encoder: text embedding + region-feature pad/cast in one launch (cpt_set_tuning key 25)
+CPT_SWITCH(static int g_resid3, 1);       // fused bf16 encoder: residual stream in the 3-byte form (bf16 hi + int8 lo) instead of fp32 + bf16 copies
+
+int cpt_build_info(void) {
+#ifdef CPT_ABLATION
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int cpt_set_tuning(int key, int value) {
+#ifndef CPT_ABLATION
+    // product build: every switch is a compile-time constant (common.h CPT_SWITCH) -- nothing to set, nothing global to restore
+    (void)value;
+    if (key == -1) return CPT_OK;
+    return fail(CPT_ERR_ARCH, "cpt_set_tuning(%d): the kernel-variant switches exist in the CPT_ABLATION build only (libcpt_hip_abl.so, CPT_AMD_ABLATION=1); "
+                              "this library always runs its shipped configuration", key);
+#else
     if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
         g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_panel_ffn_multi = 1; cpt::set_lncons4(1); g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1; g_rpanel = 1;
         cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
@@ -202,6 +217,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 26) { g_dec_pf_pct = value < 0 ? 0 : (value > 100 ? 100 : value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
     return fail(CPT_ERR_SHAPE, "cpt_set_tuning: unknown key %d", key);
+#endif
 }
 
 int cpt_debug_gemm_trace(void* buf) {
@@ -290,12 +306,33 @@ int cpt_gemm_ln_prod3(const void* A, int lda, const void* W, int ldw, const floa
 int cpt_panel_pack(const void* src_bf16, int ld, void* dst_bf16, int M, int K, int to_panel, void* stream) {
     return check_launch(cpt::panel_pack(src_bf16, ld, dst_bf16, M, K, to_panel, (hipStream_t)stream), "cpt_panel_pack");
 }
+// ---- operator-level test entry points with a per-call kernel choice (cpt_hip_debug.h) ----
+int cpt_gemm_tile(int tile, int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias,
+                  const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K, void* stream) {
+    cpt::OverrideScope sc(tile, -1);
+    return cpt_gemm(dtype, epi, A, lda, W, ldw, bias, resid, ldr, out, out_dtype, ldo, M, N, K, stream);
+}
+int cpt_gemm_ln_cons_tile(int tile, const void* A_bf16, int lda, const void* Wf_bf16, int ldw, const float* st_in, const float* colc,
+                          const float* cold, float eps, int hidden, int gelu, void* out_bf16, int ldo, int M, int N, int K, void* stream) {
+    cpt::OverrideScope sc(tile, -1);
+    return cpt_gemm_ln_cons(A_bf16, lda, Wf_bf16, ldw, st_in, colc, cold, eps, hidden, gelu, out_bf16, ldo, M, N, K, stream);
+}
+int cpt_gemm_ln_prod3_panel_waves(int waves, const void* A_panel, const void* W, int ldw, const float* bias, const void* resid_hi, const void* resid_lo, int ldr,
+                                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi, void* out_lo,
+                                  float* st_out, int ldo, int M, int N, int K, void* stream) {
+    if (waves != 0 && waves != 4 && waves != 8) return fail(CPT_ERR_SHAPE, "cpt_gemm_ln_prod3_panel_waves: waves %d (0, 4 or 8)", waves);
+    cpt::OverrideScope sc(-1, waves);
+    return cpt_gemm_ln_prod3_panel(A_panel, W, ldw, bias, resid_hi, resid_lo, ldr, st_in, g_in, b_in, eps, hidden, out_hi, out_lo, st_out, ldo, M, N, K, stream);
+}
+
 int cpt_panel_pack_bytes(const void* src_i8, int ld, void* dst_i8, int M, int K, int to_panel, void* stream) {
     return check_launch(cpt::panel_pack(src_i8, ld, dst_i8, M, K, to_panel, (hipStream_t)stream, 1), "cpt_panel_pack_bytes");
 }
 int cpt_gemm_ln_prod3_rpanel(const void* A_panel, const void* W, int ldw, const float* bias, const void* resid_hi_panel, const void* resid_lo_panel,
                              const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi_panel, void* out_lo_panel,
-                             float* st_out, int M, int N, int K, void* stream) {
+                             float* st_out, int M, int N, int K, int waves, void* stream) {
+    if (waves != 0 && waves != 4 && waves != 8) return fail(CPT_ERR_SHAPE, "cpt_gemm_ln_prod3_rpanel: waves %d (0 = by shape, 4 or 8)", waves);
+    cpt::OverrideScope sc(-1, waves == 0 ? -1 : waves);
     if (!cpt::panel_eligible(M, N, K))
         return fail(CPT_ERR_SHAPE, "cpt_gemm_ln_prod3_rpanel: needs M %% 128 == 0, N %% 192 == 0, K %% 256 == 0, K >= 512 (got M=%d N=%d K=%d)", M, N, K);
     return check_launch(cpt::gemm_ln_prod3_panel(A_panel, W, ldw, bias, resid_hi_panel, resid_lo_panel, N, st_in, g_in, b_in, eps, hidden, out_hi_panel, out_lo_panel,

@@ -1125,9 +1125,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group3_kernel(TnProb p0, TnPro
 long long* g_gemm_trace = nullptr;
 int g_trace_epi = -1, g_trace_k = 0;       // diagnostic builds: stamp only launches of this epilogue / this K (-1 / 0: all)
 void set_gemm_trace_filter(int epi, int k) { g_trace_epi = epi == 255 ? -1 : epi; g_trace_k = k; }
-extern int g_gemm_abl;
-int g_gemm_skew = 0;
-void set_gemm_skew(int v) { g_gemm_skew = v; }
+CPT_SWITCH(int g_gemm_abl, 0);
+CPT_SWITCH(int g_gemm_skew, 0);
+void set_gemm_skew(int v) { CPT_SWITCH_SET(g_gemm_skew = v); (void)v; }
 
 template <typename T, int EPI, typename OT, int TBM, int TBN, int WM, int WN, int STAGES, int EP = 1, int FD = 4, int OCC = 1, int TN = 0>
 static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bias, const float* resid, int ldr,
@@ -1150,8 +1150,10 @@ static int launch_pipe(const T* A, int lda, const T* W, int ldw, const float* bi
     return CPT_OK;
 }
 
-int g_gemm_abl = 0;
-int g_gemm_variant = 3;      // 0: generic register-staged kernel only; 3: pipelined kernel, tile shape chosen per GEMM; 10/11/13/14/15: one fixed shape
+CallOverride& call_override() { static thread_local CallOverride o; return o; }
+CPT_SWITCH(int g_gemm_variant_sw, 3);
+#define g_gemm_variant (call_override().gemm_variant >= 0 ? call_override().gemm_variant : g_gemm_variant_sw)
+// g_gemm_variant: 0: generic register-staged kernel only; 3: pipelined kernel, tile shape chosen per GEMM; 10/11/13/14/15: one fixed shape
 
 // the five tile configurations of the pipelined kernel
 #define CPT_CFG_128x192 128, 192, 4, 2, 3
@@ -1323,8 +1325,8 @@ int gemm_head_transform(const void* A, int lda, const void* W, int ldw, const fl
     return launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, partials, N, M, N, K, s, head_transform_splits(K));
 }
 
-int g_splitk_target = 384;
-void set_splitk_target(int v) { g_splitk_target = v; }
+CPT_SWITCH(int g_splitk_target, 384);
+void set_splitk_target(int v) { CPT_SWITCH_SET(g_splitk_target = v); (void)v; }
 
 // out[M][N] (fp32, caller-zeroed or holding a partial sum) += A[M][K] . W[N][K]^T, K split over
 // enough workgroups to fill the chip; used for weight gradients (M, N small; K = rows of the batch)
@@ -1680,8 +1682,8 @@ int gemm_gelu_x3(const void* A3, int lda, const void* W3, int ldw, const float* 
     return CPT_OK;
 }
 
-int g_qkv_2pass = 1;
-void set_qkv_2pass(int v) { g_qkv_2pass = v; }
+CPT_SWITCH(int g_qkv_2pass, 1);
+void set_qkv_2pass(int v) { CPT_SWITCH_SET(g_qkv_2pass = v); (void)v; }
 
 int gemm_ln_cons(const void* A, int lda, const void* Wf, int ldw, const float* st_in, const float* colc, const float* cold,
                  float eps, int hidden, int gelu, void* out_lp, int ldo, int M, int N, int K, hipStream_t s, int out_panel, const void* pf, size_t pf_bytes, int a_panel) {
@@ -1777,8 +1779,8 @@ int gemm_qkv_attn(const void* A, int lda, const void* W, int ldw, const float* b
                  : launch_qkv_attn<CPT_EPI_ATTN, 2, 2, 2>(a, lda, w, ldw, bias, c, ldo, M, N, K, ex, B, s);
 }
 
-void set_gemm_variant(int v) { g_gemm_variant = v; }
-void set_gemm_abl(int v) { g_gemm_abl = v; }
+void set_gemm_variant(int v) { CPT_SWITCH_SET(g_gemm_variant_sw = v); (void)v; }
+void set_gemm_abl(int v) { CPT_SWITCH_SET(g_gemm_abl = v); (void)v; }
 void set_gemm_trace(void* p) { g_gemm_trace = (long long*)p; }
 
 }  // namespace cpt

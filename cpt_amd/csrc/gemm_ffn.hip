@@ -458,10 +458,10 @@ int launch_2pass(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int 
 
 }  // namespace
 
-int g_ffn_2pass_min_tiles = 192;      // (cpt_set_tuning key 16: experiments with half batches on two streams)
-void set_ffn_2pass_min_tiles(int v) { g_ffn_2pass_min_tiles = v; }
-int g_ffn_dma_late = 1;      // A/B switch (cpt_set_tuning key 12): 0 = refill DMA issued right behind the barrier (round 2)
-void set_ffn_dma_late(int v) { g_ffn_dma_late = v; }
+CPT_SWITCH(int g_ffn_2pass_min_tiles, 192);      // (cpt_set_tuning key 16: experiments with half batches on two streams)
+void set_ffn_2pass_min_tiles(int v) { CPT_SWITCH_SET(g_ffn_2pass_min_tiles = v); (void)v; }
+CPT_SWITCH(int g_ffn_dma_late, 1);      // A/B switch (cpt_set_tuning key 12): 0 = refill DMA issued right behind the barrier (round 2)
+void set_ffn_dma_late(int v) { CPT_SWITCH_SET(g_ffn_dma_late = v); (void)v; }
 
 // shapes the two-pass kernel can run / shapes it is the better choice for
 int ffn_up_2pass_legal(int M, int N, int K) { return (K == 768 || K == 1024) && N % TN == 0 && M >= TM; }
@@ -496,7 +496,9 @@ int gemm_ffn_up_2pass(const void* A, int lda, const void* Wf, int ldw, const flo
     }
     if (lda % 8 || ldw % 8 || ldo % 8 || (((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)out | (uintptr_t)colc | (uintptr_t)cold) & 15)) return CPT_ERR_ALIGN;
     const float inv_h = 1.0f / (float)hidden;
+#ifdef CPT_ABLATION
     if (K == 768 && !g_ffn_dma_late) return launch_2pass<12, false>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);
+#endif
     if (K == 768) return launch_2pass<12>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);
     return launch_2pass<16>((const bf16*)A, lda, (const bf16*)Wf, ldw, (bf16*)out, ldo, M, N, st_in, st_parts, colc, cold, eps, inv_h, (long long*)trace, abl, s);
 }

@@ -314,8 +314,8 @@ int launch4(const bf16* A, int lda, const bf16* W, int ldw, bf16* out, int ldo, 
 
 }  // namespace
 
-int g_lncons4 = 1;      // cpt_set_tuning key 29: 1 (default) = the 4-wave consumer kernel where the two-pass kernel ran, 0 = the two-pass kernel (round 3)
-void set_lncons4(int v) { g_lncons4 = v; }
+CPT_SWITCH(int g_lncons4, 1);      // cpt_set_tuning key 29: 1 (default) = the 4-wave consumer kernel where the two-pass kernel ran, 0 = the two-pass kernel (round 3)
+void set_lncons4(int v) { CPT_SWITCH_SET(g_lncons4 = v); (void)v; }
 int lncons4_enabled() { return g_lncons4; }
 
 // same shapes as the two-pass kernel (gemm_ffn.hip ffn_up_2pass_legal): K = 768 or 1024, N % 256 == 0

@@ -653,10 +653,10 @@ __global__ __launch_bounds__(256) void panel_pack_kernel(const U* __restrict__ s
 
 extern long long* g_gemm_trace;
 extern int g_trace_k, g_trace_epi;       // diagnostics: stamp only launches of this K (0: all) / this epilogue id (-1: all; the producers are 11)
-int g_prod_abl = 0;          // timing experiments (cpt_set_tuning key 13), see prod3_panel_kernel
-void set_prod_abl(int v) { g_prod_abl = v; }
-int g_prod_waves = 0;        // wave shape of the tile (cpt_set_tuning key 24): 8 = 4 x 2 waves of 32 x 96, 4 = 4 x 1 waves of 32 x 192, 0 = by shape (4 when the tiles run several rounds); same bits
-void set_prod_waves(int v) { g_prod_waves = (v == 4 || v == 0) ? v : 8; }
+CPT_SWITCH(int g_prod_abl, 0);          // timing experiments (cpt_set_tuning key 13), see prod3_panel_kernel
+void set_prod_abl(int v) { CPT_SWITCH_SET(g_prod_abl = v); (void)v; }
+CPT_SWITCH(int g_prod_waves, 0);        // wave shape of the tile (cpt_set_tuning key 24): 8 = 4 x 2 waves of 32 x 96, 4 = 4 x 1 waves of 32 x 192, 0 = by shape (4 when the tiles run several rounds); same bits
+void set_prod_waves(int v) { CPT_SWITCH_SET(g_prod_waves = (v == 4 || v == 0) ? v : 8); (void)v; }
 
 int panel_eligible(int M, int N, int K) { return M > 0 && M % TM == 0 && N > 0 && N % TN == 0 && K >= 512 && K % 256 == 0 && (size_t)M * K * 2 <= (size_t)0x7fffffff; }
 
@@ -686,11 +686,19 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     static bool attr_done_dev[CPT_MAX_DEV] = {};
     bool& attr_done = attr_done_dev[current_device_slot()];
     if (!attr_done) {
-        for (const void* k : {(const void*)prod3_panel_kernel<0, 8, 0, true>, (const void*)prod3_panel_kernel<0, 8, 1, true>, (const void*)prod3_panel_kernel<0, 8, 0>, (const void*)prod3_panel_kernel<0, 8, 1>, (const void*)prod3_panel_kernel<1, 8, 1>, (const void*)prod3_panel_kernel<2, 8, 1>, (const void*)prod3_panel_kernel<3, 8, 1>, (const void*)prod3_panel_kernel<4, 8, 1>}) {
+        for (const void* k : {(const void*)prod3_panel_kernel<0, 8, 0, true>, (const void*)prod3_panel_kernel<0, 8, 1, true>, (const void*)prod3_panel_kernel<0, 8, 0>, (const void*)prod3_panel_kernel<0, 8, 1>
+#ifdef CPT_ABLATION
+                              , (const void*)prod3_panel_kernel<1, 8, 1>, (const void*)prod3_panel_kernel<2, 8, 1>, (const void*)prod3_panel_kernel<3, 8, 1>, (const void*)prod3_panel_kernel<4, 8, 1>
+#endif
+             }) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<8>::LDS_BYTES);
             if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         }
-        for (const void* k : {(const void*)prod3_panel_kernel<0, 4, 0, true>, (const void*)prod3_panel_kernel<0, 4, 1, true>, (const void*)prod3_panel_kernel<0, 4, 0>, (const void*)prod3_panel_kernel<0, 4, 1>, (const void*)prod3_panel_kernel<2, 4, 1>, (const void*)prod3_panel_kernel<3, 4, 1>}) {
+        for (const void* k : {(const void*)prod3_panel_kernel<0, 4, 0, true>, (const void*)prod3_panel_kernel<0, 4, 1, true>, (const void*)prod3_panel_kernel<0, 4, 0>, (const void*)prod3_panel_kernel<0, 4, 1>
+#ifdef CPT_ABLATION
+                              , (const void*)prod3_panel_kernel<2, 4, 1>, (const void*)prod3_panel_kernel<3, 4, 1>
+#endif
+             }) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Shape<4>::LDS_BYTES);
             if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         }
@@ -711,24 +719,29 @@ int gemm_ln_prod3_panel(const void* A_panel, const void* W, int ldw, const float
     // per step at B = 256, L = 210).  In one round (the bench shape, 240 tiles) the 4-wave FFN-down launch is 2.5 us shorter by its own
     // brackets, but the step is not (1.706 vs 1.696 ms, 1.741 vs 1.739 on a second box): the chip sits at its power cap and the denser
     // launch takes clock from its neighbours (profiles/r04_kloop_vs_hipblaslt.md), so the 8-wave shape stays there.
+    const int prod_waves = call_override().prod_waves >= 0 ? call_override().prod_waves : g_prod_waves;      // (per-call test override, kernels.h)
     if (resid_panel) {      // residual stream in the panel layout, register-direct epilogue (round 5)
         if ((size_t)M * N * 2 > (size_t)0x7fffffff) return CPT_ERR_SHAPE;
-        const bool w4 = g_prod_waves == 4 || (g_prod_waves == 0 && ntile > 256);
+        const bool w4 = prod_waves == 4 || (prod_waves == 0 && ntile > 256);
         if (w4) { if (K <= 1024) CPT_LAUNCH4(0, 4, 0, true); else CPT_LAUNCH4(0, 4, 1, true); }
         else { if (K <= 1024) CPT_LAUNCH4(0, 8, 0, true); else CPT_LAUNCH4(0, 8, 1, true); }
     } else
-    if (g_prod_waves == 4 || (g_prod_waves == 0 && ntile > 256)) {
+    if (prod_waves == 4 || (prod_waves == 0 && ntile > 256)) {
         switch (g_prod_abl) {
+#ifdef CPT_ABLATION
             case 2: CPT_LAUNCH(2, 4); break;
             case 3: CPT_LAUNCH(3, 4); break;
+#endif
             default: if (K <= 1024) CPT_LAUNCH3(0, 4, 0); else CPT_LAUNCH3(0, 4, 1); break;
         }
     } else
     switch (g_prod_abl) {
+#ifdef CPT_ABLATION
         case 1: CPT_LAUNCH(1, 8); break;
         case 2: CPT_LAUNCH(2, 8); break;
         case 3: CPT_LAUNCH(3, 8); break;
         case 4: CPT_LAUNCH(4, 8); break;
+#endif
         default: if (K <= 1024) CPT_LAUNCH3(0, 8, 0); else CPT_LAUNCH3(0, 8, 1); break;
     }
 #undef CPT_LAUNCH4

@@ -4,6 +4,7 @@
 #include "../../include/cpt_hip.h"
 #include "../../include/cpt_hip_debug.h"
 #include "dropout.h"
+#include "switches.h"
 
 namespace cpt {
 
@@ -205,6 +206,16 @@ void set_lncons4(int v);
 void set_ffn_dma_late(int v);
 void set_prod_abl(int v);    // timing experiments of the panel producer (gemm_prod.hip)
 void set_prod_waves(int v);  // wave shape of the panel producer: 8 (4 x 2 waves of 32 x 96) or 4 (4 x 1 waves of 32 x 192)
+// Per-CALL kernel choice for the operator-level test entry points (cpt_gemm_tile, cpt_gemm_ln_cons_tile, cpt_gemm_ln_prod3_panel_waves, the
+// waves argument of cpt_gemm_ln_prod3_rpanel): thread-local, set for the duration of one entry-point call by an OverrideScope and restored on
+// return -- no process-global state, other threads and later calls are untouched.  -1 = the library's own choice.
+struct CallOverride { int gemm_variant = -1; int prod_waves = -1; };
+CallOverride& call_override();
+struct OverrideScope {
+    CallOverride saved;
+    OverrideScope(int gemm_variant, int prod_waves) : saved(call_override()) { call_override().gemm_variant = gemm_variant; call_override().prod_waves = prod_waves; }
+    ~OverrideScope() { call_override() = saved; }
+};
 void set_gemm_trace(void* p);
 void set_gemm_trace_filter(int epi, int k);
 

@@ -366,7 +366,8 @@ int q3_launch(const Q3Args& a, int B, hipStream_t s) {
 
 }  // namespace
 
-extern int g_q3_abl, g_trace_epi;
+CPT_SWITCH(int g_q3_abl, 0);
+extern int g_trace_epi;
 long long* g_q3_trace = nullptr;
 void set_q3_trace(void* p) { g_q3_trace = (long long*)p; }
 // (K = hidden <= 768: the rows' partial LayerNorm sums fit 8 slots = the 8 KB the kernel parks them in)
@@ -404,7 +405,6 @@ int gemm_qkv_attn3(const void* A, int lda, const void* W, int ldw, const float* 
     if (ctx_panel) return st_in ? q3_launch<true, 0, true>(a, B, s) : q3_launch<false, 0, true>(a, B, s);
     return st_in ? q3_launch<true>(a, B, s) : q3_launch<false>(a, B, s);
 }
-int g_q3_abl = 0;
-void set_q3_abl(int v) { g_q3_abl = v; }
+void set_q3_abl(int v) { CPT_SWITCH_SET(g_q3_abl = v); (void)v; }
 
 }  // namespace cpt

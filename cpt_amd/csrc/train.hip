@@ -12,20 +12,20 @@ namespace cpt { int abi_fail(int code, const char* fmt, ...); int abi_check(int 
 using cpt::abi_check;
 using cpt::abi_fail;
 
-namespace cpt { int g_wgrad_tn = 1; void set_wgrad_tn(int v) { g_wgrad_tn = v; } }
+namespace cpt { CPT_SWITCH(int g_wgrad_tn, 1); void set_wgrad_tn(int v) { CPT_SWITCH_SET(g_wgrad_tn = v); (void)v; } }
 using cpt::g_wgrad_tn;
 // cpt_set_tuning(18, bits): bias-gradient column sums inside their producers -- bit 0: b_in in the GELU-gradient epilogue of
 // dgrad(ffn down) (off: its end-of-launch atomics cost more than the colsum launch, gemm.hip), bit 1: b_qkv in the attention
 // backward kernel (on: 43.3 vs 42.0 us per launch, no colsum launch); a cleared bit runs the stand-alone colsum launch instead
 // cpt_set_tuning(19, v): 2 (default) = FFN down | FFN up | attention output in ONE launch (216 workgroups, whole contraction each) + Q|K|V alone
 // with its own three-way split, where the shapes allow it (else as 1); 1 = two paired launches (gemm_tn_pair); 0 = four single ones
-namespace cpt { int g_wgrad_pair = 2; void set_wgrad_pair(int v) { g_wgrad_pair = v; } }
+namespace cpt { CPT_SWITCH(int g_wgrad_pair, 2); void set_wgrad_pair(int v) { CPT_SWITCH_SET(g_wgrad_pair = v); (void)v; } }
 using cpt::g_wgrad_pair;
 // cpt_set_tuning(22, v): 1 (default) = the FFN-down of the training forward runs on 128 x 192 tiles with K split in two (gemm_img_proj's
 // kernel) and the dropout + residual + LayerNorm pass adds the two partial matrices, 0 = 64 x 192 tiles over the whole K
-namespace cpt { int g_fwd_split2 = 1; void set_fwd_split2(int v) { g_fwd_split2 = v; } }
+namespace cpt { CPT_SWITCH(int g_fwd_split2, 1); void set_fwd_split2(int v) { CPT_SWITCH_SET(g_fwd_split2 = v); (void)v; } }
 using cpt::g_fwd_split2;
-namespace cpt { int g_bias_fuse = 2; void set_bias_fuse(int v) { g_bias_fuse = v; } }
+namespace cpt { CPT_SWITCH(int g_bias_fuse, 2); void set_bias_fuse(int v) { CPT_SWITCH_SET(g_bias_fuse = v); (void)v; } }
 using cpt::g_bias_fuse;
 
 namespace {

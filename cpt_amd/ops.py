@@ -22,8 +22,8 @@ def _need_cuda(*ts):
             raise RuntimeError("cpt_amd: tensors must be on the GPU (the HIP path has no CPU fallback)")
 
 
-def gemm(a, w, bias=None, epi=L.EPI_NONE, resid=None, out_dtype=None):
-    """epi(a[M,K] @ w[N,K].T + bias (+ resid))."""
+def gemm(a, w, bias=None, epi=L.EPI_NONE, resid=None, out_dtype=None, tile=None):
+    """epi(a[M,K] @ w[N,K].T + bias (+ resid)).  tile: one of the shipped tile configurations for THIS call (cpt_gemm_tile; None: by shape)."""
     _need_cuda(a, w, bias, resid)
     assert a.dim() == 2 and w.dim() == 2 and a.size(1) == w.size(1) and a.dtype == w.dtype
     assert a.stride(1) == 1 and w.stride(1) == 1
@@ -33,10 +33,13 @@ def gemm(a, w, bias=None, epi=L.EPI_NONE, resid=None, out_dtype=None):
     out = torch.empty((M, N), device=a.device, dtype=out_dtype)
     if resid is not None:
         assert resid.dtype == torch.float32 and resid.shape == (M, N) and resid.stride(1) == 1
-    L.check(L.lib().cpt_gemm(_dt(a), epi, a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), L.ptr(bias),
-                             L.ptr(resid), resid.stride(0) if resid is not None else 0, out.data_ptr(),
-                             L.CPT_BF16 if out_dtype == torch.bfloat16 else L.CPT_F32, out.stride(0), M, N, K,
-                             L.stream_ptr()), "cpt_gemm")
+    args = (_dt(a), epi, a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), L.ptr(bias),
+            L.ptr(resid), resid.stride(0) if resid is not None else 0, out.data_ptr(),
+            L.CPT_BF16 if out_dtype == torch.bfloat16 else L.CPT_F32, out.stride(0), M, N, K, L.stream_ptr())
+    if tile is None:
+        L.check(L.lib().cpt_gemm(*args), "cpt_gemm")
+    else:
+        L.check(L.lib().cpt_gemm_tile(int(tile), *args), "cpt_gemm_tile")
     return out
 
 
@@ -206,8 +209,9 @@ def panel_pack(a, to_panel=True, K=None):
     return out
 
 
-def gemm_ln_prod3_panel(a_panel, K, w, bias, resid_hi, resid_lo, st_in=None, g_in=None, b_in=None, eps=1e-12, hidden=None):
-    """gemm_ln_prod3 with A given as its panel copy (panel_pack): A goes straight to registers, only W through LDS."""
+def gemm_ln_prod3_panel(a_panel, K, w, bias, resid_hi, resid_lo, st_in=None, g_in=None, b_in=None, eps=1e-12, hidden=None, waves=None):
+    """gemm_ln_prod3 with A given as its panel copy (panel_pack): A goes straight to registers, only W through LDS.  waves: 8 / 4 = that wave
+    shape of the tile for this call (cpt_gemm_ln_prod3_panel_waves; None: by shape)."""
     _need_cuda(a_panel, w, bias, resid_hi, resid_lo)
     M = a_panel.numel() // K
     N = w.size(0)
@@ -215,9 +219,13 @@ def gemm_ln_prod3_panel(a_panel, K, w, bias, resid_hi, resid_lo, st_in=None, g_i
     out_hi = torch.empty((M, N), device=w.device, dtype=torch.bfloat16)
     out_lo = torch.empty((M, N), device=w.device, dtype=torch.int8)
     st_out = torch.zeros((M, ln_stat_slots(N), 2), device=w.device, dtype=torch.float32)
-    L.check(L.lib().cpt_gemm_ln_prod3_panel(a_panel.data_ptr(), w.data_ptr(), w.stride(0), L.ptr(bias), resid_hi.data_ptr(), resid_lo.data_ptr(),
-                                            resid_hi.stride(0), L.ptr(st_in), L.ptr(g_in), L.ptr(b_in), float(eps), hidden, out_hi.data_ptr(),
-                                            out_lo.data_ptr(), st_out.data_ptr(), out_hi.stride(0), M, N, K, L.stream_ptr()), "cpt_gemm_ln_prod3_panel")
+    args = (a_panel.data_ptr(), w.data_ptr(), w.stride(0), L.ptr(bias), resid_hi.data_ptr(), resid_lo.data_ptr(),
+            resid_hi.stride(0), L.ptr(st_in), L.ptr(g_in), L.ptr(b_in), float(eps), hidden, out_hi.data_ptr(),
+            out_lo.data_ptr(), st_out.data_ptr(), out_hi.stride(0), M, N, K, L.stream_ptr())
+    if waves is None:
+        L.check(L.lib().cpt_gemm_ln_prod3_panel(*args), "cpt_gemm_ln_prod3_panel")
+    else:
+        L.check(L.lib().cpt_gemm_ln_prod3_panel_waves(int(waves), *args), "cpt_gemm_ln_prod3_panel_waves")
     return out_hi, out_lo, st_out
 
 
@@ -235,7 +243,7 @@ def panel_pack_bytes(a, to_panel=True, K=None):
     return out
 
 
-def gemm_ln_prod3_rpanel(a_panel, K, w, bias, resid_hi_panel, resid_lo_panel, st_in=None, g_in=None, b_in=None, eps=1e-12, hidden=None):
+def gemm_ln_prod3_rpanel(a_panel, K, w, bias, resid_hi_panel, resid_lo_panel, st_in=None, g_in=None, b_in=None, eps=1e-12, hidden=None, waves=0):
     """gemm_ln_prod3_panel with the residual stream (input and output) in the panel layout too (round 5): returns the PANEL copies
     (out_hi bf16 flat, out_lo int8 flat) and st_out."""
     _need_cuda(a_panel, w, bias, resid_hi_panel, resid_lo_panel)
@@ -247,18 +255,23 @@ def gemm_ln_prod3_rpanel(a_panel, K, w, bias, resid_hi_panel, resid_lo_panel, st
     st_out = torch.zeros((M, ln_stat_slots(N), 2), device=w.device, dtype=torch.float32)
     L.check(L.lib().cpt_gemm_ln_prod3_rpanel(a_panel.data_ptr(), w.data_ptr(), w.stride(0), L.ptr(bias), resid_hi_panel.data_ptr(), resid_lo_panel.data_ptr(),
                                              L.ptr(st_in), L.ptr(g_in), L.ptr(b_in), float(eps), hidden, out_hi.data_ptr(), out_lo.data_ptr(),
-                                             st_out.data_ptr(), M, N, K, L.stream_ptr()), "cpt_gemm_ln_prod3_rpanel")
+                                             st_out.data_ptr(), M, N, K, int(waves), L.stream_ptr()), "cpt_gemm_ln_prod3_rpanel")
     return out_hi, out_lo, st_out
 
 
-def gemm_ln_cons(a, wf, st_in, colc, cold, eps, hidden, gelu):
-    """[gelu]( rstd * (a @ wf.T - mean * colc) + cold ): bf16 a[M,K], wf[N,K]; st_in from row_stats_table / gemm_ln_prod."""
+def gemm_ln_cons(a, wf, st_in, colc, cold, eps, hidden, gelu, tile=None):
+    """[gelu]( rstd * (a @ wf.T - mean * colc) + cold ): bf16 a[M,K], wf[N,K]; st_in from row_stats_table / gemm_ln_prod.  tile: one of the
+    shipped kernels / tile configurations for THIS call (cpt_gemm_ln_cons_tile; None: by shape)."""
     _need_cuda(a, wf, st_in, colc, cold)
     M, K = a.shape
     N = wf.size(0)
     out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
-    L.check(L.lib().cpt_gemm_ln_cons(a.data_ptr(), a.stride(0), wf.data_ptr(), wf.stride(0), st_in.data_ptr(), colc.data_ptr(), cold.data_ptr(),
-                                     float(eps), hidden, 1 if gelu else 0, out.data_ptr(), out.stride(0), M, N, K, L.stream_ptr()), "cpt_gemm_ln_cons")
+    args = (a.data_ptr(), a.stride(0), wf.data_ptr(), wf.stride(0), st_in.data_ptr(), colc.data_ptr(), cold.data_ptr(),
+            float(eps), hidden, 1 if gelu else 0, out.data_ptr(), out.stride(0), M, N, K, L.stream_ptr())
+    if tile is None:
+        L.check(L.lib().cpt_gemm_ln_cons(*args), "cpt_gemm_ln_cons")
+    else:
+        L.check(L.lib().cpt_gemm_ln_cons_tile(int(tile), *args), "cpt_gemm_ln_cons_tile")
     return out
 
 

@@ -384,7 +384,9 @@ int cpt_resid3_merge(const void* hi_bf16, const void* lo_i8, const int64_t* pos,
 int cpt_panel_pack_bytes(const void* src_i8, int ld, void* dst_i8, int M, int K, int to_panel, void* stream);
 int cpt_gemm_ln_prod3_rpanel(const void* A_panel, const void* W_bf16, int ldw, const float* bias, const void* resid_hi_panel, const void* resid_lo_panel,
                              const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi_panel, void* out_lo_panel,
-                             float* st_out, int M, int N, int K, void* stream);
+                             float* st_out, int M, int N, int K, int waves, void* stream);
+/* (waves: 0 = the library's choice by shape -- 4 x 2 waves of 32 x 96 when the tiles fit one round, 4 x 1 waves of 32 x 192 over several rounds --,
+ *  8 / 4 = that shape for THIS call; same bits either way) */
 
 /* Weight-gradient GEMM in the TN form (what cpt_train_bwd runs for dW = dY^T . X, fewshot/refcoco_cpt.py:248's autograd of
  * every nn.Linear): out[M][N] fp32 = sum over k < K of A[k][m] * W[k][n], A bf16 [K][lda], W bf16 [K][ldw] -- both operands

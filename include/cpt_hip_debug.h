@@ -1,8 +1,10 @@
 /* libcpt_hip.so -- measurement and development entry points (round 4: split out of cpt_hip.h).
  *
  * Exported by the same library; NOT part of the hot-path interface of cpt_hip.h.  bench.py's roofline leg uses the per-kernel event
- * timing; tools/ and the A/B tests use cpt_set_tuning (process-global switches between kernel variants that produce the same results,
- * defaults = the shipped configuration) and the per-workgroup trace.  A product host never needs to call any of them.
+ * timing; tools/ and the A/B tests use cpt_set_tuning and the per-workgroup trace.  A product host never needs to call any of them.
+ * Round 5: the kernel-variant switches are process-global state only in the DEVELOPMENT build of the library (-DCPT_ABLATION,
+ * cpt_amd/libcpt_hip_abl.so, selected by CPT_AMD_ABLATION=1); in the product build they are compile-time constants, the code behind the
+ * losing settings is not compiled, and cpt_set_tuning refuses every key but -1 (cpt_build_info tells the two apart).
  */
 #ifndef CPT_HIP_DEBUG_H
 #define CPT_HIP_DEBUG_H
@@ -22,7 +24,25 @@ enum { CPT_K_GEMM_QKV = 0, CPT_K_ATTN, CPT_K_GEMM_AO, CPT_K_LN, CPT_K_GEMM_FFN1,
 int cpt_prof_enable(int on);                          /* resets accumulators */
 int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchronises */
 
-/* Kernel-variant switches for A/B measurements; defaults are the shipped configuration.
+/* Operator-level entry points with a PER-CALL kernel choice (round 5; product and development build alike): which of the SHIPPED tile
+ * configurations / wave shapes serves a GEMM is normally the library's choice by shape; the parity and race tests walk through all of them on
+ * small problems with these.  The choice is an argument of the call (thread-local for its duration): no state survives it.
+ *   tile (cpt_gemm_tile, cpt_gemm_ln_cons_tile): 3 = by shape; 0 = generic register-staged kernel; 13 = 128x192 (3-stage), 11 = 192x192, 10 = 128x384,
+ *     14 = 384x192, 15 = 128x192 two workgroups per CU, 18 = 64x192, 19 = 384x256 one pass; consumers also 20 = two-pass 384x256, 21 = 4-wave 192x256
+ *   waves (cpt_gemm_ln_prod3_panel_waves; also an argument of cpt_gemm_ln_prod3_rpanel in cpt_hip.h): 0 = by shape, 8 = 4x2 waves of 32x96, 4 = 4x1 waves of 32x192 */
+int cpt_gemm_tile(int tile, int dtype, int epi, const void* A, int lda, const void* W, int ldw, const float* bias,
+                  const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K, void* stream);
+int cpt_gemm_ln_cons_tile(int tile, const void* A_bf16, int lda, const void* Wf_bf16, int ldw, const float* st_in, const float* colc,
+                          const float* cold, float eps, int hidden, int gelu, void* out_bf16, int ldo, int M, int N, int K, void* stream);
+int cpt_gemm_ln_prod3_panel_waves(int waves, const void* A_panel, const void* W_bf16, int ldw, const float* bias, const void* resid_hi, const void* resid_lo,
+                                  int ldr, const float* st_in, const float* g_in, const float* b_in, float eps, int hidden, void* out_hi, void* out_lo,
+                                  float* st_out, int ldo, int M, int N, int K, void* stream);
+
+/* 0 = product build (libcpt_hip.so: every kernel-variant switch below is a compile-time constant, cpt_set_tuning refuses every key but -1);
+ * bit 0 set = the CPT_ABLATION development build (libcpt_hip_abl.so), where the switches are process-global (round 5). */
+int cpt_build_info(void);
+
+/* Kernel-variant switches for A/B measurements (CPT_ABLATION build only); defaults are the shipped configuration.
  *   key 0  GEMM (20 / 21: force the two-pass / the 4-wave LayerNorm-consumer kernel where legal): 0 = generic register-staged kernel only; 3 (default) = pipelined LDS-DMA kernel, tile shape chosen
  *          per GEMM; fixed shapes 13 = 128x192 (3-stage), 11 = 192x192, 10 = 128x384, 14 = 384x192,
  *          15 = 128x192 two workgroups per CU, 18 = 64x192 (small M)
@@ -72,6 +92,8 @@ int cpt_prof_read(int kernel_id, double* total_ms, int64_t* launches); /* synchr
  *   key 29 the 4-wave 192 x 256 LayerNorm-consumer kernel with the operand stream between the MFMAs (gemm_ffn4.hip) in place of the two-pass
  *          384 x 256 kernel (gemm_ffn.hip): 1 (default) = where its tiles fill their rounds at least 10 % better (Oscar-large FFN-up), 2 = wherever
  *          legal, 0 = nowhere; same bits
+ *   key 30 fused bf16 encoder at the full-panel shapes: 1 (default) = the residual stream itself in the panel layout and the LayerNorm producers'
+ *          register-direct epilogue (cpt_gemm_ln_prod3_rpanel), 0 = row-major 3-byte stream + slab epilogue (round 3); same bits
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at

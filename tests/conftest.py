@@ -12,6 +12,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ablation: compares kernel VARIANTS through cpt_set_tuning -- needs the development build of the library "
+                                       "(python -m cpt_amd.build --ablation; CPT_AMD_ABLATION=1 python -m pytest tests -m 'gpu and ablation'); skipped on the product build, "
+                                       "whose switches are compile-time constants (VERDICT r4 item 9)")
+
+
+def pytest_runtest_setup(item):
+    if item.get_closest_marker("ablation") is not None:
+        from cpt_amd import _lib as L
+        if not L.ablation_build():
+            pytest.skip("kernel-variant comparison: needs the CPT_ABLATION build (CPT_AMD_ABLATION=1); the product library has no switches")
 
 
 @pytest.fixture(scope="session")
@@ -21,8 +31,8 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def _restore_library_tuning(request):
-    """cpt_set_tuning is process-global (A/B switches): whatever a GPU test flips -- also one that fails half way -- is put
-    back to the defaults before the next test runs (a failing test used to leave the library mis-tuned)."""
+    """Development build only (CPT_AMD_ABLATION=1): cpt_set_tuning is process-global there, so whatever a test flips -- also one that fails half
+    way -- is put back to the defaults before the next test runs.  On the product build key -1 is a no-op: there is nothing to restore."""
     yield
     if request.node.get_closest_marker("gpu") is not None:
         try:

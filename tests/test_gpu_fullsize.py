@@ -29,12 +29,7 @@ def _dev(b, dev):
     return {k: v.to(dev) for k, v in b.items()}
 
 
-def test_config2_panel_mode_is_bit_identical(dev):
-    """Round 3: at the bench size (B = 64, L = 70 + 50) the fused bf16 encoder runs in PANEL mode -- the attention kernel and the
-    FFN-up epilogue write ctx / h as MFMA A fragments, the LayerNorm producers read them straight into registers, every big
-    output store is write-through.  Same bits as the row-major encoder (cpt_set_tuning(14, 0)), for the [MASK]-row logits, the
-    pooled output and the all-row sequence output; a ragged attention mask included; repeated runs identical."""
-    from cpt_amd import _lib as L
+def _panel_model(dev):
     from cpt_amd.modeling_rec import REC_MLM_CPT
     cfg = cfgmod.oscar_base()
     sd = synth.init_state_dict(cfg, 88, head="cpt")
@@ -47,17 +42,43 @@ def test_config2_panel_mode_is_bit_identical(dev):
     def run():
         with torch.no_grad():
             return m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0].clone()
+    return m, d, run
+
+
+def test_config2_panel_mode_rows_equal_small_batch(dev):
+    """At the bench size (B = 64, L = 70 + 50) the fused bf16 encoder runs in its full PANEL mode -- ctx, the FFN activation and (round 5) the
+    residual stream itself travel as MFMA fragments, the LayerNorm producers run their register-direct epilogue -- while a 4-sequence batch
+    runs the row-major kernels (below the panel shapes).  Sequences are independent and every epilogue adds a row's partial sums in ONE order
+    (common.h rowsum_chunk_pair): rows of the big batch equal the small batch BIT FOR BIT, a ragged attention mask included; repeated runs identical."""
+    m, d, run = _panel_model(dev)
     on = run()
     again = run()
+    assert torch.isfinite(on).all()
+    assert torch.equal(on, again)
+    ds = {k: v[:4].contiguous() for k, v in d.items()}
+    with torch.no_grad():
+        small = m(ds["input_ids"], ds["segment_ids"], ds["attention_mask"], img_feats=ds["img_feats"], mask_token_pos=ds["mask_token_pos"])[0]
+    assert torch.equal(on[:4], small)
+    # ... and so do the all-row sequence output and the pooled output (heads reading the panel directly)
+    with torch.no_grad():
+        seq, pooled = m.bert(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])[:2]
+        seq, pooled = seq.clone(), pooled.clone()
+        seq4, pooled4 = m.bert(ds["input_ids"], ds["segment_ids"], ds["attention_mask"], img_feats=ds["img_feats"])[:2]
+    assert torch.equal(seq[:4], seq4) and torch.equal(pooled[:4], pooled4)
+
+
+@pytest.mark.ablation
+def test_config2_panel_mode_is_bit_identical(dev):
+    """Development build: the same batch with the panel mode switched off (cpt_set_tuning(14, 0): row-major tensors), with the round-3 form of the
+    residual stream (key 30 = 0: row-major 3-byte stream, slab epilogue) and with both wave shapes of the producer tile (key 24): the same bits
+    for the [MASK]-row logits, the pooled output and the all-row sequence output."""
+    from cpt_amd import _lib as L
+    m, d, run = _panel_model(dev)
+    on = run()
     L.check(L.lib().cpt_set_tuning(14, 0))
     off = run()
     L.check(L.lib().cpt_set_tuning(14, 1))
-    assert torch.isfinite(on).all()
-    assert torch.equal(on, again)
     assert torch.equal(on, off)
-    # round 5: by default the residual stream itself travels in the panel layout and the LayerNorm producers run their register-direct
-    # epilogue (cpt_set_tuning key 30); the round-3 form (row-major 3-byte stream, slab epilogue) gives the same bits, with both wave
-    # shapes of the producer tile, and so do the pooled output and the all-row sequence output
     for waves in (8, 4):
         L.check(L.lib().cpt_set_tuning(24, waves))
         assert torch.equal(run(), on), "producer tile as %d waves" % waves
@@ -71,11 +92,6 @@ def test_config2_panel_mode_is_bit_identical(dev):
         seq_off, pooled_off = m.bert(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])[:2]
     L.check(L.lib().cpt_set_tuning(30, 1))
     assert torch.equal(on, rowmajor) and torch.equal(seq_on, seq_off) and torch.equal(pooled_on, pooled_off)
-    # and the rows of the big batch reproduce a 4-sequence batch (which runs the row-major kernels: below the panel shapes)
-    ds = {k: v[:4].contiguous() for k, v in d.items()}
-    with torch.no_grad():
-        small = m(ds["input_ids"], ds["segment_ids"], ds["attention_mask"], img_feats=ds["img_feats"], mask_token_pos=ds["mask_token_pos"])[0]
-    assert torch.equal(on[:4], small)
 
 
 def test_config4_gqa_12_layers_b256(dev):

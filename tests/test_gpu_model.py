@@ -194,6 +194,7 @@ def test_config2_vs_oracle(dev, mode):
     assert _stats("B=64 rows 0..7 vs B=8", got64[:8], got.cpu()) < 1e-6          # observed: identical bits in both modes
 
 
+@pytest.mark.ablation
 def test_bf16_folded_layernorm_and_fused_attention(dev):
     """bf16 mode folds the encoder LayerNorms into the GEMMs around them and fuses the QKV projection with the
     attention core.  Every combination of the two switches computes the same function: each must
@@ -264,6 +265,7 @@ def test_bf16_forward_is_bit_reproducible(dev):
     assert torch.equal(outs[0][8:24], part)
 
 
+@pytest.mark.ablation
 def test_round4_kernel_choices_are_bit_identical(dev):
     """Round 4's switches between kernels that must produce the same BITS, at the bench shape (B = 64: one round of tiles) and at a shape whose
     tiles run several rounds (B = 160): producer wave shape (key 24: 8 / 4 waves), merged embedding + pad/cast launch (key 25), decoder-table
@@ -286,6 +288,7 @@ def test_round4_kernel_choices_are_bit_identical(dev):
                 assert torch.equal(got, ref), "B = %d: cpt_set_tuning(%d, %d) changes the logits" % (B, key, v)
 
 
+@pytest.mark.ablation
 def test_bf16x3_attention_kernels_agree(dev):
     """bf16x3 parity mode: the split-operand MFMA attention (round 4, key 27 = 1) against the fp32 MFMA attention kernel + cpt_split3 pass it replaces:
     both within the mode's 1e-3 bar of each other on the [MASK] logits (observed ~1e-5), at L = 120, L = 210 (seven key blocks) and L = 265 (nine: the

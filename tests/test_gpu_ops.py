@@ -180,14 +180,13 @@ def test_gemm_variants_agree(dev, variant):
     ragged M/N edges and the unaligned-ldo decoder shape."""
     from cpt_amd import ops, _lib as L
     rng = _rng(77)
-    try:
-        L.check(L.lib().cpt_set_tuning(0, variant))
+    if True:
         for (M, N, K, epi) in [(7680 // 4, 2304, 768, L.EPI_NONE), (333, 200, 128, L.EPI_GELU), (64, 30522, 768, L.EPI_NONE),
                                (500, 768, 3072, L.EPI_RESID)]:
             a, w, b = _t(rng, M, K).to(torch.bfloat16), _t(rng, N, K, scale=0.05).to(torch.bfloat16), _t(rng, N)
             r = _t(rng, M, N) if epi == L.EPI_RESID else None
             out = ops.gemm(a.to(dev), w.to(dev), b.to(dev), epi=epi, resid=None if r is None else r.to(dev),
-                           out_dtype=torch.float32).cpu()
+                           out_dtype=torch.float32, tile=variant).cpu()
             ref = a.float() @ w.float().T + b
             if epi == L.EPI_GELU:
                 ref = ref * 0.5 * (1.0 + torch.erf(ref / math.sqrt(2.0)))
@@ -195,10 +194,8 @@ def test_gemm_variants_agree(dev, variant):
                 ref = ref + r
             assert _stats("variant %d %dx%dx%d" % (variant, M, N, K), out, ref) < 3e-4 * max(1.0, math.sqrt(K / 64))
             a32, w32 = a.float().to(dev), w.float().to(dev)
-            o32 = ops.gemm(a32, w32, b.to(dev), epi=epi, resid=None if r is None else r.to(dev)).cpu()
+            o32 = ops.gemm(a32, w32, b.to(dev), epi=epi, resid=None if r is None else r.to(dev), tile=variant).cpu()
             assert _stats("variant %d fp32" % variant, o32, ref) < 3e-5 * max(1.0, math.sqrt(K / 64))
-    finally:
-        L.check(L.lib().cpt_set_tuning(0, 3))
 
 
 def test_select_regions_device_matches_reference_rule(dev):
@@ -263,12 +260,8 @@ def test_gemm_ln_consumer(dev, M, N, K, variant):
     for gelu in (True, False):
         pre = rs * (a.double() @ wf.double().T - mu * colc.double()) + cold.double()
         ref = pre * 0.5 * (1.0 + torch.erf(pre / math.sqrt(2.0))) if gelu else pre
-        try:
-            L.check(L.lib().cpt_set_tuning(0, variant))
-            got = ops.gemm_ln_cons(a.to(dev), wf.to(dev), st, colc.to(dev), cold.to(dev), eps, K, gelu).float().cpu()
-            again = ops.gemm_ln_cons(a.to(dev), wf.to(dev), st, colc.to(dev), cold.to(dev), eps, K, gelu).float().cpu()
-        finally:
-            L.check(L.lib().cpt_set_tuning(0, 3))
+        got = ops.gemm_ln_cons(a.to(dev), wf.to(dev), st, colc.to(dev), cold.to(dev), eps, K, gelu, tile=variant).float().cpu()
+        again = ops.gemm_ln_cons(a.to(dev), wf.to(dev), st, colc.to(dev), cold.to(dev), eps, K, gelu, tile=variant).float().cpu()
         assert torch.equal(got, again)                    # no run-to-run variation (counted-vmcnt pipeline)
         d = (got.double() - ref).abs()
         tol = 2.0 ** -8 * ref.abs() + 2e-3                # bf16 output rounding (half an ulp = 2^-9 relative) + fp32 accumulation
@@ -291,14 +284,10 @@ def test_ln_consumer_kernels_are_bit_identical(dev):
     colc = wf.float().sum(1).contiguous()
     cold = _t(rng, N, scale=0.1).to(dev)
     outs = {}
-    try:
-        for v in (3, 15, 19, 20, 21):         # (3: the default choice = round 4's 4-wave kernel here; 20 / 21 force the two-pass / 4-wave kernels)
-            L.check(L.lib().cpt_set_tuning(0, v))
-            outs[v] = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, True)
-            # the first 960 rows as their own (small) problem: other tile shape choices, ragged last tiles
-            outs[(v, "small")] = ops.gemm_ln_cons(a[:960], wf, st[:960], colc, cold, 1e-12, K, True)
-    finally:
-        L.check(L.lib().cpt_set_tuning(0, 3))
+    for v in (3, 15, 19, 20, 21):         # (3: the library's own choice here; 20 / 21: the two-pass / 4-wave kernels)
+        outs[v] = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, True, tile=v)
+        # the first 960 rows as their own (small) problem: other tile shape choices, ragged last tiles
+        outs[(v, "small")] = ops.gemm_ln_cons(a[:960], wf, st[:960], colc, cold, 1e-12, K, True, tile=v)
     for v in (15, 19, 20, 21):
         assert torch.equal(outs[3], outs[v]), "variant %d differs from the default" % v
     for v in (3, 15, 19, 20, 21):
@@ -321,13 +310,8 @@ def test_qkv_projection_two_pass_kernel_is_bit_identical(dev, M, N, K):
     cold = _t(rng, N, scale=0.1).to(dev)
     two = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, False)
     small = ops.gemm_ln_cons(a[:960], wf, st[:960], colc, cold, 1e-12, K, False)
-    for forced in (20, 21):           # the two-pass and the 4-wave consumer kernels, whatever the default chose
-        L.check(L.lib().cpt_set_tuning(0, forced))
-        assert torch.equal(ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, False), two), forced
-    L.check(L.lib().cpt_set_tuning(0, 3))
-    L.check(L.lib().cpt_set_tuning(20, 0))
-    pipe = ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, False)
-    assert torch.equal(two, pipe)
+    for forced in (20, 21, 14):       # the two-pass and the 4-wave consumer kernels and the 384 x 192 pipelined kernel, whatever the library chose
+        assert torch.equal(ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, False, tile=forced), two), forced
     assert torch.equal(two[:960], small)
     xs = x[:256]
     ref = ((xs.to(torch.bfloat16).float() - xs.mean(1, keepdim=True)) / xs.var(1, unbiased=False, keepdim=True).add(1e-12).sqrt()) @ wf.float().cpu().T
@@ -497,7 +481,6 @@ def test_gemm_ln_prod3_panel_is_bit_identical(dev, K, H, M, waves):
     LayerNorm; the panel copy round-trips through cpt_panel_pack; 20 back-to-back launches give identical bits.  Both wave shapes of the
     tile (round 4, cpt_set_tuning key 24: 4 x 2 waves of 32 x 96, 4 x 1 waves of 32 x 192) give the same bits."""
     from cpt_amd import ops, _lib as L
-    L.check(L.lib().cpt_set_tuning(24, waves))
     rng = _rng(K + 5)          # (K = 512: the shortest K loop the kernel runs, 8 K-tiles; one row tile; 1, 2 and 4 column tiles)
     x = (_t(rng, M, H, scale=1.2) + 0.3).to(dev)
     hi, lo = ops.resid3_split(x)
@@ -515,10 +498,10 @@ def test_gemm_ln_prod3_panel_is_bit_identical(dev, K, H, M, waves):
     for fold in (True, False):
         gi, bi, si = (g, bt, st) if fold else (None, None, None)
         r_hi, r_lo, r_st = ops.gemm_ln_prod3(a, w, bias, hi, lo, si, gi, bi, 1e-12, H)
-        p_hi, p_lo, p_st = ops.gemm_ln_prod3_panel(ap, K, w, bias, hi, lo, si, gi, bi, 1e-12, H)
+        p_hi, p_lo, p_st = ops.gemm_ln_prod3_panel(ap, K, w, bias, hi, lo, si, gi, bi, 1e-12, H, waves=waves)
         assert torch.equal(p_hi, r_hi) and torch.equal(p_lo, r_lo) and torch.equal(p_st, r_st)
         for _ in range(20):
-            q_hi, q_lo, q_st = ops.gemm_ln_prod3_panel(ap, K, w, bias, hi, lo, si, gi, bi, 1e-12, H)
+            q_hi, q_lo, q_st = ops.gemm_ln_prod3_panel(ap, K, w, bias, hi, lo, si, gi, bi, 1e-12, H, waves=waves)
             assert torch.equal(q_hi, r_hi) and torch.equal(q_lo, r_lo) and torch.equal(q_st, r_st)
 
 
@@ -529,7 +512,6 @@ def test_gemm_ln_prod3_rpanel_is_bit_identical(dev, K, H, M, waves):
     LDS slab) against the row-major producer: hi, lo (unpacked from their panels) and the partial row sums bit for bit, with and without
     the on-the-fly residual LayerNorm, both wave shapes; the byte panel round-trips; 20 back-to-back launches give identical bits."""
     from cpt_amd import ops, _lib as L
-    L.check(L.lib().cpt_set_tuning(24, waves))
     rng = _rng(K + 11)
     x = (_t(rng, M, H, scale=1.2) + 0.3).to(dev)
     hi, lo = ops.resid3_split(x)
@@ -548,7 +530,7 @@ def test_gemm_ln_prod3_rpanel_is_bit_identical(dev, K, H, M, waves):
         gi, bi, si = (g, bt, st) if fold else (None, None, None)
         r_hi, r_lo, r_st = ops.gemm_ln_prod3(a, w, bias, hi, lo, si, gi, bi, 1e-12, H)
         for rep in range(21):
-            q_hi, q_lo, q_st = ops.gemm_ln_prod3_rpanel(ap, K, w, bias, hp, lp, si, gi, bi, 1e-12, H)
+            q_hi, q_lo, q_st = ops.gemm_ln_prod3_rpanel(ap, K, w, bias, hp, lp, si, gi, bi, 1e-12, H, waves=waves)
             assert torch.equal(q_st, r_st), "row sums (fold %s, launch %d)" % (fold, rep)
             assert torch.equal(ops.panel_pack(q_hi, to_panel=False, K=H), r_hi) and torch.equal(ops.panel_pack_bytes(q_lo, to_panel=False, K=H), r_lo)
 

@@ -52,11 +52,7 @@ def test_gemm_ring_race_screen(dev, variant, M, N, K, epi):
     r = torch.randn(M, N, device=dev) if epi == "resid" else None
     code = {"resid": L.EPI_RESID, "gelu": L.EPI_GELU, "none": L.EPI_NONE}[epi]
     odt = torch.float32 if epi == "resid" else torch.bfloat16
-    try:
-        L.check(L.lib().cpt_set_tuning(0, variant))
-        bad = _screen(dev, lambda s: (ops.gemm(a, w, b, epi=code, resid=r, out_dtype=odt),), n=LAUNCHES if K < 3000 else 300)
-    finally:
-        L.check(L.lib().cpt_set_tuning(0, 3))
+    bad = _screen(dev, lambda s: (ops.gemm(a, w, b, epi=code, resid=r, out_dtype=odt, tile=variant),), n=LAUNCHES if K < 3000 else 300)
     assert bad == 0, "%d of the launches differed from the first one" % bad
 
 
@@ -90,11 +86,7 @@ def test_ln_consumer_race_screen(dev, variant, M, N, K):
     wf = (torch.randn(N, K, device=dev) * 0.04).to(torch.bfloat16)
     colc = wf.float().sum(1).contiguous()
     cold = torch.randn(N, device=dev) * 0.1
-    try:
-        L.check(L.lib().cpt_set_tuning(0, variant))
-        bad = _screen(dev, lambda s: (ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, True),))
-    finally:
-        L.check(L.lib().cpt_set_tuning(0, 3))
+    bad = _screen(dev, lambda s: (ops.gemm_ln_cons(a, wf, st, colc, cold, 1e-12, K, True, tile=variant),))
     assert bad == 0, "%d of the launches differed from the first one" % bad
 
 

@@ -214,6 +214,7 @@ def test_no_img_layernorm_forward_and_gradients(dev, mode):
     assert err < (1e-3 if mode == "fp32" else 4e-2), err
 
 
+@pytest.mark.ablation
 @pytest.mark.parametrize("size", ["base", "large"])
 def test_weight_gradients_tn_gemm_vs_transposed_operands(dev, size):
     """bf16 weight / data gradients: the TN / NN GEMM forms (operands read as stored) against the explicit-transpose + NT GEMM path
@@ -244,6 +245,7 @@ def test_weight_gradients_tn_gemm_vs_transposed_operands(dev, size):
         assert rel < 6e-3 or mx < 1e-7, (n, rel, mx)
 
 
+@pytest.mark.ablation
 def test_attention_backward_variants_agree(dev):
     """MFMA attention backward (bf16) against the generic fp32-math kernel on the same inputs."""
     from cpt_amd import _lib as L
@@ -390,6 +392,7 @@ def test_backward_needs_no_whole_buffer_fill_base_shape(dev, B):
     st.grad.zero_()
 
 
+@pytest.mark.ablation
 @pytest.mark.parametrize("B", [4, 32])
 def test_bias_gradients_summed_inside_their_producers(dev, B):
     """Round 3: the stacked Q|K|V bias gradient is summed by the attention backward kernel (cpt_set_tuning key 18 bit 1, default),
@@ -424,6 +427,7 @@ def test_bias_gradients_summed_inside_their_producers(dev, B):
             assert rel < 2e-3, (bits, n, rel)
 
 
+@pytest.mark.ablation
 @pytest.mark.parametrize("B", [4, 32])
 def test_paired_weight_gradient_launches_match_single_ones(dev, B):
     """Round 3: a layer's four weight gradients as two paired launches (gemm_tn_pair: FFN down | FFN up without a K split, attention
@@ -553,6 +557,7 @@ def test_training_with_a_three_dimensional_attention_mask(dev, mode, Lt, Li, p):
     assert n > 30
 
 
+@pytest.mark.ablation
 def test_forward_ffn_down_split_in_two_matches_the_unsplit_form(dev):
     """Round 3: at 2048..6144 rows the training forward runs the FFN-down on 128 x 192 tiles with K split over two workgroups and lets the
     dropout + residual + LayerNorm pass add the two partial matrices (cpt_set_tuning key 22).  Against the 64 x 192 form over the whole K

@@ -29,10 +29,9 @@ def main():
         w = (torch.randn(H, K, device=dev) * 0.03).to(torch.bfloat16)
         apn = ops.panel_pack(A)
         for waves in (8, 4):
-            L.check(L.lib().cpt_set_tuning(24, waves))
             res = {}
-            for name, fn in (("slab", lambda: ops.gemm_ln_prod3_panel(apn, K, w, bias, hi, lo, st, g, bt, 1e-12, H)),
-                             ("direct", lambda: ops.gemm_ln_prod3_rpanel(apn, K, w, bias, hp, lp, st, g, bt, 1e-12, H))):
+            for name, fn in (("slab", lambda: ops.gemm_ln_prod3_panel(apn, K, w, bias, hi, lo, st, g, bt, 1e-12, H, waves=waves)),
+                             ("direct", lambda: ops.gemm_ln_prod3_rpanel(apn, K, w, bias, hp, lp, st, g, bt, 1e-12, H, waves=waves))):
                 for _ in range(10):
                     fn()
                 torch.cuda.synchronize()
@@ -44,7 +43,6 @@ def main():
                 torch.cuda.synchronize()
                 res[name] = e0.elapsed_time(e1) / a.iters * 1e3
             print("K %4d waves %d  slab %.2f us  direct %.2f us  (includes ~3 torch allocs per call)" % (K, waves, res["slab"], res["direct"]), flush=True)
-    L.check(L.lib().cpt_set_tuning(24, 0))
 
 
 if __name__ == "__main__":
