@@ -10,6 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcpt_hip.so")
 LIB_ABL = os.path.join(HERE, "libcpt_hip_abl.so")      # development build (-DCPT_ABLATION): kernel-variant switches live (include/cpt_hip_debug.h)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HOSTCXX = os.environ.get("CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result", "-I" + os.path.join(os.path.dirname(HERE), "include")]
 
@@ -51,6 +52,13 @@ def build(force=False, verbose=True, ablation=False):
             raise RuntimeError("hipcc failed:\n" + r.stdout)
         return r.stdout
 
+    # host-only C++ translation units with their own ISA flags (b64_avx2.cpp: the AVX2 base64 loop, called behind a run-time CPU check)
+    for f, extra in (("b64_avx2.cpp", ["-mavx2"]),):
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(odir, f[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src]):
+            jobs.append([HOSTCXX, "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", src, "-o", obj])
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):

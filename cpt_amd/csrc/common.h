@@ -139,14 +139,29 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 template <> __device__ __forceinline__ float gelu_grad_for<float>(float x) { return gelu_erf_grad(x); }
 template <> __device__ __forceinline__ float gelu_grad_for<bf16>(float x) { return gelu_grad_fast(x); }
 
+// Butterfly over the 64 lanes, partner distances 32, 16, 8, 4, 2, 1 (round 5: the SAME pairings in the same order as the __shfl_xor loop this
+// replaces, so the same bits, but without six dependent ds_bpermute round trips -- the row kernels run one row per wave and sat at the
+// latency of their reduce -> reduce -> store chain): v_permlane32_swap for 32, ds_swizzle (no address operand) for 16 and 4, DPP row
+// rotate / quad permutes for 8, 2 and 1.
+__device__ __forceinline__ float lane_xor32(float v) {
+    const int i = __float_as_int(v);
+    const auto s = __builtin_amdgcn_permlane32_swap(i, i, false, false);      // {[lo, lo], [hi, hi]} of the input's two half-waves
+    return (threadIdx.x & 32) ? __int_as_float((int)s[0]) : __int_as_float((int)s[1]);
+}
+template <int PATTERN> __device__ __forceinline__ float lane_swizzle(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN)); }
+template <int CTRL> __device__ __forceinline__ float lane_dpp(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
+__device__ __forceinline__ float lane_xor16(float v) { return lane_swizzle<0x401f>(v); }     // bit mode: and 0x1f, or 0, xor 0x10
+__device__ __forceinline__ float lane_xor8(float v) { return lane_dpp<0x128>(v); }           // row_ror:8 (rotation by half a row of 16 = xor 8)
+__device__ __forceinline__ float lane_xor4(float v) { return lane_swizzle<0x101f>(v); }     // xor 0x04
+__device__ __forceinline__ float lane_xor2(float v) { return lane_dpp<0x4e>(v); }            // quad_perm [2, 3, 0, 1]
+__device__ __forceinline__ float lane_xor1(float v) { return lane_dpp<0xb1>(v); }            // quad_perm [1, 0, 3, 2]
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += lane_xor32(v); v += lane_xor16(v); v += lane_xor8(v); v += lane_xor4(v); v += lane_xor2(v); v += lane_xor1(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, lane_xor32(v)); v = fmaxf(v, lane_xor16(v)); v = fmaxf(v, lane_xor8(v));
+    v = fmaxf(v, lane_xor4(v)); v = fmaxf(v, lane_xor2(v)); v = fmaxf(v, lane_xor1(v));
     return v;
 }
 

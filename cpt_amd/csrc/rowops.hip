@@ -3,6 +3,8 @@
 // One 64-lane wavefront per row, 16-byte loads, statistics by wave shuffles; fp32 math.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -12,7 +14,9 @@ constexpr int ROW_THREADS = 256;            // 4 waves = 4 rows per workgroup
 constexpr int MAXV = 4;                     // float4 per lane: H <= 1024
 
 // two-pass mean / biased variance over a row held as up to MAXV float4 per lane
-__device__ __forceinline__ void ln_stats(const f32x4 (&v)[MAXV], int nv, int lane, int H, float& mean, float& rstd, float eps) {
+template <int NA = MAXV>      // NA: float4 per lane the caller holds (MAXV = any H <= 1024; 3 = the H = 768 fast kernel: a third fewer registers)
+__device__ __forceinline__ void ln_stats(const f32x4 (&v)[NA], int nv, int lane, int H, float& mean, float& rstd, float eps) {
+    constexpr int MAXV = NA;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
@@ -33,9 +37,10 @@ __device__ __forceinline__ size_t panel_quad(size_t row, int c, int H) {
     return ((size_t)panel_unit((int)row, c >> 3, H >> 4) << 1) + ((c >> 2) & 1);
 }
 
-template <typename LP>
-__device__ __forceinline__ void ln_write(const f32x4 (&v)[MAXV], int nv, int lane, int H, float mean, float rstd,
+template <typename LP, int NA = MAXV>
+__device__ __forceinline__ void ln_write(const f32x4 (&v)[NA], int nv, int lane, int H, float mean, float rstd,
                                          const float* g, const float* b, float* of, LP* ol, signed char* olo = nullptr, long long panel_row = -1) {
+    constexpr int MAXV = NA;
     // olo != NULL (bf16 LP only): the row leaves in the 3-byte residual form (common.h r3_encode): hi -> ol, lo -> olo
     // panel_row >= 0 (round 5, with olo): ol / olo are the BASES of the panel-layout residual stream and the row lands at its quads there
 #pragma unroll
@@ -154,6 +159,38 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     }
 }
 
+// Round 5: the plain LayerNorm of H = 768 rows (no residual, no dropout, no GELU, no split-K partials: the inference-side launches and
+// bench.py's hbm_kernels) with RPW rows per wave and only the registers those rows need -- three float4 per lane per row, no residual
+// copy: 2 rows per wave at the occupancy the general kernel has with one (its MAXV = 4 arrays of the row AND of the residual made RPW = 2
+// cost half the waves, so the bytes in flight per CU never grew).  The same helpers, the same arithmetic in the same order: the same bits.
+template <typename LP, int RPW>
+__global__ __launch_bounds__(ROW_THREADS) void layernorm768_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                                                   float* __restrict__ out_f32, LP* __restrict__ out_lp, int R, int grp, int grp_stride, int grp_off,
+                                                                   signed char* __restrict__ out_lo, int out_panel) {
+    constexpr int H = 768, NV = 3;
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6)) * RPW;
+    if (r0 >= R) return;
+    f32x4 v[RPW][NV];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+        const int r = min(r0 + u, R - 1);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[u][i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + (lane + 64 * i) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+        const int r = r0 + u;
+        if (r >= R) continue;
+        float mean = 0.f, rstd = 1.f;
+        if (g) ln_stats<NV>(v[u], NV, lane, H, mean, rstd, eps);
+        const size_t orow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
+        if (out_panel) ln_write<LP, NV>(v[u], NV, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
+        else ln_write<LP, NV>(v[u], NV, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr, out_lp ? out_lp + orow * H : nullptr,
+                              out_lo ? out_lo + orow * H : nullptr);
+    }
+}
+
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
                       int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride, int out_panel) {
@@ -164,6 +201,19 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
     const DropSpec dr = drop ? *drop : DropSpec{};
     if (grp_stride == 0 && grp != R) grp_stride = grp;
+    static const int rpw_env = [] { const char* e = getenv("CPT_LN_RPW"); return e ? atoi(e) : 0; }();      // experiment hook (tools/hbm_rows.py): rows per wave of the H = 768 fast kernel
+    if (H == 768 && !gelu_in && !resid && dr.thresh == 0 && !pre_out && x_parts == 1 && (rpw_env >= 0)) {
+        // measured (tools/hbm_rows.py, CPT_LN_RPW): one row per wave wins at every size -- bf16 out 0.59 / 0.72 of 8 TB/s at 7680 / 61440 rows against
+        // 0.58 / 0.71 with two rows and 0.49 / 0.67 with four (the general kernel: 0.56 / 0.55): what helped is the register diet (44 VGPRs), not rows in flight
+        const int rp = rpw_env > 0 ? rpw_env : 1;
+        dim3 g768((R + 4 * rp - 1) / (4 * rp)), b768(ROW_THREADS);
+        const bool lp16f = out_lp && lp_dtype == CPT_BF16;
+#define LN768(LPT, RP) layernorm768_kernel<LPT, RP><<<g768, b768, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, grp, grp_stride, grp_off, (signed char*)out_lo, out_panel)
+        if (lp16f) { if (rp == 2) LN768(bf16, 2); else LN768(bf16, 1); }
+        else       { if (rp == 2) LN768(float, 2); else LN768(float, 1); }
+#undef LN768
+        return CPT_OK;
+    }
     const int rpw = R >= 24576 ? 2 : 1;
     dim3 grid((R + 4 * rpw - 1) / (4 * rpw)), block(ROW_THREADS);
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
@@ -195,8 +245,9 @@ struct EmbedArgs {
     int B, Lt, L, H, vocab, max_pos, type_vocab;
     int out_panel;      // round 5: out_lp / out_lo are the panel-layout residual stream (3-byte form)
 };
-template <typename LP>
+template <typename LP, int NA = MAXV>      // NA = 3: the H = 768 instantiation (a quarter fewer row registers, as layernorm768_kernel)
 __device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
+    constexpr int MAXV = NA;
     const int64_t* __restrict__ ids = a.ids; const int64_t* __restrict__ tt = a.tt; const int64_t* __restrict__ pos = a.pos;
     const float* __restrict__ word = a.word; const float* __restrict__ posw = a.posw; const float* __restrict__ typew = a.typew;
     const float* __restrict__ g = a.g; const float* __restrict__ bta = a.bta;
@@ -228,15 +279,15 @@ __device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
         }
     }
     float mean, rstd;
-    ln_stats(v, nv, lane, H, mean, rstd, eps);
+    ln_stats<NA>(v, nv, lane, H, mean, rstd, eps);
     const size_t orow = (size_t)b * L + t;
-    if (a.out_panel) ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
+    if (a.out_panel) ln_write<LP, NA>(v, nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
     else
-    ln_write<LP>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
-                 out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
+    ln_write<LP, NA>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
+                     out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
 }
-template <typename LP>
-__global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(EmbedArgs a) { embed_ln_block<LP>(a, blockIdx.x); }
+template <typename LP, int NA = MAXV>
+__global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(EmbedArgs a) { embed_ln_block<LP, NA>(a, blockIdx.x); }
 
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
@@ -249,8 +300,8 @@ int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const fl
     if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
     dim3 grid((B * Lt + 3) / 4), block(ROW_THREADS);
     EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0};
-    if (out_lp && lp_dtype == CPT_BF16) embed_ln_kernel<bf16><<<grid, block, 0, s>>>(a);
-    else { a.out_lo = nullptr; embed_ln_kernel<float><<<grid, block, 0, s>>>(a); }
+    if (out_lp && lp_dtype == CPT_BF16) { if (H == 768) embed_ln_kernel<bf16, 3><<<grid, block, 0, s>>>(a); else embed_ln_kernel<bf16><<<grid, block, 0, s>>>(a); }
+    else { a.out_lo = nullptr; if (H == 768) embed_ln_kernel<float, 3><<<grid, block, 0, s>>>(a); else embed_ln_kernel<float><<<grid, block, 0, s>>>(a); }
     return CPT_OK;
 }
 
@@ -311,9 +362,10 @@ __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__
 // runs both (the first `npad` workgroups convert the regions, the rest gather + normalise the text rows), so that the embedding's gathers
 // ride under the HBM-bound conversion instead of a 10 us launch of their own in front of it.
 static_assert(ROW_THREADS == 256, "embed_pad_kernel: both bodies are written for 256 threads");
+template <int NA>
 __global__ __launch_bounds__(256) void embed_pad_kernel(EmbedArgs a, const float* __restrict__ x, bf16* __restrict__ xo, int R, int K, int Kp, int npad) {
     if ((int)blockIdx.x < npad) pad_cast_block<bf16>(x, xo, R, K, Kp, blockIdx.x, npad);
-    else embed_ln_block<bf16>(a, blockIdx.x - npad);
+    else embed_ln_block<bf16, NA>(a, blockIdx.x - npad);
 }
 
 int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
@@ -327,7 +379,8 @@ int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos,
     const size_t n = (size_t)R * (Kp / 8);
     const int npad = (int)((n + 256 * PC_UNR - 1) / (256 * PC_UNR));
     EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, nullptr, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0};
-    embed_pad_kernel<<<dim3(npad + (B * Lt + 3) / 4), dim3(256), 0, s>>>(a, x, (bf16*)xo, R, K, Kp, npad);
+    if (H == 768) embed_pad_kernel<3><<<dim3(npad + (B * Lt + 3) / 4), dim3(256), 0, s>>>(a, x, (bf16*)xo, R, K, Kp, npad);
+    else embed_pad_kernel<MAXV><<<dim3(npad + (B * Lt + 3) / 4), dim3(256), 0, s>>>(a, x, (bf16*)xo, R, K, Kp, npad);
     return CPT_OK;
 }
 
