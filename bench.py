@@ -28,11 +28,11 @@ BF16_DLOGIT_LIMIT = 0.03       # bf16 throughput mode against the fp32 oracle on
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}      # MI355X_MICROARCH.md: dense MFMA peaks
 def _latest(name):
     """newest committed round artefact profiles/rNN_<name>"""
-    for r in ("r04", "r03", "r02"):
+    for r in ("r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", "%s_%s" % (r, name))
         if os.path.exists(f):
             return f
-    return os.path.join(ROOT, "profiles", "r04_" + name)
+    return os.path.join(ROOT, "profiles", "r05_" + name)
 
 
 PMC_FILE = _latest("pmc_bench_summary.json")

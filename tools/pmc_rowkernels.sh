@@ -11,7 +11,7 @@ done
 cd $R
 python - <<P
 import csv, glob, json, collections
-fam = lambda n: next((k for k in ("layernorm_rows_kernel", "ln_bwd_kernel", "ln_bwd_reduce", "embed_pad_kernel", "embed_ln_kernel", "embed_bwd", "adamw_kernel", "head_rows_ln3", "head_finish", "pad_cast_kernel",
+fam = lambda n: next((k for k in ("layernorm768_kernel", "layernorm_rows_kernel", "ln_bwd_kernel", "ln_bwd_reduce", "embed_pad_kernel", "embed_ln_kernel", "embed_bwd", "adamw_kernel", "head_rows_ln3", "head_finish", "pad_cast_kernel",
                                     "colsum_kernel", "reduce_partials", "ce_rows", "zero_segments", "dropout_rows") if k in n), None)
 res = {}
 for leg in ("inf", "trn"):
