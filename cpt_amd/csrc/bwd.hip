@@ -207,7 +207,7 @@ int gelu_bwd(const void* dh, const void* u, void* du, int dtype, size_t n, hipSt
 // in the forward).  dx (fp32) and dx_lp (optional) are written compact at row r; dg/db accumulated
 // with one atomicAdd per column per workgroup.
 constexpr int LNB_MAXV = 4;
-template <typename LP, bool GELU_IN>
+template <typename LP, bool GELU_IN, int NA = 4>      // NA: float4 per lane per row array (4: any H <= 1024; 3: the H = 768 instantiation -- a quarter fewer registers, 36 instead of 48 KB of staging: four workgroups per CU)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ g, float eps, float* __restrict__ dx,
                                                      LP* __restrict__ dx_lp, float* __restrict__ dg, float* __restrict__ db,
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     // layer -- dx through the dropout mask of the forward (regenerated, dropout.h; thresh 0: identity) -- and dbias its column
     // sums = the gradient of the dense bias; dx itself stays unmasked (it feeds the residual path).  Replaces a dropout_rows and
     // a colsum launch per LayerNorm.
-    __shared__ float red[3][4][256 * LNB_MAXV];     // [dg|db|dbias][wave][column]  (48 KB)
+    constexpr int LNB_MAXV = NA;
+    __shared__ float red[3][4][256 * LNB_MAXV];     // [dg|db|dbias][wave][column]  (48 KB; 36 KB at NA = 3)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = (H + 255) / 256;
     f32x4 gsum[LNB_MAXV], bsum[LNB_MAXV], gg[LNB_MAXV], xsum[LNB_MAXV];
@@ -408,7 +409,8 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
     if (g && part && R >= 1024 && (size_t)((R + 3) / 4) * nsum * H * 4 <= part_bytes) rpb = g_lnb_rpb > 0 ? g_lnb_rpb : (R >= 2048 ? 8 : 4); else part = nullptr;      // 8: two rows per wave, half the partial rows (3840 rows: 5.83 vs 5.89 ms per step; 960 blocks of 4 rows are 1.25 rounds of the 3 blocks per CU the 48 KB staging array allows)
     dim3 grid((R + rpb - 1) / rpb), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
-#define LNB(LPT, GI) ln_bwd_kernel<LPT, GI><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias)
+#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias); \
+                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias); } while (0)
     if (lp16) { if (gelu_in) LNB(bf16, true); else LNB(bf16, false); }
     else      { if (gelu_in) LNB(float, true); else LNB(float, false); }
 #undef LNB

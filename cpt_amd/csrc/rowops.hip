@@ -91,7 +91,7 @@ __device__ __forceinline__ void ln_write(const f32x4 (&v)[NA], int nv, int lane,
 // Per-row arithmetic and order are unchanged: same bits.
 // Chosen per launch: two rows per wave from 24576 rows on (> 256 MB working sets: 3.85 -> 4.9 TB/s for the bf16-only output form); below
 // that one row per wave keeps twice the waves on the chip, which is what hides the latency of a small launch (7680 rows: 9.1 vs 11.3 us).
-template <typename LP, bool GELU_IN, int LN_RPW>
+template <typename LP, bool GELU_IN, int LN_RPW, int NA = 4>      // NA = 3: the H = 768 instantiation (row and residual arrays of three float4 per lane instead of four)
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const int lane = threadIdx.x & 63;
     const int r0 = (blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6)) * LN_RPW;
     if (r0 >= R) return;
+    constexpr int MAXV = NA;
     const int nv = (H + 255) / 256;
     f32x4 v[LN_RPW][MAXV], rr[LN_RPW][MAXV];
 #pragma unroll
@@ -150,11 +151,11 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
             }
         }
         float mean = 0.f, rstd = 1.f;
-        if (g) ln_stats(v[u], nv, lane, H, mean, rstd, eps);
+        if (g) ln_stats<NA>(v[u], nv, lane, H, mean, rstd, eps);
         const size_t orow = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
-        if (out_panel) ln_write<LP>(v[u], nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
+        if (out_panel) ln_write<LP, NA>(v[u], nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
         else
-        ln_write<LP>(v[u], nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
+        ln_write<LP, NA>(v[u], nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
                      out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
     }
 }
@@ -220,6 +221,7 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
 #define LNK(LPT, GI)                                                                                                                              \
     do {                                                                                                                                          \
         if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel); \
+        else if (H == 768) layernorm_rows_kernel<LPT, GI, 1, 3><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel); \
         else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel);          \
     } while (0)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
