@@ -296,43 +296,60 @@ int cpt_decode_tsv_rows(const char* const* rows, const size_t* lens, int n_rows,
         w.groups = sc.n_groups;
         stripped_len[r] = sc.stripped_len;
     };
-    parallel(n_rows, scan_row);
+    // Round 5: a row is DECODED by the thread that scanned it, right behind the scan (its 4.4 MB of text are still in that core's caches: the
+    // two-phase form read all rows' text from memory twice).  Where a row's sequences land depends on the rows in front of it only through
+    // their sequence COUNT, which every row publishes as soon as its scan is done; rows are handed out in order, so the rows a thread waits
+    // for are always already being scanned by someone.
+    const size_t seq_elems = (size_t)max_regions * dim;
+    std::vector<std::atomic<int>> published(n_rows > 0 ? n_rows : 1);
+    for (auto& p : published) p.store(-1, std::memory_order_relaxed);
+    std::vector<int> dec_status(n_rows > 0 ? n_rows : 1, CPT_OK);
+    std::atomic<int> overflow(0);
+    auto decode_row = [&](int r, int base, bool report) -> int {          // sequences base .. base + groups of row r
+        const Row& w = R[r];
+        std::vector<int> first(w.groups, 0), count(w.groups, 0);
+        for (size_t v = 0; v < w.group.size(); ++v) {
+            const int g = w.group[v];
+            if (count[g] == 0) first[g] = (int)v;
+            ++count[g];
+        }
+        for (int g = 0; g < w.groups; ++g) {
+            const int s = base + g;
+            regions_per_seq[s] = count[g];
+            if (count[g] > max_regions)
+                return report ? io_fail(CPT_ERR_SHAPE, "sequence %d: %d regions do not fit max_regions %d", s, count[g], max_regions) : CPT_ERR_SHAPE;
+            float* o = out + s * seq_elems;
+            for (int i = 0; i < count[g]; ++i) {
+                const int rc = decode_one(rows[r] + w.off[first[g] + i], w.len[first[g] + i], o + (size_t)i * dim, dim);
+                if (rc != CPT_OK) return rc;
+            }
+            memset(o + (size_t)count[g] * dim, 0, (size_t)(max_regions - count[g]) * dim * sizeof(float));
+            if (mask_img)
+                for (int i = 0; i < max_regions; ++i) mask_img[(size_t)s * max_regions + i] = i < count[g] ? 1 : 0;
+        }
+        return CPT_OK;
+    };
+    auto row_job = [&](int r) {
+        scan_row(r);
+        published[r].store(R[r].status == CPT_OK ? R[r].groups : 0, std::memory_order_release);
+        if (R[r].status != CPT_OK) return;
+        int base = 0;
+        for (int q = 0; q < r; ++q) {
+            int g;
+            while ((g = published[q].load(std::memory_order_acquire)) < 0) std::this_thread::yield();
+            base += g;
+        }
+        if (base + R[r].groups > max_seqs) { overflow.store(1); return; }
+        dec_status[r] = decode_row(r, base, false);
+    };
+    parallel(n_rows, row_job);
     for (int r = 0; r < n_rows; ++r)
         if (R[r].status != CPT_OK) { scan_row(r); return R[r].status; }     // redo in this thread to report its message
-    // phase 2: sequence numbering
-    std::vector<int> seq0(n_rows + 1, 0);
-    for (int r = 0; r < n_rows; ++r) { seqs_per_row[r] = R[r].groups; seq0[r + 1] = seq0[r] + R[r].groups; }
-    const int n_seq = seq0[n_rows];
-    if (n_seq > max_seqs) return io_fail(CPT_ERR_SHAPE, "%d sequences in %d rows do not fit max_seqs %d", n_seq, n_rows, max_seqs);
-    struct Job { int row, first, count; };
-    std::vector<Job> jobs(n_seq);
-    for (int r = 0; r < n_rows; ++r) {
-        for (int g = 0; g < R[r].groups; ++g) jobs[seq0[r] + g] = {r, 0, 0};
-        for (size_t v = 0; v < R[r].group.size(); ++v) {
-            Job& j = jobs[seq0[r] + R[r].group[v]];
-            if (j.count == 0) j.first = (int)v;
-            ++j.count;
-        }
-    }
-    // phase 3: decode every sequence
-    const size_t seq_elems = (size_t)max_regions * dim;
-    std::vector<int> st(n_seq > 0 ? n_seq : 1, CPT_OK);
-    auto decode_seq_job = [&](int s) {
-        const Job& j = jobs[s];
-        regions_per_seq[s] = j.count;
-        if (j.count > max_regions) { st[s] = io_fail(CPT_ERR_SHAPE, "sequence %d: %d regions do not fit max_regions %d", s, j.count, max_regions); return; }
-        float* o = out + s * seq_elems;
-        for (int i = 0; i < j.count; ++i) {
-            const int rc = decode_one(rows[j.row] + R[j.row].off[j.first + i], R[j.row].len[j.first + i], o + (size_t)i * dim, dim);
-            if (rc != CPT_OK) { st[s] = rc; return; }
-        }
-        memset(o + (size_t)j.count * dim, 0, (size_t)(max_regions - j.count) * dim * sizeof(float));
-        if (mask_img)
-            for (int i = 0; i < max_regions; ++i) mask_img[(size_t)s * max_regions + i] = i < j.count ? 1 : 0;
-    };
-    parallel(n_seq, decode_seq_job);
-    for (int s = 0; s < n_seq; ++s)
-        if (st[s] != CPT_OK) { decode_seq_job(s); return st[s]; }
+    int n_seq = 0;
+    for (int r = 0; r < n_rows; ++r) { seqs_per_row[r] = R[r].groups; n_seq += R[r].groups; }
+    if (n_seq > max_seqs || overflow.load()) return io_fail(CPT_ERR_SHAPE, "%d sequences in %d rows do not fit max_seqs %d", n_seq, n_rows, max_seqs);
+    for (int r = 0, base = 0; r < n_rows; base += R[r].groups, ++r)
+        if (dec_status[r] != CPT_OK) return decode_row(r, base, true);       // redo in this thread to report its message
     return CPT_OK;
 }
 
