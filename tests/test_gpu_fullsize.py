@@ -67,6 +67,33 @@ def test_config2_panel_mode_rows_equal_small_batch(dev):
     assert torch.equal(seq[:4], seq4) and torch.equal(pooled[:4], pooled4)
 
 
+@pytest.mark.parametrize("B,Lt,Li", [(160, 70, 50), (65, 78, 50), (96, 70, 58)])
+def test_panel_mode_other_shapes_rows_equal_small_batch(dev, B, Lt, Li):
+    """The full panel mode away from the bench shape: B = 160 (19200 rows: the producers' tiles run several rounds, so the 4-wave shape of the
+    register-direct producer serves them), B = 65 at L = 128 (8320 rows = 65 row tiles of 128 but 21.67 FFN-up tiles of 384: the last one hangs over the
+    matrix and its panel units are clamped) and B = 96 at L = 128.  Rows of the big batch equal a 3-sequence batch (row-major kernels) bit for bit."""
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    cfg = cfgmod.oscar_base(num_hidden_layers=3)
+    cfg.max_position_embeddings = max(cfg.max_position_embeddings, Lt)
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, 31, head="cpt"))
+    m.tie_weights()
+    m.to(dev).eval().set_compute_dtype("bf16")
+    d = _dev(synth.make_batch(B, cfg, seed=12, max_seq_len=Lt, img_seq_len=Li, vary_regions=True), dev)
+    with torch.no_grad():
+        big = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0].clone()
+        again = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0]
+        seq = m.bert(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"])[0].clone()
+    assert torch.isfinite(big).all() and torch.equal(big, again)
+    for lo in (0, B - 3):
+        ds = {k: v[lo:lo + 3].contiguous() for k, v in d.items()}
+        with torch.no_grad():
+            small = m(ds["input_ids"], ds["segment_ids"], ds["attention_mask"], img_feats=ds["img_feats"], mask_token_pos=ds["mask_token_pos"])[0]
+            seq3 = m.bert(ds["input_ids"], ds["segment_ids"], ds["attention_mask"], img_feats=ds["img_feats"])[0]
+        assert torch.equal(big[lo:lo + 3], small), "rows %d.." % lo
+        assert torch.equal(seq[lo:lo + 3], seq3), "sequence output, rows %d.." % lo
+
+
 @pytest.mark.ablation
 def test_config2_panel_mode_is_bit_identical(dev):
     """Development build: the same batch with the panel mode switched off (cpt_set_tuning(14, 0): row-major tensors), with the round-3 form of the

@@ -192,3 +192,47 @@ def test_tsvfile_subset_and_reordered_lineidx(tmp_path):
     (tmp_path / "bad.lineidx").write_text("0\n99999\n")
     with pytest.raises(ValueError):
         TSVFile(str(bad)).seek(0)
+
+
+def test_base64_vector_and_scalar_loops_agree(tmp_path):
+    """Round 5: the AVX2 base64 loop (csrc/b64_avx2.cpp, taken when the CPU has AVX2) and the table-driven scalar loop (CPT_B64_SCALAR=1) decode the same
+    bits and report the same error positions: random float32 payloads incl. NaN / Inf / denormal patterns, every length class of the 32-character blocks,
+    '=' padding, and a character outside the alphabet at the first / a middle / the last position of a block."""
+    import subprocess
+    import sys
+    script = r'''
+import base64, ctypes as C, json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from cpt_amd import _lib as L
+lib = L.lib()
+rng = np.random.default_rng(5)
+out = []
+for dim in (1, 2, 5, 6, 7, 8, 23, 24, 25, 48, 2054):
+    x = rng.standard_normal(dim).astype(np.float32)
+    special = np.array([0x7fc00000, 0x7f800000, 0xff800000, 0x00000001], dtype=np.uint32)
+    x.view(np.uint32)[: min(dim, 4)] = special[: min(dim, 4)]
+    if dim > 40:
+        x.view(np.uint32)[dim - 4:] = special
+    s = base64.b64encode(x.tobytes())
+    got = np.empty(dim, np.float32)
+    rc = lib.cpt_b64_decode_f32(s, len(s), got.ctypes.data, dim)
+    out.append([dim, rc, got.view(np.uint32).tolist() == x.view(np.uint32).tolist()])
+    for pos in (0, len(s) // 2, max(len(s) - 5, 0), 33 if len(s) > 40 else 1):
+        bad = bytearray(s)
+        bad[pos] = ord("*")
+        rc = lib.cpt_b64_decode_f32(bytes(bad), len(bad), got.ctypes.data, dim)
+        out.append([dim, pos, rc, lib.cpt_last_error().decode()])
+print(json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for scalar in ("0", "1"):
+        env = dict(os.environ, CPT_B64_SCALAR=scalar)
+        p = subprocess.run([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[scalar] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["0"] == res["1"]
+    ok = [r for r in res["0"] if len(r) == 3]
+    assert ok and all(r[1] == 0 and r[2] for r in ok)
+    errs = [r for r in res["0"] if len(r) == 4]
+    assert errs and all(r[2] != 0 and ("character %d " % (r[1] // 4 * 4)) in r[3] for r in errs)      # (the decoder names the 4-character group of the offender)
