@@ -25,7 +25,8 @@ find $O/${T}_prof_train -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $
 # keep the merge-back small
 rm -rf $O/${T}_prof $O/${T}_prof_train
 find $O/${T}_pmc -name "*.csv" -size +1M -delete 2>/dev/null
-python tools/panel_model_trace.py > $O/${T}_panel_model_trace.txt 2>&1
-python tools/q3_timeline.py > $O/${T}_q3_timeline.txt 2>&1
-python tools/panel_bench.py --rounds 2 > $O/${T}_panel_bench.txt 2>&1
+CPT_AMD_ABLATION=1 python tools/panel_model_trace.py > $O/${T}_panel_model_trace.txt 2>&1
+CPT_AMD_ABLATION=1 python tools/q3_timeline.py > $O/${T}_q3_timeline.txt 2>&1
+CPT_AMD_ABLATION=1 python tools/panel_bench.py --rounds 2 > $O/${T}_panel_bench.txt 2>&1
+python tools/rp_bench.py > $O/${T}_rp_bench.txt 2>&1
 ls -la $O | grep ${T}_

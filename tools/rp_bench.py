@@ -43,6 +43,22 @@ def main():
                 torch.cuda.synchronize()
                 res[name] = e0.elapsed_time(e1) / a.iters * 1e3
             print("K %4d waves %d  slab %.2f us  direct %.2f us  (includes ~3 torch allocs per call)" % (K, waves, res["slab"], res["direct"]), flush=True)
+            # per-workgroup phase stamps (shader clock ticks; the kernels stamp start / after the prologue / after the K loop / end)
+            import ctypes as C
+            nwg = (M // 128) * (H // 192)
+            for name, fn in (("slab", lambda: ops.gemm_ln_prod3_panel(apn, K, w, bias, hi, lo, st, g, bt, 1e-12, H, waves=waves)),
+                             ("direct", lambda: ops.gemm_ln_prod3_rpanel(apn, K, w, bias, hp, lp, st, g, bt, 1e-12, H, waves=waves))):
+                tr = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+                fn()
+                L.lib().cpt_debug_gemm_trace(C.c_void_p(tr.data_ptr()))
+                fn()
+                torch.cuda.synchronize()
+                L.lib().cpt_debug_gemm_trace(None)
+                t = tr.view(nwg, 8).cpu()
+                pro, kl, ep = ((t[:, 1] - t[:, 0]).float().mean().item(), (t[:, 2] - t[:, 1]).float().mean().item(), (t[:, 4] - t[:, 2]).float().mean().item())
+                wall = ((t[:, 5] - t[:, 3]).float() * 0.01)
+                print("        %-6s ticks per workgroup: prologue %.0f  K loop %.0f (%.0f per K-tile)  epilogue %.0f; workgroup wall %.2f us; first start -> last end %.2f us"
+                      % (name, pro, kl, kl / (K // 64), ep, wall.mean().item(), (t[:, 5].max() - t[:, 3].min()).item() * 0.01), flush=True)
 
 
 if __name__ == "__main__":
