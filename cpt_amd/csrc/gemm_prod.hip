@@ -26,6 +26,9 @@
 #ifndef CPT_PROD_AUX0
 #define CPT_PROD_AUX0 1
 #endif
+#ifndef CPT_PROD_RAMP
+#define CPT_PROD_RAMP 1          // 8-wave shape: prologue requests two tiles, the rest of the ring fills under tile 0 (0: the whole ring in front of the first MFMA, rounds 3-4)
+#endif
 
 namespace cpt {
 namespace {
@@ -190,12 +193,24 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     // Loads complete in issue order, so "tile t+1 has landed" (its A fragments, older: its W pieces) = at most the ops issued
     // after A(t+1) outstanding: W(t+2), A(t+2), W(t+3) = 2 GW + GA -- except in iteration 0, where W(1) is the younger one of
     // tile 1's two parts and only W(2) W(3) may stay in flight.
+    // RAMP (round 5, 8 waves): the prologue requests TILES 0 AND 1 ONLY -- 14 instead of 31 KiB-requests per wave in front of the first MFMA (the full fill of
+    // the ring took 6.5 k ticks per workgroup: a quarter of the attention-output launch); the side data, A(2), W(2) and W(3) are issued between the k-steps
+    // of tile 0, under its MFMAs.  Issue order:  A(0) W(0) A(1) W(1) | side A(2) W(2) W(3) inside iteration 0 | iteration t: A(t+3) W(t+4) ...
+    //   first wait (tile 0): younger than W(0) are A(1) W(1) = GA + GW;  iteration 0 (KIND 7): tile 1's younger part is W(1), younger than it side A(2) W(2) W(3)
+    //   = NSIDE + GA + 2 GW;  iteration 1 (KIND 6: the side data, older than A(2), has landed -> parked): younger than W(2) are W(3) A(3) W(4) = 2 GW + GA, the
+    //   steady-state count, and from there on the sequence IS the steady state.
+    constexpr bool RAMP = NWV == 8 && CPT_PROD_SIDE == 2 && ABL == 0 && CPT_PROD_RAMP;
     if (trace) tra = clock64();
+    if (RAMP) {
+        CPT_A_LOAD(0, 0); CPT_SB(); stage_w(0, 0); CPT_SB();
+        CPT_A_LOAD(1, 1); CPT_SB(); stage_w(1, 1); CPT_SB();
+    } else {
     if (CPT_PROD_SIDE == 1) { CPT_SIDE_LOADS(); CPT_SB(); }
     CPT_A_LOAD(0, 0); CPT_SB(); stage_w(0, 0); CPT_SB();
     if (CPT_PROD_SIDE == 2) { CPT_SIDE_LOADS(); CPT_SB(); }
     CPT_A_LOAD(1, 1); CPT_A_LOAD(2, 2); CPT_SB();
     stage_w(1, 1); stage_w(2, 2); stage_w(3, 3); CPT_SB();
+    }
     if (trace) trb = clock64();
 
     bf16x8 fb[4][NJ];
@@ -217,7 +232,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, fb[KS][j_], acc[j_], 0, 0, 0);               \
     } while (0)
 
-    wait_vm<(CPT_PROD_SIDE == 2 ? NSIDE : 0) + 2 * GA + 3 * GW>();            // tile 0 landed: younger than W(0) are the side data, A(1) A(2), W(1) W(2) W(3)
+    if (RAMP) wait_vm<GA + GW>();
+    else wait_vm<(CPT_PROD_SIDE == 2 ? NSIDE : 0) + 2 * GA + 3 * GW>();            // tile 0 landed: younger than W(0) are the side data, A(1) A(2), W(1) W(2) W(3)
     __builtin_amdgcn_s_barrier();
     CPT_SB();
     CPT_A_TOUCH(0);
@@ -281,27 +297,30 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     do {                                                                                                           \
         constexpr int NB_ = ((B) + 1) & 3, PB_ = ((B) + 3) & 3;                                                     \
         touch(0); CPT_SB(); ldfrag(B, 2, 2); CPT_SB(); CPT_MMA(B, 0); CPT_SB();                                     \
+        if ((KIND) == 7) { CPT_SIDE_LOADS(); CPT_SB(); CPT_A_LOAD(2, 2); CPT_SB(); }       /* RAMP: the rest of the ring's first fill, under tile 0 */ \
         touch(1); CPT_SB(); ldfrag(B, 3, 3); CPT_SB(); CPT_MMA(B, 1); CPT_SB();                                     \
+        if ((KIND) == 7) { stage_w(2, 2); stage_w(3, 3); CPT_SB(); }                                                \
         touch(2); touch(3); CPT_SB();              /* this wave's reads of tile t are retired before the barrier */ \
         if ((KIND) != 4) {                                                                                         \
-            if ((KIND) == 5) wait_vm<2 * GW>(); else if ((KIND) <= 1) wait_vm<2 * GW + GA>();                       \
+            if ((KIND) == 5) wait_vm<2 * GW>(); else if ((KIND) == 7) wait_vm<NSIDE + GA + 2 * GW>();               \
+            else if ((KIND) <= 1 || (KIND) == 6) wait_vm<2 * GW + GA>();                                            \
             else if ((KIND) == 2) wait_vm<GW + GA>(); else wait_vm<0>();                                            \
             CPT_SB();                                                                                              \
             __builtin_amdgcn_s_barrier();          /* tile t+1 visible to all waves; nobody still reads tile t */   \
             CPT_SB();                                                                                              \
             CPT_A_TOUCH(NB_);                                                                                      \
-            if ((KIND) == 5 && CPT_PROD_SIDE != 0) { CPT_SIDE_PARK(); CPT_SB(); }                                    \
+            if (((KIND) == 5 && CPT_PROD_SIDE != 0) || (KIND) == 6) { CPT_SIDE_PARK(); CPT_SB(); }                   \
             if ((KIND) == 3 && CPT_PROD_AUX0) { CPT_AUX0(); CPT_SB(); }   /* nothing else is in flight: the first residual slice rides under the last tile */ \
         }                                                                                                          \
         if (LATE_) { CPT_MMA(B, 2); CPT_SB(); }                                                                     \
         if ((KIND) != 4) {                                                                                         \
-            if ((KIND) <= 1 || (KIND) == 5) { CPT_A_LOAD(PB_, (T) + 3); CPT_SB(); }                                 \
-            if (!LATE_ && ((KIND) == 0 || (KIND) == 5)) { stage_w(B, (T) + 4); CPT_SB(); }                          \
+            if ((KIND) <= 1 || (KIND) >= 5) { CPT_A_LOAD(PB_, (T) + 3); CPT_SB(); }                                 \
+            if (!LATE_ && ((KIND) == 0 || (KIND) >= 5)) { stage_w(B, (T) + 4); CPT_SB(); }                          \
             ldfrag(NB_, 0, 0); CPT_SB();                                                                            \
         }                                                                                                          \
         if (!LATE_) { CPT_MMA(B, 2); CPT_SB(); }                                                                    \
         if (LATE_) { CPT_MMA(B, 3); CPT_SB(); }                                                                     \
-        if (LATE_ && ((KIND) == 0 || (KIND) == 5)) { stage_w(B, (T) + 4); CPT_SB(); }                               \
+        if (LATE_ && ((KIND) == 0 || (KIND) >= 5)) { stage_w(B, (T) + 4); CPT_SB(); }                               \
         if ((KIND) != 4) { ldfrag(NB_, 1, 1); CPT_SB(); }                                                           \
         if (!LATE_) { CPT_MMA(B, 3); CPT_SB(); }                                                                    \
     } while (0)
@@ -386,8 +405,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void prod3_panel_kernel(
     //   t = nt-3 (KIND 2): younger than A(nt-2): W(nt-1) A(nt-1)              = GW + GA
     //   t = nt-2 (KIND 3): younger than A(nt-1): nothing                      = 0
     const int groups = nt / 4 - 1;
-    CPT_TILE(0, 5, 0);
-    CPT_TILE(1, 0, 1);
+    if constexpr (RAMP) { CPT_TILE(0, 7, 0); CPT_TILE(1, 6, 1); }
+    else { CPT_TILE(0, 5, 0); CPT_TILE(1, 0, 1); }
     CPT_TILE(2, 0, 2);
     CPT_TILE(3, 0, 3);
     int t = 4;
