@@ -202,17 +202,14 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
     const DropSpec dr = drop ? *drop : DropSpec{};
     if (grp_stride == 0 && grp != R) grp_stride = grp;
-    static const int rpw_env = [] { const char* e = getenv("CPT_LN_RPW"); return e ? atoi(e) : 0; }();      // experiment hook (tools/hbm_rows.py): rows per wave of the H = 768 fast kernel
-    if (H == 768 && !gelu_in && !resid && dr.thresh == 0 && !pre_out && x_parts == 1 && (rpw_env >= 0)) {
-        // measured (tools/hbm_rows.py, CPT_LN_RPW): one row per wave wins at every size -- bf16 out 0.59 / 0.72 of 8 TB/s at 7680 / 61440 rows against
-        // 0.58 / 0.71 with two rows and 0.49 / 0.67 with four (the general kernel: 0.56 / 0.55): what helped is the register diet (44 VGPRs), not rows in flight
-        const int rp = rpw_env > 0 ? rpw_env : 1;
-        dim3 g768((R + 4 * rp - 1) / (4 * rp)), b768(ROW_THREADS);
-        const bool lp16f = out_lp && lp_dtype == CPT_BF16;
-#define LN768(LPT, RP) layernorm768_kernel<LPT, RP><<<g768, b768, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, grp, grp_stride, grp_off, (signed char*)out_lo, out_panel)
-        if (lp16f) { if (rp == 2) LN768(bf16, 2); else LN768(bf16, 1); }
-        else       { if (rp == 2) LN768(float, 2); else LN768(float, 1); }
-#undef LN768
+    // H = 768 rows without residual / dropout / GELU / split-K partials: the lean kernel, one row per wave (measured against two and four rows per wave:
+    // profiles/r05_ab_log.md -- 0.59 / 0.72 of 8 TB/s at 7680 / 61440 rows for the bf16 output against 0.58 / 0.71 and 0.49 / 0.67; the general kernel: 0.56 / 0.55)
+    if (H == 768 && !gelu_in && !resid && dr.thresh == 0 && !pre_out && x_parts == 1) {
+        dim3 g768((R + 3) / 4), b768(ROW_THREADS);
+        if (out_lp && lp_dtype == CPT_BF16)
+            layernorm768_kernel<bf16, 1><<<g768, b768, 0, s>>>(x, g, bta, eps, out_f32, (bf16*)out_lp, R, grp, grp_stride, grp_off, (signed char*)out_lo, out_panel);
+        else
+            layernorm768_kernel<float, 1><<<g768, b768, 0, s>>>(x, g, bta, eps, out_f32, (float*)out_lp, R, grp, grp_stride, grp_off, (signed char*)out_lo, out_panel);
         return CPT_OK;
     }
     const int rpw = R >= 24576 ? 2 : 1;

@@ -7,6 +7,10 @@
  * At the GPU's rate (3e4 sequences/s x 0.55 MB of base64 each) that Python path is the bottleneck.  These entry
  * points decode straight into caller-owned (pinned) host memory; nothing is allocated or retained.
  *
+ * Round 5: on CPUs with AVX2 (checked once per process) the base64 inner loop decodes 32 characters per iteration (csrc/b64_avx2.cpp); results and
+ * error reports are those of the scalar loop, which still serves tails, padded groups and every block that holds an invalid character.  The
+ * environment variable CPT_B64_SCALAR=1 (read once, at load time) keeps the scalar loop everywhere: a test / measurement hook, not an interface.
+ *
  * Part of libcpt_hip.so; plain pointers and sizes only; every function returns CPT_OK (0) or a negative
  * status from cpt_hip.h (CPT_ERR_NULL / CPT_ERR_SHAPE), with the message in cpt_last_error().
  */
