@@ -94,6 +94,24 @@ def test_panel_mode_other_shapes_rows_equal_small_batch(dev, B, Lt, Li):
         assert torch.equal(seq[lo:lo + 3], seq3), "sequence output, rows %d.." % lo
 
 
+def test_panel_mode_text_only_rows_equal_small_batch(dev):
+    """Panel mode without region features (img_feats = None, modeling_bert.py:261): 64 sequences of 120 text tokens -- the text embedding launch
+    alone writes the panel-layout residual stream (no merged pad + cast launch).  Rows of the big batch equal a 3-sequence batch bit for bit."""
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    cfg = cfgmod.oscar_base(num_hidden_layers=2)
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, 33, head="cpt"))
+    m.tie_weights()
+    m.to(dev).eval().set_compute_dtype("bf16")
+    b = synth.make_batch(64, cfg, seed=14, max_seq_len=120, img_seq_len=4)
+    d = _dev({k: (v[:, :120] if k == "attention_mask" else v) for k, v in b.items() if k != "img_feats"}, dev)
+    with torch.no_grad():
+        big = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=None, mask_token_pos=d["mask_token_pos"])[0].clone()
+        ds = {k: v[5:8].contiguous() for k, v in d.items()}
+        small = m(ds["input_ids"], ds["segment_ids"], ds["attention_mask"], img_feats=None, mask_token_pos=ds["mask_token_pos"])[0]
+    assert torch.isfinite(big).all() and torch.equal(big[5:8], small)
+
+
 @pytest.mark.ablation
 def test_config2_panel_mode_is_bit_identical(dev):
     """Development build: the same batch with the panel mode switched off (cpt_set_tuning(14, 0): row-major tensors), with the round-3 form of the
