@@ -14,6 +14,7 @@ CPT_F32, CPT_BF16, CPT_BF16X3, CPT_BF16X3_MASTERS = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID = 0, 1, 2, 3
 OUT_SEQ, OUT_POOLED, OUT_MASK_LOGITS, OUT_ALL_LOGITS, OUT_LOSS, OUT_REL = 1, 2, 4, 8, 16, 32
 ATTN_MASK_3D = 256        # input flag: attention mask is (B, L, L)
+ADAMW_HF, ADAMW_NO_BIAS_CORRECTION = 1, 2      # cpt_adamw_ex flags
 K_NAMES = ["gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up", "gemm_ffn_down",
            "embed_ln", "img_proj", "head", "op"]
 
@@ -100,6 +101,8 @@ _SIGS = {
     "cpt_comm_destroy": (C.c_int, []),
     "cpt_adamw": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                             C.c_int, C.c_float, vp]),
+    "cpt_adamw_ex": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                               C.c_int, C.c_float, C.c_int, vp]),
     "cpt_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int,
                            C.c_int, C.c_int, C.c_int, vp]),
     "cpt_embed_ln": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int,

@@ -1844,7 +1844,10 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
 
 // ---- fused AdamW over the flat parameter buffer (torch.optim.AdamW single-tensor update) ---------
 // code[i]: 0 = parameter has no gradient (skipped, as torch skips grad=None), 1 = weight decay, 2 = no decay
-template <bool SHADOW>
+// HF (round 5): the arithmetic of pytorch_transformers.AdamW (transformers@067923d optimization.py, the optimizer of the GQA / VCR few-shot drivers,
+// fewshot/vcr_nsp_cpt.py:385, gqa_cpt.py:342) instead of torch.optim.AdamW's: eps is added to sqrt(v) BEFORE the bias corrections scale the step
+// (step = lr sqrt(bc2) / bc1, or lr without correct_bias: bc1 = bc2_sqrt = 1 then), and the decoupled decay p -= lr wd p acts on the UPDATED parameter.
+template <bool SHADOW, bool HF = false>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, const unsigned char* __restrict__ code,
                                                     bf16* __restrict__ shadow, size_t n, float lr, float beta1, float beta2,
@@ -1862,6 +1865,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     for (int e = 0; e < 4; ++e) {
         if (cc[e] == 0) continue;
         const float gr = gv[e] * grad_scale;
+        if constexpr (HF) {
+            mv[e] = mv[e] * beta1 + (1.0f - beta1) * gr;                   // exp_avg.mul_(beta1).add_(1 - beta1, grad)
+            vv[e] = vv[e] * beta2 + (1.0f - beta2) * gr * gr;              // exp_avg_sq.mul_(beta2).addcmul_(1 - beta2, grad, grad)
+            const float denom = sqrtf(vv[e]) + eps;
+            float pe = pv[e] - (lr * bc2_sqrt / bc1) * (mv[e] / denom);
+            if (cc[e] == 1) pe = pe - lr * wd * pe;
+            po[e] = pe;
+            continue;
+        }
         float pe = pv[e] * (1.0f - lr * (cc[e] == 1 ? wd : 0.f));
         mv[e] = mv[e] + (gr - mv[e]) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1-beta1)
         vv[e] = vv[e] * beta2 + gr * gr * (1.0f - beta2);
@@ -1881,12 +1893,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16, size_t n,
-               float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s) {
+               float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s, int flags) {
     if (!p || !g || !m || !v || !code) return CPT_ERR_NULL;
-    if (n % 4 || step < 1) return CPT_ERR_SHAPE;
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    if (n % 4 || step < 1 || (flags & ~3)) return CPT_ERR_SHAPE;
+    const bool hf = flags & 1, no_bc = flags & 2;
+    const float bc1 = no_bc ? 1.0f : 1.0f - powf(beta1, (float)step);
+    const float bc2s = no_bc ? 1.0f : sqrtf(1.0f - powf(beta2, (float)step));
     dim3 grid((unsigned)((n / 4 + 255) / 256)), block(256);
+    if (hf) {
+        if (shadow_bf16) adamw_kernel<true, true><<<grid, block, 0, s>>>(p, g, m, v, code, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
+        else adamw_kernel<false, true><<<grid, block, 0, s>>>(p, g, m, v, code, nullptr, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
+        return CPT_OK;
+    }
     if (shadow_bf16) adamw_kernel<true><<<grid, block, 0, s>>>(p, g, m, v, code, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
     else adamw_kernel<false><<<grid, block, 0, s>>>(p, g, m, v, code, nullptr, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
     return CPT_OK;

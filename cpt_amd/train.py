@@ -335,8 +335,13 @@ class FusedAdamW(object):
     force_collectives: run the collectives even at world size 1 (exercises the RCCL stream choreography on one GPU)."""
 
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_wire=None, defer_reduce=False,
-                 force_collectives=False):
+                 force_collectives=False, hf_arithmetic=False, correct_bias=True):
         self.model = model
+        # hf_arithmetic: the update of pytorch_transformers.AdamW (the GQA / VCR few-shot drivers' optimizer) instead of torch.optim.AdamW's --
+        # eps outside the bias correction, decay applied to the updated parameter (include/cpt_hip.h cpt_adamw_ex); see the AdamW class below
+        self.flags = (L.ADAMW_HF if hf_arithmetic else 0) | (0 if correct_bias else L.ADAMW_NO_BIAS_CORRECTION)
+        if not correct_bias and not hf_arithmetic:
+            raise ValueError("correct_bias=False belongs to the pytorch_transformers arithmetic (hf_arithmetic=True)")
         self.defer_reduce = bool(defer_reduce)
         self.force_collectives = bool(force_collectives)
         self.eng = model._engine()
@@ -432,6 +437,10 @@ class FusedAdamW(object):
         return norm
 
     def _adamw(self, p_ptr, g_ptr, m_ptr, v_ptr, code_ptr, shadow_ptr, n, lr, wd, scale):
+        if self.flags:
+            L.check(L.lib().cpt_adamw_ex(p_ptr, g_ptr, m_ptr, v_ptr, code_ptr, shadow_ptr, n, lr, self.betas[0], self.betas[1], self.eps,
+                                         wd, self.step_count, scale, self.flags, L.stream_ptr()), "cpt_adamw_ex")
+            return
         L.check(L.lib().cpt_adamw(p_ptr, g_ptr, m_ptr, v_ptr, code_ptr, shadow_ptr, n, lr, self.betas[0], self.betas[1], self.eps,
                                   wd, self.step_count, scale, L.stream_ptr()), "cpt_adamw")
 
@@ -570,6 +579,78 @@ def load_checkpoint(save_dir, model, optimizer=None):
         optimizer.load_state_dict(torch.load(os.path.join(save_dir, "optimizer.pt"), map_location="cpu"))
     p = os.path.join(save_dir, "training_state.json")
     return json.load(open(p))["global_step"] if os.path.exists(p) else 0
+
+
+class AdamW(FusedAdamW):
+    """Drop-in for ``pytorch_transformers.AdamW`` as the GQA / VCR few-shot drivers build it (fewshot/vcr_nsp_cpt.py:380-385, gqa_cpt.py:337-342:
+    ``AdamW(optimizer_grouped_parameters, lr=args.learning_rate, eps=args.adam_epsilon)`` with weight decay on everything but ``bias`` /
+    ``LayerNorm.weight``): same defaults (betas (0.9, 0.999), eps 1e-6, weight_decay 0.0, correct_bias True) and the SAME update arithmetic
+    (``cpt_adamw_ex(CPT_ADAMW_HF)``), one launch over the flat buffers.  Takes the MODEL where the reference passes its two parameter groups --
+    the no-decay rule of those groups is the one ``FusedAdamW`` applies -- and exposes two ``param_groups`` (decay, no decay) for
+    ``WarmupLinearSchedule`` / ``WarmupConstantSchedule`` below."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, **kw):
+        FusedAdamW.__init__(self, model, lr, betas=betas, eps=eps, weight_decay=weight_decay, hf_arithmetic=True, correct_bias=correct_bias, **kw)
+        # FusedAdamW reads lr / weight_decay from param_groups[2]: keep its four-slot list, show the two groups the reference has
+        self.param_groups = [self.param_groups[2], self.param_groups[3]]
+
+    def step(self):
+        g = self.param_groups
+        self.param_groups = [g[0], g[1], g[0], g[1]]          # (FusedAdamW.step reads slot 2: the decay group)
+        try:
+            FusedAdamW.step(self)
+        finally:
+            self.param_groups = g
+
+
+class _WarmupSchedule(object):
+    """torch.optim.lr_scheduler.LambdaLR's behaviour on an optimizer that only has ``param_groups`` (FusedAdamW / AdamW): construction sets
+    lr = base_lr x lambda(0), every ``step()`` moves to the next epoch.  ``step(epoch)`` is accepted as pytorch_transformers 1.x callers pass it."""
+
+    def __init__(self, optimizer, last_epoch=-1):
+        self.optimizer = optimizer
+        self.base_lrs = [g.setdefault("initial_lr", g["lr"]) for g in optimizer.param_groups]
+        self.last_epoch = last_epoch
+        self.step()
+
+    def lr_lambda(self, step):
+        raise NotImplementedError
+
+    def get_lr(self):
+        return [b * self.lr_lambda(self.last_epoch) for b in self.base_lrs]
+
+    def step(self, epoch=None):
+        self.last_epoch = self.last_epoch + 1 if epoch is None else epoch
+        for g, lr in zip(self.optimizer.param_groups, self.get_lr()):
+            g["lr"] = lr
+
+
+class WarmupLinearSchedule(_WarmupSchedule):
+    """``pytorch_transformers.WarmupLinearSchedule`` (fewshot/vcr_nsp_cpt.py:386, gqa_cpt.py:348): the multiplier rises linearly from 0 to 1 over
+    ``warmup_steps`` and falls linearly to 0 at ``t_total`` (transformers.get_linear_schedule_with_warmup is today's name of the same lambda:
+    tests/test_host_cpu.py checks them against each other)."""
+
+    def __init__(self, optimizer, warmup_steps, t_total, last_epoch=-1):
+        self.warmup_steps, self.t_total = warmup_steps, t_total
+        _WarmupSchedule.__init__(self, optimizer, last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1, self.warmup_steps))
+        return max(0.0, float(self.t_total - step) / float(max(1.0, self.t_total - self.warmup_steps)))
+
+
+class WarmupConstantSchedule(_WarmupSchedule):
+    """``pytorch_transformers.WarmupConstantSchedule`` (gqa_cpt.py:346): linear warm-up, then 1."""
+
+    def __init__(self, optimizer, warmup_steps, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        _WarmupSchedule.__init__(self, optimizer, last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1.0, self.warmup_steps))
+        return 1.0
 
 
 def build_optimizer(model, opts):

@@ -282,6 +282,17 @@ int cpt_adamw(float* p, const float* g, float* m, float* v, const unsigned char*
               size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
               float grad_scale, void* stream);
 
+/* Round 5 (ABI 6): the same launch with the arithmetic of the GQA / VCR few-shot drivers' optimizer, pytorch_transformers.AdamW
+ * (Oscar/oscar/fewshot/vcr_nsp_cpt.py:385, gqa_cpt.py:342; transformers@067923d optimization.py, not vendored):
+ *   CPT_ADAMW_HF: m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;  p -= lr sqrt(1 - beta2^t) / (1 - beta1^t) m / (sqrt(v) + eps);
+ *                 then, for code 1, p -= lr weight_decay p (on the UPDATED p).  eps sits outside the bias correction, the decay behind the step: both differ
+ *                 from torch.optim.AdamW (flags = 0 = cpt_adamw) in the last digits only, but a drop-in follows its driver's optimizer.
+ *   CPT_ADAMW_NO_BIAS_CORRECTION: correct_bias = False (both corrections 1). */
+enum { CPT_ADAMW_HF = 1, CPT_ADAMW_NO_BIAS_CORRECTION = 2 };
+int cpt_adamw_ex(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16,
+                 size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                 float grad_scale, int flags, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (the kernels cpt_model_fwd is built from; also what the parity
  * tests call one by one).

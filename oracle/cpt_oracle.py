@@ -270,6 +270,31 @@ def adamw_step(p, g, m, v, step, lr, beta1, beta2, eps, wd):
     return p, m, v
 
 
+def adamw_step_hf(p, g, m, v, step, lr, beta1, beta2, eps, wd, correct_bias=True):
+    """pytorch_transformers.AdamW single-tensor update, the optimizer of the GQA / VCR few-shot drivers (Oscar/oscar/fewshot/vcr_nsp_cpt.py:385,
+    gqa_cpt.py:342).  Its source (transformers@067923d optimization.py) is NOT under /root/reference: restated from the published algorithm
+    (SURVEY.md Appendix A) -- exp_avg.mul_(b1).add_(1 - b1, grad); exp_avg_sq.mul_(b2).addcmul_(1 - b2, grad, grad); denom = exp_avg_sq.sqrt() + eps;
+    step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) when correct_bias; p.addcdiv_(-step_size, exp_avg, denom); then p.add_(-lr * wd, p).
+    Parity unpinned beyond that restatement (no vendored source, no golden vector): tests compare the HIP kernel with THIS function."""
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    denom = v.sqrt() + eps
+    step_size = lr
+    if correct_bias:
+        step_size = lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    p = p - step_size * (m / denom)
+    if wd > 0.0:
+        p = p - lr * wd * p
+    return p, m, v
+
+
+def warmup_linear_schedule(step, warmup_steps, t_total):
+    """pytorch_transformers.WarmupLinearSchedule's multiplier (fewshot/vcr_nsp_cpt.py:386)."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(t_total - step) / float(max(1.0, t_total - warmup_steps)))
+
+
 def train_step_grads(sd, cfg, batch, names=None, drop=None):
     """loss.backward() of fewshot/refcoco_cpt.py:231-248 with dropout disabled (or, with ``drop``, with the given masks):
     returns (loss, {name: grad}).  The tied decoder/word-embedding tensor gets the

@@ -588,3 +588,62 @@ def test_forward_ffn_down_split_in_two_matches_the_unsplit_form(dev):
             continue
         rel = float((g0[n] - g1[n]).norm()) / (float(g0[n].norm()) + 1e-30)
         assert rel < 2e-2, (n, rel)
+
+
+@pytest.mark.parametrize("correct_bias", [True, False])
+def test_hf_adamw_kernel_and_drop_in_optimizer(dev, correct_bias):
+    """Round 5: pytorch_transformers.AdamW, the optimizer of the GQA / VCR few-shot drivers (fewshot/vcr_nsp_cpt.py:385, gqa_cpt.py:342).
+    (1) cpt_adamw_ex(CPT_ADAMW_HF [| NO_BIAS_CORRECTION]) on flat buffers with all three element codes and the bf16 shadow against the oracle's
+    restatement over three steps; (2) train.AdamW + WarmupLinearSchedule on the tiny model: after each of three scheduled steps every parameter
+    equals adamw_step_hf applied to the gradients the step produced, weight decay on everything but bias / LayerNorm parameters."""
+    import ctypes as C
+    from cpt_amd import _lib as L
+    from cpt_amd import train as T
+    from oracle import cpt_oracle as O
+    g = torch.Generator().manual_seed(3)
+    n = 4096 * 3
+    p = torch.randn(n, generator=g)
+    m, v = torch.zeros(n), torch.zeros(n)
+    code = torch.randint(0, 3, (n,), generator=g, dtype=torch.uint8)
+    lr, b1, b2, eps, wd = 3e-3, 0.9, 0.999, 1e-6, 0.05
+    flags = L.ADAMW_HF | (0 if correct_bias else L.ADAMW_NO_BIAS_CORRECTION)
+    pd, md, vd, cd = p.to(dev), m.to(dev), v.to(dev), code.to(dev)
+    sh = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    for step in (1, 2, 3):
+        gr = torch.randn(n, generator=g) * (0.1 * step)
+        gd = gr.to(dev)
+        L.check(L.lib().cpt_adamw_ex(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), cd.data_ptr(), sh.data_ptr(), n, lr, b1, b2, eps, wd,
+                                     step, 0.5, flags, L.stream_ptr()), "cpt_adamw_ex")
+        pn, mn, vn = O.adamw_step_hf(p, gr * 0.5, m, v, step, lr, b1, b2, eps, wd, correct_bias)
+        pn0, _, _ = O.adamw_step_hf(p, gr * 0.5, m, v, step, lr, b1, b2, eps, 0.0, correct_bias)
+        upd = code != 0
+        p = torch.where(code == 1, pn, torch.where(code == 2, pn0, p))
+        m, v = torch.where(upd, mn, m), torch.where(upd, vn, v)
+        assert (pd.cpu() - p).abs().max().item() < 2e-6 and (md.cpu() - m).abs().max().item() < 1e-6 and (vd.cpu() - v).abs().max().item() < 1e-6
+        assert torch.equal(sh.float().cpu(), pd.cpu().to(torch.bfloat16).float())
+    # (2) the drop-in optimizer + schedule on the tiny model
+    cfg = cfgmod.tiny()
+    mdl = _model(cfg, 5, dev, "fp32")
+    opt = T.AdamW(mdl, lr=2e-3, eps=1e-6, weight_decay=0.05, correct_bias=correct_bias)
+    sched = T.WarmupLinearSchedule(opt, warmup_steps=2, t_total=6)
+    assert len(opt.param_groups) == 2 and opt.param_groups[0]["lr"] == 0.0
+    b = {k: t.to(dev) for k, t in synth.make_batch(4, cfg, seed=8, max_seq_len=20, img_seq_len=6).items()}
+    names = dict(mdl.named_parameters())
+    st = {k: (torch.zeros_like(t, device="cpu"), torch.zeros_like(t, device="cpu")) for k, t in names.items()}
+    for step in (1, 2, 3):
+        sched.step()
+        lr_now = opt.param_groups[0]["lr"]
+        assert abs(lr_now - 2e-3 * O.warmup_linear_schedule(step, 2, 6)) < 1e-12
+        before = {k: t.detach().cpu().clone() for k, t in names.items()}
+        opt.zero_grad()
+        loss, _ = mdl(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+        loss.backward()
+        grads = {k: (t.grad.detach().cpu().clone() if t.grad is not None else None) for k, t in names.items()}
+        opt.step()
+        for k, t in names.items():
+            if grads[k] is None or k == "cls.decoder.weight":          # (no gradient on this path: untouched; the tied table is checked under its embedding name)
+                continue
+            w = 0.0 if any(nd in k for nd in T.NO_DECAY) else 0.05
+            pn, mn, vn = O.adamw_step_hf(before[k], grads[k], st[k][0], st[k][1], step, lr_now, 0.9, 0.999, 1e-6, w, correct_bias)
+            st[k] = (mn, vn)
+            assert (t.detach().cpu() - pn).abs().max().item() < 3e-6, (step, k)

@@ -1,6 +1,7 @@
 """CPU: host-side logic of the drop-in surface -- scoring/IoU vs golden vectors and the oracle,
 LR schedule, optimizer grouping codes, config/checkpoint round trip, data-parallel helpers with
 world_size 2 on gloo."""
+import math
 import os
 import sys
 import tempfile
@@ -247,3 +248,63 @@ def test_train_batch_helpers_accept_what_the_reference_accepts():
         assert [g["lr"] for g in opt.param_groups] == ([5.0, 5.0, 0.5, 0.5])[:n]
     with pytest.raises(ValueError):
         drivers._apply_lr(torch.optim.AdamW([{"params": [p]} for p in ps], lr=1.0), 0.5, 10.0)
+
+
+def test_warmup_schedules_match_torch_lambdalr_and_transformers():
+    """The GQA / VCR few-shot drivers schedule with pytorch_transformers.WarmupLinearSchedule / WarmupConstantSchedule (fewshot/vcr_nsp_cpt.py:386,
+    gqa_cpt.py:346-348; not vendored).  cpt_amd.train's classes against torch.optim.lr_scheduler.LambdaLR driven by the INSTALLED transformers'
+    get_linear_schedule_with_warmup / get_constant_schedule_with_warmup (today's names of the same lambdas) and against the oracle's multiplier:
+    identical learning rates at construction and after every step, for two parameter groups (these were checked by nothing)."""
+    import transformers
+    from cpt_amd import train as T
+
+    class Opt(object):          # what the schedules need of FusedAdamW / AdamW: param_groups
+        def __init__(self):
+            self.param_groups = [{"lr": 5e-5, "weight_decay": 0.05}, {"lr": 5e-5, "weight_decay": 0.0}]
+
+    for warm, total in ((0, 20), (4, 20), (7, 7), (30, 20)):
+        ps = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
+        ref_opt = torch.optim.SGD([{"params": [ps[0]]}, {"params": [ps[1]]}], lr=5e-5)
+        ref = transformers.get_linear_schedule_with_warmup(ref_opt, warm, total)
+        mine = T.WarmupLinearSchedule(Opt(), warmup_steps=warm, t_total=total)
+        for step in range(total + 4):
+            got = [g["lr"] for g in mine.optimizer.param_groups]
+            assert got == [g["lr"] for g in ref_opt.param_groups], (warm, total, step)
+            assert got[0] == 5e-5 * O.warmup_linear_schedule(step, warm, total)
+            ref_opt.step()
+            ref.step()
+            mine.step()
+        ref_opt = torch.optim.SGD([{"params": [ps[0]]}, {"params": [ps[1]]}], lr=5e-5)
+        ref = transformers.get_constant_schedule_with_warmup(ref_opt, warm)
+        mine = T.WarmupConstantSchedule(Opt(), warmup_steps=warm)
+        for step in range(total):
+            assert [g["lr"] for g in mine.optimizer.param_groups] == [g["lr"] for g in ref_opt.param_groups], (warm, step)
+            ref_opt.step()
+            ref.step()
+            mine.step()
+
+
+def test_oracle_hf_adamw_against_closed_forms():
+    """oracle.adamw_step_hf (pytorch_transformers.AdamW restated): with eps = 0 and no decay the first step is p - lr * sign(g) whatever the betas
+    (bias corrections cancel); without correct_bias it is p - lr (1 - b1) / sqrt(1 - b2) * sign(g); the decay multiplies the UPDATED parameter; and
+    against torch.optim.AdamW the difference is only where eps enters (denominator before vs after the sqrt(bc2) scaling) and the order of the decay."""
+    g = torch.tensor([0.3, -2.0, 1e-3, 7.0])
+    p = torch.tensor([1.0, -1.0, 0.5, 2.0])
+    z = torch.zeros(4)
+    lr, b1, b2 = 1e-2, 0.9, 0.999
+    p1, m1, v1 = O.adamw_step_hf(p, g, z, z, 1, lr, b1, b2, 0.0, 0.0)
+    assert torch.allclose(p1, p - lr * torch.sign(g), atol=1e-7)
+    p2, _, _ = O.adamw_step_hf(p, g, z, z, 1, lr, b1, b2, 0.0, 0.0, correct_bias=False)
+    assert torch.allclose(p2, p - lr * (1 - b1) / math.sqrt(1 - b2) * torch.sign(g), atol=1e-6)
+    p3, _, _ = O.adamw_step_hf(p, g, z, z, 1, lr, b1, b2, 0.0, 0.1)
+    assert torch.allclose(p3, p1 * (1 - lr * 0.1), atol=1e-7)
+    # three steps against torch.optim.AdamW with eps -> 0 and wd = 0: the two algorithms coincide there
+    pt = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([pt], lr=lr, betas=(b1, b2), eps=1e-30, weight_decay=0.0)
+    ph, mh, vh = p.clone(), z.clone(), z.clone()
+    for t in range(1, 4):
+        gt = g * t
+        pt.grad = gt.clone()
+        opt.step()
+        ph, mh, vh = O.adamw_step_hf(ph, gt, mh, vh, t, lr, b1, b2, 1e-30, 0.0)
+        assert torch.allclose(ph, pt.detach(), atol=1e-6), t
