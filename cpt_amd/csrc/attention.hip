@@ -262,13 +262,83 @@ static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* pro
     return CPT_OK;
 }
 
+// ---- sequences beyond 288 positions (round 5; inference) -----------------------------------------------------------------------------
+// The reference takes whatever fits its position table plus the region slots (modeling_bert.py:244-269: up to 512 text positions + regions); no CPT
+// configuration goes beyond L = 265, so this is a coverage kernel, not a fast one: one wave per query, no MFMA, nothing tiled.
+//   pass 1: lane = key (64 keys per step): s = q . k / 8 + mask from the lane's own K row (vector loads of the whole row), scores parked in LDS, running maximum;
+//   pass 2: p = exp(s - max), row sum;   pass 3: lane = head-dim column: ctx[d] = sum_j p_j v[j][d] / sum, V rows read coalesced, p_j broadcast from LDS.
+// fp32 everywhere (libm expf), inputs / outputs in T.  2-D and 3-D masks; no dropout, no saved probabilities, row-major ctx.
+constexpr int ATT_LONG_MAX = 1024;
+template <typename T>
+__global__ __launch_bounds__(ATT_THREADS) void attention_long_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
+                                                                      int B, int L, int heads, int mask3) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* sS = reinterpret_cast<float*>(smem) + (size_t)wave * (L + 64);          // this wave's scores, then probabilities
+    float* sQ = sS + L;                                                           // its query row (64 floats)
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int q = blockIdx.y * 4 + wave;
+    if (q >= L) return;
+    const int H = heads * HD;
+    const size_t ldq = (size_t)3 * H;
+    const T* base = qkv + (size_t)b * L * ldq + h * HD;
+    sQ[lane] = to_f32(base[(size_t)q * ldq + lane]);
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < L; j0 += 64) {
+        const int j = j0 + lane;
+        float sc = -INFINITY;
+        if (j < L) {
+            const T* kr = base + (size_t)j * ldq + H;
+            float acc = 0.f;
+            constexpr int CE = Chunk<T>::N;
+#pragma unroll
+            for (int c = 0; c < HD / CE; ++c) {
+                const uint4 t = *reinterpret_cast<const uint4*>(kr + c * CE);
+                const T* e = reinterpret_cast<const T*>(&t);
+#pragma unroll
+                for (int i = 0; i < CE; ++i) acc = fmaf(sQ[c * CE + i], to_f32(e[i]), acc);
+            }
+            float mv = 0.f;
+            if (attn_mask) mv = (1.0f - (float)(mask3 ? attn_mask[((size_t)b * L + q) * L + j] : attn_mask[(size_t)b * L + j])) * -10000.0f;
+            sc = acc * 0.125f + mv;
+            sS[j] = sc;
+        }
+        mx = fmaxf(mx, sc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        const float pj = expf(sS[j] - mx);
+        sS[j] = pj;
+        sum += pj;
+    }
+    sum = wave_sum(sum);
+    // (the wave's own LDS writes above are visible to its reads below: LDS operations of one wave execute in order)
+    float o = 0.f;
+    const T* vcol = base + 2 * H + lane;
+    for (int j = 0; j < L; ++j) o = fmaf(sS[j], to_f32(vcol[(size_t)j * ldq]), o);
+    ctx[((size_t)b * L + q) * H + h * HD + lane] = from_f32<T>(o / sum);
+}
+
+template <typename T>
+static int att_long(const void* qkv, const int64_t* mask, void* ctx, int B, int L, int heads, hipStream_t s, int mask3) {
+    const size_t lds = (size_t)4 * (L + 64) * sizeof(float);
+    attention_long_kernel<T><<<dim3(B * heads, (L + 3) / 4), dim3(ATT_THREADS), lds, s>>>((const T*)qkv, mask, (T*)ctx, B, L, heads, mask3);
+    return CPT_OK;
+}
+
+int attention_max_len(int inference) { return inference ? ATT_LONG_MAX : 288; }
+
 template <typename T>
 static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3, int ctx_panel) {
+    if (L > 288) {      // beyond the register-resident score strip: the coverage kernel (inference only: no dropout, no saved probabilities, row-major ctx)
+        if (L > ATT_LONG_MAX || probs || dr.thresh != 0 || ctx_panel) return CPT_ERR_SHAPE;
+        return att_long<T>(qkv, mask, ctx, B, L, heads, s, mask3);
+    }
     if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
     if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
     if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
-    if (L <= 288) return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
-    return CPT_ERR_SHAPE;
+    return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
 }
 
 int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s,

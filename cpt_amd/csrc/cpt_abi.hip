@@ -431,7 +431,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const int B = b->B, Lt = b->Lt, Li = b->Li, L = Lt + Li, M = B * L, H = d.hidden, I = d.inter;
     if (B <= 0 || Lt <= 0 || Li < 0) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: bad batch shape B=%d Lt=%d Li=%d", B, Lt, Li);
     if (d.heads <= 0 || H != d.heads * 64) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: hidden %d / heads %d: head_dim must be 64", H, d.heads);
-    if (L > 288) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: sequence length %d > 288 not supported", L);
+    if (L > cpt::attention_max_len(1)) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: sequence length %d > %d not supported", L, cpt::attention_max_len(1));
     if (d.dtype == CPT_BF16X3_MASTERS)
         return fail(CPT_ERR_DTYPE, "cpt_model_fwd: CPT_BF16X3_MASTERS (fp32 master weights) is the training step's tag; inference reads the split copies under CPT_BF16X3");
     if (d.dtype != CPT_F32 && d.dtype != CPT_BF16 && d.dtype != CPT_BF16X3) return fail(CPT_ERR_DTYPE, "cpt_model_fwd: dtype %d", d.dtype);
@@ -527,7 +527,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     // LayerNorm producers read them straight into registers; same bits as the row-major kernels.  Needs the (sequence, three heads)
     // attention form, the two-pass FFN-up kernel and tile-aligned shapes; everything else keeps the row-major tensors.
     const bool fused3 = fuse_attn && g_fuse_attn == 3 && cpt::qkv_attn3_eligible(L, d.heads, H);
-    const bool two_kernel = lp && !fuse_attn && !mask3;        // L > 128 (the GQA shape): QKV GEMM, then the stand-alone attention kernel writes the panel
+    const bool two_kernel = lp && !fuse_attn && !mask3 && L <= 288;        // 128 < L <= 288 (the GQA shape): QKV GEMM, then the stand-alone attention kernel writes the panel (beyond 288: row-major ctx)
     const bool panel = r3 && g_panel && (fused3 || two_kernel) && cpt::ffn_up_2pass_preferred(M, I, H) &&
                        cpt::panel_eligible(M, H, H) && cpt::panel_eligible(M, H, I);
     if (rpanel && !(panel && fused3)) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: panel residual mode outside the full panel mode");

@@ -40,6 +40,7 @@ int attention_x3_supported(int L);
 int attention_x3(const float* qkv, const int64_t* attn_mask, float* ctx, void* ctx_split, int B, int L, int heads, hipStream_t s,
                  const DropSpec* drop = nullptr);      // drop: dropout on the probabilities (the training forward of the mode)
 
+int attention_max_len(int inference);      // 1024 for the inference kernels (beyond 288: the one-wave-per-query coverage kernel), 288 for the training step
 int pad_cast(const float* x, void* out, int dtype, int R, int K, int Kp, hipStream_t s);
 int split3(const float* x, int ld, void* out_bf16, int R, int K, int weight_order, hipStream_t s);
 // [3][Rp][C] row-stacked split (blocks hi, hi, lo or hi, lo, hi; rows beyond R zero): operands of a product contracting over rows

@@ -321,7 +321,8 @@ int cpt_layernorm_rows(const float* x, const float* g, const float* bta, float e
                        int grp_off, void* stream);
 
 /* CaptionBertSelfAttention core (modeling_bert.py:42-67) for head_dim 64: qkv [B*L][3H] ->
- * ctx [B*L][H]; softmax(QK^T/8 + (1-mask)*-10000) V, scores never leave the chip.
+ * ctx [B*L][H]; softmax(QK^T/8 + (1-mask)*-10000) V, scores never leave the chip.  L <= 288: MFMA kernels (score strip in registers); 288 < L <= 1024
+ * (round 5; the reference accepts 512 text positions + regions, no CPT configuration needs more than 265): a one-wave-per-query coverage kernel, inference only.
  * probs (optional, [B][heads][L][L] in `dtype`) is written only for the backward pass. */
 int cpt_attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs,
                   int B, int L, int heads, void* stream);

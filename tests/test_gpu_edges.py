@@ -96,22 +96,47 @@ def test_one_sequence_of_minimal_length(dev, mode):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_longest_sequence_and_the_first_refused_one(dev, mode):
-    """L = 288 (188 text + 100 regions) is the longest sequence the attention kernels take; L = 289 is refused with an error that says so,
-    before anything is launched -- never a silent truncation."""
+def test_longest_mfma_sequence_and_the_first_beyond_it(dev, mode):
+    """L = 288 (188 text + 100 regions) is the longest sequence the MFMA attention kernels take (score strip in registers); from L = 289 on the
+    inference path runs the one-wave-per-query coverage kernel (round 5) -- same numbers against the oracle -- and the TRAINING step refuses
+    with an error that says so, before anything is launched."""
     cfg = cfgmod.tiny(max_position_embeddings=192)
     m = _model(cfg, 47, dev, mode)
-    b = synth.make_batch(2, cfg, seed=6, max_seq_len=188, img_seq_len=100, vary_regions=True)
+    for Lt in (188, 189):
+        b = synth.make_batch(2, cfg, seed=6, max_seq_len=Lt, img_seq_len=100, vary_regions=True)
+        d = {k: v.to(dev) for k, v in b.items()}
+        with torch.no_grad():
+            got = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0]
+        want = _oracle_logits(m, cfg, b)
+        assert (got.float().cpu() - want).abs().max().item() < TOL[mode], Lt
+    m.train()
+    with pytest.raises(RuntimeError, match="288"):
+        m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], masked_lm_labels=d["colors"], mask_token_pos=d["mask_token_pos"])
+    m.eval()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("Lt,Li", [(300, 50), (512, 100)])
+def test_sequences_as_long_as_the_reference_accepts(dev, mode, Lt, Li):
+    """The reference takes up to max_position_embeddings = 512 text positions plus the region slots (modeling_bert.py:244-269).  L = 350 and L = 612
+    through the whole inference path against the oracle: logits of the [MASK] rows, a ragged 2-D mask, and (fp32) a 3-D mask on a short batch."""
+    cfg = cfgmod.tiny(max_position_embeddings=512)
+    m = _model(cfg, 49, dev, mode)
+    b = synth.make_batch(2, cfg, seed=7, max_seq_len=Lt, img_seq_len=Li, vary_regions=True)
+    b["attention_mask"][1, Lt - 37:Lt] = 0
     d = {k: v.to(dev) for k, v in b.items()}
     with torch.no_grad():
         got = m(d["input_ids"], d["segment_ids"], d["attention_mask"], img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0]
     want = _oracle_logits(m, cfg, b)
+    assert torch.isfinite(got).all()
     assert (got.float().cpu() - want).abs().max().item() < TOL[mode]
-    b2 = synth.make_batch(2, cfg, seed=6, max_seq_len=189, img_seq_len=100)
-    d2 = {k: v.to(dev) for k, v in b2.items()}
-    with pytest.raises(RuntimeError, match="288"):
+    if mode == "fp32" and Lt == 300:
+        L = Lt + Li
+        m3 = torch.tril(torch.ones(L, L, dtype=torch.long)).unsqueeze(0).repeat(2, 1, 1) * b["attention_mask"][:, None, :]
+        b3 = dict(b, attention_mask=m3)
         with torch.no_grad():
-            m(d2["input_ids"], d2["segment_ids"], d2["attention_mask"], img_feats=d2["img_feats"], mask_token_pos=d2["mask_token_pos"])
+            got3 = m(d["input_ids"], d["segment_ids"], m3.to(dev), img_feats=d["img_feats"], mask_token_pos=d["mask_token_pos"])[0]
+        assert (got3.float().cpu() - _oracle_logits(m, cfg, b3)).abs().max().item() < TOL[mode]
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
