@@ -75,6 +75,51 @@ def pmc_traffic_bytes(kernel):
         return None
 
 
+def live_pmc_traffic(kernel, timeout_s=240):
+    """HBM-side traffic of `kernel` (bytes per launch) MEASURED DURING THIS RUN: two child passes of this same command under `rocprofv3 --pmc` (FETCH_SIZE, then
+    WRITE_SIZE: separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes), a few steps each, summed per kernel family by tools/pmc_summary.py;
+    2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for 16 B/lane streams), both in KiB.  Returns (bytes, note) or (None, why)."""
+    import shutil
+    import subprocess
+    import tempfile
+    fam = {"gemm_ffn_up": "gemm_ffn_up(+gelu)", "gemm_qkv": "gemm_qkv_attn", "gemm_attn_out": "gemm_attn_out", "gemm_ffn_down": "gemm_ffn_down"}.get(kernel)
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if fam is None or not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="cpt_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--steps", "4", "--warmup", "2", "--no-cpu", "--no-roofline", "--no-extra", "--no-io", "--no-sustained"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
+        with open(os.devnull, "w") as devnull:
+            stdout, sys.stdout = sys.stdout, devnull
+            try:
+                pmc_summary.main(tmp)
+            finally:
+                sys.stdout = stdout
+        d = json.load(open(os.path.join(tmp, "summary.json")))
+        if fam not in d or "FETCH_SIZE" not in d[fam] or "WRITE_SIZE" not in d[fam]:
+            return None, "kernel family %s missing from the counter passes" % fam
+        f, w = d[fam]["FETCH_SIZE"], d[fam]["WRITE_SIZE"]
+        return int((2.0 * f["mean_per_launch"] + w["mean_per_launch"]) * 1024), \
+            "measured in this run: two child passes of this command under rocprofv3 --pmc (FETCH_SIZE: %d launches, WRITE_SIZE: %d launches; 2 x FETCH + WRITE, MI355X_MICROARCH.md)" \
+            % (f["launches"], w["launches"])
+    except Exception as e:
+        return None, "live PMC passes failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gemm_flops(kind, M, H, I):
     return {"gemm_qkv": 2.0 * M * 3 * H * H, "gemm_attn_out": 2.0 * M * H * H,
             "gemm_ffn_up": 2.0 * M * I * H, "gemm_ffn_down": 2.0 * M * I * H}[kind]
@@ -441,6 +486,7 @@ def main():
                          "(configs[2]: forward+backward+grad all-reduce+AdamW, 32 sequences per GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed profiles/ summary instead of two rocprofv3 --pmc child passes of this run")
     ap.add_argument("--no-io", action="store_true", help="skip the measured input-pipeline leg (extra.io_pipeline_measured)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations (the `extra` object of the line)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained run behind the K timed steps")
@@ -654,6 +700,7 @@ def main():
                 "traffic": pmc_traffic_bytes(dom) if (B == 64 and args.dtype == "bf16" and args.workload == "refcoco") else None,
                 "traffic_source": "profiles/%s: rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled, see MI355X_MICROARCH.md), committed "
                                   "with the round's artefacts -- NOT measured inside this run" % os.path.basename(PMC_FILE),
+                "_want_live_pmc": bool(B == 64 and args.dtype == "bf16" and args.workload == "refcoco" and n_gpus == 1 and not args.no_live_pmc and not args.tune),
                 "peak_note": "2.5 PF/s is the 2.4 GHz spec figure; on this workload the package power limiter (PPT) is active for 43-47 % of the step's time and the "
                              "shader clock averages 1.95 GHz (DESIGN.md 5j, profiles/r04_throttle_step_vs_chain.txt, r04_power_step_vs_chain.txt)",
                 "avg_launch_ms": round(avg_ms, 5),
@@ -726,6 +773,17 @@ def main():
                 extra["parity_modes"][md].update({k: pb[k] for k in ("max_abs_dlogit", "colour_argmax_flips_zsl", "colour_argmax_flips_fsl", "vocab_argmax_flips")})
         else:
             line["parity"] = None
+        roof_ = line.get("roofline")
+        if isinstance(roof_, dict) and roof_.pop("_want_live_pmc", False):
+            # HBM-side traffic of the dominant kernel measured in THIS run (two rocprofv3 --pmc child passes; the parent idles meanwhile); the committed
+            # profiles/ figure stays beside it, and stands in when the passes cannot run on the box
+            tb, note = live_pmc_traffic(roof_["kernel"])
+            if tb is not None:
+                roof_["traffic_committed_artefact"] = roof_["traffic"]
+                roof_["traffic"] = tb
+                roof_["traffic_source"] = note
+            else:
+                roof_["traffic_live_note"] = note
         if extra is not None:
             line["extra"] = extra
     if world > 1 or args.force_collectives:
