@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 
 #include "kernels.h"
 
@@ -156,6 +157,7 @@ CPT_SWITCH(static int g_lp_resid, 0);     // bf16 mode: keep the residual stream
 CPT_SWITCH(static int g_panel, 1);        // fused bf16 encoder: ctx and the FFN activation travel in the fragment-major panel layout and the LayerNorm producers read them straight into registers (gemm_prod.hip) where the shapes allow
 CPT_SWITCH(static int g_x3_fuse, 1);      // bf16x3 parity mode: split copies written by the producing kernels (FFN-up GELU epilogue, LayerNorm passes) instead of stand-alone split3 passes (cpt_set_tuning key 23)
 CPT_SWITCH(static int g_rpanel, 1);       // round 5: the residual stream itself travels in the panel layout and the LayerNorm producers run their register-direct epilogue (gemm_prod.hip RP; cpt_set_tuning key 30)
+CPT_SWITCH(static int g_tail, 1);         // round 5: with only [MASK] (or only [CLS]) rows read behind the encoder, the last layer's attention output / FFN / LayerNorms run on those rows alone (cpt_set_tuning key 31)
 CPT_SWITCH(static int g_prefetch, 1);     // panel mode: the 240-tile launches carry 16 workgroups that read the next launch's weights into the Infinity Cache (common.h prefetch_region)
 CPT_SWITCH(static int g_panel_ffn_multi, 1);   // panel layout for the FFN activation also when the producers run several rounds of tiles (cpt_set_tuning key 28; experiments)
 CPT_SWITCH(static int g_x3_attn, 1);      // bf16x3 parity mode: attention on bf16 MFMA with split operands (0: the fp32 MFMA kernel + a split3 pass over ctx)
@@ -180,7 +182,7 @@ int cpt_set_tuning(int key, int value) {
                               "this library always runs its shipped configuration", key);
 #else
     if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
-        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_panel_ffn_multi = 1; cpt::set_lncons4(1); g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1; g_rpanel = 1;
+        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_panel_ffn_multi = 1; cpt::set_lncons4(1); g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1; g_rpanel = 1; g_tail = 1;
         cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
         cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_ffn_2pass_min_tiles(192); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0); cpt::set_lnb_rpb(0); cpt::set_bias_fuse(2); cpt::set_wgrad_pair(2); cpt::set_qkv_2pass(1); cpt::set_fwd_split2(1); g_x3_fuse = 1; cpt::set_attn_qt_all(1); cpt::set_prod_waves(0);
         return CPT_OK;
@@ -213,6 +215,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 27) { g_x3_attn = value; return CPT_OK; }
     if (key == 28) { g_panel_ffn_multi = value; return CPT_OK; }
     if (key == 30) { g_rpanel = value; return CPT_OK; }
+    if (key == 31) { g_tail = value; return CPT_OK; }
     if (key == 29) { cpt::set_lncons4(value); return CPT_OK; }
     if (key == 26) { g_dec_pf_pct = value < 0 ? 0 : (value > 100 ? 100 : value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
@@ -537,6 +540,17 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const bool panel_ffn = panel && ((long)(M / 128) * (H / 192) <= 256 || g_panel_ffn_multi);
     if (rpanel && !panel_ffn) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: panel residual mode without the panel FFN activation");
     const bool pfw = panel && g_prefetch;           // spare workgroups prefetch the next launch's weights (common.h prefetch_region)
+    // Round 5: the last layer on the head's rows only.  When nothing but the B [MASK] rows (MLM head) or nothing but the B [CLS] rows (pooler / relation
+    // head) is read behind the encoder, the last layer's attention output, FFN and LayerNorms are row-wise work on rows nobody reads: they run on
+    // those B rows (gather + previous LayerNorm, three K-split dense layers with their row passes) -- the reference computes every row and then indexes
+    // (modeling_rec.py:143-146, modeling_vcr.py:120-124); same values on the rows that are read.  The layer's attention still sees every row (K / V).
+    const bool want_mask = (flags & CPT_OUT_MASK_LOGITS) != 0, want_cls = (flags & (CPT_OUT_POOLED | CPT_OUT_REL)) != 0;
+    const int S_h = cpt::rows_gemm_splits(H), S_i = cpt::rows_gemm_splits(I);
+    const size_t tail_part = std::max((size_t)S_h * B * (size_t)(H > I ? H : I), (size_t)S_i * B * H) * 4;
+    const bool tail = g_tail && fold && r3 && d.layers >= 2 && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) && want_mask != want_cls &&
+                      H % 64 == 0 && I % 64 == 0 && tail_part <= (size_t)M * I * 2 && (size_t)B * I * 2 <= (size_t)M * H * 4;
+    const size_t dec_bytes_t = (size_t)d.vocab * H * 2;
+    const size_t dec_pf0_t = (want_mask && m->w_dec && g_prefetch) ? ((dec_bytes_t / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023) : 0;
     if (fold) {
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
         // producer GEMMs accumulate their row sums, the consumer GEMMs normalise in their epilogue.
@@ -561,6 +575,26 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
               else TRY(cpt::gemm_ln_cons(x_lp, H, f.w_qkv_f, H, st2p, f.c_qkv, f.d_qkv, d.ln_eps, H, 0, qkv, 3 * H, M, 3 * H, H, s), "gemm(qkv, folded LN)"); }
             { Scope p(CPT_K_ATTN, s);
               TRY(cpt::attention(dt, qkv, b->attn_mask, ctx, nullptr, B, L, d.heads, s, nullptr, mask3, panel), "attention"); }
+            }
+            if (tail && l + 1 == d.layers) {
+                Scope p(CPT_K_HEAD, s);
+                float* part = (float*)ffn;                       // split-K partial matrices (the FFN activation's region: no launch of this layer writes it)
+                float* resid = (float*)(ws + w.rows_f32);         // LayerNorm of the previous layer's output on the head rows
+                void* ctx_rows = ws + w.t1;
+                void* h_rows = pre;
+                const int64_t* pos = want_mask ? b->mask_pos : nullptr;
+                TRY(cpt::tail_rows(x_lp, x_lo, pos, yp->ln2_g, yp->ln2_b, d.ln_eps, ctx, ctx_rows, resid, B, L, H, s, rpanel, panel,
+                                   dec_pf0_t ? m->w_dec : nullptr, dec_pf0_t / 2), "tail: gather head rows + previous LayerNorm");
+                TRY(cpt::gemm_rows_split(ctx_rows, H, y.w_ao, H, y.b_ao, part, B, H, H, s), "tail: gemm(attn out, split K)");
+                TRY(cpt::layernorm_rows_ex(part, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, a_lp, dt, B, H, B, 0, 0, 0, s, resid, nullptr, nullptr, nullptr, S_h, (size_t)B * H, 0),
+                    "tail: partials + residual + layernorm(attn)");
+                TRY(cpt::gemm_rows_split(a_lp, H, y.w_in, H, y.b_in, part, B, I, H, s), "tail: gemm(ffn up, split K)");
+                TRY(cpt::gelu_parts(part, S_h, h_rows, (size_t)B * I, s, dec_pf0_t ? (const unsigned char*)m->w_dec + dec_pf0_t / 2 : nullptr, dec_pf0_t - dec_pf0_t / 2),
+                    "tail: partials + gelu");
+                TRY(cpt::gemm_rows_split(h_rows, I, y.w_out, I, y.b_out, part, B, H, I, s), "tail: gemm(ffn down, split K)");
+                TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, nullptr, ws + w.rows, dt, B, H, B, 0, 0, 0, s, a_f32, nullptr, nullptr, nullptr, S_i, (size_t)B * H, 0),
+                    "tail: partials + residual + layernorm(ffn)");
+                break;
             }
             { Scope p(CPT_K_GEMM_AO, s);
               if (panel) TRY(cpt::gemm_ln_prod3_panel(ctx, y.w_ao, H, y.b_ao, x_lp, x_lo, H, st2p, yp ? yp->ln2_g : nullptr, yp ? yp->ln2_b : nullptr, d.ln_eps, H,
@@ -654,6 +688,9 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         void* rows = ws + w.rows;
         float* pooled = (flags & CPT_OUT_POOLED) ? o->pooled : (float*)(ws + w.pooled_f32);
         if (!pooled) return fail(CPT_ERR_NULL, "cpt_model_fwd: pooled output is NULL");
+        if (tail) {
+            // rows = the [CLS] rows of the encoder output (written by the tail above)
+        } else
         if (pre_ln) {
             const cpt_layer& yl = m->layers[d.layers - 1];
             float* rf = (float*)(ws + w.rows_f32);
@@ -687,6 +724,9 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         const size_t dec_pf0 = (dec_bytes / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023;
         if (!all) {
             void* g = ws + w.rows;
+            if (tail) {
+                // g = the [MASK] rows of the encoder output (written by the tail above, which also carried the first part of the decoder prefetch)
+            } else
             if (pre_ln) {
                 const cpt_layer& yl = m->layers[d.layers - 1];
                 float* rf = (float*)(ws + w.rows_f32);

@@ -1325,6 +1325,24 @@ int gemm_head_transform(const void* A, int lda, const void* W, int ldw, const fl
     return launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, partials, N, M, N, K, s, head_transform_splits(K));
 }
 
+// The dense layers of the LAST encoder layer on the head's rows only (cpt_abi.hip `tail`, rowops.hip tail_rows): a few rows against a whole weight
+// matrix is the head transform's problem again -- K split over S workgroups per 64 x 192 tile, fp32 partial matrices partials[S][M][N] (bias in the
+// first) added in split order by the row pass behind (layernorm_rows_ex x_parts / gelu_parts).  S depends on K only (two K-tiles per split, at
+// most 24 splits): a row's bits do not depend on the batch it travels in.
+int rows_gemm_splits(int K) {
+    const int nt = K / 64;
+    if (nt < 4) return 1;
+    int S = nt / 2;
+    while (S > 24 || nt % S) --S;
+    return S;
+}
+int gemm_rows_split(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K < 64 || K % 64 || lda % 8 || ldw % 8 || N % 4) return CPT_ERR_SHAPE;
+    if (!A || !W || !partials) return CPT_ERR_NULL;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)partials | (uintptr_t)bias) & 15)) return CPT_ERR_ALIGN;
+    return launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, partials, N, M, N, K, s, rows_gemm_splits(K));
+}
+
 CPT_SWITCH(int g_splitk_target, 384);
 void set_splitk_target(int v) { CPT_SWITCH_SET(g_splitk_target = v); (void)v; }
 

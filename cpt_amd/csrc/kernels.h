@@ -134,6 +134,12 @@ int head_transform_splits(int K);
 int gemm_head_transform(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s);
 int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s,
                 const void* pf = nullptr, size_t pf_bytes = 0);     // pf: as head_rows_ln3 (the rest of the decoder table)
+// last encoder layer on the head's rows only (round 5; rowops.hip / gemm.hip): gather + previous LayerNorm of the head rows, K-split dense layers on them
+int tail_rows(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, const void* ctx, void* ctx_out, float* resid_out,
+              int R, int L, int H, hipStream_t s, int src_panel, int ctx_panel, const void* pf = nullptr, size_t pf_bytes = 0);
+int gelu_parts(const float* partials, int S, void* out_bf16, size_t n, hipStream_t s, const void* pf = nullptr, size_t pf_bytes = 0);
+int rows_gemm_splits(int K);
+int gemm_rows_split(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s);
 int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s);
 int gemm_ln_prod(const void* A, int lda, const void* W, int ldw, const float* bias, const float* resid, int ldr,
                  const float* st_in, const float* g_in, const float* b_in, float eps, int hidden,

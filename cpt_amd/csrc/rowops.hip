@@ -683,6 +683,97 @@ int head_finish(const float* partials, int S, const float* g, const float* bta, 
     return CPT_OK;
 }
 
+// ---- last encoder layer on the head's rows only (round 5) -------------------------------------------------------------------
+// With only the [MASK] (or [CLS]) rows read after the encoder, everything of the LAST layer behind its attention -- attention output + LayerNorm,
+// FFN, LayerNorm -- is row-wise work whose other rows nobody reads: cpt_model_fwd runs it on the R = B head rows (cpt_abi.hip, `tail`).
+// tail_rows: row r of the outputs = source row r * L + pos[r] (pos NULL: 0) of
+//   ctx_out  [R][H] bf16 : the attention context (panel layout or row-major [M][H])
+//   resid_out[R][H] fp32 : LayerNorm(decode(hi, lo); g, bta) -- the residual operand of the attention-output dense layer, i.e. the previous
+//                          layer's output LayerNorm, which the folded encoder never materialises
+// One wave per row; the same arithmetic as head_rows_ln3.
+__global__ __launch_bounds__(ROW_THREADS) void tail_rows_kernel(const u32x2_t* __restrict__ hi, const unsigned* __restrict__ lo, const int64_t* __restrict__ pos,
+                                                                const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                                                const u32x2_t* __restrict__ ctx, bf16* __restrict__ ctx_out, float* __restrict__ resid_out,
+                                                                int R, int L, int H, int src_panel, int ctx_panel,
+                                                                const void* __restrict__ pf, size_t pf_bytes, int pf_blocks) {
+    __shared__ __attribute__((aligned(16))) unsigned char pf_scratch[4 * 1024];
+    if ((int)blockIdx.x < pf_blocks) {
+        prefetch_region(pf, pf_bytes, blockIdx.x, pf_blocks, threadIdx.x, ROW_THREADS, pf_scratch);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int r = (blockIdx.x - pf_blocks) * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    long p = pos ? pos[r] : 0;
+    p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+    const size_t row = (size_t)r * L + p;
+    const int nv = (H + 255) / 256;
+    f32x4 v[MAXV];
+    u32x2_t cq[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (i < nv && c * 4 < H) {
+            const size_t qd = src_panel ? panel_quad(row, c * 4, H) : row * (H / 4) + c;
+            v[i] = r3_decode(hi[qd], lo[qd]);
+            cq[i] = ctx[ctx_panel ? panel_quad(row, c * 4, H) : row * (H / 4) + c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (i < nv && c * 4 < H) reinterpret_cast<u32x2_t*>(ctx_out + (size_t)r * H)[c] = cq[i];
+    }
+    float mean, rstd;
+    ln_stats(v, nv, lane, H, mean, rstd, eps);
+    ln_write<float>(v, nv, lane, H, mean, rstd, g, bta, resid_out + (size_t)r * H, (float*)nullptr);
+}
+int tail_rows(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, const void* ctx, void* ctx_out, float* resid_out,
+              int R, int L, int H, hipStream_t s, int src_panel, int ctx_panel, const void* pf, size_t pf_bytes) {
+    if (!hi || !lo || !g || !bta || !ctx || !ctx_out || !resid_out) return CPT_ERR_NULL;
+    if (R <= 0 || L <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || ((src_panel || ctx_panel) && H % 16)) return CPT_ERR_SHAPE;
+    const int nb = (R + 3) / 4;
+    const int pfb = (pf && pf_bytes && !((uintptr_t)pf & 15) && nb < 224) ? 224 - (nb & ~7) : 0;
+    tail_rows_kernel<<<dim3(nb + pfb), dim3(ROW_THREADS), 0, s>>>((const u32x2_t*)hi, (const unsigned*)lo, pos, g, bta, eps, (const u32x2_t*)ctx, (bf16*)ctx_out, resid_out,
+                                                                   R, L, H, src_panel, ctx_panel, pfb ? pf : nullptr, pf_bytes, pfb);
+    return CPT_OK;
+}
+// gelu_parts: out[r][c] (bf16) = gelu(sum over the S split-K partial matrices part[k][r][c]) (bias in partial 0), added in split order: the reduction
+// + activation behind the FFN-up GEMM of the tail rows (gelu_fast2, as the FFN-up epilogue of the big launches)
+__global__ __launch_bounds__(256) void gelu_parts_kernel(const f32x4* __restrict__ part, int S, bf16* __restrict__ out, size_t n4,
+                                                         const void* __restrict__ pf, size_t pf_bytes, int pf_blocks) {
+    __shared__ __attribute__((aligned(16))) unsigned char pf_scratch[4 * 1024];
+    if ((int)blockIdx.x < pf_blocks) {
+        prefetch_region(pf, pf_bytes, blockIdx.x, pf_blocks, threadIdx.x, 256, pf_scratch);
+        return;
+    }
+    const size_t i = (size_t)(blockIdx.x - pf_blocks) * 256 + threadIdx.x;
+    if (i >= n4) return;
+    constexpr int SMAX = 8;
+    f32x4 pb[SMAX];
+#pragma unroll
+    for (int k = 0; k < SMAX; ++k) pb[k] = part[(size_t)min(k, S - 1) * n4 + i];
+    f32x4 a = pb[0];
+#pragma unroll
+    for (int k = 1; k < SMAX; ++k)
+        if (k < S) { a[0] += pb[k][0]; a[1] += pb[k][1]; a[2] += pb[k][2]; a[3] += pb[k][3]; }
+    for (int k = SMAX; k < S; ++k) { const f32x4 b = part[(size_t)k * n4 + i]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+    const f32x2 g0 = gelu_fast2(f32x2{a[0], a[1]}), g1 = gelu_fast2(f32x2{a[2], a[3]});
+    bf16x4 o;
+    o[0] = (bf16)g0[0]; o[1] = (bf16)g0[1]; o[2] = (bf16)g1[0]; o[3] = (bf16)g1[1];
+    reinterpret_cast<bf16x4*>(out)[i] = o;
+}
+int gelu_parts(const float* partials, int S, void* out_bf16, size_t n, hipStream_t s, const void* pf, size_t pf_bytes) {
+    if (!partials || !out_bf16) return CPT_ERR_NULL;
+    if (S <= 0 || n == 0 || n % 4) return CPT_ERR_SHAPE;
+    const size_t n4 = n / 4;
+    const size_t nb = (n4 + 255) / 256;
+    if (nb > (size_t)1 << 24) return CPT_ERR_SHAPE;
+    const int pfb = (pf && pf_bytes && !((uintptr_t)pf & 15) && nb < 224) ? 224 - ((int)nb & ~7) : 0;
+    gelu_parts_kernel<<<dim3((unsigned)nb + pfb), dim3(256), 0, s>>>((const f32x4*)partials, S, (bf16*)out_bf16, n4, pfb ? pf : nullptr, pf_bytes, pfb);
+    return CPT_OK;
+}
+
 // ---- cross entropy over rows (ignore_index = -1) ----------------------------------------------
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                       float* __restrict__ loss, float* __restrict__ dlogits, int R, int V) {

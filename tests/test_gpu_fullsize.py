@@ -139,6 +139,26 @@ def test_config2_panel_mode_is_bit_identical(dev):
     assert torch.equal(on, rowmajor) and torch.equal(seq_on, seq_off) and torch.equal(pooled_on, pooled_off)
 
 
+@pytest.mark.ablation
+def test_config2_last_layer_on_head_rows_matches_all_rows(dev):
+    """Development build: the last encoder layer on the [MASK] rows only (the shipped form; cpt_set_tuning(31, 0) runs every row through it, as
+    the reference does before it indexes the [MASK] rows, modeling_rec.py:143-146).  Different kernels and summation orders behind the last
+    attention, so not the same bits: the logits agree to bf16 accuracy, in the panel mode and with row-major tensors."""
+    from cpt_amd import _lib as L
+    m, d, run = _panel_model(dev)
+    for key14 in (1, 0):
+        L.check(L.lib().cpt_set_tuning(14, key14))
+        rows_only = run().clone()
+        L.check(L.lib().cpt_set_tuning(31, 0))
+        all_rows = run().clone()
+        L.check(L.lib().cpt_set_tuning(31, 1))
+        assert torch.isfinite(rows_only).all()
+        diff = (rows_only - all_rows).abs().max().item()
+        assert 0 < diff < 0.025, diff
+        assert (rows_only.argmax(-1) == all_rows.argmax(-1)).sum().item() >= 60      # (random-init weights: near-ties over 30522 words may flip)
+    L.check(L.lib().cpt_set_tuning(14, 1))
+
+
 def test_config4_gqa_12_layers_b256(dev):
     from cpt_amd.modeling_rec import REC_MLM_CPT
     cfg = cfgmod.oscar_base()
