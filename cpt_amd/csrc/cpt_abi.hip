@@ -586,14 +586,12 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                 TRY(cpt::tail_rows(x_lp, x_lo, pos, yp->ln2_g, yp->ln2_b, d.ln_eps, ctx, ctx_rows, resid, B, L, H, s, rpanel, panel,
                                    dec_pf0_t ? m->w_dec : nullptr, dec_pf0_t / 2), "tail: gather head rows + previous LayerNorm");
                 TRY(cpt::gemm_rows_split(ctx_rows, H, y.w_ao, H, y.b_ao, part, B, H, H, s), "tail: gemm(attn out, split K)");
-                TRY(cpt::layernorm_rows_ex(part, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, a_lp, dt, B, H, B, 0, 0, 0, s, resid, nullptr, nullptr, nullptr, S_h, (size_t)B * H, 0),
-                    "tail: partials + residual + layernorm(attn)");
+                TRY(cpt::tail_finish(part, S_h, resid, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, a_lp, B, H, s), "tail: partials + residual + layernorm(attn)");
                 TRY(cpt::gemm_rows_split(a_lp, H, y.w_in, H, y.b_in, part, B, I, H, s), "tail: gemm(ffn up, split K)");
                 TRY(cpt::gelu_parts(part, S_h, h_rows, (size_t)B * I, s, dec_pf0_t ? (const unsigned char*)m->w_dec + dec_pf0_t / 2 : nullptr, dec_pf0_t - dec_pf0_t / 2),
                     "tail: partials + gelu");
                 TRY(cpt::gemm_rows_split(h_rows, I, y.w_out, I, y.b_out, part, B, H, I, s), "tail: gemm(ffn down, split K)");
-                TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, nullptr, ws + w.rows, dt, B, H, B, 0, 0, 0, s, a_f32, nullptr, nullptr, nullptr, S_i, (size_t)B * H, 0),
-                    "tail: partials + residual + layernorm(ffn)");
+                TRY(cpt::tail_finish(part, S_i, a_f32, y.ln2_g, y.ln2_b, d.ln_eps, nullptr, ws + w.rows, B, H, s), "tail: partials + residual + layernorm(ffn)");
                 break;
             }
             { Scope p(CPT_K_GEMM_AO, s);

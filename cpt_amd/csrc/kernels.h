@@ -138,6 +138,8 @@ int head_finish(const float* partials, int S, const float* g, const float* bta, 
 int tail_rows(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, const void* ctx, void* ctx_out, float* resid_out,
               int R, int L, int H, hipStream_t s, int src_panel, int ctx_panel, const void* pf = nullptr, size_t pf_bytes = 0);
 int gelu_parts(const float* partials, int S, void* out_bf16, size_t n, hipStream_t s, const void* pf = nullptr, size_t pf_bytes = 0);
+int tail_finish(const float* partials, int S, const float* resid, const float* g, const float* bta, float eps, float* out_f32, void* out_bf16, int R, int H, hipStream_t s,
+                const void* pf = nullptr, size_t pf_bytes = 0);
 int rows_gemm_splits(int K);
 int gemm_rows_split(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s);
 int gemm_splitk_accum(int dtype, const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, hipStream_t s);

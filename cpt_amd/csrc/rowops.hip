@@ -738,6 +738,77 @@ int tail_rows(const void* hi, const void* lo, const int64_t* pos, const float* g
                                                                    R, L, H, src_panel, ctx_panel, pfb ? pf : nullptr, pf_bytes, pfb);
     return CPT_OK;
 }
+// tail_finish: row r of the outputs = LayerNorm(sum over the S split-K partial matrices of row r (bias in partial 0) + resid[r]) -- fp32 (the next
+// residual operand, optional) and bf16 (the next GEMM operand).  ONE WORKGROUP PER ROW: wave w adds partials [w S / 4, (w + 1) S / 4) in split order with
+// every load in flight at once (layernorm_rows_ex walks its x_parts one memory round trip at a time: 24 of them behind the FFN-down), wave 0 adds the
+// four wave sums in wave order, the residual, and normalises.  The order depends on S only.
+template <int NA>
+__global__ __launch_bounds__(256) void tail_finish_kernel(const float* __restrict__ part, int S, size_t stride, const float* __restrict__ resid,
+                                                          const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                                          float* __restrict__ out_f32, bf16* __restrict__ out_lp, int R, int H,
+                                                          const void* __restrict__ pf, size_t pf_bytes, int pf_blocks) {
+    __shared__ __attribute__((aligned(16))) float red[3][256 * NA];
+    if ((int)blockIdx.x < pf_blocks) {
+        prefetch_region(pf, pf_bytes, blockIdx.x, pf_blocks, threadIdx.x, 256, red);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x - pf_blocks;
+    const int nv = (H + 255) / 256;
+    const int per = (S + 3) / 4, k0 = wave * per, k1 = min(S, k0 + per);
+    constexpr int KMAX = 6;                      // partials per wave held in flight (S <= 24)
+    f32x4 v[NA], rr[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        v[i] = f32x4{0, 0, 0, 0};
+        if (i < nv && c < H) {
+            f32x4 pb[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) pb[k] = *reinterpret_cast<const f32x4*>(part + (size_t)min(k0 + k, S - 1) * stride + (size_t)r * H + c);
+            if (wave == 0 && resid) rr[i] = *reinterpret_cast<const f32x4*>(resid + (size_t)r * H + c);
+            if (k0 < k1) v[i] = pb[0];
+#pragma unroll
+            for (int k = 1; k < KMAX; ++k)
+                if (k0 + k < k1) { v[i][0] += pb[k][0]; v[i][1] += pb[k][1]; v[i][2] += pb[k][2]; v[i][3] += pb[k][3]; }
+            for (int k = k0 + KMAX; k < k1; ++k) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(part + (size_t)k * stride + (size_t)r * H + c);
+                v[i][0] += b[0]; v[i][1] += b[1]; v[i][2] += b[2]; v[i][3] += b[3];
+            }
+            if (wave > 0) *reinterpret_cast<f32x4*>(&red[wave - 1][c]) = v[i];
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < H) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+                if ((w + 1) * per < S) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&red[w][c]);
+                    v[i][0] += b[0]; v[i][1] += b[1]; v[i][2] += b[2]; v[i][3] += b[3];
+                }
+            if (resid) { v[i][0] += rr[i][0]; v[i][1] += rr[i][1]; v[i][2] += rr[i][2]; v[i][3] += rr[i][3]; }
+        }
+    }
+    float mean, rstd;
+    ln_stats<NA>(v, nv, lane, H, mean, rstd, eps);
+    ln_write<bf16, NA>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + (size_t)r * H : nullptr, out_lp + (size_t)r * H);
+}
+int tail_finish(const float* partials, int S, const float* resid, const float* g, const float* bta, float eps, float* out_f32, void* out_bf16, int R, int H, hipStream_t s,
+                const void* pf, size_t pf_bytes) {
+    if (!partials || !g || !bta || !out_bf16) return CPT_ERR_NULL;
+    if (R <= 0 || S <= 0 || H <= 0 || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
+    const int pfb = (pf && pf_bytes && !((uintptr_t)pf & 15) && R < 224) ? 224 - (R & ~7) : 0;
+    const size_t stride = (size_t)R * H;
+    if (H <= 768)
+        tail_finish_kernel<3><<<dim3(R + pfb), dim3(256), 0, s>>>(partials, S, stride, resid, g, bta, eps, out_f32, (bf16*)out_bf16, R, H, pfb ? pf : nullptr, pf_bytes, pfb);
+    else
+        tail_finish_kernel<4><<<dim3(R + pfb), dim3(256), 0, s>>>(partials, S, stride, resid, g, bta, eps, out_f32, (bf16*)out_bf16, R, H, pfb ? pf : nullptr, pf_bytes, pfb);
+    return CPT_OK;
+}
 // gelu_parts: out[r][c] (bf16) = gelu(sum over the S split-K partial matrices part[k][r][c]) (bias in partial 0), added in split order: the reduction
 // + activation behind the FFN-up GEMM of the tail rows (gelu_fast2, as the FFN-up epilogue of the big launches)
 __global__ __launch_bounds__(256) void gelu_parts_kernel(const f32x4* __restrict__ part, int S, bf16* __restrict__ out, size_t n4,

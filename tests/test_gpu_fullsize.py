@@ -149,6 +149,7 @@ def test_config2_last_layer_on_head_rows_matches_all_rows(dev):
     for key14 in (1, 0):
         L.check(L.lib().cpt_set_tuning(14, key14))
         rows_only = run().clone()
+        assert torch.equal(run(), rows_only)
         L.check(L.lib().cpt_set_tuning(31, 0))
         all_rows = run().clone()
         L.check(L.lib().cpt_set_tuning(31, 1))
