@@ -202,11 +202,12 @@ def parity_block(mode, got, ref):
             "bar": "north_star: 1e-3 and identical argmax (met by the fp32 and bf16x3 modes; bf16 is the throughput mode, see extra.parity_modes)"}
 
 
-def io_pipeline_leg(dev, model, b, seconds=2.0, workers=None, threads=2):
+def io_pipeline_leg(dev, model, b, seconds=2.0, workers=None, threads=2, device_decode=False):
     """The input side of the hot path INSIDE this run (zeroshot/refcoco_cpt.py:213-218, utils/tsv_file.py:20-85,
-    refcoco_zsl_cpt_dataset.py:161-180): generated predictions.tsv rows -> cpt_decode_tsv_rows in worker processes -> shared pinned ring ->
-    H2D on a side stream -> forward, every step on freshly decoded and freshly copied region features, timed for `seconds` of steady state
-    beside `seconds / 2` of the forward alone on a resident batch."""
+    refcoco_zsl_cpt_dataset.py:161-180): generated predictions.tsv rows -> worker processes -> shared pinned ring -> H2D on a side stream ->
+    forward, every step on freshly decoded and freshly copied region features, timed for `seconds` of steady state beside `seconds / 2` of the
+    forward alone on a resident batch.  device_decode (round 5): the workers only locate and copy the base64 strings (cpt_pack_tsv_rows), the
+    text travels to the GPU and cpt_b64_decode_regions_device decodes it on the side stream; False: cpt_decode_tsv_rows on the host cores."""
     import tempfile
     from cpt_amd import io, synth
     B, rows_per_batch, n_rows = 64, 8, 48
@@ -219,11 +220,14 @@ def io_pipeline_leg(dev, model, b, seconds=2.0, workers=None, threads=2):
     def fwd(feats, mask):
         with torch.no_grad():
             return model(b["input_ids"], b["segment_ids"], mask, img_feats=feats, mask_token_pos=b["mask_token_pos"])[0]
-    pool = io.DecodePool(tsv_path, max_seqs=B, workers=workers, slots=2 * workers, threads=threads)
+    pool = io.DecodePool(tsv_path, max_seqs=B, workers=workers, slots=2 * workers, threads=threads, device_decode=device_decode)
     try:
         side = torch.cuda.Stream(dev)
         dfe = [torch.empty((B, 50, 2054), device=dev) for _ in range(2)]
         dma = [b["attention_mask"].clone() for _ in range(2)]
+        dtx = [torch.empty((B, 50, io.b64_chars(2054)), dtype=torch.uint8, device=dev) for _ in range(2)] if device_decode else None
+        dmi = [torch.zeros((B, 50), dtype=torch.int64, device=dev) for _ in range(2)]
+        derr = torch.zeros(1, dtype=torch.int64, device=dev)
         consumed = [None, None]
         state = {"next": 0, "wait": 0.0}
 
@@ -241,8 +245,13 @@ def io_pipeline_leg(dev, model, b, seconds=2.0, workers=None, threads=2):
             with torch.cuda.stream(side):
                 if consumed[k] is not None:
                     side.wait_event(consumed[k])            # the forward that read this device buffer is done
-                dfe[k][:S].copy_(pool.feats[slot][:S], non_blocking=True)
-                dma[k][:S, 70:].copy_(pool.masks[slot][:S], non_blocking=True)
+                dmi[k][:S].copy_(pool.masks[slot][:S], non_blocking=True)
+                dma[k][:S, 70:].copy_(dmi[k][:S], non_blocking=True)
+                if device_decode:
+                    dtx[k][:S].copy_(pool.feats[slot][:S], non_blocking=True)
+                    io.decode_text_device(dtx[k][:S], dmi[k][:S], dfe[k][:S], derr, stream=side)
+                else:
+                    dfe[k][:S].copy_(pool.feats[slot][:S], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(side)
             torch.cuda.current_stream().wait_event(ev)
@@ -281,16 +290,21 @@ def io_pipeline_leg(dev, model, b, seconds=2.0, workers=None, threads=2):
             n += 1
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        io.check_device_decode(derr, 50)
     finally:
         pool.close()
     rate = B * n / dt
     return {"measured_in_this_run": True, "end_to_end_pairs_per_s": round(rate, 1), "forward_only_pairs_per_s": round(fwd_only, 1),
             "fraction_of_forward_only": round(rate / fwd_only, 4), "workers": workers, "threads_per_worker": threads, "steps": n,
             "ms_per_step": round(dt / n * 1e3, 4), "ms_waiting_for_decode_per_step": round(state["wait"] / n * 1e3, 4),
-            "h2d_MB_per_step": round(B * 50 * 2054 * 4 / 1e6, 1), "distinct_batches_in_file": n_rows // rows_per_batch, "host_cores": usable_cores(),
+            "decode": "device" if device_decode else "host",
+            "h2d_MB_per_step": round(B * 50 * (io.b64_chars(2054) if device_decode else 2054 * 4) / 1e6, 1), "distinct_batches_in_file": n_rows // rows_per_batch, "host_cores": usable_cores(),
             "device_batch_equals_host_decode": check,
-            "path": "generated predictions.tsv (48 rows x 8 proposals x 50 boxes, base64 float32[2054]) -> cpt_amd.io.DecodePool (C decoder in worker processes, "
-                    "shared pinned ring) -> hipMemcpyAsync on a side stream -> REC_MLM_CPT forward; 64 sequences per step, fresh features every step"}
+            "path": ("generated predictions.tsv (48 rows x 8 proposals x 50 boxes, base64 float32[2054]) -> cpt_amd.io.DecodePool(device_decode=True): worker "
+                     "processes locate + copy the base64 strings into the shared pinned ring -> hipMemcpyAsync of the TEXT on a side stream -> "
+                     "cpt_b64_decode_regions_device on that stream -> REC_MLM_CPT forward; 64 sequences per step, fresh features every step") if device_decode else
+                    ("generated predictions.tsv (48 rows x 8 proposals x 50 boxes, base64 float32[2054]) -> cpt_amd.io.DecodePool (C decoder in worker processes, "
+                     "shared pinned ring) -> hipMemcpyAsync on a side stream -> REC_MLM_CPT forward; 64 sequences per step, fresh features every step")}
 
 
 def hbm_kernels(cfg, B, dev, iters=20):
@@ -756,9 +770,13 @@ def main():
             if not args.no_io and B == 64:
                 # the input side measured in THIS run (default-on, about 3 s timed): decode workers -> pinned ring -> side-stream H2D -> forward
                 try:
-                    extra["io_pipeline_measured"] = io_pipeline_leg(dev, model, b)
+                    extra["io_pipeline_measured"] = io_pipeline_leg(dev, model, b, device_decode=False)
                 except Exception as e:
                     extra["io_pipeline_measured"] = {"error": repr(e)[:300]}
+                try:        # round 5: the same leg with the base64 TEXT copied to the GPU and decoded there (35.1 instead of 26.3 MB per step over PCIe), half as long
+                    extra["io_pipeline_device_decode"] = io_pipeline_leg(dev, model, b, seconds=1.0, device_decode=True)
+                except Exception as e:
+                    extra["io_pipeline_device_decode"] = {"error": repr(e)[:300]}
         ref_logits = None
         if n_gpus == 1 and not args.no_cpu and not train and args.workload == "refcoco":
             ref_logits, line["cpu_baseline"] = cpu_baseline(cfg, seed, min(usable_cores(), 64))

@@ -147,6 +147,10 @@ _SIGS = {
     "cpt_decode_regions_batch": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]),
     "cpt_decode_tsv_rows": (C.c_int, [C.POINTER(C.c_char_p), vp, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp,
                                       vp, vp, vp, vp, vp, C.c_int]),
+    "cpt_pack_tsv_rows": (C.c_int, [C.POINTER(C.c_char_p), vp, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp,
+                                    vp, vp, vp, vp, vp, C.c_int]),
+    "cpt_b64_chars": (C.c_size_t, [C.c_int]),
+    "cpt_b64_decode_regions_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "cpt_json_find_strings": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, vp, vp, C.c_int, vp, C.c_size_t,
                                         C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
 }

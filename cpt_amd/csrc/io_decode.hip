@@ -263,13 +263,18 @@ int cpt_json_find_strings(const char* json, size_t len, const char* key, size_t*
     return CPT_OK;
 }
 
-int cpt_decode_tsv_rows(const char* const* rows, const size_t* lens, int n_rows, const char* key, int dim,
-                        int max_regions, int max_seqs, float* out, int64_t* mask_img, char* const* stripped,
-                        const size_t* stripped_cap, size_t* stripped_len, int* seqs_per_row, int* regions_per_seq,
-                        int n_threads) {
-    if (!rows || !lens || !key || !out || !stripped || !stripped_cap || !stripped_len || !seqs_per_row || !regions_per_seq)
-        return io_fail(CPT_ERR_NULL, "cpt_decode_tsv_rows: null argument");
-    if (n_rows < 0 || dim <= 0 || max_regions <= 0 || max_seqs < 0) return io_fail(CPT_ERR_SHAPE, "cpt_decode_tsv_rows: bad sizes");
+}  // extern "C"
+
+namespace {
+// cpt_decode_tsv_rows (out: decoded float32) and cpt_pack_tsv_rows (text: the located strings copied as they are, for the device decoder) share the row walk
+int tsv_rows_impl(const char* who, const char* const* rows, const size_t* lens, int n_rows, const char* key, int dim,
+                  int max_regions, int max_seqs, float* out, char* text, int64_t* mask_img, char* const* stripped,
+                  const size_t* stripped_cap, size_t* stripped_len, int* seqs_per_row, int* regions_per_seq,
+                  int n_threads) {
+    if (!rows || !lens || !key || (!out && !text) || !stripped || !stripped_cap || !stripped_len || !seqs_per_row || !regions_per_seq)
+        return io_fail(CPT_ERR_NULL, "%s: null argument", who);
+    if (n_rows < 0 || dim <= 0 || max_regions <= 0 || max_seqs < 0) return io_fail(CPT_ERR_SHAPE, "%s: bad sizes", who);
+    const size_t chars = cpt_b64_chars(dim);
     const size_t min_chars = ((size_t)dim * 16) / 3;       // a value is the base64 of dim float32
     struct Row { std::vector<size_t> off, len; std::vector<int> group; int groups = 0, status = CPT_OK; };
     std::vector<Row> R(n_rows);
@@ -318,12 +323,22 @@ int cpt_decode_tsv_rows(const char* const* rows, const size_t* lens, int n_rows,
             regions_per_seq[s] = count[g];
             if (count[g] > max_regions)
                 return report ? io_fail(CPT_ERR_SHAPE, "sequence %d: %d regions do not fit max_regions %d", s, count[g], max_regions) : CPT_ERR_SHAPE;
+            if (text) {
+                // device decode: the strings travel as text, [max_seqs][max_regions][chars]; slots without a region are left alone (the mask tells)
+                char* o = text + (size_t)s * max_regions * chars;
+                for (int i = 0; i < count[g]; ++i) {
+                    if (w.len[first[g] + i] != chars)
+                        return report ? io_fail(CPT_ERR_SHAPE, "base64 feature of %zu characters does not decode to %d float32 values", w.len[first[g] + i], dim) : CPT_ERR_SHAPE;
+                    memcpy(o + (size_t)i * chars, rows[r] + w.off[first[g] + i], chars);
+                }
+            } else {
             float* o = out + s * seq_elems;
             for (int i = 0; i < count[g]; ++i) {
                 const int rc = decode_one(rows[r] + w.off[first[g] + i], w.len[first[g] + i], o + (size_t)i * dim, dim);
                 if (rc != CPT_OK) return rc;
             }
             memset(o + (size_t)count[g] * dim, 0, (size_t)(max_regions - count[g]) * dim * sizeof(float));
+            }
             if (mask_img)
                 for (int i = 0; i < max_regions; ++i) mask_img[(size_t)s * max_regions + i] = i < count[g] ? 1 : 0;
         }
@@ -351,6 +366,27 @@ int cpt_decode_tsv_rows(const char* const* rows, const size_t* lens, int n_rows,
     for (int r = 0, base = 0; r < n_rows; base += R[r].groups, ++r)
         if (dec_status[r] != CPT_OK) return decode_row(r, base, true);       // redo in this thread to report its message
     return CPT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int cpt_decode_tsv_rows(const char* const* rows, const size_t* lens, int n_rows, const char* key, int dim,
+                        int max_regions, int max_seqs, float* out, int64_t* mask_img, char* const* stripped,
+                        const size_t* stripped_cap, size_t* stripped_len, int* seqs_per_row, int* regions_per_seq,
+                        int n_threads) {
+    if (!out) return io_fail(CPT_ERR_NULL, "cpt_decode_tsv_rows: null argument");
+    return tsv_rows_impl("cpt_decode_tsv_rows", rows, lens, n_rows, key, dim, max_regions, max_seqs, out, nullptr, mask_img, stripped, stripped_cap, stripped_len,
+                         seqs_per_row, regions_per_seq, n_threads);
+}
+
+int cpt_pack_tsv_rows(const char* const* rows, const size_t* lens, int n_rows, const char* key, int dim,
+                      int max_regions, int max_seqs, char* text, int64_t* mask_img, char* const* stripped,
+                      const size_t* stripped_cap, size_t* stripped_len, int* seqs_per_row, int* regions_per_seq,
+                      int n_threads) {
+    if (!text || !mask_img) return io_fail(CPT_ERR_NULL, "cpt_pack_tsv_rows: null argument");
+    return tsv_rows_impl("cpt_pack_tsv_rows", rows, lens, n_rows, key, dim, max_regions, max_seqs, nullptr, text, mask_img, stripped, stripped_cap, stripped_len,
+                         seqs_per_row, regions_per_seq, n_threads);
 }
 
 }  // extern "C"

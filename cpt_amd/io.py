@@ -222,15 +222,28 @@ def decode_rows(payloads, img_seq_len=50, dim=2054, out=None, mask=None, key=b"f
     return decode_rows_at(rows, lens, n, img_seq_len, dim, out, mask, key, threads, max_seqs, parse)
 
 
+def b64_chars(dim=2054):
+    """Characters of one region's base64 string (cpt_b64_chars): 10956 for float32[2054]."""
+    return int(L.lib().cpt_b64_chars(int(dim)))
+
+
 def decode_rows_at(rows, lens, n, img_seq_len=50, dim=2054, out=None, mask=None, key=b"feature", threads=4, max_seqs=None,
-                   parse=True):
+                   parse=True, text=None):
     """decode_rows on row texts given by ADDRESS: ``rows`` a ctypes array of n pointers (c_char_p / c_void_p), ``lens``
     their byte lengths (uint64 array).  Lets a caller decode straight out of a memory-mapped predictions file without
-    materialising 4 MB ``bytes`` objects per row (DecodePool's workers)."""
+    materialising 4 MB ``bytes`` objects per row (DecodePool's workers).
+
+    ``text`` (round 5, a uint8 tensor (max_seqs, img_seq_len, b64_chars(dim))): the device-decode form -- the located strings are COPIED
+    there as text (cpt_pack_tsv_rows) instead of decoded; the returned feats is then that tensor's first S sequences, to be copied to the
+    GPU and decoded there (``decode_text_device``)."""
     if max_seqs is None:
-        max_seqs = out.size(0) if out is not None else int(sum(int(l) // ((16 * dim) // 3) + 1 for l in lens[:n]))
-    if out is None:
+        ref = text if text is not None else out
+        max_seqs = ref.size(0) if ref is not None else int(sum(int(l) // ((16 * dim) // 3) + 1 for l in lens[:n]))
+    if out is None and text is None:
         out = torch.empty((max_seqs, img_seq_len, dim), dtype=torch.float32)
+    if text is not None:
+        assert text.dtype == torch.uint8 and text.is_contiguous() and tuple(text.shape[1:]) == (img_seq_len, b64_chars(dim)) and text.size(0) >= max_seqs
+        out = text
     if mask is None:
         mask = torch.empty((max_seqs, img_seq_len), dtype=torch.int64)
     assert out.is_contiguous() and mask.is_contiguous() and out.size(0) >= max_seqs and mask.size(0) >= max_seqs
@@ -240,14 +253,39 @@ def decode_rows_at(rows, lens, n, img_seq_len=50, dim=2054, out=None, mask=None,
     slen = np.zeros(max(n, 1), dtype=np.uint64)
     seqs_per_row = np.zeros(max(n, 1), dtype=np.int32)
     regions = np.zeros(max(max_seqs, 1), dtype=np.int32)
-    L.check(L.lib().cpt_decode_tsv_rows(C.cast(rows, C.POINTER(C.c_char_p)), lens.ctypes.data, n, key, dim, img_seq_len, max_seqs, out.data_ptr(),
-                                        mask.data_ptr(), sptr.ctypes.data, scap.ctypes.data, slen.ctypes.data,
-                                        seqs_per_row.ctypes.data, regions.ctypes.data, threads), "cpt_decode_tsv_rows")
+    fn = L.lib().cpt_pack_tsv_rows if text is not None else L.lib().cpt_decode_tsv_rows
+    L.check(fn(C.cast(rows, C.POINTER(C.c_char_p)), lens.ctypes.data, n, key, dim, img_seq_len, max_seqs, out.data_ptr(),
+               mask.data_ptr(), sptr.ctypes.data, scap.ctypes.data, slen.ctypes.data,
+               seqs_per_row.ctypes.data, regions.ctypes.data, threads), "cpt_pack_tsv_rows" if text is not None else "cpt_decode_tsv_rows")
     infos = [sbufs[i][:int(slen[i])].tobytes() for i in range(n)]      # the row's JSON without the feature strings
     if parse:
         infos = [json.loads(b) for b in infos]
     S = int(seqs_per_row[:n].sum())
     return infos, out[:S], mask[:S], seqs_per_row[:n].tolist(), regions[:S].tolist()
+
+
+def decode_text_device(text_dev, mask_dev, out_dev, err_dev, stream=None):
+    """Device half of the device decode (cpt_b64_decode_regions_device): text_dev uint8 (S, R, b64_chars(dim)) and mask_dev int64 (S, R) on the GPU
+    -> out_dev float32 (S, R, dim), one launch on ``stream`` (default: the current stream).  ``err_dev``: a zero-initialised int64 device scalar that
+    stays zero while every string is valid (``check_device_decode`` turns it into the host decoder's exception)."""
+    S, R, dim = out_dev.shape
+    assert text_dev.dtype == torch.uint8 and text_dev.is_contiguous() and tuple(text_dev.shape) == (S, R, b64_chars(dim))
+    assert mask_dev.dtype == torch.int64 and mask_dev.is_contiguous() and tuple(mask_dev.shape) == (S, R)
+    assert out_dev.dtype == torch.float32 and out_dev.is_contiguous() and err_dev.dtype == torch.int64 and err_dev.numel() >= 1
+    st = stream if stream is not None else torch.cuda.current_stream(out_dev.device)
+    L.check(L.lib().cpt_b64_decode_regions_device(text_dev.data_ptr(), mask_dev.data_ptr(), S, dim, R, out_dev.data_ptr(), err_dev.data_ptr(),
+                                                  C.c_void_p(st.cuda_stream)), "cpt_b64_decode_regions_device")
+    return out_dev
+
+
+def check_device_decode(err_dev, img_seq_len=50):
+    """Raises what the host decoder would have raised if a launch of decode_text_device met an invalid string (synchronises on err_dev)."""
+    code = int(err_dev.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
+    if code:
+        key = (~code) & 0xFFFFFFFFFFFFFFFF
+        slot, ch = key >> 32, key & 0xFFFFFFFF
+        raise RuntimeError("cpt_amd.io: device base64 decode: sequence %d region %d: character %d is outside the alphabet or the padding is wrong"
+                           % (slot // img_seq_len, slot % img_seq_len, ch))
 
 
 def decode_features(tsv, img_idx, img_seq_len=50, dim=2054):
@@ -344,6 +382,7 @@ class RegionStager(object):
 # H2D copy of a finished slot and the forward.
 
 def _pool_worker(tsv_path, img_seq_len, dim, threads, feats, masks, tasks, results, my_slots):
+    as_text = feats.dtype == torch.uint8      # device-decode ring: the slots hold base64 text
     for k in my_slots:                  # map this worker's slots now: first-touch page faults stay out of the steady state
         feats[k].zero_()
         masks[k].zero_()
@@ -376,8 +415,8 @@ def _pool_worker(tsv_path, img_seq_len, dim, threads, feats, masks, tasks, resul
                     raise ValueError("row %d: the payload column is not one JSON object" % i)
                 ptrs[j] = base + lo
                 lens[j] = hi - lo
-            infos, f, m, seqs_per_row, regions = decode_rows_at(ptrs, lens, n, img_seq_len, dim, out=feats[slot], mask=masks[slot],
-                                                                threads=threads, max_seqs=feats.size(1), parse=False)
+            infos, f, m, seqs_per_row, regions = decode_rows_at(ptrs, lens, n, img_seq_len, dim, out=None if as_text else feats[slot], mask=masks[slot],
+                                                                threads=threads, max_seqs=feats.size(1), parse=False, text=feats[slot] if as_text else None)
             results.put((ticket, slot, names, infos, seqs_per_row, regions, None))
         except Exception as e:          # the main process re-raises
             results.put((ticket, slot, None, None, None, None, "%s: %s" % (type(e).__name__, e)))
@@ -395,13 +434,19 @@ class DecodePool(object):
     e.g. prompts.PromptBuilder).  A slot is reused only after ``release(slot)``: call it once the H2D copy out of the slot
     has completed (e.g. after the copy event's synchronize())."""
 
-    def __init__(self, tsv_path, max_seqs, img_seq_len=50, dim=2054, workers=4, slots=None, threads=2, pin=None):
+    def __init__(self, tsv_path, max_seqs, img_seq_len=50, dim=2054, workers=4, slots=None, threads=2, pin=None, device_decode=False):
+        """device_decode (round 5): the ring holds the regions' base64 TEXT (uint8 (slots, max_seqs, img_seq_len, b64_chars(dim))): the workers only
+        locate and copy the strings (cpt_pack_tsv_rows); the consumer copies a slot to the GPU and decodes it there (``decode_text_device``)."""
         import torch.multiprocessing as mp
         ctx = mp.get_context("spawn")               # never fork a process that holds a HIP context
         self.slots = slots or 2 * workers
         if self.slots < workers:
             raise ValueError("DecodePool: at least one slot per worker")
-        self.feats = torch.empty((self.slots, max_seqs, img_seq_len, dim), dtype=torch.float32).share_memory_()
+        self.device_decode = bool(device_decode)
+        if self.device_decode:
+            self.feats = torch.empty((self.slots, max_seqs, img_seq_len, b64_chars(dim)), dtype=torch.uint8).share_memory_()
+        else:
+            self.feats = torch.empty((self.slots, max_seqs, img_seq_len, dim), dtype=torch.float32).share_memory_()
         self.masks = torch.empty((self.slots, max_seqs, img_seq_len), dtype=torch.int64).share_memory_()
         self.pinned = False
         if pin is None:

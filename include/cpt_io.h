@@ -63,6 +63,30 @@ int cpt_decode_tsv_rows(const char* const* rows, const size_t* lens, int n_rows,
                         const size_t* stripped_cap, size_t* stripped_len, int* seqs_per_row, int* regions_per_seq,
                         int n_threads);
 
+/* ---- Round 5: decode on the DEVICE ---------------------------------------------------------------------------------------
+ * At the GPU's rate the host decoder needs most of a 16-core host (4.4 MB of base64 per TSV row, 22 GB/s at 4e4 sequences/s).  The text can
+ * travel to the GPU as it stands instead: the host only LOCATES the strings and copies them into (pinned) memory, a HIP kernel decodes them at
+ * the memory system's rate on the stream the H2D copy ran on, straight into the [n_seq][max_regions][dim] float32 tensor cpt_batch.img_feats
+ * points at.  Same strictness and the same bytes as cpt_b64_decode_f32 (tests compare the two bit for bit). */
+
+/* Characters of one region's base64 string: 4 * ceil(4 * dim / 3)  (10956 for dim = 2054). */
+size_t cpt_b64_chars(int dim);
+
+/* Host half: cpt_decode_tsv_rows with the decode left out.  Region i of sequence s is COPIED to text[s][i][0 .. cpt_b64_chars(dim)) of
+ * text[max_seqs][max_regions][cpt_b64_chars(dim)] (a value of any other length is an error; slots without a region are not written),
+ * mask_img[max_seqs][max_regions] (required) receives 1 / 0 per slot; stripped / seqs_per_row / regions_per_seq as cpt_decode_tsv_rows. */
+int cpt_pack_tsv_rows(const char* const* rows, const size_t* lens, int n_rows, const char* key, int dim,
+                      int max_regions, int max_seqs, char* text, int64_t* mask_img, char* const* stripped,
+                      const size_t* stripped_cap, size_t* stripped_len, int* seqs_per_row, int* regions_per_seq,
+                      int n_threads);
+
+/* Device half (one launch on `stream`; all pointers DEVICE memory): text_dev[n_seq][max_regions][cpt_b64_chars(dim)] + mask_img_dev[n_seq][max_regions]
+ * -> out_dev[n_seq][max_regions][dim] float32, rows of slots whose mask is 0 zeroed.  *err_dev (8 bytes, zero before the first launch; stays zero
+ * while every string is valid) receives ~((slot << 32) | character) of the FIRST invalid character (lowest slot = s * max_regions + i, then lowest
+ * offset) -- read it back where the host decoder would have returned its error; the slot's output is undefined then. */
+int cpt_b64_decode_regions_device(const void* text_dev, const int64_t* mask_img_dev, int n_seq, int dim, int max_regions, float* out_dev,
+                                  unsigned long long* err_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -236,3 +236,37 @@ print(json.dumps(out))
     assert ok and all(r[1] == 0 and r[2] for r in ok)
     errs = [r for r in res["0"] if len(r) == 4]
     assert errs and all(r[2] != 0 and ("character %d " % (r[1] // 4 * 4)) in r[3] for r in errs)      # (the decoder names the 4-character group of the offender)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_pack_rows_for_the_device_decoder(golden_dir, threads):
+    """Round 5, host half of the device decode (cpt_pack_tsv_rows): the located strings arrive as TEXT in [sequence][region][b64_chars] slots, with
+    the masks, counts and stripped JSON of cpt_decode_tsv_rows; decoding the packed text with Python's base64 gives the reference's features."""
+    g = np.load(os.path.join(golden_dir, "tiny_rows_expected.npz"))
+    t = io.TSVFile(os.path.join(golden_dir, "tiny_rows.tsv"))
+    payloads = [t.seek_raw(i)[1].strip() for i in range(len(t))]
+    n = len(payloads)
+    import ctypes as C
+    rows = (C.c_char_p * n)(*payloads)
+    lens = np.fromiter((len(p) for p in payloads), dtype=np.uint64, count=n)
+    chars = io.b64_chars(2054)
+    assert chars == 10956 and io.b64_chars(1) == 8 and io.b64_chars(3) == 16
+    text = torch.full((8, 6, chars), 0x21, dtype=torch.uint8)          # '!': a slot that is not written stays invalid text
+    infos, packed, mask, seqs_per_row, regions = io.decode_rows_at(rows, lens, n, img_seq_len=6, threads=threads, text=text)
+    ref_infos, feats, ref_mask, ref_spr, ref_regions = io.decode_rows(payloads, img_seq_len=6, threads=threads)
+    assert seqs_per_row == ref_spr and regions == ref_regions and torch.equal(mask, ref_mask) and infos == ref_infos
+    assert packed.data_ptr() == text.data_ptr() and packed.shape == (sum(seqs_per_row), 6, chars)
+    for s, c in enumerate(regions):
+        for i in range(6):
+            raw = bytes(packed[s, i].numpy())
+            if i < c:
+                assert np.frombuffer(base64.b64decode(raw), np.float32).tobytes() == feats[s, i].numpy().tobytes()
+            else:
+                assert raw == b"!" * chars
+    # a value of another length is the host decoder's size error
+    short = json.dumps({"objects": [[[{"class": "a", "feature": _b64(np.arange(2053))}]], "c", [["red"]], [[[0, 0, 1, 1]]]]}).encode()
+    rows1 = (C.c_char_p * 1)(short)
+    with pytest.raises(RuntimeError, match="does not decode to 2054"):
+        io.decode_rows_at(rows1, np.array([len(short)], np.uint64), 1, img_seq_len=6, threads=threads, text=text)
+    with pytest.raises(RuntimeError, match="do not fit max_regions"):
+        io.decode_rows_at(rows, lens, n, img_seq_len=4, threads=threads, text=torch.zeros((8, 4, chars), dtype=torch.uint8))
