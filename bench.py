@@ -355,7 +355,18 @@ def hbm_kernels(cfg, B, dev, iters=20):
               timeit(lambda: L.check(L.lib().cpt_embed_ln(ids.data_ptr(), tt.data_ptr(), None, word.data_ptr(), posw.data_ptr(), typw.data_ptr(),
                                                            g.data_ptr(), bt.data_ptr(), 1e-12, e32.data_ptr(), e16.data_ptr(), L.CPT_BF16, Bs, 70, 120, H,
                                                            cfg.vocab_size, 512, 2, L.stream_ptr()))))
-        del x, o32, o16, e32, e16
+        # round 5: base64 text of the region features -> float32 on the device (include/cpt_io.h cpt_b64_decode_regions_device): text read once, floats written once
+        from cpt_amd import io
+        chars = io.b64_chars(2054)
+        txt = torch.randint(65, 91, (Bs, 50, chars), dtype=torch.uint8, device=dev)
+        txt[:, :, chars - 1] = 61                                     # '=': the one padding character of a float32[2054] string
+        mk = torch.ones(Bs, 50, dtype=torch.int64, device=dev)
+        fo = torch.empty(Bs, 50, 2054, device=dev)
+        derr = torch.zeros(1, dtype=torch.int64, device=dev)
+        entry("b64_decode_regions (base64 text in, fp32 out; %d x 50 regions of float32[2054]) [%s]" % (Bs, tag), Bs * 50 * (chars + 2054 * 4),
+              timeit(lambda: io.decode_text_device(txt, mk, fo, derr)))
+        io.check_device_decode(derr, 50)
+        del x, o32, o16, e32, e16, txt, fo
     n = 111_680_000 // 64 * 64
     p, gr, m, v = (torch.randn(n, device=dev) for _ in range(4))
     v.abs_()

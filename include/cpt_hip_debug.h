@@ -94,6 +94,9 @@ int cpt_build_info(void);
  *          legal, 0 = nowhere; same bits
  *   key 30 fused bf16 encoder at the full-panel shapes: 1 (default) = the residual stream itself in the panel layout and the LayerNorm producers'
  *          register-direct epilogue (cpt_gemm_ln_prod3_rpanel), 0 = row-major 3-byte stream + slab epilogue (round 3); same bits
+ *   key 31 fused bf16 encoder, only the [MASK] rows (or only the [CLS] rows) read behind it: 1 (default) = the last layer's attention output, FFN and
+ *          LayerNorms on those rows alone (rowops.hip tail_rows / tail_finish, gemm.hip gemm_rows_split), 0 = every row through the last layer;
+ *          same values to bf16 accuracy, not the same bits (different kernels behind the last attention)
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
