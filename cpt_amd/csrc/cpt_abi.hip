@@ -82,11 +82,14 @@ struct FwdLayout {
     size_t x_f32, x_lp, qkv, ctx, pre, a_f32, a_lp, ffn, imgp, rows, rows_f32, t1, t2, pooled_f32, pooled_lp, stats, loss, split, total;
 };
 
+int enc_rows(const cpt_dims& d, int B, int Lt, int Li, int flags);      // (below: rows the encoder's tensors are sized and launched for)
+
 FwdLayout fwd_layout(const cpt_dims& d, int B, int Lt, int Li, int flags) {
     const size_t es = d.dtype == CPT_BF16 ? 2 : 4;
     const bool lp = d.dtype == CPT_BF16;
-    const size_t L = (size_t)Lt + Li, M = (size_t)B * L, H = d.hidden;
-    const size_t hr = (flags & CPT_OUT_ALL_LOGITS) ? M : (size_t)B;   // rows through the MLM head
+    const size_t L = (size_t)Lt + Li, Mr = (size_t)B * L, H = d.hidden;
+    const size_t hr = (flags & CPT_OUT_ALL_LOGITS) ? Mr : (size_t)B;   // rows through the MLM head
+    const size_t M = (size_t)enc_rows(d, B, Lt, Li, flags);            // encoder tensors: B * L rows, or rounded up to the next full-panel shape (enc_rows)
     FwdLayout w;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t p = o; o += al(bytes); return p; };
@@ -157,6 +160,7 @@ CPT_SWITCH(static int g_lp_resid, 0);     // bf16 mode: keep the residual stream
 CPT_SWITCH(static int g_panel, 1);        // fused bf16 encoder: ctx and the FFN activation travel in the fragment-major panel layout and the LayerNorm producers read them straight into registers (gemm_prod.hip) where the shapes allow
 CPT_SWITCH(static int g_x3_fuse, 1);      // bf16x3 parity mode: split copies written by the producing kernels (FFN-up GELU epilogue, LayerNorm passes) instead of stand-alone split3 passes (cpt_set_tuning key 23)
 CPT_SWITCH(static int g_rpanel, 1);       // round 5: the residual stream itself travels in the panel layout and the LayerNorm producers run their register-direct epilogue (gemm_prod.hip RP; cpt_set_tuning key 30)
+CPT_SWITCH(static int g_row_pad, 1);      // round 5: ragged batches run the full panel mode on rows padded up to its next shape (enc_rows; cpt_set_tuning key 32)
 CPT_SWITCH(static int g_tail, 1);         // round 5: with only [MASK] (or only [CLS]) rows read behind the encoder, the last layer's attention output / FFN / LayerNorms run on those rows alone (cpt_set_tuning key 31)
 CPT_SWITCH(static int g_prefetch, 1);     // panel mode: the 240-tile launches carry 16 workgroups that read the next launch's weights into the Infinity Cache (common.h prefetch_region)
 CPT_SWITCH(static int g_panel_ffn_multi, 1);   // panel layout for the FFN activation also when the producers run several rounds of tiles (cpt_set_tuning key 28; experiments)
@@ -182,7 +186,7 @@ int cpt_set_tuning(int key, int value) {
                               "this library always runs its shipped configuration", key);
 #else
     if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
-        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_panel_ffn_multi = 1; cpt::set_lncons4(1); g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1; g_rpanel = 1; g_tail = 1;
+        g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_panel_ffn_multi = 1; cpt::set_lncons4(1); g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1; g_rpanel = 1; g_tail = 1; g_row_pad = 1;
         cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
         cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_ffn_2pass_min_tiles(192); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0); cpt::set_lnb_rpb(0); cpt::set_bias_fuse(2); cpt::set_wgrad_pair(2); cpt::set_qkv_2pass(1); cpt::set_fwd_split2(1); g_x3_fuse = 1; cpt::set_attn_qt_all(1); cpt::set_prod_waves(0);
         return CPT_OK;
@@ -216,6 +220,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 28) { g_panel_ffn_multi = value; return CPT_OK; }
     if (key == 30) { g_rpanel = value; return CPT_OK; }
     if (key == 31) { g_tail = value; return CPT_OK; }
+    if (key == 32) { g_row_pad = value; return CPT_OK; }
     if (key == 29) { cpt::set_lncons4(value); return CPT_OK; }
     if (key == 26) { g_dec_pf_pct = value < 0 ? 0 : (value > 100 ? 100 : value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all
@@ -416,8 +421,8 @@ size_t cpt_fwd_workspace_bytes(const cpt_dims* d, int B, int Lt, int Li, int fla
 
 // Shapes / switches at which cpt_model_fwd keeps the residual stream in the panel layout (round 5): the full panel mode of the fused bf16 encoder --
 // 3-byte stream, (sequence, three heads) QKV + attention, two-pass FFN-up with panel output, both LayerNorm producers on the panel kernel.
-static bool rpanel_mode(const cpt_dims& d, int B, int Lt, int Li, int flags, bool has_fold) {
-    const int L = Lt + Li, M = B * L, H = d.hidden, I = d.inter;
+static bool rpanel_mode_rows(const cpt_dims& d, int L, int M, int flags, bool has_fold) {
+    const int H = d.hidden, I = d.inter;
     if (d.dtype != CPT_BF16 || !has_fold || !g_fold_ln || g_lp_resid || !g_resid3 || !g_panel || !g_rpanel) return false;
     if (flags & CPT_ATTN_MASK_3D) return false;
     if (!(g_fuse_attn == 3 && L <= 128 && H % 64 == 0 && cpt::qkv_attn3_eligible(L, d.heads, H))) return false;
@@ -425,6 +430,22 @@ static bool rpanel_mode(const cpt_dims& d, int B, int Lt, int Li, int flags, boo
     if (!((long)(M / 128) * (H / 192) <= 256 || g_panel_ffn_multi)) return false;
     return cpt::lncons4_enabled() < 2;
 }
+// Round 5: ROW PADDING.  The full panel mode (the form the bench shape runs in) needs B * L to be a multiple of 128 and enough FFN-up tiles to fill the chip;
+// a ragged batch -- the reference's batches are sum-of-proposals long (zeroshot/refcoco_cpt.py:213-218) -- fell back to the row-major kernels: 63 sequences
+// took 1.80 ms where 64 take 1.63, 48 took 1.81.  Every encoder kernel between the embedding and the heads is ROW-WISE except the attention, which works per
+// sequence: so the encoder's tensors are simply sized and launched for the next row count the panel mode accepts (at most 1.5x the real rows), the rows behind
+// B * L belong to no sequence, are never initialised and never read by anything that is returned.  Same bits on the real rows (the panel mode is bit-identical
+// to the row-major encoder).
+namespace {
+int enc_rows(const cpt_dims& d, int B, int Lt, int Li, int flags) {
+    const int L = Lt + Li;
+    const long M = (long)B * L;
+    if (!g_row_pad || d.dtype != CPT_BF16 || rpanel_mode_rows(d, L, (int)M, flags, true)) return (int)M;
+    for (long Mp = (M + 127) / 128 * 128; Mp <= M + M / 2; Mp += 128)
+        if (rpanel_mode_rows(d, L, (int)Mp, flags, true)) return (int)Mp;
+    return (int)M;
+}
+}  // namespace
 
 int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, int flags,
                   void* workspace, size_t workspace_bytes, void* stream) {
@@ -492,7 +513,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     // Round 5: at the shapes of the full panel mode (below) the residual stream itself travels in the panel layout [M / 32][H / 16][64][8]
     // (hi as bf16, lo as bytes): the LayerNorm producers run a register-direct epilogue and the two consumers gather their A tiles out of it.
     // The embedding and region LayerNorm launches write their rows at their panel positions, the heads gather their rows out of it.
-    const bool rpanel = rpanel_mode(d, B, Lt, Li, flags, m->fold != nullptr);
+    const int Me = m->fold ? enc_rows(d, B, Lt, Li, flags) : M;      // rows the encoder's launches cover (enc_rows: > M = a ragged batch padded up to the panel mode's next shape)
+    const bool rpanel = rpanel_mode_rows(d, L, Me, flags, m->fold != nullptr);
     void* e_lp = x_lp;
     void* e_lo = x_lo;
     // (a2) text embeddings -> rows b*L + t.  bf16 with the 3-byte stream: the same launch also converts the region features (rowops.hip embed_pad_kernel)
@@ -531,13 +553,13 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     // attention form, the two-pass FFN-up kernel and tile-aligned shapes; everything else keeps the row-major tensors.
     const bool fused3 = fuse_attn && g_fuse_attn == 3 && cpt::qkv_attn3_eligible(L, d.heads, H);
     const bool two_kernel = lp && !fuse_attn && !mask3 && L <= 288;        // 128 < L <= 288 (the GQA shape): QKV GEMM, then the stand-alone attention kernel writes the panel (beyond 288: row-major ctx)
-    const bool panel = r3 && g_panel && (fused3 || two_kernel) && cpt::ffn_up_2pass_preferred(M, I, H) &&
-                       cpt::panel_eligible(M, H, H) && cpt::panel_eligible(M, H, I);
+    const bool panel = r3 && g_panel && (fused3 || two_kernel) && cpt::ffn_up_2pass_preferred(Me, I, H) &&
+                       cpt::panel_eligible(Me, H, H) && cpt::panel_eligible(Me, H, I);
     if (rpanel && !(panel && fused3)) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: panel residual mode outside the full panel mode");
     // h (FFN-up -> FFN-down) in the panel layout.  Round 3 kept it row-major when the producers run several rounds of tiles (GQA shape, 1680 tiles:
     // the 8-wave panel producer lost to the row-major kernel there, 4.05 vs 3.84 ms per step); with round 4's 4-wave producer the panel form wins
     // there too (3.63 ms; cpt_set_tuning key 28 = 0 restores the row-major FFN activation for multi-round shapes)
-    const bool panel_ffn = panel && ((long)(M / 128) * (H / 192) <= 256 || g_panel_ffn_multi);
+    const bool panel_ffn = panel && ((long)(Me / 128) * (H / 192) <= 256 || g_panel_ffn_multi);
     if (rpanel && !panel_ffn) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: panel residual mode without the panel FFN activation");
     const bool pfw = panel && g_prefetch;           // spare workgroups prefetch the next launch's weights (common.h prefetch_region)
     // Round 5: the last layer on the head's rows only.  When nothing but the B [MASK] rows (MLM head) or nothing but the B [CLS] rows (pooler / relation
@@ -551,7 +573,9 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                       H % 64 == 0 && I % 64 == 0 && tail_part <= (size_t)M * I * 2 && (size_t)B * I * 2 <= (size_t)M * H * 4;
     const size_t dec_bytes_t = (size_t)d.vocab * H * 2;
     const size_t dec_pf0_t = (want_mask && m->w_dec && g_prefetch) ? ((dec_bytes_t / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023) : 0;
+    if (Me != M && !rpanel) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: padded rows outside the panel residual mode");
     if (fold) {
+        const int M = Me;       // (every launch of this block is row-wise or per sequence: the padded rows are computed and never read)
         // LayerNorm folded into the GEMMs around it: x_f32/x_lp and a_f32/a_lp hold PRE-LayerNorm sums, the
         // producer GEMMs accumulate their row sums, the consumer GEMMs normalise in their epilogue.
         float* stats = (float*)(ws + w.stats);         // [layers][2] tables of [M][slots][2] partial row sums (no zeroing needed)

@@ -97,6 +97,8 @@ int cpt_build_info(void);
  *   key 31 fused bf16 encoder, only the [MASK] rows (or only the [CLS] rows) read behind it: 1 (default) = the last layer's attention output, FFN and
  *          LayerNorms on those rows alone (rowops.hip tail_rows / tail_finish, gemm.hip gemm_rows_split), 0 = every row through the last layer;
  *          same values to bf16 accuracy, not the same bits (different kernels behind the last attention)
+ *   key 32 fused bf16 encoder, batches whose row count the full panel mode does not take: 1 (default) = the encoder's tensors are sized and launched for the
+ *          next row count it takes (at most 1.5x the real rows; the padded rows belong to no sequence), 0 = such batches run the row-major kernels; same bits
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at

@@ -94,6 +94,50 @@ def test_panel_mode_other_shapes_rows_equal_small_batch(dev, B, Lt, Li):
         assert torch.equal(seq[lo:lo + 3], seq3), "sequence output, rows %d.." % lo
 
 
+@pytest.mark.parametrize("B,Lt,Li", [(63, 70, 50), (48, 70, 50), (33, 70, 50), (61, 65, 50)])
+def test_ragged_batches_run_the_panel_mode_on_padded_rows(dev, B, Lt, Li):
+    """Round 5 (cpt_abi.hip enc_rows): a batch whose row count the full panel mode does not take (63 x 120 = 7560 rows: not a multiple of 128; 48 x 120 and
+    33 x 120: too few FFN-up tiles; 61 x 115) runs it on rows padded up to the next shape it takes -- the padded rows belong to no sequence and are
+    never initialised.  The workspace is filled with NaN bit patterns first: nothing of the padding may reach a real row.  Rows of the batch equal a
+    3-sequence batch (row-major kernels) bit for bit, [MASK]-row logits and the all-row sequence output."""
+    from cpt_amd.modeling_rec import REC_MLM_CPT
+    cfg = cfgmod.oscar_base(num_hidden_layers=3)
+    m = REC_MLM_CPT(cfg)
+    m.load_state_dict(synth.init_state_dict(cfg, 35, head="cpt"))
+    m.tie_weights()
+    m.to(dev).eval().set_compute_dtype("bf16")
+    d = _dev(synth.make_batch(B, cfg, seed=16, max_seq_len=Lt, img_seq_len=Li, vary_regions=True), dev)
+
+    def poison_workspaces():
+        n = 0
+        for eng in (m._engine(), m.bert._engine()):
+            ws = eng._ws.get("fwd")
+            if ws is not None:
+                ws.fill_(0xFF)
+                n += 1
+        return n
+
+    def run(dd, poison):
+        with torch.no_grad():
+            if poison:       # (an engine keeps one workspace: run once so that it exists at this size, then poison it)
+                m(dd["input_ids"], dd["segment_ids"], dd["attention_mask"], img_feats=dd["img_feats"], mask_token_pos=dd["mask_token_pos"])
+                m.bert(dd["input_ids"], dd["segment_ids"], dd["attention_mask"], img_feats=dd["img_feats"])
+                assert poison_workspaces() >= 1
+            lg = m(dd["input_ids"], dd["segment_ids"], dd["attention_mask"], img_feats=dd["img_feats"], mask_token_pos=dd["mask_token_pos"])[0].clone()
+            if poison:
+                poison_workspaces()
+            sq = m.bert(dd["input_ids"], dd["segment_ids"], dd["attention_mask"], img_feats=dd["img_feats"])[0].clone()
+        return lg, sq
+    big, seq = run(d, True)
+    assert torch.isfinite(big).all() and torch.isfinite(seq).all()
+    assert torch.equal(run(d, True)[0], big)
+    for lo in (0, B - 3):
+        ds = {k: v[lo:lo + 3].contiguous() for k, v in d.items()}
+        small, seq3 = run(ds, False)
+        assert torch.equal(big[lo:lo + 3], small), "rows %d.." % lo
+        assert torch.equal(seq[lo:lo + 3], seq3), "sequence output, rows %d.." % lo
+
+
 def test_panel_mode_text_only_rows_equal_small_batch(dev):
     """Panel mode without region features (img_feats = None, modeling_bert.py:261): 64 sequences of 120 text tokens -- the text embedding launch
     alone writes the panel-layout residual stream (no merged pad + cast launch).  Rows of the big batch equal a 3-sequence batch bit for bit."""
