@@ -281,7 +281,9 @@ def mlm_loss_with_grad(model, input_ids, token_type_ids, attention_mask, labels,
                prep(attention_mask, torch.int64, "attention_mask"), prep(position_ids, torch.int64, "position_ids"),
                prep(img_feats, torch.float32, "img_feats"), prep(mask_token_pos, torch.int64, "mask_token_pos"),
                prep(labels, torch.int64, "labels"), prep(row_seq, torch.int64, "row_seq"))
-    trigger = torch.zeros((), device=eng.flat.device, requires_grad=True)
+    trigger = getattr(st, "trigger", None)      # one leaf per engine, made once: autograd needs an input that requires grad, backward returns None for it
+    if trigger is None or trigger.device != eng.flat.device:
+        trigger = st.trigger = torch.zeros((), device=eng.flat.device, requires_grad=True)
     loss, logits = _MLMLoss.apply(trigger, eng, tensors, dropout_for(model, st))
     return (loss, logits)
 
