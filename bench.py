@@ -441,6 +441,18 @@ def extra_configs(dev, model, cfg, seed):
     model.set_compute_dtype("bf16")
     out["parity_modes"] = pm
     out["_parity_logits"] = plog                # (compared with the oracle's logits once the CPU leg has produced them; removed from the line)
+    # ragged batches of the headline workload (the reference's batches are sum-of-proposals long, zeroshot/refcoco_cpt.py:213-218): 63 and 48 sequences
+    # run the full panel mode on rows padded up to its next shape
+    rag = {}
+    for Br in (63, 48):
+        rb = {k: v.to(dev) for k, v in synth.make_batch(Br, cfg, seed=seed, max_seq_len=70, img_seq_len=50).items()}
+
+        def fn():
+            with torch.no_grad():
+                return model(rb["input_ids"], rb["segment_ids"], rb["attention_mask"], img_feats=rb["img_feats"], mask_token_pos=rb["mask_token_pos"])[0]
+        dt = timed(fn, 3, 20)
+        rag["b%d" % Br] = {"pairs/s": round(Br / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": Br, "steps": 20}
+    out["config1_ragged_batches"] = rag
     # configs[3]: GQA shape on the Oscar-base model of the headline run
     out["config3_gqa_infer_b256"] = infer_entry(
         model, cfg, 256, 165, 45, lambda m, b: m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"],
