@@ -571,6 +571,12 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const size_t tail_part = std::max((size_t)S_h * B * (size_t)(H > I ? H : I), (size_t)S_i * B * H) * 4;
     const bool tail = g_tail && fold && r3 && d.layers >= 2 && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) && want_mask != want_cls &&
                       H % 64 == 0 && I % 64 == 0 && tail_part <= (size_t)M * I * 2 && (size_t)B * I * 2 <= (size_t)M * H * 4;
+    // the same for the bf16x3 parity mode (split-operand attention + fused split copies): the K-split row GEMMs run on the split operands (K' = 3 K),
+    // the row passes keep fp32 and re-split; same three-term products, same gelu as the mode's all-row launches
+    const int S_h3 = cpt::rows_gemm_splits(3 * H), S_i3 = cpt::rows_gemm_splits(3 * I);
+    const bool tail_x3 = g_tail && x3a && x3f && d.layers >= 2 && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) && want_mask != want_cls &&
+                         H % 64 == 0 && I % 64 == 0 && S_h3 <= 24 && S_i3 <= 24 &&
+                         std::max((size_t)S_h3 * B * (size_t)(H > I ? H : I), (size_t)S_i3 * B * H) * 4 <= (size_t)M * I * 4 && (size_t)B * I * 6 <= (size_t)M * 3 * H * 4;
     const size_t dec_bytes_t = (size_t)d.vocab * H * 2;
     const size_t dec_pf0_t = (want_mask && m->w_dec && g_prefetch) ? ((dec_bytes_t / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023) : 0;
     if (Me != M && !rpanel) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: padded rows outside the panel residual mode");
@@ -675,6 +681,25 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         }
         const bool lpr = lp && g_lp_resid;                       // residual operand read as bf16, fp32 copy not written
         const bool last = l + 1 == d.layers;
+        if (tail_x3 && last) {
+            Scope p(CPT_K_HEAD, s);
+            const int64_t* pos = want_mask ? b->mask_pos : nullptr;
+            float* part = (float*)ffn;                        // [S][B][N] split-K partial matrices
+            float* xr = (float*)(ws + w.rows_f32);             // residual rows (the previous layer's output)
+            void* ctx_r = ctx;                                 // [B][3H] split copy of the rows' attention context (the fp32 ctx region is idle in this mode)
+            void* asplit_r = pre;                              // [B][3H]
+            void* hsplit_r = qkv;                              // [B][3I] (q | k | v of this layer are consumed)
+            TRY(cpt::gather_rows(splitbuf, CPT_BF16, pos, ctx_r, B, L, 3 * H, s), "tail: gather(ctx rows, split copy)");
+            TRY(cpt::gather_rows(x_f32, CPT_F32, pos, xr, B, L, H, s), "tail: gather(residual rows)");
+            TRY(cpt::gemm_rows_split(ctx_r, 3 * H, y.w_ao, 3 * H, y.b_ao, part, B, H, 3 * H, s), "tail: gemm(attn out, split K, split operands)");
+            TRY(cpt::tail_finish(part, S_h3, xr, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, nullptr, B, H, s), "tail: partials + residual + layernorm(attn)");
+            TRY(cpt::split3(a_f32, H, asplit_r, B, H, 0, s), "tail: split3(ffn up input)");
+            TRY(cpt::gemm_rows_split(asplit_r, 3 * H, y.w_in, 3 * H, y.b_in, part, B, I, 3 * H, s), "tail: gemm(ffn up, split K, split operands)");
+            TRY(cpt::gelu_parts(part, S_h3, hsplit_r, (size_t)B * I, s, nullptr, 0, I), "tail: partials + gelu -> split copy");
+            TRY(cpt::gemm_rows_split(hsplit_r, 3 * I, y.w_out, 3 * I, y.b_out, part, B, H, 3 * I, s), "tail: gemm(ffn down, split K, split operands)");
+            TRY(cpt::tail_finish(part, S_i3, a_f32, y.ln2_g, y.ln2_b, d.ln_eps, (float*)(ws + w.rows), nullptr, B, H, s), "tail: partials + residual + layernorm(ffn)");
+            break;
+        }
         { Scope p(CPT_K_GEMM_AO, s);
           if (x3a) TRY(cpt::gemm(CPT_BF16, CPT_EPI_RESID, splitbuf, 3 * H, y.w_ao, 3 * H, y.b_ao, x_f32, H, pre, CPT_F32, H, M, H, 3 * H, s), "gemm(attn out, split ctx)");
           else
@@ -710,7 +735,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         void* rows = ws + w.rows;
         float* pooled = (flags & CPT_OUT_POOLED) ? o->pooled : (float*)(ws + w.pooled_f32);
         if (!pooled) return fail(CPT_ERR_NULL, "cpt_model_fwd: pooled output is NULL");
-        if (tail) {
+        if (tail || tail_x3) {
             // rows = the [CLS] rows of the encoder output (written by the tail above)
         } else
         if (pre_ln) {
@@ -746,7 +771,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         const size_t dec_pf0 = (dec_bytes / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023;
         if (!all) {
             void* g = ws + w.rows;
-            if (tail) {
+            if (tail || tail_x3) {
                 // g = the [MASK] rows of the encoder output (written by the tail above, which also carried the first part of the decoder prefetch)
             } else
             if (pre_ln) {

@@ -137,7 +137,8 @@ int head_finish(const float* partials, int S, const float* g, const float* bta, 
 // last encoder layer on the head's rows only (round 5; rowops.hip / gemm.hip): gather + previous LayerNorm of the head rows, K-split dense layers on them
 int tail_rows(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, const void* ctx, void* ctx_out, float* resid_out,
               int R, int L, int H, hipStream_t s, int src_panel, int ctx_panel, const void* pf = nullptr, size_t pf_bytes = 0);
-int gelu_parts(const float* partials, int S, void* out_bf16, size_t n, hipStream_t s, const void* pf = nullptr, size_t pf_bytes = 0);
+int gelu_parts(const float* partials, int S, void* out_bf16, size_t n, hipStream_t s, const void* pf = nullptr, size_t pf_bytes = 0,
+               int split_cols = 0);     // split_cols = N > 0: n = R * N values written as the bf16x3 mode's [R][hi | hi | lo] split copy (row pitch 3 N)
 int tail_finish(const float* partials, int S, const float* resid, const float* g, const float* bta, float eps, float* out_f32, void* out_bf16, int R, int H, hipStream_t s,
                 const void* pf = nullptr, size_t pf_bytes = 0);
 int rows_gemm_splits(int K);

@@ -795,11 +795,11 @@ __global__ __launch_bounds__(256) void tail_finish_kernel(const float* __restric
     }
     float mean, rstd;
     ln_stats<NA>(v, nv, lane, H, mean, rstd, eps);
-    ln_write<bf16, NA>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + (size_t)r * H : nullptr, out_lp + (size_t)r * H);
+    ln_write<bf16, NA>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + (size_t)r * H : nullptr, out_lp ? out_lp + (size_t)r * H : nullptr);
 }
 int tail_finish(const float* partials, int S, const float* resid, const float* g, const float* bta, float eps, float* out_f32, void* out_bf16, int R, int H, hipStream_t s,
                 const void* pf, size_t pf_bytes) {
-    if (!partials || !g || !bta || !out_bf16) return CPT_ERR_NULL;
+    if (!partials || !g || !bta || (!out_bf16 && !out_f32)) return CPT_ERR_NULL;
     if (R <= 0 || S <= 0 || H <= 0 || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
     const int pfb = (pf && pf_bytes && !((uintptr_t)pf & 15) && R < 224) ? 224 - (R & ~7) : 0;
     const size_t stride = (size_t)R * H;
@@ -811,8 +811,9 @@ int tail_finish(const float* partials, int S, const float* resid, const float* g
 }
 // gelu_parts: out[r][c] (bf16) = gelu(sum over the S split-K partial matrices part[k][r][c]) (bias in partial 0), added in split order: the reduction
 // + activation behind the FFN-up GEMM of the tail rows (gelu_fast2, as the FFN-up epilogue of the big launches)
+// split_q > 0 (bf16x3 parity mode): rows of split_q quads; the value leaves as the [hi | hi | lo] split copy the next three-term GEMM reads (row pitch 12 split_q)
 __global__ __launch_bounds__(256) void gelu_parts_kernel(const f32x4* __restrict__ part, int S, bf16* __restrict__ out, size_t n4,
-                                                         const void* __restrict__ pf, size_t pf_bytes, int pf_blocks) {
+                                                         const void* __restrict__ pf, size_t pf_bytes, int pf_blocks, int split_q) {
     __shared__ __attribute__((aligned(16))) unsigned char pf_scratch[4 * 1024];
     if ((int)blockIdx.x < pf_blocks) {
         prefetch_region(pf, pf_bytes, blockIdx.x, pf_blocks, threadIdx.x, 256, pf_scratch);
@@ -830,18 +831,29 @@ __global__ __launch_bounds__(256) void gelu_parts_kernel(const f32x4* __restrict
         if (k < S) { a[0] += pb[k][0]; a[1] += pb[k][1]; a[2] += pb[k][2]; a[3] += pb[k][3]; }
     for (int k = SMAX; k < S; ++k) { const f32x4 b = part[(size_t)k * n4 + i]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
     const f32x2 g0 = gelu_fast2(f32x2{a[0], a[1]}), g1 = gelu_fast2(f32x2{a[2], a[3]});
+    const float gv[4] = {g0[0], g0[1], g1[0], g1[1]};
     bf16x4 o;
-    o[0] = (bf16)g0[0]; o[1] = (bf16)g0[1]; o[2] = (bf16)g1[0]; o[3] = (bf16)g1[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)gv[e];
+    if (split_q > 0) {
+        bf16x4 lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lo[e] = (bf16)(gv[e] - (float)o[e]);
+        const size_t r = i / (size_t)split_q, c = i - r * (size_t)split_q;
+        bf16x4* row = reinterpret_cast<bf16x4*>(out) + r * 3 * (size_t)split_q;
+        row[c] = o; row[(size_t)split_q + c] = o; row[2 * (size_t)split_q + c] = lo;
+        return;
+    }
     reinterpret_cast<bf16x4*>(out)[i] = o;
 }
-int gelu_parts(const float* partials, int S, void* out_bf16, size_t n, hipStream_t s, const void* pf, size_t pf_bytes) {
+int gelu_parts(const float* partials, int S, void* out_bf16, size_t n, hipStream_t s, const void* pf, size_t pf_bytes, int split_cols) {
     if (!partials || !out_bf16) return CPT_ERR_NULL;
-    if (S <= 0 || n == 0 || n % 4) return CPT_ERR_SHAPE;
+    if (S <= 0 || n == 0 || n % 4 || split_cols < 0 || split_cols % 4 || (split_cols && n % (size_t)split_cols)) return CPT_ERR_SHAPE;
     const size_t n4 = n / 4;
     const size_t nb = (n4 + 255) / 256;
     if (nb > (size_t)1 << 24) return CPT_ERR_SHAPE;
     const int pfb = (pf && pf_bytes && !((uintptr_t)pf & 15) && nb < 224) ? 224 - ((int)nb & ~7) : 0;
-    gelu_parts_kernel<<<dim3((unsigned)nb + pfb), dim3(256), 0, s>>>((const f32x4*)partials, S, (bf16*)out_bf16, n4, pfb ? pf : nullptr, pf_bytes, pfb);
+    gelu_parts_kernel<<<dim3((unsigned)nb + pfb), dim3(256), 0, s>>>((const f32x4*)partials, S, (bf16*)out_bf16, n4, pfb ? pf : nullptr, pf_bytes, pfb, split_cols / 4);
     return CPT_OK;
 }
 

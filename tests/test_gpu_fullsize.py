@@ -202,6 +202,15 @@ def test_config2_last_layer_on_head_rows_matches_all_rows(dev):
         assert 0 < diff < 0.025, diff
         assert (rows_only.argmax(-1) == all_rows.argmax(-1)).sum().item() >= 60      # (random-init weights: near-ties over 30522 words may flip)
     L.check(L.lib().cpt_set_tuning(14, 1))
+    # the bf16x3 parity mode's form of the same thing (K-split row GEMMs on the split operands): to the mode's own accuracy
+    m.set_compute_dtype("bf16x3")
+    rows_only = run().clone()
+    L.check(L.lib().cpt_set_tuning(31, 0))
+    all_rows = run().clone()
+    L.check(L.lib().cpt_set_tuning(31, 1))
+    m.set_compute_dtype("bf16")
+    diff = (rows_only - all_rows).abs().max().item()
+    assert torch.isfinite(rows_only).all() and 0 < diff < 2e-4, diff
 
 
 def test_config4_gqa_12_layers_b256(dev):
