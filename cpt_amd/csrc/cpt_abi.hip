@@ -577,6 +577,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const bool tail_x3 = g_tail && x3a && x3f && d.layers >= 2 && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) && want_mask != want_cls &&
                          H % 64 == 0 && I % 64 == 0 && S_h3 <= 24 && S_i3 <= 24 &&
                          std::max((size_t)S_h3 * B * (size_t)(H > I ? H : I), (size_t)S_i3 * B * H) * 4 <= (size_t)M * I * 4 && (size_t)B * I * 6 <= (size_t)M * 3 * H * 4;
+    // ... and for the fp32 mode: the same launches as its all-row form (cpt_gemm + layernorm_rows), on the B gathered rows
+    const bool tail_f32 = g_tail && d.dtype == CPT_F32 && d.layers >= 2 && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) && want_mask != want_cls;
     const size_t dec_bytes_t = (size_t)d.vocab * H * 2;
     const size_t dec_pf0_t = (want_mask && m->w_dec && g_prefetch) ? ((dec_bytes_t / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023) : 0;
     if (Me != M && !rpanel) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: padded rows outside the panel residual mode");
@@ -681,6 +683,20 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         }
         const bool lpr = lp && g_lp_resid;                       // residual operand read as bf16, fp32 copy not written
         const bool last = l + 1 == d.layers;
+        if (tail_f32 && last) {
+            Scope p(CPT_K_HEAD, s);
+            const int64_t* pos = want_mask ? b->mask_pos : nullptr;
+            float* xr = (float*)(ws + w.rows_f32);
+            void* ctx_r = qkv;                                 // (q | k | v of this layer are consumed)
+            TRY(cpt::gather_rows(ctx, dt, pos, ctx_r, B, L, H, s), "tail: gather(ctx rows)");
+            TRY(cpt::gather_rows(x_f32, CPT_F32, pos, xr, B, L, H, s), "tail: gather(residual rows)");
+            TRY(gm(CPT_EPI_RESID, ctx_r, H, y.w_ao, H, y.b_ao, xr, H, pre, CPT_F32, H, B, H), "tail: gemm(attn out)");
+            TRY(cpt::layernorm_rows(pre, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, nullptr, dt, B, H, B, 0, 0, s), "tail: layernorm(attn)");
+            TRY(gm(CPT_EPI_GELU, a_f32, H, y.w_in, H, y.b_in, nullptr, 0, ffn, dt, I, B, I), "tail: gemm(ffn up)");
+            TRY(gm(CPT_EPI_RESID, ffn, I, y.w_out, I, y.b_out, a_f32, H, pre, CPT_F32, H, B, H), "tail: gemm(ffn down)");
+            TRY(cpt::layernorm_rows(pre, y.ln2_g, y.ln2_b, d.ln_eps, (float*)(ws + w.rows), nullptr, dt, B, H, B, 0, 0, s), "tail: layernorm(ffn)");
+            break;
+        }
         if (tail_x3 && last) {
             Scope p(CPT_K_HEAD, s);
             const int64_t* pos = want_mask ? b->mask_pos : nullptr;
@@ -735,7 +751,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         void* rows = ws + w.rows;
         float* pooled = (flags & CPT_OUT_POOLED) ? o->pooled : (float*)(ws + w.pooled_f32);
         if (!pooled) return fail(CPT_ERR_NULL, "cpt_model_fwd: pooled output is NULL");
-        if (tail || tail_x3) {
+        if (tail || tail_x3 || tail_f32) {
             // rows = the [CLS] rows of the encoder output (written by the tail above)
         } else
         if (pre_ln) {
@@ -771,7 +787,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         const size_t dec_pf0 = (dec_bytes / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023;
         if (!all) {
             void* g = ws + w.rows;
-            if (tail || tail_x3) {
+            if (tail || tail_x3 || tail_f32) {
                 // g = the [MASK] rows of the encoder output (written by the tail above, which also carried the first part of the decoder prefetch)
             } else
             if (pre_ln) {
