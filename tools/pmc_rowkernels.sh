@@ -12,7 +12,7 @@ cd $R
 python - <<P
 import csv, glob, json, collections
 fam = lambda n: next((k for k in ("layernorm768_kernel", "layernorm_rows_kernel", "ln_bwd_kernel", "ln_bwd_reduce", "embed_pad_kernel", "embed_ln_kernel", "embed_bwd", "adamw_kernel", "head_rows_ln3", "head_finish", "pad_cast_kernel",
-                                    "colsum_kernel", "reduce_partials", "ce_rows", "zero_segments", "dropout_rows") if k in n), None)
+                                    "colsum_kernel", "reduce_partials", "ce_rows", "zero_segments", "dropout_rows", "b64_regions_kernel", "tail_rows_kernel", "tail_finish_kernel", "gelu_parts_kernel") if k in n), None)
 res = {}
 for leg in ("inf", "trn"):
     for C in ("FETCH_SIZE", "WRITE_SIZE"):
