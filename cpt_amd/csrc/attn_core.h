@@ -92,15 +92,29 @@ __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsi
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[kb][r] *= inv;
     // training: dropout on the probabilities (modeling_bert.py:57); bh = sequence * heads + head, q = this lane's query
+    // One Philox call yields the uniforms of TWO queries (2 x 4 block, dropout.h): the neighbour lanes q and q ^ 1 (same half-wave, same key
+    // quads) each run every other call and hand the partner its half through a quad-permute (round 6: 8 calls per lane instead of 16).
     if (dr.thresh != 0) {
+        const bool odd = lane & 1;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bool keep[4];
-                drop_attn_row4(dr, bh, q, kb * 8 + 2 * g + fh, keep);
+            for (int gp = 0; gp < 2; ++gp) {
+                uint32_t u[4];
+                drop_attn_call(dr, bh, (uint32_t)q >> 2, (uint32_t)(kb * 8 + 2 * (2 * gp + (odd ? 1 : 0)) + fh), ((uint32_t)q >> 1) & 1, u);
+                const uint32_t m0 = odd ? u[2] : u[0], m1 = odd ? u[3] : u[1];      // this query's row of this lane's call
+                const uint32_t r0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd ? u[0] : u[2]), 0xb1, 0xf, 0xf, true);   // the partner's call, this query's row
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(odd ? u[1] : u[3]), 0xb1, 0xf, 0xf, true);
+                const uint32_t e0 = odd ? r0 : m0, e1 = odd ? r1 : m1;              // key quad g = 2 gp
+                const uint32_t o0 = odd ? m0 : r0, o1 = odd ? m1 : r1;              // key quad g = 2 gp + 1
+                const uint32_t w[2][2] = {{e0, e1}, {o0, o1}};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) st[kb][4 * g + j] = keep[j] ? st[kb][4 * g + j] * dr.scale : 0.f;
+                for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool keep = ((w[gg][j >> 1] >> ((j & 1) * 16)) & 0xffffu) >= dr.thresh;
+                        st[kb][4 * (2 * gp + gg) + j] = keep ? st[kb][4 * (2 * gp + gg) + j] * dr.scale : 0.f;
+                    }
             }
     }
 

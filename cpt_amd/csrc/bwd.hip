@@ -858,9 +858,10 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
     float* sMask = reinterpret_cast<float*>(tO + 64 * TROW);   // [LP]
     if constexpr (TR) { tQ = sQ; tK = sK; tO = sO; sMask = reinterpret_cast<float*>(sO + LP * 128); }
     auto roff = [](int row, int chunk) { return TR ? kq_off_tr(row, chunk) : kq_off(row, chunk); };
-    float* sM = sMask + LP;                            // row max
+    float* sM = sMask + LP;                            // row max (base 2, like the forward kernel's softmax)
     float* sLi = sM + LP;                              // 1 / row sum
     float* sD = sLi + LP;                              // rowsum(dP * P)
+    uint32_t* sBits = reinterpret_cast<uint32_t*>(sD + LP);   // [NKB][LP] keep bits of the attention dropout: bit (key & 31) of word [key >> 5][query]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
@@ -869,15 +870,22 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
     const bf16* base = qkv + (size_t)b * L * ldq + h * 64;
     bf16* dbase = dqkv + (size_t)b * L * ldq + h * 64;
 
-    for (int idx = tid; idx < LP * 8; idx += 256) {
+    // L <= 128: all global loads first (LP * 8 sixteen-byte chunks per tile = NKB per thread), the dropout bit plane under their latency, then the
+    // LDS writes.  Longer sequences (NKB >= 5: 144 staging registers at NKB = 9 would spill) fill the bit plane first and load tile rows in a loop.
+    constexpr int NST = NKB <= 4 ? NKB : 1;
+    uint4 rq[NST], rk[NST], rv[NST], ro[NST];
+    auto ld4 = [&](int idx, uint4& q4, uint4& k4, uint4& v4, uint4& o4) {
         const int r = idx >> 3, c = idx & 7;
-        uint4 q4 = make_uint4(0, 0, 0, 0), k4 = q4, v4 = q4, o4 = q4;
+        q4 = make_uint4(0, 0, 0, 0); k4 = q4; v4 = q4; o4 = q4;
         if (r < L) {
             q4 = *reinterpret_cast<const uint4*>(base + (size_t)r * ldq + c * 8);
             k4 = *reinterpret_cast<const uint4*>(base + (size_t)r * ldq + H + c * 8);
             v4 = *reinterpret_cast<const uint4*>(base + (size_t)r * ldq + 2 * H + c * 8);
             o4 = *reinterpret_cast<const uint4*>(dctx + ((size_t)b * L + r) * H + h * 64 + c * 8);
         }
+    };
+    auto st4 = [&](int idx, const uint4& q4, const uint4& k4, const uint4& v4, const uint4& o4) {
+        const int r = idx >> 3, c = idx & 7;
         *reinterpret_cast<uint4*>(sQ + roff(r, c)) = q4;
         *reinterpret_cast<uint4*>(sK + roff(r, c)) = k4;
         *reinterpret_cast<uint4*>(sV + roff(r, c)) = v4;
@@ -893,11 +901,41 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
             *reinterpret_cast<bf16*>(tO + (c * 8 + j) * TROW + r * 2) = oe[j];
         }
         }
+    };
+    if constexpr (NKB <= 4) {
+#pragma unroll
+        for (int it = 0; it < NKB; ++it) ld4(tid + it * 256, rq[it], rk[it], rv[it], ro[it]);
     }
-    for (int key = tid; key < LP; key += 256) {
+    float mreg[(LP + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (LP + 255) / 256; ++i) {
+        const int key = tid + i * 256;
         float mv = -INFINITY;
         if (key < L) mv = attn_mask ? (1.0f - (float)attn_mask[(size_t)b * L + key]) * -10000.0f : 0.f;
-        sMask[key] = mv;
+        mreg[i] = mv * ATT_LOG2E;
+    }
+    if (dr.thresh != 0) {
+        // units of (query pair, 32-key block): eight Philox calls each, LP / 2 * NKB units over 256 threads (NKB = 4: one per thread)
+        for (int u = tid; u < (LP / 2) * NKB; u += 256) {
+            const int rp = u / NKB, kb = u % NKB;
+            uint32_t w0 = 0, w1 = 0;
+            if (2 * rp < L && kb * 32 < L) drop_attn_bits2x32(dr, (uint32_t)blockIdx.x, (uint32_t)rp, (uint32_t)kb, w0, w1);
+            *reinterpret_cast<uint2*>(&sBits[kb * LP + 2 * rp]) = make_uint2(w0, w1);
+        }
+    }
+    if constexpr (NKB <= 4) {
+#pragma unroll
+        for (int it = 0; it < NKB; ++it) st4(tid + it * 256, rq[it], rk[it], rv[it], ro[it]);
+    } else {
+        for (int idx = tid; idx < LP * 8; idx += 256) {
+            ld4(idx, rq[0], rk[0], rv[0], ro[0]);
+            st4(idx, rq[0], rk[0], rv[0], ro[0]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (LP + 255) / 256; ++i) {
+        const int key = tid + i * 256;
+        if (key < LP) sMask[key] = mreg[i];           // additive mask times log2(e): the softmax runs in base 2 (one v_exp_f32 per score), as in the forward kernel
     }
     __syncthreads();
 
@@ -955,7 +993,7 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = st[kb][r] * 0.125f + sMask[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+                const float v = st[kb][r] * (0.125f * ATT_LOG2E) + sMask[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
                 st[kb][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -964,10 +1002,9 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float e = expf(st[kb][r] - mx); st[kb][r] = e; sum += e; }
+            for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(st[kb][r] - mx); st[kb][r] = e; sum += e; }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
-        const int qd = min(qb * 32 + fr, L - 1);
         bf16x8 fo[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fo[ks] = rowfrag(sO, qb * 32 + fr, ks);
@@ -978,14 +1015,10 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sV, kb * 32 + fr, ks), fo[ks], d, 0, 0, 0);
-            if (dr.thresh != 0) {
+            if (dr.thresh != 0) {      // keep bit of (this lane's query, key kb * 32 + 8 g + 4 fh + j) = bit 8 g + 4 fh + j of the plane's word
+                const uint32_t wbits = sBits[kb * LP + qb * 32 + fr] >> (4 * fh);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bool keep[4];
-                    drop_attn_row4(dr, (uint32_t)blockIdx.x, qd, kb * 8 + 2 * g + fh, keep);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) d[4 * g + j] = keep[j] ? d[4 * g + j] * dr.scale : 0.f;
-                }
+                for (int r = 0; r < 16; ++r) d[r] = ((wbits >> (8 * (r >> 2) + (r & 3))) & 1u) ? d[r] * dr.scale : 0.f;
             }
             return d;
         };
@@ -1048,7 +1081,7 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = st[kb][r] * 0.125f + sMask[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+                const float v = st[kb][r] * (0.125f * ATT_LOG2E) + sMask[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
                 st[kb][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -1057,20 +1090,16 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float e = expf(st[kb][r] - mx); st[kb][r] = e; sum += e; }
+            for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(st[kb][r] - mx); st[kb][r] = e; sum += e; }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
         if (dr.thresh != 0) {       // dp is the gradient of the DROPPED probabilities: times mask / (1-p) (same mask as forward)
-            const int qd = min(qb * 32 + fr, L - 1);
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
+            for (int kb = 0; kb < NKB; ++kb) {
+                const uint32_t wbits = sBits[kb * LP + qb * 32 + fr] >> (4 * fh);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bool keep[4];
-                    drop_attn_row4(dr, (uint32_t)blockIdx.x, qd, kb * 8 + 2 * g + fh, keep);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dp[kb][4 * g + j] = keep[j] ? dp[kb][4 * g + j] * dr.scale : 0.f;
-                }
+                for (int r = 0; r < 16; ++r) dp[kb][r] = ((wbits >> (8 * (r >> 2) + (r & 3))) & 1u) ? dp[kb][r] * dr.scale : 0.f;
+            }
         }
         float dd = 0.f;
 #pragma unroll
@@ -1132,25 +1161,25 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
                 sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sQ, qb * 32 + fr, ks), rowfrag(sK, kb * 32 + fr, ks), sb, 0, 0, 0);
                 db_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sO, qb * 32 + fr, ks), rowfrag(sV, kb * 32 + fr, ks), db_, 0, 0, 0);
             }
-            float wgt[16];
+            // registers 4 g .. 4 g + 3 = queries qb * 32 + 8 g + 4 fh + (0..3): their statistics (and dropout words) come as 16-byte LDS reads.
+            // Dropout: lane = key, so the keep bit is bit fr of the word (this key block, query) -- one word for the 32 lanes of a half-wave (broadcast).
 #pragma unroll
-            for (int r = 0; r < 16; ++r) wgt[r] = 1.f;
-            if (dr.thresh != 0) {   // lane = key, register quads = 4 consecutive queries
-                const int kd = min(kb * 32 + fr, L - 1);
+            for (int g = 0; g < 4; ++g) {
+                const int q0 = qb * 32 + 8 * g + 4 * fh;
+                const float4 m4 = *reinterpret_cast<const float4*>(&sM[q0]), l4 = *reinterpret_cast<const float4*>(&sLi[q0]), d4 = *reinterpret_cast<const float4*>(&sD[q0]);
+                uint4 b4 = make_uint4(0, 0, 0, 0);
+                if (dr.thresh != 0) b4 = *reinterpret_cast<const uint4*>(&sBits[kb * LP + q0]);
+                const float mq[4] = {m4.x, m4.y, m4.z, m4.w}, lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
+                const uint32_t bq[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bool keep[4];
-                    drop_attn_col4(dr, (uint32_t)blockIdx.x, qb * 8 + 2 * g + fh, kd, keep);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wgt[4 * g + j] = keep[j] ? dr.scale : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    const float p = __builtin_amdgcn_exp2f(sb[r] * (0.125f * ATT_LOG2E) + mk - mq[j]) * lq[j];
+                    float wgt = 1.f;
+                    if (dr.thresh != 0) wgt = ((bq[j] >> fr) & 1u) ? dr.scale : 0.f;
+                    sb[r] = p * wgt;                                      // dropped probabilities -> dV
+                    db_[r] = p * (db_[r] * wgt - dq[j]);                  // dS -> dK
                 }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const float p = expf(sb[r] * 0.125f + mk - sM[q]) * sLi[q];
-                sb[r] = p * wgt[r];                                   // dropped probabilities -> dV
-                db_[r] = p * (db_[r] * wgt[r] - sD[q]);               // dS -> dK
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -1190,7 +1219,7 @@ template <int NKB, bool TR = false>
 static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int heads, const DropSpec& dr,
                                 hipStream_t s, float* dbias) {
     constexpr int LP = NKB * 32;
-    const size_t lds = (size_t)4 * LP * 128 + (TR ? 0 : (size_t)3 * 64 * (LP * 2 + 8)) + (size_t)4 * LP * sizeof(float);
+    const size_t lds = (size_t)4 * LP * 128 + (TR ? 0 : (size_t)3 * 64 * (LP * 2 + 8)) + (size_t)4 * LP * sizeof(float) + (size_t)LP * NKB * 4;      // + the dropout bit plane
     auto k = attn_bwd_mfma_kernel<NKB, TR>;
     static bool done = false;
     if (lds > 64 * 1024 && !done) {

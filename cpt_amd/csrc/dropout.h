@@ -71,6 +71,22 @@ __host__ __device__ __forceinline__ void drop_attn_col4(const DropSpec& d, uint3
         keep[2 * half + 1] = drop_u16(u, 4 + (k & 3)) >= d.thresh;
     }
 }
+// keep bits of (queries 2 rp, 2 rp + 1) x (keys 32 kb .. 32 kb + 31): eight calls, bit i of w0 / w1 = key 32 kb + i of the even / odd query.
+// The attention backward fills a [query][key / 32] bit plane in LDS with these once per (sequence, head) -- every uniform computed once per
+// workgroup instead of once per lane that touches its 2 x 4 block in each of the kernel's passes (round 6: the Philox rounds were ~3/4 of that kernel's time).
+__host__ __device__ __forceinline__ void drop_attn_bits2x32(const DropSpec& d, uint32_t bh, uint32_t rp, uint32_t kb, uint32_t& w0, uint32_t& w1) {
+    w0 = 0; w1 = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+        uint32_t u[4];
+        drop_attn_call(d, bh, rp >> 1, kb * 8 + i, rp & 1, u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w0 |= (drop_u16(u, j) >= d.thresh ? 1u : 0u) << (4 * i + j);
+            w1 |= (drop_u16(u, 4 + j) >= d.thresh ? 1u : 0u) << (4 * i + j);
+        }
+    }
+}
 __host__ __device__ __forceinline__ bool drop_attn_one(const DropSpec& d, uint32_t bh, int q, int k) {
     uint32_t u[4];
     drop_attn_call(d, bh, (uint32_t)q >> 2, (uint32_t)k >> 2, ((uint32_t)q >> 1) & 1, u);

@@ -1,12 +1,14 @@
-"""Per-step table of a rocprofv3 kernel_stats.csv: python tools/kstats.py file.csv steps [top]"""
-import csv
-import sys
-
-rows = list(csv.DictReader(open(sys.argv[1])))
-steps = float(sys.argv[2])
-top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-for r in rows[:top]:
-    print("%-96s %7.1f/step %8.1f us  %7.3f ms/step" % (r["Name"][:96], int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3,
-                                                        float(r["TotalDurationNs"]) / 1e6 / steps))
-print("total %.3f ms/step, %.0f launches/step" % (tot / 1e6 / steps, sum(int(r["Calls"]) for r in rows) / steps))
+#!/usr/bin/env python3
+"""Per-step view of a rocprofv3 kernel_stats.csv: launches per step, average duration, time per step.   usage: tools/kstats.py file.csv steps [min_us]"""
+import csv, re, sys
+f, steps = sys.argv[1], int(sys.argv[2])
+mn = float(sys.argv[3]) if len(sys.argv) > 3 else 15.0
+rows = list(csv.DictReader(open(f)))
+tot = n = 0.0
+for r in rows:
+    c = int(r["Calls"]) / steps; t = int(r["TotalDurationNs"]) / steps / 1e3
+    tot += t; n += c
+    nm = re.sub(r"\(.*", "", r["Name"])[:100]
+    if t > mn:
+        print("%6.1f x %7.1f us = %7.1f us/step  %s" % (c, float(r["AverageNs"]) / 1e3, t, nm))
+print("total %.1f us/step, %.1f launches/step" % (tot, n))
