@@ -207,17 +207,59 @@ int gelu_bwd(const void* dh, const void* u, void* du, int dtype, size_t n, hipSt
 // in the forward).  dx (fp32) and dx_lp (optional) are written compact at row r; dg/db accumulated
 // with one atomicAdd per column per workgroup.
 constexpr int LNB_MAXV = 4;
+
+// Column-sum jobs that ride at the end of another launch's grid (round 6): dst[c / seg][c % seg] += sum over `rows` of src[r * row_stride + c].
+// The training backward leaves per-workgroup partial rows (LayerNorm gamma / beta / dense-bias sums, the FFN-up bias sums of the GELU-gradient
+// GEMM) and lets the NEXT row pass add them up in spare workgroups instead of paying a launch per reduction (24 launches of 4.9 us per step).
+__device__ __forceinline__ void col_job_run(const ColJob& jb, int j) {
+    const int gx = (jb.cols + 255) / 256;
+    const int c = (j % gx) * 256 + threadIdx.x, r0 = (j / gx) * 16;
+    if (c >= jb.cols) return;
+    float v[16];                                        // all loads in flight before the first add
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (r0 + k < jb.rows) ? jb.src[(size_t)(r0 + k) * jb.row_stride + c] : 0.f;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += v[k];
+    const int sg = c / jb.seg;
+    atomicAdd((sg == 0 ? jb.dst0 : (sg == 1 ? jb.dst1 : jb.dst2)) + (c - sg * jb.seg), a);
+}
+__device__ __forceinline__ void col_jobs_run(const ColJobs& jobs, int j) {
+    for (int k = 0; k < jobs.n; ++k) {
+        const int nj = ((jobs.j[k].cols + 255) / 256) * ((jobs.j[k].rows + 15) / 16);
+        if (j < nj) { col_job_run(jobs.j[k], j); return; }
+        j -= nj;
+    }
+}
+int col_jobs_blocks(const ColJobs* jobs) {
+    int n = 0;
+    if (jobs) for (int k = 0; k < jobs->n; ++k) n += ((jobs->j[k].cols + 255) / 256) * ((jobs->j[k].rows + 15) / 16);
+    return n;
+}
+__global__ __launch_bounds__(256) void col_jobs_kernel(ColJobs jobs) { col_jobs_run(jobs, blockIdx.x); }
+int col_jobs_flush(const ColJobs& jobs, hipStream_t s) {
+    const int n = col_jobs_blocks(&jobs);
+    if (n > 0) col_jobs_kernel<<<dim3(n), dim3(256), 0, s>>>(jobs);
+    return CPT_OK;
+}
+
 template <typename LP, bool GELU_IN, int NA = 4>      // NA: float4 per lane per row array (4: any H <= 1024; 3: the H = 768 instantiation -- a quarter fewer registers, 36 instead of 48 KB of staging: four workgroups per CU)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                     const float* __restrict__ g, float eps, float* __restrict__ dx,
+                                                     const float* __restrict__ g, float eps, float* dx,      // (dx may be dy_resid's buffer: every row is read before it is written)
                                                      LP* __restrict__ dx_lp, float* __restrict__ dg, float* __restrict__ db,
                                                      int R, int H, int grp, int grp_stride, int grp_off, int rows_per_block,
-                                                     float* __restrict__ part, DropSpec dr, float* __restrict__ dbias) {
+                                                     float* __restrict__ part, DropSpec dr, float* __restrict__ dbias,
+                                                     const float* __restrict__ stats, int dy_parts, size_t dy_stride, const float* dy_resid,
+                                                     int nb_main, ColJobs jobs) {
     // dr / dbias (training backward of LN(dropout(dense) + residual), round 2): dx_lp receives the gradient that enters the dense
     // layer -- dx through the dropout mask of the forward (regenerated, dropout.h; thresh 0: identity) -- and dbias its column
     // sums = the gradient of the dense bias; dx itself stays unmasked (it feeds the residual path).  Replaces a dropout_rows and
     // a colsum launch per LayerNorm.
+    // Round 6: stats = the forward's (mean, rstd) per row (two of the three dependent wave reductions per row go away);
+    // dy_parts / dy_stride / dy_resid = the incoming gradient as split-K partial matrices of the data-gradient GEMM in front (+ its residual),
+    // added here in split order instead of by a reduction launch; workgroups from nb_main on run the column-sum jobs of EARLIER launches.
     constexpr int LNB_MAXV = NA;
+    if ((int)blockIdx.x >= nb_main) { col_jobs_run(jobs, (int)blockIdx.x - nb_main); return; }
     __shared__ float red[3][4][256 * LNB_MAXV];     // [dg|db|dbias][wave][column]  (48 KB; 36 KB at NA = 3)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = (H + 255) / 256;
@@ -259,14 +301,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     // round 3: the NEXT row's x and dy are requested before this row is reduced (a wave walks two rows at eight rows per workgroup: the second
     // row's memory round trip used to start only after the first row's four wave reductions and stores)
     f32x4 nx[LNB_MAXV], nd[LNB_MAXV];
+    float2 nst = {0.f, 1.f};
     auto fetch = [&](int r) {
         const size_t yr = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
+        if (stats) nst = *reinterpret_cast<const float2*>(stats + 2 * (size_t)__builtin_amdgcn_readfirstlane(r));
 #pragma unroll
         for (int i = 0; i < LNB_MAXV; ++i) {
             const int c = (lane + 64 * i) * 4;
             if (i < nv && c < H) {
                 nx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
                 nd[i] = *reinterpret_cast<const f32x4*>(dy + yr * H + c);
+                for (int k = 1; k < dy_parts; ++k) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(dy + (size_t)k * dy_stride + yr * H + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nd[i][j] += t[j];
+                }
+                if (dy_resid) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(dy_resid + yr * H + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nd[i][j] += t[j];
+                }
             }
         }
     };
@@ -274,6 +328,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int r = r0 + wave; r < r1; r += 4) {
         f32x4 xv[LNB_MAXV], dv[LNB_MAXV], uv[LNB_MAXV];
         float s = 0.f;
+        const float2 st = nst;
 #pragma unroll
         for (int i = 0; i < LNB_MAXV; ++i) { xv[i] = nx[i]; dv[i] = nd[i]; }
         if (r + 4 < r1) fetch(r + 4);
@@ -289,7 +344,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 s += xv[i][0] + xv[i][1] + xv[i][2] + xv[i][3];
             }
         }
-        const float mean = wave_sum(s) / (float)H;
+        float mean, rstd;
+        if (stats) { mean = st.x; rstd = st.y; }
+        else {
+        mean = wave_sum(s) / (float)H;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < LNB_MAXV; ++i)
@@ -297,7 +355,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const float d = xv[i][j] - mean; q += d * d; }
             }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+        rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+        }
         float s1 = 0.f, s2 = 0.f;     // sum(dy*g), sum(dy*g*xhat)
 #pragma unroll
         for (int i = 0; i < LNB_MAXV; ++i)
@@ -363,7 +422,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
     __syncthreads();
     const int nsum = dbias ? 3 : 2;
-    if (part) {     // two-stage column sums: this block's partial rows [nsum][H], added up by ln_bwd_reduce_kernel
+    if (part) {     // two-stage column sums: this block's partial rows [nsum][H], added up by ln_bwd_reduce_kernel or a later launch's column-sum job
         for (int c = threadIdx.x; c < H; c += 256)
             for (int k = 0; k < nsum; ++k)
                 part[((size_t)blockIdx.x * nsum + k) * H + c] = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
@@ -395,27 +454,39 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 CPT_SWITCH(int g_lnb_rpb, 0);       // cpt_set_tuning(17, rows): rows per workgroup of the two-stage form (0: 8 from 2048 rows on, else 4 = one row per wave)
 void set_lnb_rpb(int v) { CPT_SWITCH_SET(g_lnb_rpb = v > 0 ? v : 0); (void)v; }
 
+// rows per workgroup / partial rows of the two-stage form for R rows (the training step sizes its partial buffers and chains its reductions with these)
+static int ln_bwd_rpb_two_stage(int R) { return g_lnb_rpb > 0 ? g_lnb_rpb : (R >= 2048 ? 8 : 4); }
+int ln_bwd_part_rows(int R) { const int rpb = ln_bwd_rpb_two_stage(R); return (R + rpb - 1) / rpb; }
+
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
-           float* part, size_t part_bytes, const DropSpec* drop, float* dbias) {
+           float* part, size_t part_bytes, const DropSpec* drop, float* dbias, const LnBwdExtra* ext) {
     const DropSpec dr = drop ? *drop : DropSpec{};
     if ((dr.thresh != 0 || dbias) && (!g || grp != R)) return CPT_ERR_SHAPE;      // mask / bias sums: compact rows only
     const int nsum = dbias ? 3 : 2;
     if (R <= 0 || H % 4 || H > 256 * LNB_MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!dy || (g && (!x || !dg || !db))) return CPT_ERR_NULL;      // g == NULL: identity (row gather only)
+    const LnBwdExtra e0 = {};
+    const LnBwdExtra& ex = ext ? *ext : e0;
+    if (ex.dy_parts > 1 && (grp != R || !g)) return CPT_ERR_SHAPE;
+    if (ex.defer_reduce && !(g && part && (size_t)ln_bwd_part_rows(R) * nsum * H * 4 <= part_bytes)) return CPT_ERR_WORKSPACE;
     // rows per block: with atomics fewer blocks = fewer dgamma/dbeta atomics (2*H per block); with a partial-sum buffer (two-stage
     // column sums) one row per wave keeps 4x the rows in flight: the kernel is latency-bound otherwise (22 -> ~10 us at 3840 rows)
     int rpb = R >= 2048 ? 16 : 8;
-    if (g && part && R >= 1024 && (size_t)((R + 3) / 4) * nsum * H * 4 <= part_bytes) rpb = g_lnb_rpb > 0 ? g_lnb_rpb : (R >= 2048 ? 8 : 4); else part = nullptr;      // 8: two rows per wave, half the partial rows (3840 rows: 5.83 vs 5.89 ms per step; 960 blocks of 4 rows are 1.25 rounds of the 3 blocks per CU the 48 KB staging array allows)
-    dim3 grid((R + rpb - 1) / rpb), block(256);
+    if (g && part && (R >= 1024 || ex.defer_reduce) && (size_t)ln_bwd_part_rows(R) * nsum * H * 4 <= part_bytes) rpb = ln_bwd_rpb_two_stage(R); else part = nullptr;      // 8: two rows per wave, half the partial rows (3840 rows: 5.83 vs 5.89 ms per step; 960 blocks of 4 rows are 1.25 rounds of the 3 blocks per CU the 48 KB staging array allows)
+    const int nb = (R + rpb - 1) / rpb;
+    const ColJobs j0 = {};
+    const ColJobs& jobs = ex.jobs ? *ex.jobs : j0;
+    dim3 grid(nb + col_jobs_blocks(&jobs)), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
-#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias); \
-                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias); } while (0)
+    const int dyp = ex.dy_parts > 1 ? ex.dy_parts : 1;
+#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs); \
+                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs); } while (0)
     if (lp16) { if (gelu_in) LNB(bf16, true); else LNB(bf16, false); }
     else      { if (gelu_in) LNB(float, true); else LNB(float, false); }
 #undef LNB
-    if (part) {
-        const int nb = (int)grid.x, per = 16;
+    if (part && !ex.defer_reduce) {
+        const int per = 16;
         ln_bwd_reduce_kernel<<<dim3((nsum * H + 255) / 256, (nb + per - 1) / per), dim3(256), 0, s>>>(part, dg, db, dbias, nb, H, per);
     }
     return CPT_OK;

@@ -177,6 +177,7 @@ struct EpiX {
     size_t split_stride;   // split-K partial matrices: elements between two splits' outputs (0: M * ldo)
     int x3_k;              // GELU_X3: columns of one part of the split copy (= N)
     float* colsum;         // GELUGRAD (training backward): += column sums of the finished output = the gradient of the bias in front of the GELU
+    int colsum_rows;       // 0: colsum[N] takes atomic adds; > 0 (round 6): colsum is [colsum_rows][N] partial rows, one per 32-row wave block of the output (row = first row / 32), written with plain stores and added up by a later launch's column-sum job (kernels.h ColJob)
     int skew;              // two-workgroups-per-CU shapes: start delay of every second workgroup (see skew_start)
 };
 
@@ -1022,7 +1023,7 @@ __device__ __forceinline__ void gemm_pipe_body(
                                 }
                                 else out[(size_t)row * ldo + col + e] = from_f32<OT>(x);
                                 if constexpr (LNPROD) reinterpret_cast<T*>(ex.out_lp)[(size_t)row * ldo + col + e] = from_f32<T>(x);
-                                if constexpr (GG) { if (ex.colsum) atomicAdd(ex.colsum + col + e, x); }
+                                if constexpr (GG) { if (ex.colsum && ex.colsum_rows == 0) atomicAdd(ex.colsum + col + e, x); }      // (the partial-row form needs the vector epilogues: gemm_nn checks their conditions)
                                 }
                                 fin[e] = x;
                             }
@@ -1057,18 +1058,29 @@ __device__ __forceinline__ void gemm_pipe_body(
         }
         if constexpr (FULL && GG) {
             if (ex.colsum) {
-                for (int c = lane; c < WCOLS; c += 64) side_g[c] = 0.f;
+                // round 6: the P quads of every lane go to the wave's (now free) slab as [P][64][4]; column c = chunk ch, element e then adds the lanes
+                // that met chunk ch -- lanes l = (ch - 64 q) mod CH, + CH, ... of quad q -- with plain LDS reads (no LDS atomics)
+                static_assert(!GG || P * 64 * 16 <= 16 * CPW, "column sums: the wave's slab holds the lanes' quads");
+                float* stq = reinterpret_cast<float*>(slab);
+#pragma unroll
+                for (int q = 0; q < P; ++q) *reinterpret_cast<f32x4*>(stq + (q * 64 + lane) * 4) = cs[q];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int c = lane; c < WCOLS; c += 64) {
+                    const int ch = c >> 2, e = c & 3;
+                    float t = 0.f;
 #pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    const int ch = (q * 64 + lane) % CH;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)      // explicit LDS atomic (ds_add_f32): a flat fp32 atomic add that lands in the LDS aperture is dropped
-                        __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)(side_g + ch * 4 + e), cs[q][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+                    for (int q = 0; q < P; ++q) {
+                        const int l0 = ((ch - (q * 64) % CH) + CH) % CH;
+                        for (int l = l0; l < 64; l += CH) t += stq[(q * 64 + l) * 4 + e];
+                    }
+                    if (GUARD && wcol0 + c >= N) continue;
+                    if (ex.colsum_rows > 0) {      // this wave's 32 x WCOLS block owns row wrow0 / 32 of the partial table
+                        static_assert(!GG || MI == 1, "column-sum partial rows: one 32-row block per wave");
+                        if ((wrow0 >> 5) < ex.colsum_rows) ex.colsum[(size_t)(wrow0 >> 5) * N + wcol0 + c] = t;
+                    } else {
+                        atomicAdd(ex.colsum + wcol0 + c, t);
+                    }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                for (int c = lane; c < WCOLS; c += 64)
-                    if (!GUARD || wcol0 + c < N) atomicAdd(ex.colsum + wcol0 + c, side_g[c]);
             }
         }
     };
@@ -1581,8 +1593,10 @@ int gemm_nn_eligible(int M, int N, int K, int lda, int ldw) {
 }
 
 int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
-            hipStream_t s, int w_rows, void* partials, size_t partial_bytes, const void* gelu_u, int ldu, float* gelu_colsum) {
+            hipStream_t s, int w_rows, void* partials, size_t partial_bytes, const void* gelu_u, int ldu, float* gelu_colsum, int colsum_rows, int* S_out) {
+    if (S_out) *S_out = 1;
     if (!gemm_nn_eligible(M, N, K, lda, ldw)) return CPT_ERR_SHAPE;
+    if (colsum_rows > 0 && (colsum_rows < (M + 31) / 32 || ldo % 4 || ldu % 8)) return CPT_ERR_SHAPE;      // partial-row bias sums: one row per 32-row wave block, vector epilogue
     if (!A || !W || !out) return CPT_ERR_NULL;
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)resid | (uintptr_t)partials) & 15)) return CPT_ERR_ALIGN;
     if (w_rows < 0 || w_rows > K) return CPT_ERR_SHAPE;
@@ -1594,6 +1608,7 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
     EpiX ex = {};
     ex.w_rows = w_rows;
     ex.colsum = gelu_u ? gelu_colsum : nullptr;
+    ex.colsum_rows = gelu_u && gelu_colsum ? colsum_rows : 0;
     // few output tiles and a long contraction (the decoder's data gradient: 32 x 768 outputs over K = 30528 ran on 4 CUs for 220 us):
     // split K over up to 64 workgroups per tile, partial matrices added in split order
     if (out_dtype == CPT_F32 && (!resid || ldr == N) && partials && ldo == N && n192) {
@@ -1607,6 +1622,7 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
         if (S >= 4) {
             int rc = launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, nullptr, 0, (float*)partials, ldo, M, N, K, s, S, &ex);
             if (rc != CPT_OK) return rc;
+            if (S_out) { *S_out = S; return CPT_OK; }      // the caller's consumer adds the S partial matrices (and the residual) itself
             const size_t n4 = mat / 16;
             reduce_partials_kernel<<<dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S,
                                                                                                                   (const f32x4*)resid);

@@ -56,10 +56,30 @@ int transpose_cast(const void* in, int in_dtype, int ldi, void* out, int out_dty
 int colsum(const void* x, int dtype, int ld, float* out, int R, int C, hipStream_t s);
 int gelu_fwd(const void* u, void* h, int dtype, size_t n, hipStream_t s);
 int gelu_bwd(const void* dh, const void* u, void* du, int dtype, size_t n, hipStream_t s);
+// column-sum jobs (round 6): dst[c / seg][c % seg] += sum over `rows` of src[r * row_stride + c]; up to four ride in the spare workgroups of a
+// LayerNorm backward launch (LnBwdExtra::jobs) or go out on their own (col_jobs_flush) -- the deferred second stage of earlier launches' partial sums
+struct ColJob { const float* src; float *dst0, *dst1, *dst2; int rows, cols, row_stride, seg; };
+struct ColJobs { ColJob j[4]; int n; };
+int col_jobs_flush(const ColJobs& jobs, hipStream_t s);
+inline bool col_jobs_add(ColJobs& q, const float* src, int rows, int cols, int row_stride, int seg, float* d0, float* d1 = nullptr, float* d2 = nullptr) {
+    if (q.n >= 4) return false;
+    q.j[q.n++] = ColJob{src, d0, d1, d2, rows, cols, row_stride, seg};
+    return true;
+}
+struct LnBwdExtra {
+    const float* stats;       // [R][2] (mean, rstd) of the forward (layernorm_rows_ex stat_out): the row statistics are not recomputed
+    int dy_parts;             // > 1: dy holds that many split-K partial matrices dy_stride elements apart (compact rows only), added in split order
+    size_t dy_stride;
+    const float* dy_resid;    // + this (the residual of the data-gradient GEMM whose partials dy holds)
+    const ColJobs* jobs;      // column-sum jobs of earlier launches, run by extra workgroups of this one
+    int defer_reduce;         // 1: leave this launch's partial rows [ln_bwd_part_rows(R)][2 or 3][H] in `part` for a later job instead of launching the reduction
+};
+int ln_bwd_part_rows(int R);
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
            float* part = nullptr, size_t part_bytes = 0,       // part: scratch for two-stage column sums ((R / 4) * 3 * H floats)
-           const DropSpec* drop = nullptr, float* dbias = nullptr);   // drop: dx_lp = dx through that hidden-site mask; dbias += column sums of it
+           const DropSpec* drop = nullptr, float* dbias = nullptr,    // drop: dx_lp = dx through that hidden-site mask; dbias += column sums of it
+           const LnBwdExtra* ext = nullptr);
 int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
               const float* posw, const float* typew, const float* g, float eps, float* dword, float* dposw,
               float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,
@@ -89,7 +109,7 @@ int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
                       const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr,
-                      int x_parts = 1, size_t x_stride = 0, int out_panel = 0);     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
+                      int x_parts = 1, size_t x_stride = 0, int out_panel = 0, float* stat_out = nullptr);     // stat_out (round 6): [R][2] (mean, rstd) of every row, for ln_bwd     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
 // resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients
@@ -112,7 +132,9 @@ int gemm_tn_triple(const void* A0, int lda0, const void* W0, int ldw0, float* ou
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw);
 int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
             hipStream_t s, int w_rows = 0, void* partials = nullptr, size_t partial_bytes = 0, const void* gelu_u = nullptr, int ldu = 0,
-            float* gelu_colsum = nullptr);     // gelu_colsum [N] (with gelu_u): += column sums of out (fp32, before the bf16 rounding) = the gradient of the bias in front of the GELU
+            float* gelu_colsum = nullptr,      // gelu_colsum [N] (with gelu_u): += column sums of out (fp32, before the bf16 rounding) = the gradient of the bias in front of the GELU
+            int colsum_rows = 0,               // > 0 (round 6): gelu_colsum is [colsum_rows >= M / 32][N] partial rows (plain stores, one per 32-row wave block) for a later column-sum job
+            int* S_out = nullptr);             // non-NULL (round 6): where the launch splits K, leave the *S_out partial matrices in `partials` (no reduction launch, resid NOT added); *S_out = 1: out is complete
 // gelu_u (bf16 out only): out = (A.W) * gelu'(u) with u bf16 [M][ldu] -- the GELU backward fused into the data-gradient GEMM
 // w_rows: rows of W that exist when K was rounded up to a multiple of 64 (A's extra columns must be zero); partials: split-K scratch
 // u = A.W^T + bias (bf16) and h = gelu(u) (bf16) from one bf16 GEMM (training forward of BertIntermediate)

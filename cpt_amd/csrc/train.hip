@@ -15,7 +15,7 @@ using cpt::abi_fail;
 namespace cpt { CPT_SWITCH(int g_wgrad_tn, 1); void set_wgrad_tn(int v) { CPT_SWITCH_SET(g_wgrad_tn = v); (void)v; } }
 using cpt::g_wgrad_tn;
 // cpt_set_tuning(18, bits): bias-gradient column sums inside their producers -- bit 0: b_in in the GELU-gradient epilogue of
-// dgrad(ffn down) (off: its end-of-launch atomics cost more than the colsum launch, gemm.hip), bit 1: b_qkv in the attention
+// dgrad(ffn down) (round 6: as partial rows added up by a later launch's column-sum job; round 3's end-of-launch atomics cost more than the colsum launch, gemm.hip), bit 1: b_qkv in the attention
 // backward kernel (on: 43.3 vs 42.0 us per launch, no colsum launch); a cleared bit runs the stand-alone colsum launch instead
 // cpt_set_tuning(19, v): 2 (default) = FFN down | FFN up | attention output in ONE launch (216 workgroups, whole contraction each) + Q|K|V alone
 // with its own three-way split, where the shapes allow it (else as 1); 1 = two paired launches (gemm_tn_pair); 0 = four single ones
@@ -25,7 +25,7 @@ using cpt::g_wgrad_pair;
 // kernel) and the dropout + residual + LayerNorm pass adds the two partial matrices, 0 = 64 x 192 tiles over the whole K
 namespace cpt { CPT_SWITCH(int g_fwd_split2, 1); void set_fwd_split2(int v) { CPT_SWITCH_SET(g_fwd_split2 = v); (void)v; } }
 using cpt::g_fwd_split2;
-namespace cpt { CPT_SWITCH(int g_bias_fuse, 2); void set_bias_fuse(int v) { CPT_SWITCH_SET(g_bias_fuse = v); (void)v; } }
+namespace cpt { CPT_SWITCH(int g_bias_fuse, 3); void set_bias_fuse(int v) { CPT_SWITCH_SET(g_bias_fuse = v); (void)v; } }
 using cpt::g_bias_fuse;
 
 namespace {
@@ -35,9 +35,10 @@ inline int up64(int x) { return (x + 63) / 64 * 64; }
 
 struct TrainLayout {
     size_t x_f32, a_f32, layer0, layer_stride;
-    size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2;     // offsets inside a layer block
+    size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2, o_st1, o_st2;     // offsets inside a layer block (st1 / st2, round 6: (mean, rstd) per row of the two LayerNorms, read by their backward)
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
     size_t dx, dpre, da, dpre_lp, dlp2, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
+    size_t lnp[2], lnp_bytes, csp; int csp_rows;      // round 6: partial column sums left for a later launch's column-sum job -- two alternating LayerNorm-backward tables, the FFN-up bias rows of the GELU-gradient GEMM
     size_t sA, sW, sA_bytes, sW_bytes;      // bf16x3: split copies of a GEMM's two fp32 operands ([rows][hi | hi | lo] and [rows][hi | lo | hi])
     size_t total, tA_bytes, tB_bytes;
     int Mp, Bp, Vp, Rp;
@@ -59,6 +60,7 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
         auto sub = [&](size_t bytes) { size_t p = q; q += al(bytes); return p; };
         w.o_xin = sub(M * H * es); w.o_qkv = sub(M * 3 * H * es); w.o_ctx = sub(M * H * es); w.o_pre1 = sub(M * H * 4);
         w.o_a = sub(M * H * es); w.o_u = sub(M * I * es); w.o_h = sub(M * I * es); w.o_pre2 = sub(M * H * 4);
+        w.o_st1 = sub(M * 2 * 4); w.o_st2 = sub(M * 2 * 4);
         w.layer_stride = q;
         w.layer0 = take(q * d.layers);
     }
@@ -94,6 +96,10 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
     w.dimg_lp = take(R * H * es);
     w.dmask = take(M * H * 4);        // dropout: masked gradient of a dense output (the unmasked one feeds the residual path)
     w.dmask_lp = take(M * H * es);
+    w.lnp_bytes = (M / 4 + 2) * 3 * H * 4;      // (ln_bwd_part_rows(M) <= M / 4 + 1 rows of [3][H])
+    w.lnp[0] = take(w.lnp_bytes); w.lnp[1] = take(w.lnp_bytes);
+    w.csp_rows = (int)((M + 31) / 32);
+    w.csp = take((size_t)w.csp_rows * I * 4);
     w.sA = w.sW = 0; w.sA_bytes = w.sW_bytes = 0;
     if (d.dtype == CPT_BF16X3_MASTERS) {
         // A operands: activations [M][<= max(3H, I)], transposed gradients [<= max(3H, I)][Mp], the head's [Rh][Vp] / [V][Bp], region rows [R][Dp] / [H][Rp]
@@ -285,17 +291,18 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
             if (rp) return rp;
             const cpt::DropSpec sp = drop_spec(drop, 2 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex(part, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
-                                       x_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre1), nullptr, Sp, (size_t)M * H), "partials+dropout(attn out)+residual+layernorm");
+                                       x_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre1), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st1)), "partials+dropout(attn out)+residual+layernorm");
         } else
         if (ph) {   // LN(dropout(dense(ctx)) + x): the residual add moves from the GEMM epilogue into the dropout pass
             if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, nullptr, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
             // dropout + residual + LayerNorm in one row pass (pre1 = dropout(dense) + x is stored for the backward pass)
             const cpt::DropSpec sp = drop_spec(drop, 2 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
-                                       x_f32, &sp, (float*)LB(l, w.o_pre1)), "dropout(attn out)+residual+layernorm");
+                                       x_f32, &sp, (float*)LB(l, w.o_pre1), nullptr, 1, 0, 0, (float*)LB(l, w.o_st1)), "dropout(attn out)+residual+layernorm");
         } else {
         if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, x_f32, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
-        TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, s), "layernorm(attn)");
+        TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
+                                   nullptr, nullptr, nullptr, nullptr, 1, 0, 0, (float*)LB(l, w.o_st1)), "layernorm(attn)");
         }
         if (dt == CPT_BF16 && H % 64 == 0 && I % 8 == 0) {
             TRY(cpt::gemm_gelu2(LB(l, w.o_a), H, y.w_in, H, y.b_in, LB(l, w.o_u), LB(l, w.o_h), I, M, I, H, s), "gemm(ffn up)+gelu");
@@ -309,16 +316,17 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
             if (rp) return rp;
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
-                                       a_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre2), nullptr, Sp, (size_t)M * H), "partials+dropout(ffn down)+residual+layernorm");
+                                       a_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre2), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st2)), "partials+dropout(ffn down)+residual+layernorm");
         } else
         if (ph) {
             if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
-                                       a_f32, &sp, (float*)LB(l, w.o_pre2)), "dropout(ffn down)+residual+layernorm");
+                                       a_f32, &sp, (float*)LB(l, w.o_pre2), nullptr, 1, 0, 0, (float*)LB(l, w.o_st2)), "dropout(ffn down)+residual+layernorm");
         } else {
         if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, a_f32, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
-        TRY(cpt::layernorm_rows((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, s), "layernorm(ffn)");
+        TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
+                                   nullptr, nullptr, nullptr, nullptr, 1, 0, 0, (float*)LB(l, w.o_st2)), "layernorm(ffn)");
         }
     }
     // head on the [MASK] rows
@@ -424,12 +432,16 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     };
     // out[rows][Kout] = dY[rows][Nout] . Wt[Nout][Kout]  (+ resid), Wt given as the Linear weight [Nout][Kout]
     constexpr int NOT_FUSED = 1 << 20;       // dgrad(..., gelu_u): the shape has no fused GELU-gradient epilogue
+    // colsum_rows > 0: gelu_colsum is a table of partial rows (gemm_nn); S_out: a K-split launch leaves its *S_out partial matrices in tA for the
+    // LayerNorm backward behind it, which adds them and the residual itself (*S_out = 1: `out` is complete)
     auto dgrad = [&](const void* dY, int ldy, int Nout_p, const void* Wt, int ldw, int Nout, int Kout, int rows,
-                     const float* resid, void* out, int out_dt, const char* what, const void* gelu_u = nullptr, float* gelu_colsum = nullptr) -> int {
+                     const float* resid, void* out, int out_dt, const char* what, const void* gelu_u = nullptr, float* gelu_colsum = nullptr,
+                     int colsum_rows = 0, int* S_out = nullptr) -> int {
+        if (S_out) *S_out = 1;
         // bf16, tile-aligned: the NN form reads the weight as stored (transpose reads in LDS)
         // (Nout < Nout_p: the K-tile padding columns of dY are zero and the weight rows beyond Nout read as zero)
         if (g_wgrad_tn && dt == CPT_BF16 && cpt::gemm_nn_eligible(rows, Kout, Nout_p, ldy, ldw)) {
-            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes, gelu_u, Kout, gelu_colsum), what);
+            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes, gelu_u, Kout, gelu_colsum, colsum_rows, S_out), what);
             return CPT_OK;
         }
         if (gelu_u) return NOT_FUSED;   // caller runs the unfused pair (dgrad, then gelu_bwd)
@@ -505,6 +517,8 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     void* dmask_lp = ws + w.dmask_lp;
     const void* dpre_in = ph ? (dt == CPT_BF16 ? (const void*)dmask_lp : (const void*)dmask) : (dt == CPT_BF16 ? (const void*)dpre_lp : (const void*)dpre);
     const float* dpre_f = ph ? dmask : dpre;
+    cpt::ColJobs pend = {};      // round 6: column-sum jobs waiting for a carrier launch (kernels.h)
+    int lnp_turn = 0, dxS = 1;   // dxS > 1: the gradient entering the layer lies in tA as that many K-split partial matrices (+ residual dpre)
     for (int l = d.layers - 1; l >= 0; --l) {
         const cpt_layer& y = m->layers[l];
         const cpt_layer_grads& gy = g->layers[l];
@@ -513,9 +527,20 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         // layer (written as bf16 only) and sums its columns for the bias gradient: no dropout_rows / colsum launches
         const bool fuse_db = dt == CPT_BF16;
         if (fuse_db) {
+            // round 6: the forward's row statistics; the incoming gradient possibly as the K-split partial matrices of the previous layer's
+            // dgrad(qkv) (+ its residual dpre -- the row this launch overwrites with its own output only after reading it); the column sums of this
+            // launch stay behind as partial rows and are added up by spare workgroups of the NEXT LayerNorm backward (pend), as this one adds the last one's
             const cpt::DropSpec sp2 = drop_spec(drop, 3 + 3 * l, false);
-            TRY(cpt::ln_bwd(dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, ph ? dmask_lp : dpre_lp, dt, gy.ln2_g, gy.ln2_b,
-                            M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes, ph ? &sp2 : nullptr, gy.b_out), "ln_bwd(ffn)+dropout+bias");
+            cpt::LnBwdExtra e = {};
+            e.stats = (const float*)LB(l, w.o_st2); e.jobs = &pend; e.defer_reduce = 1;
+            if (dxS > 1) { e.dy_parts = dxS; e.dy_stride = (size_t)M * H; e.dy_resid = dpre; }
+            float* part = (float*)(ws + w.lnp[lnp_turn]);
+            TRY(cpt::ln_bwd(dxS > 1 ? (const float*)tA : dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, ph ? dmask_lp : dpre_lp, dt, gy.ln2_g, gy.ln2_b,
+                            M, H, M, 0, 0, 0, s, part, w.lnp_bytes, ph ? &sp2 : nullptr, gy.b_out, &e), "ln_bwd(ffn)+dropout+bias");
+            pend = cpt::ColJobs{};
+            cpt::col_jobs_add(pend, part, cpt::ln_bwd_part_rows(M), 3 * H, 3 * H, H, gy.ln2_g, gy.ln2_b, gy.b_out);
+            lnp_turn ^= 1;
+            if (l + 1 < d.layers) ready(1 + l + 1);      // the layer above is complete now: this launch added its attention-side LayerNorm's sums
         } else {
         TRY(cpt::ln_bwd(dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln2_g, gy.ln2_b,
                         M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes), "ln_bwd(ffn)");
@@ -526,14 +551,19 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         // the attention backward -- their operands stay untouched until then; shapes the pair kernel does not take run one by one)
         // h = gelu(u); u = a W_in^T + b_in: bf16 runs the GELU backward in the epilogue of the data-gradient GEMM
         // ... and sums its columns into the bias gradient (round 3: no colsum launch over the M x I tensor)
-        rc = dt == CPT_BF16 ? dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)+gelu_bwd+bias", LB(l, w.o_u), (g_bias_fuse & 1) ? gy.b_in : nullptr) : NOT_FUSED;
+        // round 6: ... as PARTIAL rows (one per 32-row wave block, plain stores -- the end-of-launch atomics of round 3's form cost more than the
+        // colsum launch), added up by the attention-side LayerNorm backward's spare workgroups (bit 0 of key 18 cleared: the colsum launch)
+        const bool bin_parts = (g_bias_fuse & 1) != 0;
+        rc = dt == CPT_BF16 ? dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)+gelu_bwd+bias", LB(l, w.o_u),
+                                    bin_parts ? (float*)(ws + w.csp) : nullptr, w.csp_rows) : NOT_FUSED;
         if (rc == NOT_FUSED) {
             rc = dgrad(dpre_in, H, H, y.w_out, I, H, I, M, nullptr, dbig, dt, "dgrad(ffn down)");
             if (rc) return rc;
             TRY(cpt::gelu_bwd(dbig, LB(l, w.o_u), dbig, dt, (size_t)M * I, s), "gelu_bwd");
             TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
         } else if (rc) return rc;
-        else if (!(g_bias_fuse & 1)) TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
+        else if (!bin_parts) TRY(cpt::colsum(dbig, dt, I, gy.b_in, M, I, s), "colsum(b_in)");
+        else cpt::col_jobs_add(pend, (const float*)(ws + w.csp), (M + 31) / 32, I, I, I, gy.b_in);
         // round 3: where the three problems' tiles fit one round (hidden 768: 96 + 96 + 24), the two FFN weight gradients wait for the attention
         // output's and share ONE launch with it behind the attention-side LayerNorm backward (which then writes its low-precision output
         // to a second buffer: the FFN-side one is still an operand); Q|K|V runs alone behind the attention backward
@@ -548,13 +578,21 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             rc = wgrad(dbig, dt, I, I, LB(l, w.o_a), H, H, M, Mp, gy.w_in, H, "wgrad(ffn up)");
             if (rc) return rc;
         }
-        rc = dgrad(dbig, I, I, y.w_in, H, I, H, M, dpre, da, CPT_F32, "dgrad(ffn up)+residual");
+        int daS = 1;
+        rc = dgrad(dbig, I, I, y.w_in, H, I, H, M, dpre, da, CPT_F32, "dgrad(ffn up)+residual", nullptr, nullptr, 0, fuse_db ? &daS : nullptr);
         if (rc) return rc;
         // a = LN1(pre1); pre1 = ctx W_ao^T + b_ao + x_in
         if (fuse_db) {
             const cpt::DropSpec sp1 = drop_spec(drop, 2 + 3 * l, false);
-            TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, triple ? (void*)(ws + w.dlp2) : (ph ? dmask_lp : dpre_lp), dt, gy.ln1_g, gy.ln1_b,
-                            M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes, ph ? &sp1 : nullptr, gy.b_ao), "ln_bwd(attn)+dropout+bias");
+            cpt::LnBwdExtra e = {};
+            e.stats = (const float*)LB(l, w.o_st1); e.jobs = &pend; e.defer_reduce = 1;
+            if (daS > 1) { e.dy_parts = daS; e.dy_stride = (size_t)M * H; e.dy_resid = dpre; }
+            float* part = (float*)(ws + w.lnp[lnp_turn]);
+            TRY(cpt::ln_bwd(daS > 1 ? (const float*)tA : da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, triple ? (void*)(ws + w.dlp2) : (ph ? dmask_lp : dpre_lp), dt, gy.ln1_g, gy.ln1_b,
+                            M, H, M, 0, 0, 0, s, part, w.lnp_bytes, ph ? &sp1 : nullptr, gy.b_ao, &e), "ln_bwd(attn)+dropout+bias");
+            pend = cpt::ColJobs{};
+            cpt::col_jobs_add(pend, part, cpt::ln_bwd_part_rows(M), 3 * H, 3 * H, H, gy.ln1_g, gy.ln1_b, gy.b_ao);
+            lnp_turn ^= 1;
         } else {
         TRY(cpt::ln_bwd(da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln1_g, gy.ln1_b,
                         M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes), "ln_bwd(attn)");
@@ -586,9 +624,16 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)");
             if (rc) return rc;
         }
-        rc = dgrad(dbig, 3 * H, 3 * H, y.w_qkv, H, 3 * H, H, M, dpre, dx, CPT_F32, "dgrad(qkv)+residual");
+        // (layer 0's result feeds the embedding passes: complete; above that a K-split launch leaves its partial matrices to the next LayerNorm backward)
+        dxS = 1;
+        rc = dgrad(dbig, 3 * H, 3 * H, y.w_qkv, H, 3 * H, H, M, dpre, dx, CPT_F32, "dgrad(qkv)+residual", nullptr, nullptr, 0, (fuse_db && l > 0) ? &dxS : nullptr);
         if (rc) return rc;
-        ready(1 + l);
+        if (!fuse_db) ready(1 + l);
+    }
+    if (dt == CPT_BF16) {      // the last attention-side LayerNorm's sums (and whatever else still waits for a carrier launch)
+        TRY(cpt::col_jobs_flush(pend, s), "column-sum jobs");
+        pend = cpt::ColJobs{};
+        ready(1);
     }
 
     // ---- region projection and text embeddings ----------------------------------------------------
