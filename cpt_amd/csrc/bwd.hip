@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      int R, int H, int grp, int grp_stride, int grp_off, int rows_per_block,
                                                      float* __restrict__ part, DropSpec dr, float* __restrict__ dbias,
                                                      const float* __restrict__ stats, int dy_parts, size_t dy_stride, const float* dy_resid,
-                                                     int nb_main, ColJobs jobs) {
+                                                     int nb_main, ColJobs jobs, RowMap drows) {
     // dr / dbias (training backward of LN(dropout(dense) + residual), round 2): dx_lp receives the gradient that enters the dense
     // layer -- dx through the dropout mask of the forward (regenerated, dropout.h; thresh 0: identity) -- and dbias its column
     // sums = the gradient of the dense bias; dx itself stays unmasked (it feeds the residual path).  Replaces a dropout_rows and
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)r * H + c) = o;
                 if (dr.thresh != 0) {
                     bool keep[4];
-                    drop_hidden4(dr, ((uint64_t)r * H + c) >> 2, keep);
+                    drop_hidden4(dr, ((uint64_t)rowmap_row(drows, r) * H + c) >> 2, keep);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = keep[j] ? o[j] * dr.scale : 0.f;
                 }
@@ -480,8 +480,8 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
     dim3 grid(nb + col_jobs_blocks(&jobs)), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
     const int dyp = ex.dy_parts > 1 ? ex.dy_parts : 1;
-#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs); \
-                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs); } while (0)
+#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs, ex.drop_rows); \
+                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs, ex.drop_rows); } while (0)
     if (lp16) { if (gelu_in) LNB(bf16, true); else LNB(bf16, false); }
     else      { if (gelu_in) LNB(float, true); else LNB(float, false); }
 #undef LNB
@@ -513,13 +513,34 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
         const int c = (lane + 64 * i) * 4;
         gg[i] = (i < nv && c < H) ? *reinterpret_cast<const f32x4*>(g + c) : f32x4{0, 0, 0, 0};
     }
+    // round 6: rows are walked POSITION-major (r' = t * B + b), so the rows of a workgroup share their position-table row (B >= rows per
+    // workgroup): its gradient rides in registers and leaves as one atomic per column per run of equal position ids instead of one per
+    // row -- the 32 sequences of the step used to send 32-way contended atomics at the same 70 rows (53 us)
+    f32x4 pacc[LNB_MAXV];
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) pacc[i] = f32x4{0, 0, 0, 0};
+    long cur_pid = -1;
+    auto flush_pos = [&]() {
+        if (cur_pid < 0) return;
+#pragma unroll
+        for (int i = 0; i < LNB_MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (i < nv && c < H) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(&dposw[(size_t)cur_pid * H + c + j], pacc[i][j]);
+            }
+            pacc[i] = f32x4{0, 0, 0, 0};
+        }
+    };
     const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    for (int r = r0 + wave; r < r1; r += 4) {
-        const int b = r / Lt, t = r % Lt;
+    for (int rp = r0 + wave; rp < r1; rp += 4) {
+        const int t = rp / B, b = rp % B;
+        const int r = b * Lt + t;
         long wid = ids[r], pid = pos ? pos[r] : t, tid = tt ? tt[r] : 0;
         wid = wid < 0 ? 0 : (wid >= vocab ? vocab - 1 : wid);
         pid = pid < 0 ? 0 : (pid >= max_pos ? max_pos - 1 : pid);
         tid = tid < 0 ? 0 : (tid >= type_vocab ? type_vocab - 1 : tid);
+        if (pid != cur_pid) { flush_pos(); cur_pid = pid; }
         f32x4 xv[LNB_MAXV], dv[LNB_MAXV];
         float s = 0.f;
 #pragma unroll
@@ -570,7 +591,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
                     const float d = rstd * (dv[i][j] * gg[i][j] - s1 - xh * s2);
                     // nn.Embedding(padding_idx=0): the lookup contributes no gradient to row 0
                     if (wid != 0) atomicAdd(&dword[(size_t)wid * H + c + j], d);
-                    atomicAdd(&dposw[(size_t)pid * H + c + j], d);
+                    pacc[i][j] += d;
                     // token_type table: two rows shared by every token -- per-element atomics were 1100-way contended (226 us);
                     // the block keeps one partial row per type and adds it once
                     if (two_types) { if (tid == 0) t0[i][j] += d; else t1[i][j] += d; }
@@ -579,6 +600,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
             }
         }
     }
+    // the waves' position-row sums: combined over runs of waves that ended on the same position id (all four, normally), one atomic per column per run
+    __shared__ long spid[4];
+    if (lane == 0) spid[wave] = cur_pid;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[0][wave][(lane + 64 * i) * 4 + j] = pacc[i][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float acc = 0.f;
+        long p = -1;
+        for (int wv = 0; wv < 4; ++wv) {
+            const long pw = spid[wv];
+            if (pw < 0) continue;
+            if (pw != p) { if (p >= 0) atomicAdd(&dposw[(size_t)p * H + c], acc); acc = 0.f; p = pw; }
+            acc += red[0][wv][c];
+        }
+        if (p >= 0) atomicAdd(&dposw[(size_t)p * H + c], acc);
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < LNB_MAXV; ++i)
 #pragma unroll
@@ -677,7 +718,7 @@ __global__ __launch_bounds__(256) void zero_segments_kernel(ZeroSegs z) {
 int zero_segments(const ZeroSegs& z, hipStream_t s) {
     if (z.count <= 0) return CPT_OK;
     if (z.count > ZS_MAX) return CPT_ERR_SHAPE;
-    zero_segments_kernel<<<dim3((unsigned)z.count, 8), dim3(256), 0, s>>>(z);
+    zero_segments_kernel<<<dim3((unsigned)z.count, 64), dim3(256), 0, s>>>(z);      // (64 slices: the 512 x 768 position table is the long segment; 8 slices left its 393 k stores to 2048 threads, 12 us)
     return CPT_OK;
 }
 

@@ -66,6 +66,15 @@ inline bool col_jobs_add(ColJobs& q, const float* src, int rows, int cols, int r
     q.j[q.n++] = ColJob{src, d0, d1, d2, rows, cols, row_stride, seg};
     return true;
 }
+// Rows of a compact [B][H] matrix that ARE rows (b, pos[b]) of the [B][L][H] tensor (the head rows of the pruned last layer, round 6): the hidden
+// dropout masks are functions of the element index in the full tensor, so the compact passes regenerate them at row b * L + pos[b].
+struct RowMap { const int64_t* pos; int L; int on; };      // pos NULL: position 0 ([CLS]); clamped like gather_rows
+__host__ __device__ inline size_t rowmap_row(const RowMap& m, int r) {
+    if (!m.on) return (size_t)r;
+    long p = m.pos ? m.pos[r] : 0;
+    p = p < 0 ? 0 : (p >= m.L ? m.L - 1 : p);
+    return (size_t)r * m.L + (size_t)p;
+}
 struct LnBwdExtra {
     const float* stats;       // [R][2] (mean, rstd) of the forward (layernorm_rows_ex stat_out): the row statistics are not recomputed
     int dy_parts;             // > 1: dy holds that many split-K partial matrices dy_stride elements apart (compact rows only), added in split order
@@ -73,6 +82,7 @@ struct LnBwdExtra {
     const float* dy_resid;    // + this (the residual of the data-gradient GEMM whose partials dy holds)
     const ColJobs* jobs;      // column-sum jobs of earlier launches, run by extra workgroups of this one
     int defer_reduce;         // 1: leave this launch's partial rows [ln_bwd_part_rows(R)][2 or 3][H] in `part` for a later job instead of launching the reduction
+    RowMap drop_rows;         // dropout masks taken at these rows of the full tensor (compact head rows)
 };
 int ln_bwd_part_rows(int R);
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
@@ -84,6 +94,10 @@ int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int6
               const float* posw, const float* typew, const float* g, float eps, float* dword, float* dposw,
               float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,
               int type_vocab, hipStream_t s);
+// pruned last layer (round 6): out_a[b] = a[b][pos[b]] (bf16 rows), out_b[b] = bb[b][pos[b]] (fp32 rows) in one launch; and its inverse for the
+// backward: za [B][L][H] bf16 and zb [B][L][H] fp32 zero except row (b, pos[b]) = a_r[b] / b_r[b] (one launch: fill + rows)
+int tail_gather2(const void* a, const float* bb, const int64_t* pos, void* out_a, float* out_b, int B, int L, int H, hipStream_t s);
+int tail_scatter2(const void* a_r, const float* b_r, const int64_t* pos, void* za, float* zb, int B, int L, int H, hipStream_t s);
 int scatter_rows_add(const float* src, const int64_t* pos, float* dst, int B, int L, int H, hipStream_t s, const int64_t* seq = nullptr, int n_seq = 0);
 int tanh_bwd(const float* dy, const float* y, float* dx, void* dx_lp, int lp_dtype, size_t n, hipStream_t s);
 int unpad_add(const float* src, float* dst, int R, int K, int Kp, hipStream_t s);     // dst = src without the padding columns (overwrites)
@@ -109,7 +123,7 @@ int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
                       const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr,
-                      int x_parts = 1, size_t x_stride = 0, int out_panel = 0, float* stat_out = nullptr);     // stat_out (round 6): [R][2] (mean, rstd) of every row, for ln_bwd     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
+                      int x_parts = 1, size_t x_stride = 0, int out_panel = 0, float* stat_out = nullptr, const RowMap* drop_rows = nullptr);     // stat_out (round 6): [R][2] (mean, rstd) of every row, for ln_bwd     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
 // resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients
@@ -217,6 +231,7 @@ void set_attn_qt_all(int v); // stand-alone attention, L > 128: the query tiles 
 int gemm_gelu_x3(const void* A3, int lda, const void* W3, int ldw, const float* bias, void* out_split, int M, int N, int K3, hipStream_t s);
 void set_fwd_split2(int v);  // training forward: FFN-down as two split-K partial matrices summed by the LayerNorm pass (1, default)
 void set_qkv_2pass(int v);   // stand-alone LayerNorm-consumer QKV projection through the GELU-less two-pass kernel (1, default)
+void set_train_tail(int v);  // training step: the last encoder layer behind the attention on the head rows only (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
 void set_lnb_rpb(int v);     // LayerNorm backward: rows per workgroup of the two-stage column-sum form (experiments)
 void set_wgrad_tn(int v);    // 1 (default): bf16 weight gradients through the TN GEMM; 0: explicit operand transposes

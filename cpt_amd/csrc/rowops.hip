@@ -95,7 +95,7 @@ template <typename LP, bool GELU_IN, int LN_RPW, int NA = 4>      // NA = 3: the
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
-    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride, int out_panel, float* __restrict__ stat_out) {      // stat_out (round 6): [R][2] (mean, rstd) per row for the backward pass; x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
+    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride, int out_panel, float* __restrict__ stat_out, RowMap drows) {      // stat_out (round 6): [R][2] (mean, rstd) per row for the backward pass; x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
     // x_parts / x_stride (round 3): x is x_parts split-K partial matrices of the dense layer in front, x_stride elements apart; the row that is
     // processed is their sum in split order (training forward: no reduction launch between the GEMM and this pass)
     // resid / dr / pre_out (training forward of LN(dropout(dense) + residual), modeling_bert.py:85-86,145 with the third-party
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
                 }
                 if (dr.thresh != 0) {
                     bool keep[4];
-                    drop_hidden4(dr, ((uint64_t)r * H + c) >> 2, keep);
+                    drop_hidden4(dr, ((uint64_t)rowmap_row(drows, r) * H + c) >> 2, keep);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[u][i][j] = keep[j] ? v[u][i][j] * dr.scale : 0.f;
                 }
@@ -195,13 +195,14 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm768_kernel(const float* 
 
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
-                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride, int out_panel, float* stat_out) {
+                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride, int out_panel, float* stat_out, const RowMap* drop_rows) {
     if (x_parts < 1 || x_parts > 64) return CPT_ERR_SHAPE;
     if (out_panel && (!out_lo || out_f32 || H % 16)) return CPT_ERR_SHAPE;      // panel output: the 3-byte residual stream only (rows rounded up to 32 by the caller's buffer)
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
     if (R <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!x || (!out_f32 && !out_lp)) return CPT_ERR_NULL;
     const DropSpec dr = drop ? *drop : DropSpec{};
+    const RowMap drows = drop_rows ? *drop_rows : RowMap{nullptr, 0, 0};
     if (grp_stride == 0 && grp != R) grp_stride = grp;
     // H = 768 rows without residual / dropout / GELU / split-K partials: the lean kernel, one row per wave (measured against two and four rows per wave:
     // profiles/r05_ab_log.md -- 0.59 / 0.72 of 8 TB/s at 7680 / 61440 rows for the bf16 output against 0.58 / 0.71 and 0.49 / 0.67; the general kernel: 0.56 / 0.55)
@@ -218,9 +219,9 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
 #define LNK(LPT, GI)                                                                                                                              \
     do {                                                                                                                                          \
-        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out); \
-        else if (H == 768) layernorm_rows_kernel<LPT, GI, 1, 3><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out); \
-        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out);          \
+        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows); \
+        else if (H == 768) layernorm_rows_kernel<LPT, GI, 1, 3><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows); \
+        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows);          \
     } while (0)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
     else      { if (gelu_in) LNK(float, true); else LNK(float, false); }
@@ -539,6 +540,46 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restric
     q = q < 0 ? 0 : (q >= n_seq ? n_seq - 1 : q);
     const uint4* s = src + ((size_t)q * L + p) * chunks;
     for (int c = threadIdx.x; c < chunks; c += 256) out[(size_t)b * chunks + c] = s[c];
+}
+
+// pruned last layer of the training step: the head rows of two tensors in one launch (bf16 ctx rows, fp32 residual rows) ...
+__global__ __launch_bounds__(256) void tail_gather2_kernel(const uint4* __restrict__ a, const uint4* __restrict__ bb, const int64_t* __restrict__ pos,
+                                                           uint4* __restrict__ oa, uint4* __restrict__ ob, int L, int ca, int cb) {
+    const int b = blockIdx.x;
+    long p = pos ? pos[b] : 0;
+    p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+    const size_t row = (size_t)b * L + p;
+    for (int c = threadIdx.x; c < ca + cb; c += 256) {
+        if (c < ca) oa[(size_t)b * ca + c] = a[row * ca + c];
+        else ob[(size_t)b * cb + (c - ca)] = bb[row * cb + (c - ca)];
+    }
+}
+int tail_gather2(const void* a, const float* bb, const int64_t* pos, void* out_a, float* out_b, int B, int L, int H, hipStream_t s) {
+    if (B <= 0 || L <= 0 || H % 8) return CPT_ERR_SHAPE;
+    if (!a || !bb || !out_a || !out_b) return CPT_ERR_NULL;
+    tail_gather2_kernel<<<dim3(B), dim3(256), 0, s>>>((const uint4*)a, (const uint4*)bb, pos, (uint4*)out_a, (uint4*)out_b, L, H * 2 / 16, H * 4 / 16);
+    return CPT_OK;
+}
+// ... and the inverse for its backward: both [B][L][H] tensors zero except the head rows (every row written once: no fill launch, no atomics)
+__global__ __launch_bounds__(256) void tail_scatter2_kernel(const uint4* __restrict__ ar, const uint4* __restrict__ br, const int64_t* __restrict__ pos,
+                                                            uint4* __restrict__ za, uint4* __restrict__ zb, int L, int ca, int cb, int rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int b = row / L, t = row % L;
+    long p = pos ? pos[b] : 0;
+    p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+    const bool hit = t == (int)p;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int c = lane; c < ca; c += 64) za[(size_t)row * ca + c] = hit ? ar[(size_t)b * ca + c] : z;
+    for (int c = lane; c < cb; c += 64) zb[(size_t)row * cb + c] = hit ? br[(size_t)b * cb + c] : z;
+}
+int tail_scatter2(const void* a_r, const float* b_r, const int64_t* pos, void* za, float* zb, int B, int L, int H, hipStream_t s) {
+    if (B <= 0 || L <= 0 || H % 8) return CPT_ERR_SHAPE;
+    if (!a_r || !b_r || !za || !zb) return CPT_ERR_NULL;
+    const int rows = B * L;
+    tail_scatter2_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>((const uint4*)a_r, (const uint4*)b_r, pos, (uint4*)za, (uint4*)zb, L, H * 2 / 16, H * 4 / 16, rows);
+    return CPT_OK;
 }
 
 int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B, int L, int H, hipStream_t s, const int64_t* seq, int n_seq) {

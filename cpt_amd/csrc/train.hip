@@ -25,6 +25,11 @@ using cpt::g_wgrad_pair;
 // kernel) and the dropout + residual + LayerNorm pass adds the two partial matrices, 0 = 64 x 192 tiles over the whole K
 namespace cpt { CPT_SWITCH(int g_fwd_split2, 1); void set_fwd_split2(int v) { CPT_SWITCH_SET(g_fwd_split2 = v); (void)v; } }
 using cpt::g_fwd_split2;
+// cpt_set_tuning(33, v): 1 (default) = the LAST encoder layer's attention output, FFN and both LayerNorms run on the head's rows only (one per
+// sequence: the [MASK] row, or [CLS] for the NSP head) in the training forward AND backward -- every other row of that layer's output is dead
+// (the loss reads B rows; modeling_rec.py:142-150) and so is its gradient; 0 = all rows
+namespace cpt { CPT_SWITCH(int g_train_tail, 1); void set_train_tail(int v) { CPT_SWITCH_SET(g_train_tail = v); (void)v; } }
+using cpt::g_train_tail;
 namespace cpt { CPT_SWITCH(int g_bias_fuse, 3); void set_bias_fuse(int v) { CPT_SWITCH_SET(g_bias_fuse = v); (void)v; } }
 using cpt::g_bias_fuse;
 
@@ -38,6 +43,7 @@ struct TrainLayout {
     size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2, o_st1, o_st2;     // offsets inside a layer block (st1 / st2, round 6: (mean, rstd) per row of the two LayerNorms, read by their backward)
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
     size_t dx, dpre, da, dpre_lp, dlp2, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
+    size_t t_ctx, t_xres, t_pre1, t_a, t_af, t_u, t_h, t_pre2, t_st1, t_st2, t_dpre, t_dlpF, t_dlpA, t_dbig, t_da, t_dctx;      // round 6: the pruned last layer's compact [B][.] activations and gradients
     size_t lnp[2], lnp_bytes, csp; int csp_rows;      // round 6: partial column sums left for a later launch's column-sum job -- two alternating LayerNorm-backward tables, the FFN-up bias rows of the GELU-gradient GEMM
     size_t sA, sW, sA_bytes, sW_bytes;      // bf16x3: split copies of a GEMM's two fp32 operands ([rows][hi | hi | lo] and [rows][hi | lo | hi])
     size_t total, tA_bytes, tB_bytes;
@@ -100,6 +106,13 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
     w.lnp[0] = take(w.lnp_bytes); w.lnp[1] = take(w.lnp_bytes);
     w.csp_rows = (int)((M + 31) / 32);
     w.csp = take((size_t)w.csp_rows * I * 4);
+    {
+        const size_t Bq = (size_t)B;
+        w.t_ctx = take(Bq * H * es); w.t_xres = take(Bq * H * 4); w.t_pre1 = take(Bq * H * 4); w.t_a = take(Bq * H * es); w.t_af = take(Bq * H * 4);
+        w.t_u = take(Bq * I * es); w.t_h = take(Bq * I * es); w.t_pre2 = take(Bq * H * 4); w.t_st1 = take(Bq * 8); w.t_st2 = take(Bq * 8);
+        w.t_dpre = take(Bq * H * 4); w.t_dlpF = take(Bq * H * es); w.t_dlpA = take(Bq * H * es); w.t_dbig = take(Bq * I * es); w.t_da = take(Bq * H * 4);
+        w.t_dctx = take(Bq * H * es);
+    }
     w.sA = w.sW = 0; w.sA_bytes = w.sW_bytes = 0;
     if (d.dtype == CPT_BF16X3_MASTERS) {
         // A operands: activations [M][<= max(3H, I)], transposed gradients [<= max(3H, I)][Mp], the head's [Rh][Vp] / [V][Bp], region rows [R][Dp] / [H][Rp]
@@ -158,6 +171,12 @@ int check_drop(const cpt_dropout* d, const char* who) {
     if (!(d->p_hidden >= 0.f && d->p_hidden < 1.f) || !(d->p_attn >= 0.f && d->p_attn < 1.f))
         return abi_fail(CPT_ERR_SHAPE, "%s: dropout probabilities must be in [0, 1)", who);
     return CPT_OK;
+}
+
+// the pruned last layer (g_train_tail): bf16 step, one head row per sequence (no label grid), tile-aligned hidden sizes, 2-D mask
+bool train_tail_on(const cpt_dims& d, const cpt_batch* b) {
+    return g_train_tail && g_wgrad_tn && d.dtype == CPT_BF16 && b->n_rows == 0 && d.layers >= 1 && d.hidden % 192 == 0 && d.inter % 192 == 0 &&
+           (long)b->B * 4 <= (long)b->B * (b->Lt + b->Li);
 }
 
 }  // namespace
@@ -225,6 +244,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     if (L > 288) return abi_fail(CPT_ERR_SHAPE, "cpt_train_fwd: sequence length %d > 288", L);
     const int m3d = (b->mask_3d && b->attn_mask) ? 1 : 0;
     const bool x3_attn = train_x3_attention(d, L, m3d);
+    const bool tail = train_tail_on(d, b) && !m3d;
     if (!x3_attn && !cpt::attention_bwd_supported(dt, L, pa ? 1 : 0, m3d))       // reject here, not after the forward has run (the backward's attention kernel sets the limit)
     {
         int lmax = L;
@@ -276,6 +296,36 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
             TRY(cpt::attention_x3((const float*)LB(l, w.o_qkv), b->attn_mask, (float*)LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention (split operands)");
         else
         TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr, m3d), "attention");
+        if (tail && l == d.layers - 1) {
+            // ---- round 6: the rest of the last layer on the B head rows (row b = position pos[b] of sequence b) ----
+            const cpt::RowMap rm = {nsp ? nullptr : b->mask_pos, L, 1};
+            void* ctx_r = ws + w.t_ctx; float* xres_r = (float*)(ws + w.t_xres); float* pre1_r = (float*)(ws + w.t_pre1);
+            void* a_r = ws + w.t_a; float* af_r = (float*)(ws + w.t_af); float* pre2_r = (float*)(ws + w.t_pre2);
+            TRY(cpt::tail_gather2(LB(l, w.o_ctx), x_f32, rm.pos, ctx_r, xres_r, B, L, H, s), "gather(head rows of ctx, residual)");
+            const cpt::DropSpec sp1 = drop_spec(drop, 2 + 3 * l, false), sp2 = drop_spec(drop, 3 + 3 * l, false);
+            float* part = (float*)(ws + w.tA);
+            int S1 = 0;
+            int r1 = cpt::gemm_nt_partials(ctx_r, H, y.w_ao, H, y.b_ao, part, w.tA_bytes, B, H, H, s, &S1);
+            if (r1 == CPT_ERR_SHAPE) {
+                S1 = 1;
+                r1 = gm(CPT_EPI_NONE, ctx_r, H, y.w_ao, H, y.b_ao, nullptr, 0, part, CPT_F32, H, B, H, H, s);
+            }
+            TRY(r1, "gemm(attn out, head rows)");
+            TRY(cpt::layernorm_rows_ex(part, y.ln1_g, y.ln1_b, d.ln_eps, af_r, a_r, dt, B, H, B, 0, 0, 0, s, xres_r, ph ? &sp1 : nullptr, pre1_r, nullptr,
+                                       S1, (size_t)B * H, 0, (float*)(ws + w.t_st1), &rm), "dropout(attn out)+residual+layernorm (head rows)");
+            TRY(cpt::gemm_gelu2(a_r, H, y.w_in, H, y.b_in, ws + w.t_u, ws + w.t_h, I, B, I, H, s), "gemm(ffn up)+gelu (head rows)");
+            int S2 = 0;
+            int r2 = cpt::gemm_nt_partials(ws + w.t_h, I, y.w_out, I, y.b_out, part, w.tA_bytes, B, H, I, s, &S2);
+            if (r2 == CPT_ERR_SHAPE) {
+                S2 = 1;
+                r2 = gm(CPT_EPI_NONE, ws + w.t_h, I, y.w_out, I, y.b_out, nullptr, 0, part, CPT_F32, H, B, H, I, s);
+            }
+            TRY(r2, "gemm(ffn down, head rows)");
+            // ... whose LayerNorm output IS the head's input (no gather of [MASK] / [CLS] rows below)
+            TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, nullptr, ws + w.rows, dt, B, H, B, 0, 0, 0, s, af_r, ph ? &sp2 : nullptr, pre2_r, nullptr,
+                                       S2, (size_t)B * H, 0, (float*)(ws + w.t_st2), &rm), "dropout(ffn down)+residual+layernorm (head rows)");
+            continue;
+        }
         // round 3: where the dense layer's K is split over workgroups (few rows; or 2048..6144 rows with a long K), its partial matrices go
         // straight to the row pass behind it, which adds them in split order -- no reduction launch in between (cpt_set_tuning key 22)
         int Sp = 0;
@@ -336,7 +386,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     need(d.layers + 1);
     if (nsp) {
         // NSPCPT: pooled = tanh([CLS] W_pool^T + b_pool) (kept in `uh`), rel = pooled W_rel^T + b_rel, CE over n_rel classes
-        TRY(cpt::gather_rows(ws + w.xout, dt, nullptr, rows, B, L, H, s), "gather([CLS])");
+        if (!tail) TRY(cpt::gather_rows(ws + w.xout, dt, nullptr, rows, B, L, H, s), "gather([CLS])");
         TRY(gm(CPT_EPI_TANH, rows, H, m->w_pool, H, m->b_pool, nullptr, 0, uh, CPT_F32, H, B, H, H, s), "gemm(pooler)");
         const void* pin = uh;
         if (dt == CPT_BF16) {
@@ -353,7 +403,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     }
     // Rh head rows: the [MASK] position of every sequence, or the n_rows labelled positions of a label grid (row_seq, mask_pos)
     const int Rh = b->n_rows > 0 ? b->n_rows : B;
-    TRY(cpt::gather_rows(ws + w.xout, dt, b->mask_pos, rows, Rh, L, H, s, b->n_rows > 0 ? b->row_seq : nullptr, B), "gather([MASK])");
+    if (!tail) TRY(cpt::gather_rows(ws + w.xout, dt, b->mask_pos, rows, Rh, L, H, s, b->n_rows > 0 ? b->row_seq : nullptr, B), "gather([MASK])");
     TRY(gm(CPT_EPI_NONE, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, uh, CPT_F32, H, Rh, H, H, s), "gemm(head transform)");
     TRY(cpt::layernorm_rows_ex(uh, m->tr_ln_g, m->tr_ln_b, d.ln_eps, dt == CPT_F32 ? (float*)t2 : nullptr,
                                dt == CPT_F32 ? nullptr : t2, dt, Rh, H, Rh, 0, 0, 1, s), "gelu+layernorm(head)");
@@ -467,6 +517,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     void* duh_lp = ws + w.duh_lp;
     float* drows = (float*)(ws + w.drows);
     const bool nsp = !m->w_tr && !m->w_dec;
+    const bool tail = train_tail_on(d, b) && !(b->mask_3d && b->attn_mask);      // the forward's pruned last layer (same predicate)
     const int Rh = (!nsp && b->n_rows > 0) ? b->n_rows : B;      // head rows (see cpt_train_fwd)
     if (nsp) {
         if (!g->w_pool || !g->b_pool || !g->w_rel || !g->b_rel) return abi_fail(CPT_ERR_NULL, "cpt_train_bwd: NSP head needs the w_pool / b_pool / w_rel / b_rel gradient tensors");
@@ -502,9 +553,11 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     rc = dgrad(duh_in, H, H, m->w_tr, H, H, H, Rh, nullptr, drows, CPT_F32, "dgrad(head transform)");
     if (rc) return rc;
     }
+    if (!tail) {      // (pruned last layer: drows IS the gradient of that layer's compact output)
     hipError_t e = hipMemsetAsync(dx, 0, (size_t)M * H * 4, s);
     if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero dx: %s", hipGetErrorString(e));
     TRY(cpt::scatter_rows_add(drows, nsp ? nullptr : b->mask_pos, dx, Rh, L, H, s, b->n_rows > 0 ? b->row_seq : nullptr, B), "scatter([MASK] / [CLS] rows)");
+    }
     // gradient buckets: the host callback runs right AFTER the last launch that writes the bucket's gradients has
     // been enqueued on `stream` (the tied word-embedding table belongs to bucket 0: its lookup gradient comes last)
     auto ready = [&](int bucket) { if (grads_ready) grads_ready(user, bucket); };
@@ -522,10 +575,48 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     for (int l = d.layers - 1; l >= 0; --l) {
         const cpt_layer& y = m->layers[l];
         const cpt_layer_grads& gy = g->layers[l];
+        const bool fuse_db = dt == CPT_BF16;
+        bool triple = false;
+        if (tail && l == d.layers - 1) {
+            // ---- round 6: the pruned last layer -- BertOutput, BertIntermediate, BertSelfOutput backward on the B head rows; the weight gradients
+            // contract over B rows (one K-tile), the data gradient re-enters the full tensors at the head rows (everything else is zero) ----
+            const cpt::RowMap rm = {nsp ? nullptr : b->mask_pos, L, 1};
+            const cpt::DropSpec sp2 = drop_spec(drop, 3 + 3 * l, false), sp1 = drop_spec(drop, 2 + 3 * l, false);
+            float* dpre_r = (float*)(ws + w.t_dpre); float* da_r = (float*)(ws + w.t_da);
+            void* dlpF = ws + w.t_dlpF; void* dlpA = ws + w.t_dlpA; void* dbig_r = ws + w.t_dbig; void* dctx_r = ws + w.t_dctx;
+            cpt::LnBwdExtra e2 = {};
+            e2.stats = (const float*)(ws + w.t_st2); e2.drop_rows = rm;
+            TRY(cpt::ln_bwd(drows, (const float*)(ws + w.t_pre2), y.ln2_g, d.ln_eps, dpre_r, dlpF, dt, gy.ln2_g, gy.ln2_b, B, H, B, 0, 0, 0, s, nullptr, 0,
+                            ph ? &sp2 : nullptr, gy.b_out, &e2), "ln_bwd(ffn, head rows)");
+            rc = dgrad(dlpF, H, H, y.w_out, I, H, I, B, nullptr, dbig_r, dt, "dgrad(ffn down)+gelu_bwd+bias (head rows)", ws + w.t_u, gy.b_in);
+            if (rc) return rc == NOT_FUSED ? abi_fail(CPT_ERR_SHAPE, "cpt_train_bwd: pruned last layer without the fused GELU-gradient GEMM") : rc;
+            int daS = 1;
+            rc = dgrad(dbig_r, I, I, y.w_in, H, I, H, B, dpre_r, da_r, CPT_F32, "dgrad(ffn up)+residual (head rows)", nullptr, nullptr, 0, &daS);
+            if (rc) return rc;
+            cpt::LnBwdExtra e1 = {};
+            e1.stats = (const float*)(ws + w.t_st1); e1.drop_rows = rm;
+            if (daS > 1) { e1.dy_parts = daS; e1.dy_stride = (size_t)B * H; e1.dy_resid = dpre_r; }
+            TRY(cpt::ln_bwd(daS > 1 ? (const float*)tA : da_r, (const float*)(ws + w.t_pre1), y.ln1_g, d.ln_eps, dpre_r, dlpA, dt, gy.ln1_g, gy.ln1_b, B, H, B, 0, 0, 0, s,
+                            nullptr, 0, ph ? &sp1 : nullptr, gy.b_ao, &e1), "ln_bwd(attn, head rows)");
+            const int Kp = up64(B);
+            const int r3 = cpt::gemm_tn_triple(dlpF, H, ws + w.t_h, I, gy.w_out, H, I, dbig_r, I, ws + w.t_a, H, gy.w_in, I, H,
+                                               dlpA, H, ws + w.t_ctx, H, gy.w_ao, H, H, Kp, B, s);
+            if (r3 == CPT_ERR_SHAPE) {
+                rc = wgrad(dlpF, dt, H, H, ws + w.t_h, I, I, B, Kp, gy.w_out, I, "wgrad(ffn down, head rows)");
+                if (rc) return rc;
+                rc = wgrad(dbig_r, dt, I, I, ws + w.t_a, H, H, B, Kp, gy.w_in, H, "wgrad(ffn up, head rows)");
+                if (rc) return rc;
+                rc = wgrad(dlpA, dt, H, H, ws + w.t_ctx, H, H, B, Kp, gy.w_ao, H, "wgrad(attn out, head rows)");
+                if (rc) return rc;
+            } else TRY(r3, "wgrad(ffn down | ffn up | attn out, head rows)");
+            rc = dgrad(dlpA, H, H, y.w_ao, H, H, H, B, nullptr, dctx_r, dt, "dgrad(attn out, head rows)");
+            if (rc) return rc;
+            TRY(cpt::tail_scatter2(dctx_r, dpre_r, rm.pos, dctx, dpre, B, L, H, s), "scatter(head rows of dctx, dpre)");
+            triple = true;      // (below: Q|K|V's weight gradient alone)
+        } else {
         // x_out = LN2(pre2); pre2 = h W_out^T + b_out + a
         // bf16: the LayerNorm backward also applies the dense output's dropout mask to the gradient that goes on into the dense
         // layer (written as bf16 only) and sums its columns for the bias gradient: no dropout_rows / colsum launches
-        const bool fuse_db = dt == CPT_BF16;
         if (fuse_db) {
             // round 6: the forward's row statistics; the incoming gradient possibly as the K-split partial matrices of the previous layer's
             // dgrad(qkv) (+ its residual dpre -- the row this launch overwrites with its own output only after reading it); the column sums of this
@@ -567,7 +658,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         // round 3: where the three problems' tiles fit one round (hidden 768: 96 + 96 + 24), the two FFN weight gradients wait for the attention
         // output's and share ONE launch with it behind the attention-side LayerNorm backward (which then writes its low-precision output
         // to a second buffer: the FFN-side one is still an operand); Q|K|V runs alone behind the attention backward
-        const bool triple = g_wgrad_tn && g_wgrad_pair >= 2 && dt == CPT_BF16 && cpt::gemm_tn_triple_eligible(H, I, I, H, H, H, Mp);
+        triple = g_wgrad_tn && g_wgrad_pair >= 2 && dt == CPT_BF16 && cpt::gemm_tn_triple_eligible(H, I, I, H, H, H, Mp);
         if (triple) {
         } else
         if (wgrad_pair(dpre_in, H, H, LB(l, w.o_h), I, I, gy.w_out, dbig, I, I, LB(l, w.o_a), H, H, gy.w_in, rc, "wgrad(ffn down | ffn up)")) {
@@ -605,6 +696,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
                                     dao_in, H, LB(l, w.o_ctx), H, gy.w_ao, H, H, Mp, M, s), "wgrad(ffn down | ffn up | attn out)");
         rc = dgrad(dao_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
         if (rc) return rc;
+        }
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
         if (train_x3_attention(d, L, (b->mask_3d && b->attn_mask) ? 1 : 0))
             TRY(cpt::attention_bwd_x3((const float*)LB(l, w.o_qkv), b->attn_mask, (const float*)dctx, (float*)dbig, B, L, d.heads, s, pa ? &da_spec : nullptr,

@@ -67,8 +67,9 @@ int cpt_build_info(void);
  *          Infinity Cache, 0 = no prefetch workgroups
  *   key 16 FFN-up two-pass kernel (and with it panel mode) from this many 384 x 256 tiles on (default 192; experiments with small batches)
  *   key 17 LayerNorm backward, two-stage column-sum form: rows per workgroup (default 0 = 8 from 2048 rows on, else 4; experiments)
- *   key 18 training backward, bias-gradient column sums inside their producers: bit 0 = b_in in the GELU-gradient epilogue, bit 1 = b_qkv
- *          in the attention backward kernel (default 2: bit 0 measured slower than the launch it replaces); a cleared bit runs the stand-alone column-sum launch
+ *   key 18 training backward, bias-gradient column sums inside their producers: bit 0 = b_in in the GELU-gradient epilogue (round 6: as partial rows that a
+ *          later LayerNorm-backward launch adds up in spare workgroups), bit 1 = b_qkv in the attention backward kernel (default 3); a cleared bit runs the
+ *          stand-alone column-sum launch
  *   key 19 training backward, a layer's weight gradients: 2 (default) = FFN down | FFN up | attention output in one launch + Q|K|V alone where the
  *          shapes fit one round (else as 1), 1 = two paired launches (the two FFN matrices; attention output + Q|K|V), 0 = four launches with
  *          their own split-K reductions
@@ -99,6 +100,8 @@ int cpt_build_info(void);
  *          same values to bf16 accuracy, not the same bits (different kernels behind the last attention)
  *   key 32 fused bf16 encoder, batches whose row count the full panel mode does not take: 1 (default) = the encoder's tensors are sized and launched for the
  *          next row count it takes (at most 1.5x the real rows; the padded rows belong to no sequence), 0 = such batches run the row-major kernels; same bits
+ *   key 33 training step, last encoder layer: 1 (default) = everything behind its attention (attention output, FFN, both LayerNorms; forward and backward) on
+ *          the head's rows only -- one per sequence ([MASK], or [CLS] for the NSP head) -- when the batch carries no label grid; 0 = all rows
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at

@@ -647,3 +647,63 @@ def test_hf_adamw_kernel_and_drop_in_optimizer(dev, correct_bias):
             pn, mn, vn = O.adamw_step_hf(before[k], grads[k], st[k][0], st[k][1], step, lr_now, 0.9, 0.999, 1e-6, w, correct_bias)
             st[k] = (mn, vn)
             assert (t.detach().cpu() - pn).abs().max().item() < 3e-6, (step, k)
+
+
+@pytest.mark.parametrize("B", [4, 32])
+def test_last_layer_on_head_rows_matches_the_all_rows_form(dev, B):
+    """Round 6: with one head row per sequence the training step runs the last encoder layer behind its attention (attention output, FFN, both
+    LayerNorms; forward and backward) on the B [MASK] rows only.  The SAME batch handed over as a label grid (cpt_batch.n_rows = B, row_seq =
+    0..B-1) takes the all-rows path of the same library: loss, scores and every gradient of the two must agree (same products, other tile
+    splits; dropout 0.1 -- the compact passes regenerate the masks at the rows' positions in the full tensor).  Product library, no switches."""
+    from cpt_amd import train as T
+    cfg = cfgmod.oscar_base()
+    m = _model(cfg, 31, dev, "bf16", dropout=0.1)
+    b = {k: v.to(dev) for k, v in synth.make_batch(B, cfg, seed=15).items()}
+    params = dict(m.named_parameters())
+
+    def run(grid):
+        T.set_dropout_seed(m, 23)
+        for p in m.parameters():
+            p.grad = None
+        seq = torch.arange(B, device=dev) if grid else None
+        loss, scores = T.mlm_loss_with_grad(m, b["input_ids"], b["segment_ids"], b["attention_mask"], b["colors"], None, b["img_feats"],
+                                            b["mask_token_pos"], row_seq=seq)
+        loss.backward()
+        return loss.item(), scores.detach().double().clone(), {n: p.grad.double().clone() for n, p in params.items() if p.grad is not None}
+
+    l0, s0, g0 = run(True)        # all rows
+    l1, s1, g1 = run(False)       # head rows
+    assert abs(l0 - l1) < 2e-3 * max(1.0, abs(l0)), (l0, l1)
+    assert float((s0 - s1).abs().max()) < 2e-2, float((s0 - s1).abs().max())
+    assert set(g0) == set(g1) and len(g0) > 190
+    worst = ("", 0.0)
+    for n in g0:
+        if n.endswith("attention.self.key.bias"):      # zero in exact arithmetic (a constant added to every score of a query): rounding noise on both sides
+            continue
+        den = float(g0[n].norm())
+        assert den > 0, n
+        rel = float((g1[n] - g0[n]).norm()) / den
+        if rel > worst[1]:
+            worst = (n, rel)
+    # bf16 activations are rounded after differently split sums: a few 1e-3 on the smallest gradients
+    assert worst[1] < 1e-2, worst
+
+
+def test_development_library_variant_comparisons_in_a_subprocess():
+    """the `ablation`-marked tests (kernel VARIANTS against each other through cpt_set_tuning) need the development build of
+    the library, which the driver's `pytest -m gpu` does not load -- so this test runs them in a child process with CPT_AMD_ABLATION=1 and
+    fails when any of them fails.  The child loads libcpt_hip_abl.so; this process keeps the product library."""
+    import subprocess
+    import sys
+    from cpt_amd import _lib as L
+    if L.ablation_build():
+        pytest.skip("already running on the development library: the marked tests run in this process")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "cpt_amd", "libcpt_hip_abl.so")):
+        pytest.fail("cpt_amd/libcpt_hip_abl.so is missing: __graft_entry__.build() builds it (python -m cpt_amd.build --ablation)")
+    env = dict(os.environ, CPT_AMD_ABLATION="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests"), "-q", "-x", "-m", "gpu and ablation", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=3000)
+    tail = "\n".join(r.stdout.strip().splitlines()[-15:])
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "skipped" not in tail.splitlines()[-1], tail
