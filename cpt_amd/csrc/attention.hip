@@ -37,10 +37,11 @@ __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >>
 template <typename T, int NKB, int LEAN>      // 1: inference; 2: training without the rare extras (dropout on, 2-D mask, no saved probabilities); 0: everything
 __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kernel(
     const T* __restrict__ qkv, const int64_t* __restrict__ attn_mask, T* __restrict__ ctx,
-    T* __restrict__ probs_arg, int B, int L, int heads, DropSpec dr_arg, int mask3_arg, int ctx_panel, int remap) {
+    T* __restrict__ probs_arg, int B, int L, int heads, DropSpec dr_arg, int mask3_arg, int ctx_panel, int remap, float* __restrict__ stats_arg) {
     const DropSpec dr = LEAN == 1 ? DropSpec{} : dr_arg;
     const int mask3 = LEAN ? 0 : mask3_arg;
     T* __restrict__ probs = LEAN ? nullptr : probs_arg;
+    float* __restrict__ stats = LEAN == 1 ? nullptr : stats_arg;      // training forward (bf16): [B * heads][L][2] softmax statistics of every query row
     // remap (round 3, sequences of several 128-query tiles): a 1-D grid whose workgroups id, id + 8, .. (same XCD -- workgroups go to
     // the XCDs round robin -- dispatched back to back) are the query tiles of ONE (sequence, head), so the K / V rows the tiles share are
     // fetched from memory once and hit that XCD's L2 for the other tiles.  With the (pair, tile) grid the tiles of a pair ran 3072
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(ATT_THREADS, NKB >= 7 ? 2 : 1) void attention_kerne
             attn_core_bf16<NKB, VSWZ, true>(fq, sK, sV, sMask, lane, q < L, nullptr, nullptr, L, dr, (uint32_t)bh, min(q, L - 1), mrow,
                                             (void*)ctx, (int)min((size_t)(((size_t)B * L + 31) & ~(size_t)31) * H * 2, (size_t)0x7fffffff), b * L + min(q, L - 1), h * 8, H >> 4);
         else
-        attn_core_bf16<NKB, VSWZ>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)bh, min(q, L - 1), mrow);
+        attn_core_bf16<NKB, VSWZ>(fq, sK, sV, sMask, lane, q < L, crow, prow, L, dr, (uint32_t)bh, min(q, L - 1), mrow, nullptr, 0, 0, 0, 0,
+                                  stats ? reinterpret_cast<float2*>(stats) + (size_t)bh * L + min(q, L - 1) : nullptr);
         return;
     }
 
@@ -247,9 +249,9 @@ static size_t att_lds_bytes() {
 }
 
 template <typename T, int NKB>
-static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3, int ctx_panel) {
+static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3, int ctx_panel, float* stats) {
     const size_t lds = att_lds_bytes<T, NKB>();
-    const int lean = (!mask3 && !probs) ? (dr.thresh == 0 ? 1 : 2) : 0;
+    const int lean = (!mask3 && !probs) ? ((dr.thresh == 0 && !stats) ? 1 : 2) : 0;
     auto kern = lean == 1 ? attention_kernel<T, NKB, 1> : (lean == 2 ? attention_kernel<T, NKB, 2> : attention_kernel<T, NKB, 0>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -258,7 +260,7 @@ static int att_launch(const void* qkv, const int64_t* mask, void* ctx, void* pro
     const int nqt = (L + 127) / 128;
     const int remap = (nqt > 1 && g_attn_remap) ? 1 : 0;
     dim3 grid(remap ? ((B * heads + 7) / 8 * 8) * nqt : B * heads, remap ? 1 : nqt), block(ATT_THREADS);
-    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads, dr, mask3, ctx_panel, remap);
+    kern<<<grid, block, lds, s>>>((const T*)qkv, mask, (T*)ctx, (T*)probs, B, L, heads, dr, mask3, ctx_panel, remap, stats);
     return CPT_OK;
 }
 
@@ -330,25 +332,26 @@ static int att_long(const void* qkv, const int64_t* mask, void* ctx, int B, int 
 int attention_max_len(int inference) { return inference ? ATT_LONG_MAX : 288; }
 
 template <typename T>
-static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3, int ctx_panel) {
+static int att_dispatch(const void* qkv, const int64_t* mask, void* ctx, void* probs, int B, int L, int heads, const DropSpec& dr, hipStream_t s, int mask3, int ctx_panel, float* stats) {
     if (L > 288) {      // beyond the register-resident score strip: the coverage kernel (inference only: no dropout, no saved probabilities, row-major ctx)
-        if (L > ATT_LONG_MAX || probs || dr.thresh != 0 || ctx_panel) return CPT_ERR_SHAPE;
+        if (L > ATT_LONG_MAX || probs || dr.thresh != 0 || ctx_panel || stats) return CPT_ERR_SHAPE;
         return att_long<T>(qkv, mask, ctx, B, L, heads, s, mask3);
     }
-    if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
-    if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
-    if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
-    return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel);
+    if (L <= 32) return att_launch<T, 1>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel, stats);
+    if (L <= 128) return att_launch<T, 4>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel, stats);
+    if (L <= 224) return att_launch<T, 7>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel, stats);
+    return att_launch<T, 9>(qkv, mask, ctx, probs, B, L, heads, dr, s, mask3, ctx_panel, stats);
 }
 
 int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B, int L, int heads, hipStream_t s,
-              const DropSpec* drop, int mask_3d, int ctx_panel) {
+              const DropSpec* drop, int mask_3d, int ctx_panel, float* stats) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
     if (!qkv || !ctx) return CPT_ERR_NULL;
+    if (stats && (dtype != CPT_BF16 || mask_3d || probs)) return CPT_ERR_SHAPE;      // statistics export: the bf16 training forward with a per-key mask
     if (ctx_panel && (dtype != CPT_BF16 || probs || ((uintptr_t)ctx & 15) || ((size_t)B * L) % 32)) return CPT_ERR_SHAPE;     // panel output: bf16 inference, whole 32-row blocks
     const DropSpec dr = drop ? *drop : DropSpec{};
-    if (dtype == CPT_BF16) return att_dispatch<bf16>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d, ctx_panel);
-    if (dtype == CPT_F32) return att_dispatch<float>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d, 0);
+    if (dtype == CPT_BF16) return att_dispatch<bf16>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d, ctx_panel, stats);
+    if (dtype == CPT_F32) return att_dispatch<float>(qkv, attn_mask, ctx, probs, B, L, heads, dr, s, mask_3d, 0, nullptr);
     return CPT_ERR_DTYPE;
 }
 

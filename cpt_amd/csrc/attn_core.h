@@ -50,7 +50,8 @@ __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsi
                                                const float* sMask, int lane, bool valid, bf16* ctx_row,
                                                bf16* probs_row, int L, const DropSpec& dr = DropSpec{}, uint32_t bh = 0, int q = 0,
                                                const int64_t* mrow = nullptr,   // mrow: this lane's row of a 3-D attention mask (modeling_bert.py:215-216)
-                                               void* pbase = nullptr, int pbytes = 0, int prow = 0, int pc8 = 0, int pk16 = 0) {
+                                               void* pbase = nullptr, int pbytes = 0, int prow = 0, int pc8 = 0, int pk16 = 0,
+                                               float2* stat_row = nullptr) {     // stat_row (training forward, round 6): this query's (row max in base 2, 1 / row sum) for the backward kernel
     const int fr = lane & 31, fh = lane >> 5;
     // S^T = K . Q^T : accumulator rows = keys, column (lane&31) = query
     f32x16 st[NKB];
@@ -87,6 +88,7 @@ __device__ __forceinline__ void attn_core_bf16(const bf16x8 (&fq)[4], const unsi
         }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+    if (stat_row && valid && fh == 0) *stat_row = float2{mx, inv};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll

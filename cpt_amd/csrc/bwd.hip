@@ -311,10 +311,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             if (i < nv && c < H) {
                 nx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
                 nd[i] = *reinterpret_cast<const f32x4*>(dy + yr * H + c);
-                for (int k = 1; k < dy_parts; ++k) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(dy + (size_t)k * dy_stride + yr * H + c);
+                for (int k0 = 1; k0 < dy_parts; k0 += 8) {      // eight partial matrices' loads in flight at a time, added in split order
+                    f32x4 t[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) nd[i][j] += t[j];
+                    for (int kk = 0; kk < 8; ++kk)
+                        if (k0 + kk < dy_parts) t[kk] = *reinterpret_cast<const f32x4*>(dy + (size_t)(k0 + kk) * dy_stride + yr * H + c);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk)
+                        if (k0 + kk < dy_parts) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) nd[i][j] += t[kk][j];
+                        }
                 }
                 if (dy_resid) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(dy_resid + yr * H + c);
@@ -950,10 +957,13 @@ __device__ __forceinline__ int kq_off_tr(int row, int chunk) {
     return row * 128 + ((chunk ^ (((p & 1) << 2) | (p >> 1))) << 4);
 }
 
-template <int NKB, bool TR = false>
+template <int NKB, bool TR = false, bool HAVE = false>      // HAVE (TR only): ctx + stats given
 __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
                                                             const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int B, int L, int heads,
-                                                            DropSpec dr, float* __restrict__ dbias) {
+                                                            DropSpec dr, float* __restrict__ dbias, const bf16* __restrict__ ctx, const float* __restrict__ stats) {
+    // ctx + stats (round 6, TR variants): the forward's context rows O and per-query softmax statistics (row max in base 2, 1 / row sum; attn_core.h
+    // stat_row).  Phase A then needs neither the row reductions nor a second evaluation of the dP blocks: D = rowsum(dP . P) = rowsum(dO . O) (also
+    // under dropout: O = P~ V) comes from the tile loads, and every key block is finished in one go (scores, dP, dS, dQ) instead of held.
     // dbias (optional, [3 * heads * 64]): += column sums of dqkv over this (sequence, head)'s rows = the gradient of the stacked
     // Q|K|V bias (replaces a colsum launch over the M x 3H tensor): every lane owns one column of its 32 x 32 block, the two
     // half-waves hold the two row halves
@@ -996,8 +1006,20 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
             o4 = *reinterpret_cast<const uint4*>(dctx + ((size_t)b * L + r) * H + h * 64 + c * 8);
         }
     };
+    constexpr bool have = TR && HAVE;
     auto st4 = [&](int idx, const uint4& q4, const uint4& k4, const uint4& v4, const uint4& o4) {
         const int r = idx >> 3, c = idx & 7;
+        if constexpr (have) {      // D = rowsum(dO . O): the eight lanes that hold the row's chunks
+            uint4 c4 = make_uint4(0, 0, 0, 0);
+            if (r < L) c4 = *reinterpret_cast<const uint4*>(ctx + ((size_t)b * L + r) * H + h * 64 + c * 8);
+            const bf16* oe = reinterpret_cast<const bf16*>(&o4);
+            const bf16* ce = reinterpret_cast<const bf16*>(&c4);
+            float dsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum += (float)oe[j] * (float)ce[j];
+            dsum += lane_xor1(dsum); dsum += lane_xor2(dsum); dsum += lane_xor4(dsum);
+            if (c == 0) sD[r] = dsum;
+        }
         *reinterpret_cast<uint4*>(sQ + roff(r, c)) = q4;
         *reinterpret_cast<uint4*>(sK + roff(r, c)) = k4;
         *reinterpret_cast<uint4*>(sV + roff(r, c)) = v4;
@@ -1047,7 +1069,13 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
 #pragma unroll
     for (int i = 0; i < (LP + 255) / 256; ++i) {
         const int key = tid + i * 256;
-        if (key < LP) sMask[key] = mreg[i];           // additive mask times log2(e): the softmax runs in base 2 (one v_exp_f32 per score), as in the forward kernel
+        if (key < LP) {
+            sMask[key] = mreg[i];           // additive mask times log2(e): the softmax runs in base 2 (one v_exp_f32 per score), as in the forward kernel
+            if constexpr (have) {                     // (rows beyond L: 1 / sum = 0 -> their probabilities are 0)
+                const float2 sv = key < L ? *reinterpret_cast<const float2*>(stats + 2 * ((size_t)blockIdx.x * L + key)) : float2{0.f, 0.f};
+                sM[key] = sv.x; sLi[key] = sv.y;
+            }
+        }
     }
     __syncthreads();
 
@@ -1087,6 +1115,59 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
     };
 
     // ================= phase A: query blocks (lane = query) =================
+    if constexpr (have) {
+    for (int qb = wave; qb < NKB; qb += 4) {
+        const float mq = sM[qb * 32 + fr], lq = sLi[qb * 32 + fr], dq = sD[qb * 32 + fr];
+        bf16x8 fo[4], fqv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fo[ks] = rowfrag(sO, qb * 32 + fr, ks); fqv[ks] = rowfrag(sQ, qb * 32 + fr, ks); }
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll(NKB <= 4 ? NKB : 1)      // (longer sequences: one key block at a time -- unrolled, the scheduler hoists every block's operand reads and spills)
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 st, d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; d[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sK, kb * 32 + fr, ks), fqv[ks], st, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sV, kb * 32 + fr, ks), fo[ks], d, 0, 0, 0);
+            }
+            uint32_t wbits = 0xffffffffu;
+            float sc = 1.f;
+            if (dr.thresh != 0) { wbits = sBits[kb * LP + qb * 32 + fr] >> (4 * fh); sc = dr.scale; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(st[r] * (0.125f * ATT_LOG2E) + sMask[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh] - mq) * lq;
+                const float dpr = ((wbits >> (8 * (r >> 2) + (r & 3))) & 1u) ? d[r] * sc : 0.f;
+                d[r] = p * (dpr - dq);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pa = pack8(d, s2);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, ldT(tK, db * 32 + fr, kb * 32 + 16 * s2 + 4 * fh), o[db], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + acc_row(r, lane);
+                if (q < L) { dbase[(size_t)q * ldq + db * 32 + acc_col(lane)] = (bf16)(o[db][r] * 0.125f); cs += o[db][r] * 0.125f; }
+            }
+            if (dbias) {
+                cs += __shfl_xor(cs, 32, 64);
+                if (lane < 32) atomicAdd(&dbias[h * 64 + db * 32 + lane], cs);
+            }
+        }
+    }
+    } else
     if constexpr (TR) {
     // Long sequences: only the scores of all key blocks stay in registers (16 NKB); the dP blocks are computed twice --
     // once for D = rowsum(dP . P), once for dS -- instead of being held (another 16 NKB registers: spills at NKB >= 7).
@@ -1329,17 +1410,19 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
 
 template <int NKB, bool TR = false>
 static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int heads, const DropSpec& dr,
-                                hipStream_t s, float* dbias) {
+                                hipStream_t s, float* dbias, const void* ctx = nullptr, const float* stats = nullptr) {
     constexpr int LP = NKB * 32;
     const size_t lds = (size_t)4 * LP * 128 + (TR ? 0 : (size_t)3 * 64 * (LP * 2 + 8)) + (size_t)4 * LP * sizeof(float) + (size_t)LP * NKB * 4;      // + the dropout bit plane
-    auto k = attn_bwd_mfma_kernel<NKB, TR>;
-    static bool done = false;
-    if (lds > 64 * 1024 && !done) {
+    const bool have = TR && ctx != nullptr && stats != nullptr;
+    auto k = have ? attn_bwd_mfma_kernel<NKB, TR, TR> : attn_bwd_mfma_kernel<NKB, TR, false>;
+    static bool done[2][CPT_MAX_DEV] = {};
+    const int dev = current_device_slot();
+    if (lds > 64 * 1024 && !done[have ? 1 : 0][dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
-        done = true;
+        done[have ? 1 : 0][dev] = true;
     }
-    k<<<dim3(B * heads), dim3(256), lds, s>>>((const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, heads, dr, dbias);
+    k<<<dim3(B * heads), dim3(256), lds, s>>>((const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, heads, dr, dbias, (const bf16*)ctx, stats);
     return CPT_OK;
 }
 
@@ -1926,7 +2009,7 @@ int attention_bwd_supported(int dtype, int L, int has_drop, int mask_3d) {
 }
 
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
-                  const DropSpec* drop, float* dbias, int mask_3d) {
+                  const DropSpec* drop, float* dbias, int mask_3d, const void* ctx, const float* stats) {
     if (B <= 0 || L <= 0 || heads <= 0) return CPT_ERR_SHAPE;
     const DropSpec dr = drop ? *drop : DropSpec{};
     // a [B][L][L] mask (one row per query) goes through the generic kernels, which read it per score; the MFMA kernels keep one
@@ -1934,16 +2017,16 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
     const bool mfma_ok = !(mask_3d && attn_mask);
     // L <= 128: the transpose-read kernel needs 68 KB of LDS and 209 registers -> two workgroups per CU (B * heads = 384 workgroups
     // in one round instead of two): 43.6 vs 51.2 us at B = 32 (rocprofv3)
-    if (mfma_ok && dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L > 64 && L <= 128) return attn_bwd_mfma_launch<4, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+    if (mfma_ok && dtype == CPT_BF16 && g_attn_bwd_variant == 1 && L > 64 && L <= 128) return attn_bwd_mfma_launch<4, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias, ctx, stats);
     if (mfma_ok && dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 128) {
         if (L <= 32) return attn_bwd_mfma_launch<1>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
         if (L <= 64) return attn_bwd_mfma_launch<2>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
         return attn_bwd_mfma_launch<4>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
     }
     if (mfma_ok && dtype == CPT_BF16 && g_attn_bwd_variant != 0 && L <= 288) {      // GQA / VCR shapes: transpose-read variant
-        if (L <= 160) return attn_bwd_mfma_launch<5, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
-        if (L <= 224) return attn_bwd_mfma_launch<7, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
-        return attn_bwd_mfma_launch<9, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias);
+        if (L <= 160) return attn_bwd_mfma_launch<5, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias, ctx, stats);
+        if (L <= 224) return attn_bwd_mfma_launch<7, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias, ctx, stats);
+        return attn_bwd_mfma_launch<9, true>(qkv, attn_mask, dctx, dqkv, B, L, heads, dr, s, dbias, ctx, stats);
     }
     size_t lds = ((size_t)2 * L * 65 + 2 * AB_QB * 65 + (dr.thresh ? 3 : 2) * AB_QB * (L + 1) + L) * sizeof(float);
     const bool vg = lds > 160 * 1024;                      // beyond L ~ 176: the form that reads V from global memory (L <= 288)

@@ -32,7 +32,8 @@ int layernorm_rows(const float* x, const float* g, const float* bta, float eps, 
 
 int attention(int dtype, const void* qkv, const int64_t* attn_mask, void* ctx, void* probs, int B,
               int L, int heads, hipStream_t s, const DropSpec* drop = nullptr, int mask_3d = 0,   // mask_3d: attn_mask is [B][L][L]
-              int ctx_panel = 0);   // ctx_panel (bf16 inference): ctx leaves in the panel layout of the attn-out producer (gemm_prod.hip)
+              int ctx_panel = 0,    // ctx_panel (bf16 inference): ctx leaves in the panel layout of the attn-out producer (gemm_prod.hip)
+              float* stats = nullptr);   // stats (bf16 training forward, round 6): [B * heads][L][2] (row max in base 2, 1 / row sum) of every query, read by attention_bwd
 
 // bf16x3 parity mode: attention on bf16 MFMA with split operands (three-term products); ctx fp32 [M][H] or, with ctx_split, the split copy
 // [M][hi | hi | lo] bf16 (ld 3H) for the attention-output GEMM; 2-D masks, L <= 288 (attention_x3_supported)
@@ -107,7 +108,8 @@ int zero_segments(const ZeroSegs& z, hipStream_t s);
 int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
                hipStream_t s);
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
-                  const DropSpec* drop = nullptr, float* dbias = nullptr, int mask_3d = 0);     // dbias [3H]: += column sums of dqkv (the stacked Q|K|V bias gradient); mask_3d: attn_mask is [B][L][L]
+                  const DropSpec* drop = nullptr, float* dbias = nullptr, int mask_3d = 0,
+                  const void* ctx = nullptr, const float* stats = nullptr);     // ctx + stats (round 6): the forward's context rows and softmax statistics -- the L <= 128 bf16 kernel then skips its statistics pass;     dbias [3H]: += column sums of dqkv (the stacked Q|K|V bias gradient); mask_3d: attn_mask is [B][L][L]
 // y = dropout(x) (+ resid): x, y fp32 [R][H] (in place allowed), y_lp optional copy in lp_dtype; element index of the mask =
 // row * H + col.  Forward of the hidden dropouts and, with resid = NULL, their backward (the mask applied to a gradient).
 // bf16x3 training: the MFMA backward on split fp32 operands (bwd.hip attn_bwd_x3_kernel / attn_bwd_x3_long_kernel), L <= 288, per-key masks

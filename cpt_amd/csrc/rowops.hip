@@ -116,10 +116,18 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
             const int c = (lane + 64 * i) * 4;
             if (i < nv && c < H) {
                 v[u][i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
-                for (int k = 1; k < x_parts; ++k) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(x + (size_t)k * x_stride + (size_t)r * H + c);
+                // (eight partial matrices' loads in flight at a time, added in split order: a one-by-one loop serialised up to 15 memory round trips per row)
+                for (int k0 = 1; k0 < x_parts; k0 += 8) {
+                    f32x4 t[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[u][i][j] += t[j];
+                    for (int kk = 0; kk < 8; ++kk)
+                        if (k0 + kk < x_parts) t[kk] = *reinterpret_cast<const f32x4*>(x + (size_t)(k0 + kk) * x_stride + (size_t)r * H + c);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk)
+                        if (k0 + kk < x_parts) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[u][i][j] += t[kk][j];
+                        }
                 }
                 if (resid) rr[u][i] = *reinterpret_cast<const f32x4*>(resid + (size_t)r * H + c);
             }

@@ -40,7 +40,7 @@ inline int up64(int x) { return (x + 63) / 64 * 64; }
 
 struct TrainLayout {
     size_t x_f32, a_f32, layer0, layer_stride;
-    size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2, o_st1, o_st2;     // offsets inside a layer block (st1 / st2, round 6: (mean, rstd) per row of the two LayerNorms, read by their backward)
+    size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2, o_st1, o_st2, o_ast;     // offsets inside a layer block (st1 / st2, round 6: (mean, rstd) per row of the two LayerNorms, read by their backward)
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
     size_t dx, dpre, da, dpre_lp, dlp2, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
     size_t t_ctx, t_xres, t_pre1, t_a, t_af, t_u, t_h, t_pre2, t_st1, t_st2, t_dpre, t_dlpF, t_dlpA, t_dbig, t_da, t_dctx;      // round 6: the pruned last layer's compact [B][.] activations and gradients
@@ -67,6 +67,7 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
         w.o_xin = sub(M * H * es); w.o_qkv = sub(M * 3 * H * es); w.o_ctx = sub(M * H * es); w.o_pre1 = sub(M * H * 4);
         w.o_a = sub(M * H * es); w.o_u = sub(M * I * es); w.o_h = sub(M * I * es); w.o_pre2 = sub(M * H * 4);
         w.o_st1 = sub(M * 2 * 4); w.o_st2 = sub(M * 2 * 4);
+        w.o_ast = sub((size_t)B * d.heads * L * 2 * 4);      // softmax statistics (row max, 1 / row sum) of every (sequence, head, query): the one-pass attention backward reads them
         w.layer_stride = q;
         w.layer0 = take(q * d.layers);
     }
@@ -295,7 +296,8 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         if (x3_attn)      // bf16x3: the mode's split-operand MFMA attention (fp32 ctx out), same dropout stream
             TRY(cpt::attention_x3((const float*)LB(l, w.o_qkv), b->attn_mask, (float*)LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr), "attention (split operands)");
         else
-        TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr, m3d), "attention");
+        TRY(cpt::attention(dt, LB(l, w.o_qkv), b->attn_mask, LB(l, w.o_ctx), nullptr, B, L, d.heads, s, pa ? &da_spec : nullptr, m3d, 0,
+                           (dt == CPT_BF16 && !m3d) ? (float*)LB(l, w.o_ast) : nullptr), "attention");
         if (tail && l == d.layers - 1) {
             // ---- round 6: the rest of the last layer on the B head rows (row b = position pos[b] of sequence b) ----
             const cpt::RowMap rm = {nsp ? nullptr : b->mask_pos, L, 1};
@@ -702,7 +704,8 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             TRY(cpt::attention_bwd_x3((const float*)LB(l, w.o_qkv), b->attn_mask, (const float*)dctx, (float*)dbig, B, L, d.heads, s, pa ? &da_spec : nullptr,
                                       (g_bias_fuse & 2) ? gy.b_qkv : nullptr), "attention_bwd (split operands)");
         else
-        TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr, (g_bias_fuse & 2) ? gy.b_qkv : nullptr, (b->mask_3d && b->attn_mask) ? 1 : 0), "attention_bwd+bias");
+        TRY(cpt::attention_bwd(dt, LB(l, w.o_qkv), b->attn_mask, dctx, dbig, B, L, d.heads, s, pa ? &da_spec : nullptr, (g_bias_fuse & 2) ? gy.b_qkv : nullptr, (b->mask_3d && b->attn_mask) ? 1 : 0,
+                               (dt == CPT_BF16 && !(b->mask_3d && b->attn_mask)) ? LB(l, w.o_ctx) : nullptr, (dt == CPT_BF16 && !(b->mask_3d && b->attn_mask)) ? (const float*)LB(l, w.o_ast) : nullptr), "attention_bwd+bias");
         if (!(g_bias_fuse & 2)) TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
         if (triple) {
             rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)");

@@ -267,10 +267,10 @@ def test_attention_backward_variants_agree(dev):
             continue
         rel, mx = _rel(grads[1][n], grads[0][n].cpu())
         assert rel < 3e-2, (n, rel, mx)
-        # the two MFMA kernels issue the same products in the same order (operands read two ways); what is left is the
-        # unordered fp32 atomics of the bias / embedding gradient sums
+        # the two MFMA kernels issue the same score / dP products (operands read two ways); round 6: the default one takes the forward's softmax
+        # statistics and D = rowsum(dO . O) over the bf16-rounded context rows where the other recomputes rowsum(dP . P): 2^-9-grade differences in dS
         rel2, mx2 = _rel(grads[2][n], grads[1][n].cpu())
-        assert rel2 < 1e-4, (n, rel2, mx2)
+        assert rel2 < 8e-3, (n, rel2, mx2)
 
 
 def test_checkpoint_resume_reproduces_reference_trace(dev, golden_dir, tmp_path):
