@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      int R, int H, int grp, int grp_stride, int grp_off, int rows_per_block,
                                                      float* __restrict__ part, DropSpec dr, float* __restrict__ dbias,
                                                      const float* __restrict__ stats, int dy_parts, size_t dy_stride, const float* dy_resid,
-                                                     int nb_main, ColJobs jobs, RowMap drows) {
+                                                     int nb_main, ColJobs jobs, RowMap drows, const unsigned short* __restrict__ keep_bits) {
     // dr / dbias (training backward of LN(dropout(dense) + residual), round 2): dx_lp receives the gradient that enters the dense
     // layer -- dx through the dropout mask of the forward (regenerated, dropout.h; thresh 0: identity) -- and dbias its column
     // sums = the gradient of the dense bias; dx itself stays unmasked (it feeds the residual path).  Replaces a dropout_rows and
@@ -302,9 +302,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     // row's memory round trip used to start only after the first row's four wave reductions and stores)
     f32x4 nx[LNB_MAXV], nd[LNB_MAXV];
     float2 nst = {0.f, 1.f};
+    unsigned nkb = 0;      // the row's keep bits (keep_bits), fetched with the row
     auto fetch = [&](int r) {
         const size_t yr = (size_t)(r / grp) * grp_stride + grp_off + (r % grp);
         if (stats) nst = *reinterpret_cast<const float2*>(stats + 2 * (size_t)__builtin_amdgcn_readfirstlane(r));
+        if (keep_bits) nkb = keep_bits[(size_t)r * 64 + lane];
 #pragma unroll
         for (int i = 0; i < LNB_MAXV; ++i) {
             const int c = (lane + 64 * i) * 4;
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         f32x4 xv[LNB_MAXV], dv[LNB_MAXV], uv[LNB_MAXV];
         float s = 0.f;
         const float2 st = nst;
+        const unsigned kb_row = nkb;
 #pragma unroll
         for (int i = 0; i < LNB_MAXV; ++i) { xv[i] = nx[i]; dv[i] = nd[i]; }
         if (r + 4 < r1) fetch(r + 4);
@@ -395,6 +398,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)r * H + c) = o;
                 if (dr.thresh != 0) {
                     bool keep[4];
+                    if (keep_bits) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) keep[j] = (kb_row >> (4 * i + j)) & 1u;
+                    } else
                     drop_hidden4(dr, ((uint64_t)rowmap_row(drows, r) * H + c) >> 2, keep);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = keep[j] ? o[j] * dr.scale : 0.f;
@@ -487,8 +494,8 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
     dim3 grid(nb + col_jobs_blocks(&jobs)), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
     const int dyp = ex.dy_parts > 1 ? ex.dy_parts : 1;
-#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs, ex.drop_rows); \
-                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs, ex.drop_rows); } while (0)
+#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr); \
+                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr); } while (0)
     if (lp16) { if (gelu_in) LNB(bf16, true); else LNB(bf16, false); }
     else      { if (gelu_in) LNB(float, true); else LNB(float, false); }
 #undef LNB

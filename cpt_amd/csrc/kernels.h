@@ -84,6 +84,8 @@ struct LnBwdExtra {
     const ColJobs* jobs;      // column-sum jobs of earlier launches, run by extra workgroups of this one
     int defer_reduce;         // 1: leave this launch's partial rows [ln_bwd_part_rows(R)][2 or 3][H] in `part` for a later job instead of launching the reduction
     RowMap drop_rows;         // dropout masks taken at these rows of the full tensor (compact head rows)
+    const unsigned short* keep_bits;   // [R][64] the forward pass's keep bits (layernorm_rows_ex keep_out): bit 4 i + j of word [row][lane] = element (lane + 64 i) * 4 + j;
+                              // the mask is then read, not regenerated (the Philox rounds were ~1/3 of the launch's VALU time); H <= 1024
 };
 int ln_bwd_part_rows(int R);
 int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx, void* dx_lp, int lp_dtype,
@@ -125,7 +127,8 @@ int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
                       const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr,
-                      int x_parts = 1, size_t x_stride = 0, int out_panel = 0, float* stat_out = nullptr, const RowMap* drop_rows = nullptr);     // stat_out (round 6): [R][2] (mean, rstd) of every row, for ln_bwd     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
+                      int x_parts = 1, size_t x_stride = 0, int out_panel = 0, float* stat_out = nullptr, const RowMap* drop_rows = nullptr,
+                      unsigned short* keep_out = nullptr);     // keep_out (round 6, with drop): [R][64] keep bits of the row's dropout mask for ln_bwd (LnBwdExtra::keep_bits)     // stat_out (round 6): [R][2] (mean, rstd) of every row, for ln_bwd     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
 // resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients

@@ -95,7 +95,7 @@ template <typename LP, bool GELU_IN, int LN_RPW, int NA = 4>      // NA = 3: the
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
-    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride, int out_panel, float* __restrict__ stat_out, RowMap drows) {      // stat_out (round 6): [R][2] (mean, rstd) per row for the backward pass; x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
+    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride, int out_panel, float* __restrict__ stat_out, RowMap drows, unsigned short* __restrict__ keep_out) {      // stat_out (round 6): [R][2] (mean, rstd) per row for the backward pass; x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
     // x_parts / x_stride (round 3): x is x_parts split-K partial matrices of the dense layer in front, x_stride elements apart; the row that is
     // processed is their sum in split order (training forward: no reduction launch between the GEMM and this pass)
     // resid / dr / pre_out (training forward of LN(dropout(dense) + residual), modeling_bert.py:85-86,145 with the third-party
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     for (int u = 0; u < LN_RPW; ++u) {
         const int r = r0 + u;
         if (r >= R) continue;
+        unsigned kbits = 0;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c = (lane + 64 * i) * 4;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
                     bool keep[4];
                     drop_hidden4(dr, ((uint64_t)rowmap_row(drows, r) * H + c) >> 2, keep);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[u][i][j] = keep[j] ? v[u][i][j] * dr.scale : 0.f;
+                    for (int j = 0; j < 4; ++j) { v[u][i][j] = keep[j] ? v[u][i][j] * dr.scale : 0.f; kbits |= (keep[j] ? 1u : 0u) << (4 * i + j); }
                 }
                 if (resid) {
 #pragma unroll
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
                 if (pre_out) *reinterpret_cast<f32x4*>(pre_out + (size_t)r * H + c) = v[u][i];
             }
         }
+        if (keep_out) keep_out[(size_t)r * 64 + lane] = (unsigned short)kbits;
         float mean = 0.f, rstd = 1.f;
         if (g) ln_stats<NA>(v[u], nv, lane, H, mean, rstd, eps);
         if (stat_out && lane == 0) *reinterpret_cast<float2*>(stat_out + 2 * (size_t)r) = float2{mean, rstd};
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm768_kernel(const float* 
 
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
-                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride, int out_panel, float* stat_out, const RowMap* drop_rows) {
+                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride, int out_panel, float* stat_out, const RowMap* drop_rows, unsigned short* keep_out) {
     if (x_parts < 1 || x_parts > 64) return CPT_ERR_SHAPE;
     if (out_panel && (!out_lo || out_f32 || H % 16)) return CPT_ERR_SHAPE;      // panel output: the 3-byte residual stream only (rows rounded up to 32 by the caller's buffer)
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
@@ -214,6 +216,7 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     if (grp_stride == 0 && grp != R) grp_stride = grp;
     // H = 768 rows without residual / dropout / GELU / split-K partials: the lean kernel, one row per wave (measured against two and four rows per wave:
     // profiles/r05_ab_log.md -- 0.59 / 0.72 of 8 TB/s at 7680 / 61440 rows for the bf16 output against 0.58 / 0.71 and 0.49 / 0.67; the general kernel: 0.56 / 0.55)
+    if (keep_out && dr.thresh == 0) keep_out = nullptr;
     if (H == 768 && !gelu_in && !resid && dr.thresh == 0 && !pre_out && x_parts == 1 && !stat_out) {
         dim3 g768((R + 3) / 4), b768(ROW_THREADS);
         if (out_lp && lp_dtype == CPT_BF16)
@@ -227,9 +230,9 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
 #define LNK(LPT, GI)                                                                                                                              \
     do {                                                                                                                                          \
-        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows); \
-        else if (H == 768) layernorm_rows_kernel<LPT, GI, 1, 3><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows); \
-        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows);          \
+        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out); \
+        else if (H == 768) layernorm_rows_kernel<LPT, GI, 1, 3><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out); \
+        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out);          \
     } while (0)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
     else      { if (gelu_in) LNK(float, true); else LNK(float, false); }

@@ -40,10 +40,10 @@ inline int up64(int x) { return (x + 63) / 64 * 64; }
 
 struct TrainLayout {
     size_t x_f32, a_f32, layer0, layer_stride;
-    size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2, o_st1, o_st2, o_ast;     // offsets inside a layer block (st1 / st2, round 6: (mean, rstd) per row of the two LayerNorms, read by their backward)
+    size_t o_xin, o_qkv, o_ctx, o_pre1, o_a, o_u, o_h, o_pre2, o_st1, o_st2, o_ast, o_kb1, o_kb2;     // offsets inside a layer block (st1 / st2, round 6: (mean, rstd) per row of the two LayerNorms, read by their backward)
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
     size_t dx, dpre, da, dpre_lp, dlp2, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
-    size_t t_ctx, t_xres, t_pre1, t_a, t_af, t_u, t_h, t_pre2, t_st1, t_st2, t_dpre, t_dlpF, t_dlpA, t_dbig, t_da, t_dctx;      // round 6: the pruned last layer's compact [B][.] activations and gradients
+    size_t t_ctx, t_xres, t_pre1, t_a, t_af, t_u, t_h, t_pre2, t_st1, t_st2, t_kb1, t_kb2, t_dpre, t_dlpF, t_dlpA, t_dbig, t_da, t_dctx;      // round 6: the pruned last layer's compact [B][.] activations and gradients
     size_t lnp[2], lnp_bytes, csp; int csp_rows;      // round 6: partial column sums left for a later launch's column-sum job -- two alternating LayerNorm-backward tables, the FFN-up bias rows of the GELU-gradient GEMM
     size_t sA, sW, sA_bytes, sW_bytes;      // bf16x3: split copies of a GEMM's two fp32 operands ([rows][hi | hi | lo] and [rows][hi | lo | hi])
     size_t total, tA_bytes, tB_bytes;
@@ -67,6 +67,7 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
         w.o_xin = sub(M * H * es); w.o_qkv = sub(M * 3 * H * es); w.o_ctx = sub(M * H * es); w.o_pre1 = sub(M * H * 4);
         w.o_a = sub(M * H * es); w.o_u = sub(M * I * es); w.o_h = sub(M * I * es); w.o_pre2 = sub(M * H * 4);
         w.o_st1 = sub(M * 2 * 4); w.o_st2 = sub(M * 2 * 4);
+        w.o_kb1 = sub(M * 64 * 2); w.o_kb2 = sub(M * 64 * 2);      // keep bits of the two hidden dropouts (one 16-bit word per lane of the row pass), read back by the LayerNorm backward
         w.o_ast = sub((size_t)B * d.heads * L * 2 * 4);      // softmax statistics (row max, 1 / row sum) of every (sequence, head, query): the one-pass attention backward reads them
         w.layer_stride = q;
         w.layer0 = take(q * d.layers);
@@ -110,7 +111,7 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
     {
         const size_t Bq = (size_t)B;
         w.t_ctx = take(Bq * H * es); w.t_xres = take(Bq * H * 4); w.t_pre1 = take(Bq * H * 4); w.t_a = take(Bq * H * es); w.t_af = take(Bq * H * 4);
-        w.t_u = take(Bq * I * es); w.t_h = take(Bq * I * es); w.t_pre2 = take(Bq * H * 4); w.t_st1 = take(Bq * 8); w.t_st2 = take(Bq * 8);
+        w.t_u = take(Bq * I * es); w.t_h = take(Bq * I * es); w.t_pre2 = take(Bq * H * 4); w.t_st1 = take(Bq * 8); w.t_st2 = take(Bq * 8); w.t_kb1 = take(Bq * 128); w.t_kb2 = take(Bq * 128);
         w.t_dpre = take(Bq * H * 4); w.t_dlpF = take(Bq * H * es); w.t_dlpA = take(Bq * H * es); w.t_dbig = take(Bq * I * es); w.t_da = take(Bq * H * 4);
         w.t_dctx = take(Bq * H * es);
     }
@@ -314,7 +315,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
             }
             TRY(r1, "gemm(attn out, head rows)");
             TRY(cpt::layernorm_rows_ex(part, y.ln1_g, y.ln1_b, d.ln_eps, af_r, a_r, dt, B, H, B, 0, 0, 0, s, xres_r, ph ? &sp1 : nullptr, pre1_r, nullptr,
-                                       S1, (size_t)B * H, 0, (float*)(ws + w.t_st1), &rm), "dropout(attn out)+residual+layernorm (head rows)");
+                                       S1, (size_t)B * H, 0, (float*)(ws + w.t_st1), &rm, (unsigned short*)(ws + w.t_kb1)), "dropout(attn out)+residual+layernorm (head rows)");
             TRY(cpt::gemm_gelu2(a_r, H, y.w_in, H, y.b_in, ws + w.t_u, ws + w.t_h, I, B, I, H, s), "gemm(ffn up)+gelu (head rows)");
             int S2 = 0;
             int r2 = cpt::gemm_nt_partials(ws + w.t_h, I, y.w_out, I, y.b_out, part, w.tA_bytes, B, H, I, s, &S2);
@@ -325,7 +326,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
             TRY(r2, "gemm(ffn down, head rows)");
             // ... whose LayerNorm output IS the head's input (no gather of [MASK] / [CLS] rows below)
             TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, nullptr, ws + w.rows, dt, B, H, B, 0, 0, 0, s, af_r, ph ? &sp2 : nullptr, pre2_r, nullptr,
-                                       S2, (size_t)B * H, 0, (float*)(ws + w.t_st2), &rm), "dropout(ffn down)+residual+layernorm (head rows)");
+                                       S2, (size_t)B * H, 0, (float*)(ws + w.t_st2), &rm, (unsigned short*)(ws + w.t_kb2)), "dropout(ffn down)+residual+layernorm (head rows)");
             continue;
         }
         // round 3: where the dense layer's K is split over workgroups (few rows; or 2048..6144 rows with a long K), its partial matrices go
@@ -343,14 +344,14 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
             if (rp) return rp;
             const cpt::DropSpec sp = drop_spec(drop, 2 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex(part, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
-                                       x_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre1), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st1)), "partials+dropout(attn out)+residual+layernorm");
+                                       x_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre1), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st1), nullptr, (unsigned short*)LB(l, w.o_kb1)), "partials+dropout(attn out)+residual+layernorm");
         } else
         if (ph) {   // LN(dropout(dense(ctx)) + x): the residual add moves from the GEMM epilogue into the dropout pass
             if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, nullptr, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
             // dropout + residual + LayerNorm in one row pass (pre1 = dropout(dense) + x is stored for the backward pass)
             const cpt::DropSpec sp = drop_spec(drop, 2 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
-                                       x_f32, &sp, (float*)LB(l, w.o_pre1), nullptr, 1, 0, 0, (float*)LB(l, w.o_st1)), "dropout(attn out)+residual+layernorm");
+                                       x_f32, &sp, (float*)LB(l, w.o_pre1), nullptr, 1, 0, 0, (float*)LB(l, w.o_st1), nullptr, (unsigned short*)LB(l, w.o_kb1)), "dropout(attn out)+residual+layernorm");
         } else {
         if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, x_f32, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
         TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
@@ -368,13 +369,13 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
             if (rp) return rp;
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
-                                       a_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre2), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st2)), "partials+dropout(ffn down)+residual+layernorm");
+                                       a_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre2), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st2), nullptr, (unsigned short*)LB(l, w.o_kb2)), "partials+dropout(ffn down)+residual+layernorm");
         } else
         if (ph) {
             if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
             TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
-                                       a_f32, &sp, (float*)LB(l, w.o_pre2), nullptr, 1, 0, 0, (float*)LB(l, w.o_st2)), "dropout(ffn down)+residual+layernorm");
+                                       a_f32, &sp, (float*)LB(l, w.o_pre2), nullptr, 1, 0, 0, (float*)LB(l, w.o_st2), nullptr, (unsigned short*)LB(l, w.o_kb2)), "dropout(ffn down)+residual+layernorm");
         } else {
         if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, a_f32, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
         TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
@@ -587,7 +588,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             float* dpre_r = (float*)(ws + w.t_dpre); float* da_r = (float*)(ws + w.t_da);
             void* dlpF = ws + w.t_dlpF; void* dlpA = ws + w.t_dlpA; void* dbig_r = ws + w.t_dbig; void* dctx_r = ws + w.t_dctx;
             cpt::LnBwdExtra e2 = {};
-            e2.stats = (const float*)(ws + w.t_st2); e2.drop_rows = rm;
+            e2.stats = (const float*)(ws + w.t_st2); e2.drop_rows = rm; e2.keep_bits = (const unsigned short*)(ws + w.t_kb2);
             TRY(cpt::ln_bwd(drows, (const float*)(ws + w.t_pre2), y.ln2_g, d.ln_eps, dpre_r, dlpF, dt, gy.ln2_g, gy.ln2_b, B, H, B, 0, 0, 0, s, nullptr, 0,
                             ph ? &sp2 : nullptr, gy.b_out, &e2), "ln_bwd(ffn, head rows)");
             rc = dgrad(dlpF, H, H, y.w_out, I, H, I, B, nullptr, dbig_r, dt, "dgrad(ffn down)+gelu_bwd+bias (head rows)", ws + w.t_u, gy.b_in);
@@ -596,7 +597,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             rc = dgrad(dbig_r, I, I, y.w_in, H, I, H, B, dpre_r, da_r, CPT_F32, "dgrad(ffn up)+residual (head rows)", nullptr, nullptr, 0, &daS);
             if (rc) return rc;
             cpt::LnBwdExtra e1 = {};
-            e1.stats = (const float*)(ws + w.t_st1); e1.drop_rows = rm;
+            e1.stats = (const float*)(ws + w.t_st1); e1.drop_rows = rm; e1.keep_bits = (const unsigned short*)(ws + w.t_kb1);
             if (daS > 1) { e1.dy_parts = daS; e1.dy_stride = (size_t)B * H; e1.dy_resid = dpre_r; }
             TRY(cpt::ln_bwd(daS > 1 ? (const float*)tA : da_r, (const float*)(ws + w.t_pre1), y.ln1_g, d.ln_eps, dpre_r, dlpA, dt, gy.ln1_g, gy.ln1_b, B, H, B, 0, 0, 0, s,
                             nullptr, 0, ph ? &sp1 : nullptr, gy.b_ao, &e1), "ln_bwd(attn, head rows)");
@@ -625,7 +626,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             // launch stay behind as partial rows and are added up by spare workgroups of the NEXT LayerNorm backward (pend), as this one adds the last one's
             const cpt::DropSpec sp2 = drop_spec(drop, 3 + 3 * l, false);
             cpt::LnBwdExtra e = {};
-            e.stats = (const float*)LB(l, w.o_st2); e.jobs = &pend; e.defer_reduce = 1;
+            e.stats = (const float*)LB(l, w.o_st2); e.jobs = &pend; e.defer_reduce = 1; e.keep_bits = (const unsigned short*)LB(l, w.o_kb2);
             if (dxS > 1) { e.dy_parts = dxS; e.dy_stride = (size_t)M * H; e.dy_resid = dpre; }
             float* part = (float*)(ws + w.lnp[lnp_turn]);
             TRY(cpt::ln_bwd(dxS > 1 ? (const float*)tA : dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, ph ? dmask_lp : dpre_lp, dt, gy.ln2_g, gy.ln2_b,
@@ -678,7 +679,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         if (fuse_db) {
             const cpt::DropSpec sp1 = drop_spec(drop, 2 + 3 * l, false);
             cpt::LnBwdExtra e = {};
-            e.stats = (const float*)LB(l, w.o_st1); e.jobs = &pend; e.defer_reduce = 1;
+            e.stats = (const float*)LB(l, w.o_st1); e.jobs = &pend; e.defer_reduce = 1; e.keep_bits = (const unsigned short*)LB(l, w.o_kb1);
             if (daS > 1) { e.dy_parts = daS; e.dy_stride = (size_t)M * H; e.dy_resid = dpre; }
             float* part = (float*)(ws + w.lnp[lnp_turn]);
             TRY(cpt::ln_bwd(daS > 1 ? (const float*)tA : da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, triple ? (void*)(ws + w.dlp2) : (ph ? dmask_lp : dpre_lp), dt, gy.ln1_g, gy.ln1_b,
