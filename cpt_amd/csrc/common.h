@@ -143,6 +143,8 @@ template <> __device__ __forceinline__ float gelu_grad_for<bf16>(float x) { retu
 // replaces, so the same bits, but without six dependent ds_bpermute round trips -- the row kernels run one row per wave and sat at the
 // latency of their reduce -> reduce -> store chain): v_permlane32_swap for 32, ds_swizzle (no address operand) for 16 and 4, DPP row
 // rotate / quad permutes for 8, 2 and 1.
+// CONTRACT: 1-D workgroups whose size is a multiple of 64 (lane id = threadIdx.x & 63) with the WHOLE wave active -- the DPP / swizzle
+// steps read inactive lanes as 0 and lane_xor32 picks its half by threadIdx.x.  Every call site (23) is a one-row-per-wave or full-wave pass.
 __device__ __forceinline__ float lane_xor32(float v) {
     const int i = __float_as_int(v);
     const auto s = __builtin_amdgcn_permlane32_swap(i, i, false, false);      // {[lo, lo], [hi, hi]} of the input's two half-waves

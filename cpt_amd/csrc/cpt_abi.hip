@@ -587,7 +587,8 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     const int S_h3 = cpt::rows_gemm_splits(3 * H), S_i3 = cpt::rows_gemm_splits(3 * I);
     const bool tail_x3 = g_tail && x3a && x3f && d.layers >= 2 && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) && want_mask != want_cls &&
                          H % 64 == 0 && I % 64 == 0 && S_h3 <= 24 && S_i3 <= 24 &&
-                         std::max((size_t)S_h3 * B * (size_t)(H > I ? H : I), (size_t)S_i3 * B * H) * 4 <= (size_t)M * I * 4 && (size_t)B * I * 6 <= (size_t)M * 3 * H * 4;
+                         std::max((size_t)S_h3 * B * (size_t)(H > I ? H : I), (size_t)S_i3 * B * H) * 4 <= (size_t)M * I * 4 && (size_t)B * I * 6 <= (size_t)M * 3 * H * 4 &&
+                         (size_t)B * 3 * H * 2 <= (size_t)M * H * 4;      // (the [B][3H] bf16 split copies of the gathered rows live in the ctx / pre regions of M * H * 4 bytes: L = 1 would overrun them)
     // ... and for the fp32 mode: the same launches as its all-row form (cpt_gemm + layernorm_rows), on the B gathered rows
     const bool tail_f32 = g_tail && d.dtype == CPT_F32 && d.layers >= 2 && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) && want_mask != want_cls;
     const size_t dec_bytes_t = (size_t)d.vocab * H * 2;

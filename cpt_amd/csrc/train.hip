@@ -791,10 +791,9 @@ int cpt_train_zero_grads(const cpt_model* m, const cpt_model_grads* g, int Li, v
     if (nsp) {      // no decoder GEMM writes the word table: the lookup gradient adds into it
         if ((rc = big(g->word_emb, (size_t)d.vocab * H))) return rc;
         if ((rc = big(g->w_tr, H * H))) return rc;
-    } else {        // the MLM path leaves the pooler / relation head without a gradient
-        if ((rc = big(g->w_pool, H * H))) return rc;
-        if ((rc = big(g->w_rel, (size_t)d.n_rel * H))) return rc;
     }
+    // (the MLM path leaves the pooler / relation head without a gradient: nothing writes those regions of the caller's gradient buffer and the
+    // optimizer skips them (code 0) -- round 6: no per-step fill of them either)
     if (Li <= 0 && (rc = big(g->w_img, H * (size_t)d.img_dim))) return rc;      // no regions: the projection gets no gradient
     return CPT_OK;
 }

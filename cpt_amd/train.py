@@ -189,6 +189,7 @@ class _MLMLoss(torch.autograd.Function):
         st.saved = (bt, tensors, st.gen, drop)    # keep the input tensors alive until backward; same masks in backward
         ctx.logits = logits
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)      # (no zero-filled (R, V) gradient tensor for the scores on every backward)
         return loss_acc[0] / loss_acc[1], logits
 
     @staticmethod

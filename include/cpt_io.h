@@ -57,7 +57,9 @@ int cpt_json_find_strings(const char* json, size_t len, const char* key, size_t*
  * empty ones included), and decode group g of row r into sequence seq0 + g of out[max_seqs][max_regions][dim]
  * (zero padded; mask_img[max_seqs][max_regions] or NULL), where seq0 is the number of groups of the rows before.
  *   stripped[r] / stripped_cap[r]: per-row buffers for the JSON without the values; stripped_len[r] out
- *   seqs_per_row[n_rows], regions_per_seq[max_seqs]: out.  Temporary host vectors only; nothing is retained. */
+ *   seqs_per_row[n_rows], regions_per_seq[max_seqs]: out.  Temporary host vectors only; nothing is retained.  * Outputs on a non-OK return: UNDEFINED -- rows are scanned and decoded in one pass by the worker threads, so the rows in front of the one that
+ * fails (or of the max_seqs overflow) have already been written and later rows may have been decoded at a wrong base; nothing is written out of
+ * bounds.  A ring slot that saw an error must be refilled before it is used. */
 int cpt_decode_tsv_rows(const char* const* rows, const size_t* lens, int n_rows, const char* key, int dim,
                         int max_regions, int max_seqs, float* out, int64_t* mask_img, char* const* stripped,
                         const size_t* stripped_cap, size_t* stripped_len, int* seqs_per_row, int* regions_per_seq,

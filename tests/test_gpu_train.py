@@ -707,3 +707,25 @@ def test_development_library_variant_comparisons_in_a_subprocess():
     tail = "\n".join(r.stdout.strip().splitlines()[-15:])
     assert r.returncode == 0, tail
     assert " passed" in tail and "skipped" not in tail.splitlines()[-1], tail
+
+
+def test_hf_adamw_kernel_against_the_float64_vectors(dev, golden_dir):
+    """cpt_adamw_ex(CPT_ADAMW_HF) against the golden vectors of the INDEPENDENT float64 restatement of pytorch_transformers.AdamW
+    (oracle/make_hf_adamw_fixture.py; tests/golden/META.json says what that pin is and is not): six steps, three hyper-parameter sets."""
+    from cpt_amd import _lib as L
+    g = np.load(os.path.join(golden_dir, "hf_adamw.npz"))
+    for tag in ("gqa", "vcr", "nobias"):
+        b1, b2, eps, wd, cb = [float(x) for x in g[tag + "_hyper"]]
+        flags = L.ADAMW_HF | (0 if cb else L.ADAMW_NO_BIAS_CORRECTION)
+        n = g[tag + "_p0"].shape[0]
+        pd = torch.from_numpy(g[tag + "_p0"]).float().to(dev)
+        md, vd = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        cd = torch.ones(n, device=dev, dtype=torch.uint8)          # code 1: decayed parameter
+        for t in range(1, g[tag + "_g"].shape[0] + 1):
+            gd = torch.from_numpy(g[tag + "_g"][t - 1]).float().to(dev)
+            L.check(L.lib().cpt_adamw_ex(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), cd.data_ptr(), None, n, float(g[tag + "_lr"][t - 1]),
+                                         b1, b2, eps, wd, t, 1.0, flags, L.stream_ptr()), "cpt_adamw_ex")
+        for got, key, tol in ((pd, "_p", 4e-6), (md, "_m", 4e-6), (vd, "_v", 4e-6)):
+            ref = torch.from_numpy(g[tag + key][-1])
+            err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+            assert err < tol, (tag, key, err)

@@ -25,7 +25,7 @@ def main():
     torch.manual_seed(0)
     lib = L.lib()
     for kv in [t for t in a.tune.split(",") if t]:
-        lib.cpt_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
+        L.check(lib.cpt_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1])), "cpt_set_tuning")
     for name, K in (("attn_out", 768), ("ffn_down", I)):
         x = torch.randn(M, H, device=dev) * 1.2 + 0.3
         hi, lo = ops.resid3_split(x)
@@ -59,7 +59,7 @@ def main():
         # per-workgroup phase stamps of the panel kernel (prologue / K loop / epilogue, shader clocks)
         nwg = (M // 128) * (H // 192)
         for abl in ((0, 2, 3) if a.tune else (0,)):       # timing experiments (results garbage unless 0): 1 half the A loads, 2 no A loads, 3 no W DMA
-            lib.cpt_set_tuning(13, abl)
+            L.check(lib.cpt_set_tuning(13, abl), "cpt_set_tuning")
             tr = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
             for _ in range(3):
                 pan()
@@ -89,7 +89,7 @@ def main():
                 xcc = t[:, 6] & 15
                 print("          per XCD (workgroups, mean duration, mean K loop): " + "  ".join(
                     "%d: %d %.0f %.0f" % (x, int((xcc == x).sum()), dur[xcc == x].mean().item(), (t[:, 2] - t[:, 1]).float()[xcc == x].mean().item()) for x in range(8)), flush=True)
-        lib.cpt_set_tuning(13, 0)
+        L.check(lib.cpt_set_tuning(13, 0), "cpt_set_tuning")
         if a.no_cold:
             continue
         # operand temperature, as inside the model: caches flushed by a 1 GiB fill, then chosen operands touched again

@@ -35,7 +35,7 @@ def main():
     nwg = (M // 128) * 4
     for name, K in (("attn_out", 768), ("ffn_down", 3072)):
         tr = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
-        lib.cpt_set_tuning(8, 11 | (K << 8))
+        L.check(lib.cpt_set_tuning(8, 11 | (K << 8)), "cpt_set_tuning")
         lib.cpt_debug_gemm_trace(C.c_void_p(tr.data_ptr()))
         for _ in range(3):
             fwd()
@@ -49,7 +49,7 @@ def main():
               "workgroup wall time mean %.2f max %.2f us; first start -> last end %.2f us"
               % (name, pro, kl, kl / (K // 64), ep, (dur / wdur).mean().item() * 1e-3, wdur.mean().item(), wdur.max().item(),
                  (t[:, 5].max() - t[:, 3].min()).item() * 0.01), flush=True)
-    lib.cpt_set_tuning(-1, 0)
+    L.check(lib.cpt_set_tuning(-1, 0), "cpt_set_tuning")
 
 
 if __name__ == "__main__":

@@ -50,7 +50,7 @@ def timed(fn, steps=30, warm=5):
 
 ref = fwd(full).clone()
 print("one forward of 64:                     %.4f ms" % timed(lambda: fwd(full)))
-L.lib().cpt_set_tuning(16, 96)          # two-pass FFN-up (and with it panel mode) from 96 tiles on
+L.check(L.lib().cpt_set_tuning(16, 96), "cpt_set_tuning")          # two-pass FFN-up (and with it panel mode) from 96 tiles on
 print("two forwards of 32, one stream:        %.4f ms" % timed(lambda: [fwd(h) for h in halves]))
 eng.workspace = ws_per_stream
 
@@ -67,4 +67,4 @@ o = two()
 torch.cuda.synchronize()
 print("halves equal the full batch bit for bit:", torch.equal(torch.cat(o), ref))
 print("two forwards of 32, two streams:       %.4f ms" % timed(two))
-L.lib().cpt_set_tuning(-1, 0)
+L.check(L.lib().cpt_set_tuning(-1, 0), "cpt_set_tuning")
