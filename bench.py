@@ -28,14 +28,15 @@ BF16_DLOGIT_LIMIT = 0.03       # bf16 throughput mode against the fp32 oracle on
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}      # MI355X_MICROARCH.md: dense MFMA peaks
 def _latest(name):
     """newest committed round artefact profiles/rNN_<name>"""
-    for r in ("r05", "r04", "r03", "r02"):
+    for r in ("r06", "r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", "%s_%s" % (r, name))
         if os.path.exists(f):
             return f
-    return os.path.join(ROOT, "profiles", "r05_" + name)
+    return os.path.join(ROOT, "profiles", "r06_" + name)
 
 
 PMC_FILE = _latest("pmc_bench_summary.json")
+LIVE_MFMA_BUSY = {}        # per kernel family, filled by live_pmc_traffic: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of this run's counter pass
 YARDSTICK_FILE = _latest("yardstick.json")
 
 
@@ -47,6 +48,23 @@ def yardstick_us():
         return {k.split(" ")[0]: v["best_us"] for k, v in d.items()}
     except Exception:
         return {}
+
+
+def yardstick_live(timeout_s=180):
+    """hipBLASLt's best plain bf16 GEMM of the four encoder projections measured IN THIS RUN on this box (tools/yardstick.bin, built by
+    __graft_entry__.build(); a measurement tool, never on the product path): ({family: best_us}, note) or ({}, why)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "yardstick.bin")
+    if not os.path.exists(exe):
+        return {}, "tools/yardstick.bin not built"
+    try:
+        r = subprocess.run([exe], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        if r.returncode != 0:
+            return {}, "tools/yardstick.bin failed (rc %d)" % r.returncode
+        d = json.loads(r.stdout)["hipblaslt_bf16"]
+        return {k.split(" ")[0]: v["best_us"] for k, v in d.items()}, "tools/yardstick.bin run inside this bench.py run, same box (hipBLASLt, plain GEMM, best of the heuristic's algorithms, back-to-back launches)"
+    except Exception as e:
+        return {}, "tools/yardstick.bin: %r" % (e,)
 
 
 def fwd_gflop_per_seq(cfg, Lt, Li, mlm_head=True):
@@ -91,15 +109,17 @@ def live_pmc_traffic(kernel, timeout_s=240):
     out = {}
     tmp = tempfile.mkdtemp(prefix="cpt_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                   "--steps", "4", "--warmup", "2", "--no-cpu", "--no-roofline", "--no-extra", "--no-io", "--no-sustained"]
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
+            d = os.path.join(tmp, counter.split(" ")[0])
+            cmd = [exe, "--pmc"] + counter.split(" ") + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                    "--steps", "4", "--warmup", "2", "--no-cpu", "--no-roofline", "--no-extra", "--no-io", "--no-sustained"]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
             if r.returncode != 0:
+                if counter.startswith("SQ_"):
+                    continue            # (the MFMA-busy pass is a side figure: the traffic figure stands without it)
                 return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
         with open(os.devnull, "w") as devnull:
             stdout, sys.stdout = sys.stdout, devnull
@@ -111,6 +131,11 @@ def live_pmc_traffic(kernel, timeout_s=240):
         if fam not in d or "FETCH_SIZE" not in d[fam] or "WRITE_SIZE" not in d[fam]:
             return None, "kernel family %s missing from the counter passes" % fam
         f, w = d[fam]["FETCH_SIZE"], d[fam]["WRITE_SIZE"]
+        global LIVE_MFMA_BUSY
+        # SQ_VALU_MFMA_BUSY_CYCLES = matrix-pipe cycles summed over the chip's 1024 SIMDs (32 per v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md);
+        # GRBM_GUI_ACTIVE = the launch's cycles summed over the 8 XCDs -> busy share of all SIMD cycles = MFMA_BUSY / (GRBM / 8 * 1024)
+        LIVE_MFMA_BUSY = {k: round(v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / (128.0 * v["GRBM_GUI_ACTIVE"]["mean_per_launch"]), 4)
+                          for k, v in d.items() if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE", {}).get("mean_per_launch")}
         return int((2.0 * f["mean_per_launch"] + w["mean_per_launch"]) * 1024), \
             "measured in this run: two child passes of this command under rocprofv3 --pmc (FETCH_SIZE: %d launches, WRITE_SIZE: %d launches; 2 x FETCH + WRITE, MI355X_MICROARCH.md)" \
             % (f["launches"], w["launches"])
@@ -744,11 +769,16 @@ def main():
                 "flop_per_launch": gemm_flops(dom, M, H, I),
                 # every encoder GEMM against the same peak (gemm_qkv: projection flops only; its launches also run the attention)
                 "all_kernels_frac": {k: round(gemm_flops(k, M, H, I) / (gem[k][0] / gem[k][1] * 1e-3) / 1e12 / peak, 4) for k in gem}}
-        ys = yardstick_us() if (B == 64 and args.dtype == "bf16" and args.workload == "refcoco") else {}
+        ys, ys_note = {}, None
+        if B == 64 and args.dtype == "bf16" and args.workload == "refcoco":
+            if n_gpus == 1 and not args.tune and not args.no_live_pmc:
+                ys, ys_note = yardstick_live()
+            if not ys:
+                ys, ys_note = yardstick_us(), "profiles/%s (hipBLASLt, plain GEMM, stand-alone back-to-back launches; ANOTHER box -- %s)" % (os.path.basename(YARDSTICK_FILE), ys_note or "live run skipped")
         if ys:
             # the same launches against hipBLASLt's best PLAIN bf16 GEMM of the shape on this chip (tools/yardstick.hip; the fused
             # launches also do bias / GELU / LayerNorm / residual / attention, so 1.0 is not the bar, the trend is)
-            roof["yardstick"] = {"source": "profiles/%s (hipBLASLt, plain GEMM, stand-alone back-to-back launches)" % os.path.basename(YARDSTICK_FILE),
+            roof["yardstick"] = {"source": ys_note,
                                  "hipblaslt_us": {k: ys[k] for k in gem if k in ys},
                                  "hipblaslt_frac_of_peak": {k: round(gemm_flops(k, M, H, I) / (ys[k] * 1e-6) / 1e12 / peak, 4) for k in gem if k in ys},
                                  "ours_us": {k: round(gem[k][0] / gem[k][1] * 1e3, 2) for k in gem},
@@ -823,6 +853,11 @@ def main():
                 roof_["traffic_committed_artefact"] = roof_["traffic"]
                 roof_["traffic"] = tb
                 roof_["traffic_source"] = note
+                if LIVE_MFMA_BUSY:
+                    # north_star: "evidenced by ... MFMA utilisation": share of the chip's SIMD cycles in which the matrix pipe is busy, per kernel family of
+                    # the step: SQ_VALU_MFMA_BUSY_CYCLES / (128 x GRBM_GUI_ACTIVE) from a third rocprofv3 --pmc child pass of this run (the counter pass runs
+                    # at a slightly lower clock than the timed region: MI355X_MICROARCH.md, DVFS note)
+                    roof_["mfma_busy_frac_of_simd_cycles"] = LIVE_MFMA_BUSY
             else:
                 roof_["traffic_live_note"] = note
         if extra is not None:

@@ -66,5 +66,22 @@ def build(force=False, verbose=True, ablation=False):
     return lib
 
 
+def build_tools(verbose=True):
+    """tools/yardstick.bin: hipBLASLt's best plain bf16 GEMM of the four encoder projections + HBM streaming figures -- the ceiling probe bench.py runs
+    beside its own kernels ("re-measure, do not trust").  A measurement tool: it links hipBLASLt, the product library does not."""
+    root = os.path.dirname(HERE)
+    src, out = os.path.join(root, "tools", "yardstick.hip"), os.path.join(root, "tools", "yardstick.bin")
+    if not os.path.exists(src):
+        return None
+    if _stale(out, [src]):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", src, "-lhipblaslt", "-ldl", "-o", out]
+        if verbose:
+            print("[cpt_amd.build]", " ".join(cmd[-6:]), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed (tools/yardstick.hip):\n" + r.stdout)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, ablation="--ablation" in sys.argv))
