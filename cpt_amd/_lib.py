@@ -99,9 +99,9 @@ _SIGS = {
     "cpt_reduce_scatter": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp]),
     "cpt_allgather": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp]),
     "cpt_comm_destroy": (C.c_int, []),
-    "cpt_adamw": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+    "cpt_adamw": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                             C.c_int, C.c_float, vp]),
-    "cpt_adamw_ex": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+    "cpt_adamw_ex": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                C.c_int, C.c_float, C.c_int, vp]),
     "cpt_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int,
                            C.c_int, C.c_int, C.c_int, vp]),
@@ -191,8 +191,8 @@ def lib():
             fn = getattr(l, name)        # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if l.cpt_version() != 6:
-            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 6" % l.cpt_version())
+        if l.cpt_version() != 7:
+            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 7" % l.cpt_version())
         _lib = l
     return _lib
 

@@ -2078,11 +2078,15 @@ int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const vo
 // HF (round 5): the arithmetic of pytorch_transformers.AdamW (transformers@067923d optimization.py, the optimizer of the GQA / VCR few-shot drivers,
 // fewshot/vcr_nsp_cpt.py:385, gqa_cpt.py:342) instead of torch.optim.AdamW's: eps is added to sqrt(v) BEFORE the bias corrections scale the step
 // (step = lr sqrt(bc2) / bc1, or lr without correct_bias: bc1 = bc2_sqrt = 1 then), and the decoupled decay p -= lr wd p acts on the UPDATED parameter.
+// Scalars (round 6, ABI 7): everything derived from lr / betas / eps / weight decay is formed in DOUBLE on the host and rounded to fp32 once, exactly where torch
+// rounds the Python-float scalars it multiplies into fp32 tensors (1 - beta2 in fp32 from a fp32 beta2 was 1.3e-5 off):
+//   torch.optim.AdamW (single tensor):  p *= decay = 1 - lr wd;  m = lerp(m, g, om1);  v = v b2 + (om2 g) g;  p -= step (m / (sqrt(v) / bc2s + eps)),  step = lr / bc1
+//   pytorch_transformers.AdamW:         m = m b1 + om1 g;  v = v b2 + (om2 g) g;  p -= step (m / (sqrt(v) + eps)),  step = lr sqrt(bc2) / bc1;  p += nlw p,  nlw = -lr wd
+struct AdamScalars { float b1, b2, om1, om2, eps, step, bc2s, decay, nlw; };
 template <bool SHADOW, bool HF = false>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, const unsigned char* __restrict__ code,
-                                                    bf16* __restrict__ shadow, size_t n, float lr, float beta1, float beta2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt, float grad_scale) {
+                                                    bf16* __restrict__ shadow, size_t n, AdamScalars a, float grad_scale) {
     const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
     const f32x4 pv = *reinterpret_cast<const f32x4*>(p + i0);
@@ -2097,19 +2101,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         if (cc[e] == 0) continue;
         const float gr = gv[e] * grad_scale;
         if constexpr (HF) {
-            mv[e] = mv[e] * beta1 + (1.0f - beta1) * gr;                   // exp_avg.mul_(beta1).add_(1 - beta1, grad)
-            vv[e] = vv[e] * beta2 + (1.0f - beta2) * gr * gr;              // exp_avg_sq.mul_(beta2).addcmul_(1 - beta2, grad, grad)
-            const float denom = sqrtf(vv[e]) + eps;
-            float pe = pv[e] - (lr * bc2_sqrt / bc1) * (mv[e] / denom);
-            if (cc[e] == 1) pe = pe - lr * wd * pe;
+            mv[e] = mv[e] * a.b1 + a.om1 * gr;                             // exp_avg.mul_(beta1).add_(1 - beta1, grad)
+            vv[e] = vv[e] * a.b2 + (a.om2 * gr) * gr;                      // exp_avg_sq.mul_(beta2).addcmul_(1 - beta2, grad, grad)
+            const float denom = sqrtf(vv[e]) + a.eps;
+            float pe = pv[e] - a.step * (mv[e] / denom);                   // p.addcdiv_(-step_size, exp_avg, denom)
+            if (cc[e] == 1) pe = pe + a.nlw * pe;                          // p.add_(-lr * weight_decay, p)
             po[e] = pe;
             continue;
         }
-        float pe = pv[e] * (1.0f - lr * (cc[e] == 1 ? wd : 0.f));
-        mv[e] = mv[e] + (gr - mv[e]) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1-beta1)
-        vv[e] = vv[e] * beta2 + gr * gr * (1.0f - beta2);
-        const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
-        pe = pe - (lr / bc1) * (mv[e] / denom);
+        float pe = cc[e] == 1 ? pv[e] * a.decay : pv[e];                   // param.mul_(1 - lr * weight_decay)
+        mv[e] = mv[e] + (gr - mv[e]) * a.om1;                              // exp_avg.lerp_(grad, 1 - beta1)
+        vv[e] = vv[e] * a.b2 + (a.om2 * gr) * gr;                          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float denom = sqrtf(vv[e]) / a.bc2s + a.eps;                 // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+        pe = pe - a.step * (mv[e] / denom);                                // param.addcdiv_(exp_avg, denom, value=-step_size)
         po[e] = pe;
     }
     *reinterpret_cast<f32x4*>(p + i0) = po;
@@ -2124,20 +2128,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16, size_t n,
-               float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s, int flags) {
+               double lr, double beta1, double beta2, double eps, double wd, int step, float grad_scale, hipStream_t s, int flags) {
     if (!p || !g || !m || !v || !code) return CPT_ERR_NULL;
     if (n % 4 || step < 1 || (flags & ~3)) return CPT_ERR_SHAPE;
     const bool hf = flags & 1, no_bc = flags & 2;
-    const float bc1 = no_bc ? 1.0f : 1.0f - powf(beta1, (float)step);
-    const float bc2s = no_bc ? 1.0f : sqrtf(1.0f - powf(beta2, (float)step));
+    const double bc1 = no_bc ? 1.0 : 1.0 - pow(beta1, (double)step);
+    const double bc2 = no_bc ? 1.0 : 1.0 - pow(beta2, (double)step);
+    AdamScalars a;
+    a.b1 = (float)beta1; a.b2 = (float)beta2; a.om1 = (float)(1.0 - beta1); a.om2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.bc2s = (float)sqrt(bc2);
+    a.step = hf ? (float)(lr * sqrt(bc2) / bc1) : (float)(lr / bc1);
+    a.decay = (float)(1.0 - lr * wd);
+    a.nlw = (float)(-lr * wd);
     dim3 grid((unsigned)((n / 4 + 255) / 256)), block(256);
     if (hf) {
-        if (shadow_bf16) adamw_kernel<true, true><<<grid, block, 0, s>>>(p, g, m, v, code, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
-        else adamw_kernel<false, true><<<grid, block, 0, s>>>(p, g, m, v, code, nullptr, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
+        if (shadow_bf16) adamw_kernel<true, true><<<grid, block, 0, s>>>(p, g, m, v, code, (bf16*)shadow_bf16, n, a, grad_scale);
+        else adamw_kernel<false, true><<<grid, block, 0, s>>>(p, g, m, v, code, nullptr, n, a, grad_scale);
         return CPT_OK;
     }
-    if (shadow_bf16) adamw_kernel<true><<<grid, block, 0, s>>>(p, g, m, v, code, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
-    else adamw_kernel<false><<<grid, block, 0, s>>>(p, g, m, v, code, nullptr, n, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale);
+    if (shadow_bf16) adamw_kernel<true><<<grid, block, 0, s>>>(p, g, m, v, code, (bf16*)shadow_bf16, n, a, grad_scale);
+    else adamw_kernel<false><<<grid, block, 0, s>>>(p, g, m, v, code, nullptr, n, a, grad_scale);
     return CPT_OK;
 }
 

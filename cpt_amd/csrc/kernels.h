@@ -123,7 +123,7 @@ int dropout_rows(const float* x, const float* resid, float* y, void* y_lp, int l
 // keep-mask export (tests): kind 0 hidden [R][H]; kind 1 attention [BH][L][L]; out = 1 keep / 0 drop
 int dropout_mask(int kind, unsigned char* out, int n0, int n1, int n2, const DropSpec& d, hipStream_t s);
 int adamw_flat(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16, size_t n,
-               float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s, int flags = 0);     // flags: CPT_ADAMW_* (cpt_hip.h)
+               double lr, double beta1, double beta2, double eps, double wd, int step, float grad_scale, hipStream_t s, int flags = 0);     // flags: CPT_ADAMW_* (cpt_hip.h)
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32, void* out_lp,
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
                       const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr,

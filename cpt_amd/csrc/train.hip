@@ -849,14 +849,14 @@ int cpt_embed_ln_bwd(const float* dy, const int64_t* ids, const int64_t* tt, con
 }
 
 int cpt_adamw(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16,
-              size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+              size_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
               float grad_scale, void* stream) {
     return abi_check(cpt::adamw_flat(p, g, m, v, code, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
                                      (hipStream_t)stream), "cpt_adamw");
 }
 
 int cpt_adamw_ex(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16,
-                 size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                 size_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                  float grad_scale, int flags, void* stream) {
     if (flags & ~(CPT_ADAMW_HF | CPT_ADAMW_NO_BIAS_CORRECTION)) return abi_fail(CPT_ERR_SHAPE, "cpt_adamw_ex: unknown flags %d", flags);
     return abi_check(cpt::adamw_flat(p, g, m, v, code, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,

@@ -38,9 +38,10 @@
 extern "C" {
 #endif
 
-#define CPT_ABI_VERSION 6     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads, cpt_batch.n_rows / mask_3d / row_seq;
+#define CPT_ABI_VERSION 7     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads, cpt_batch.n_rows / mask_3d / row_seq;
                                * 6: CPT_BF16X3 in cpt_train_* (fp32 master weights there, NOT the split copies cpt_model_fwd reads under the same tag: the training step's own tag is CPT_BF16X3_MASTERS),
-                               *    cpt_set_tuning / cpt_prof_* / cpt_debug_gemm_trace declared in cpt_hip_debug.h, operator-level backward entry points, cpt_comm_* */
+                               *    cpt_set_tuning / cpt_prof_* / cpt_debug_gemm_trace declared in cpt_hip_debug.h, operator-level backward entry points, cpt_comm_*;
+                               * 7: cpt_adamw / cpt_adamw_ex take lr, betas, eps and weight decay as doubles (round 6) */
 
 enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2,
        CPT_BF16X3_MASTERS = 3 /* ABI 6, cpt_dims.dtype for cpt_train_* only: CPT_BF16X3 arithmetic on plain fp32 weight matrices (split per GEMM) */ };
@@ -277,9 +278,12 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
 /* torch.optim.AdamW update (fewshot/refcoco_cpt.py:343,249) over flat buffers of n fp32 elements
  * (n % 4 == 0).  code[i]: 0 = no gradient on this path (skipped), 1 = weight decay, 2 = no decay
  * (fewshot/refcoco_cpt.py:320-338).  grad is multiplied by grad_scale first (1/world after a
- * sum all-reduce).  shadow_bf16 (optional) receives the bf16 copy of the updated parameters. */
+ * sum all-reduce).  shadow_bf16 (optional) receives the bf16 copy of the updated parameters.
+ * ABI 7 (round 6): lr, beta1, beta2, eps, weight_decay are DOUBLES, as the reference's optimizers hold them (Python floats): the derived scalars
+ * (1 - beta, 1 - lr * weight_decay, lr / (1 - beta1^t), sqrt(1 - beta2^t)) are formed in double on the host and rounded to fp32 ONCE, where torch
+ * rounds them -- with float betas 1 - 0.999f was 1.3e-5 off 0.001 (found by the float64 golden vectors of tests/golden/hf_adamw.npz). */
 int cpt_adamw(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16,
-              size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+              size_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
               float grad_scale, void* stream);
 
 /* Round 5 (ABI 6): the same launch with the arithmetic of the GQA / VCR few-shot drivers' optimizer, pytorch_transformers.AdamW
@@ -290,7 +294,7 @@ int cpt_adamw(float* p, const float* g, float* m, float* v, const unsigned char*
  *   CPT_ADAMW_NO_BIAS_CORRECTION: correct_bias = False (both corrections 1). */
 enum { CPT_ADAMW_HF = 1, CPT_ADAMW_NO_BIAS_CORRECTION = 2 };
 int cpt_adamw_ex(float* p, const float* g, float* m, float* v, const unsigned char* code, void* shadow_bf16,
-                 size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                 size_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                  float grad_scale, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------

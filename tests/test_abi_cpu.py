@@ -28,7 +28,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), "libcpt_hip.so does not export %s" % n
     assert set(_lib.exported_symbols()) == set(names), set(_lib.exported_symbols()) ^ set(names)
-    assert lib.cpt_version() == 6
+    assert lib.cpt_version() == 7
     assert isinstance(lib.cpt_last_error(), bytes)
 
 
