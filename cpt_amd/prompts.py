@@ -1,4 +1,5 @@
-"""Prompt assembly for the RefCOCO colour-prompt data sets, host side.
+"""Prompt assembly for the RefCOCO colour-prompt data sets, host side; at the end of the file, round 6: the same for the
+GQA and VCR few-shot drivers (gqa_cpt.py:109-267, vcr_nsp_cpt.py:141-311).
 
 Counterpart of /root/reference/Oscar/oscar/datasets/refcoco_zsl_cpt_dataset.py:
   * ``TEMPLATES``            -- template1..6 (:18-54): where the ``[MASK]`` colour slot goes in the caption;
@@ -198,3 +199,99 @@ class PromptBuilder(object):
         k = np.asarray(keep, dtype=np.int64)
         return {"img_name": img_name, "input_ids": input_ids[k], "input_mask": input_mask[k], "segment_ids": segment_ids[k],
                 "mask_token_pos": mask_pos[k], "gts": [gts[i] for i in keep], "colors": colors, "rects": rects, "keep": keep}
+
+
+# ---- GQA and VCR few-shot drivers (round 6; SURVEY 8(f).2 cites the RefCOCO data sets only -- these are the next callers out) ----------------------
+# Counterparts of GQADataset.tensorize_example / get_img_feature (/root/reference/Oscar/oscar/fewshot/gqa_cpt.py:109-193, 231-267) and of
+# VCRDataset._vcr_textize / tensorize_example / _tensorize (fewshot/vcr_nsp_cpt.py:156-311).  As above: the region features stay with cpt_amd.io (only
+# their count enters the mask), the tokenizer object is the caller's, arrays come back as int64 numpy, one row per sequence.
+
+def tokenize_pair(tokenizer, text_a, text_b, n_img_feats, max_seq_length=165, max_img_seq_length=45, cls_token="[CLS]", sep_token="[SEP]",
+                  pad_token=0, sequence_a_segment_id=0, sequence_b_segment_id=1, cls_token_segment_id=0, pad_token_segment_id=0,
+                  split_b_on_semicolons=False):
+    """The text side both drivers share (gqa_cpt.py:117-160, vcr_nsp_cpt.py:205-262; the BERT branch: [CLS] in front, padding on the right):
+    tokens = [CLS] a [SEP] (b [SEP]); the pair is cut longest-first to max_seq_length - 3 (a alone to max_seq_length - 2); segment ids 0 / 1 with the
+    [CLS] slot's own id; the attention mask covers the text and then one slot per region, zero-padded to max_img_seq_length (regions beyond it are
+    cut, as the drivers cut the feature rows: gqa_cpt.py:163-167).  ``split_b_on_semicolons``: VCR's text_b handling (';' separates object-label
+    groups; they are joined by blanks before tokenising, vcr_nsp_cpt.py:213-222).
+    Returns (input_ids (max_seq_length,), input_mask (max_seq_length + max_img_seq_length,), segment_ids (max_seq_length,), mask_positions [list of the
+    positions holding id 103])."""
+    tokens_a = tokenizer.tokenize(text_a)
+    tokens_b = None
+    if text_b:
+        tb = text_b.replace(";", " ").strip() if split_b_on_semicolons else text_b
+        tokens_b = tokenizer.tokenize(tb)
+        truncate_seq_pair(tokens_a, tokens_b, max_seq_length - 3)
+    elif len(tokens_a) > max_seq_length - 2:
+        tokens_a = tokens_a[:max_seq_length - 2]
+    tokens = tokens_a + [sep_token]
+    seg = [sequence_a_segment_id] * len(tokens)
+    if tokens_b:
+        tokens += tokens_b + [sep_token]
+        seg += [sequence_b_segment_id] * (len(tokens_b) + 1)
+    tokens = [cls_token] + tokens
+    seg = [cls_token_segment_id] + seg
+    ids = tokenizer.convert_tokens_to_ids(tokens)
+    n = len(ids)
+    if n > max_seq_length:
+        raise AssertionError("sequence of %d tokens exceeds max_seq_length %d" % (n, max_seq_length))
+    input_ids = np.full(max_seq_length, pad_token, dtype=np.int64)
+    input_ids[:n] = ids
+    segment_ids = np.full(max_seq_length, pad_token_segment_id, dtype=np.int64)
+    segment_ids[:n] = seg
+    L_img = max(max_img_seq_length, 0)
+    input_mask = np.zeros(max_seq_length + L_img, dtype=np.int64)
+    input_mask[:n] = 1
+    if L_img > 0:
+        input_mask[max_seq_length:max_seq_length + min(int(n_img_feats), L_img)] = 1
+    return input_ids, input_mask, segment_ids, [int(p) for p in np.nonzero(input_ids == MASK_ID)[0]]
+
+
+def gqa_question(question, positions_and_colors):
+    """gqa_cpt.py:237-249: the colour words of the painted objects spliced into the question at their character positions
+    (meta_infos[0] of the colour-feature row: [[[position, ...], colour], ...])."""
+    positions = [0] + [x[0][0] for x in positions_and_colors]
+    colors = [x[1] for x in positions_and_colors]
+    parts = []
+    for i in range(len(positions) - 1):
+        parts.append(question[positions[i]:positions[i + 1]])
+        parts.append(colors[i] + " ")
+    parts.append(question[positions[-1]:])
+    return "".join(parts)
+
+
+def assemble_gqa(tokenizer, question, label, n_labels, n_regions, positions_and_colors=None, q_id=0, max_seq_length=165, max_img_seq_length=45):
+    """GQADataset.tensorize_example (gqa_cpt.py:109-193) for one question: text_a = the question (with the colour words spliced in when the
+    colour-feature row carries them), text_b = "[MASK]"; label ids (None / [] -> [0]) and the n_labels-wide 0/1 target (target_tensor, :765-771)."""
+    text_a = gqa_question(question, positions_and_colors) if positions_and_colors is not None else question
+    ids, msk, seg, mpos = tokenize_pair(tokenizer, text_a, "[MASK]", n_regions, max_seq_length, max_img_seq_length)
+    label_id = [0] if (label is None or len(label) == 0) else [int(l) for l in label]
+    target = np.zeros(n_labels, dtype=np.float32)
+    for l in label_id:
+        target[l] = 1.0
+    return {"text_a": text_a, "input_ids": ids, "input_mask": msk, "segment_ids": seg, "label_id": np.array([label_id[0]], dtype=np.int64),
+            "target": target, "q_id": np.array([int(q_id)], dtype=np.int64), "mask_token_pos": mpos}
+
+
+def vcr_textize(sentence, colors, names, colorful=True):
+    """VCRDataset._vcr_textize (vcr_nsp_cpt.py:156-166): words stay, object references (lists of box indices) become the objects' names -- with
+    " in <colour>" behind a painted one when ``colorful``; colors / names are keyed by the sorted indices joined with '_'."""
+    def word(w):
+        k = "_".join(str(y) for y in sorted(w))
+        if k in colors and colorful:
+            return names[k] + " in {}".format(colors[k])
+        return names[k]
+    return " ".join(word(w) if type(w) is list else w for w in sentence)
+
+
+def assemble_vcr(tokenizer, question, choices, colors, names, n_regions, label=None, q_id=0, max_seq_length=165, max_img_seq_length=45):
+    """VCRDataset.tensorize_example + _tensorize (vcr_nsp_cpt.py:168-311): one sequence per answer choice -- text_a = the question, text_b = the
+    choice, both with the objects' names (and colours) written out.  Stacked (n_choices, ...) int64 arrays."""
+    text_a = vcr_textize(question, colors, names)
+    ids, msk, seg, mpos, texts_b = [], [], [], [], []
+    for c in choices:
+        tb = vcr_textize(c, colors, names, colorful=True)
+        i, m, s, p = tokenize_pair(tokenizer, text_a, tb, n_regions, max_seq_length, max_img_seq_length, split_b_on_semicolons=True)
+        ids.append(i); msk.append(m); seg.append(s); mpos.append(p); texts_b.append(tb)
+    return {"text_a": text_a, "texts_b": texts_b, "input_ids": np.stack(ids), "input_mask": np.stack(msk), "segment_ids": np.stack(seg),
+            "mask_token_pos": mpos, "label": [0] if label is None else label, "q_id": int(q_id)}
