@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      LP* __restrict__ dx_lp, float* __restrict__ dg, float* __restrict__ db,
                                                      int R, int H, int grp, int grp_stride, int grp_off, int rows_per_block,
                                                      float* __restrict__ part, DropSpec dr, float* __restrict__ dbias,
-                                                     const float* __restrict__ stats, int dy_parts, size_t dy_stride, const float* dy_resid,
+                                                     const float* __restrict__ stats, int dy_parts, size_t dy_stride, const float* dy_resid, int dy_bf16,
                                                      int nb_main, ColJobs jobs, RowMap drows, const unsigned short* __restrict__ keep_bits) {
     // dr / dbias (training backward of LN(dropout(dense) + residual), round 2): dx_lp receives the gradient that enters the dense
     // layer -- dx through the dropout mask of the forward (regenerated, dropout.h; thresh 0: identity) -- and dbias its column
@@ -312,6 +312,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             const int c = (lane + 64 * i) * 4;
             if (i < nv && c < H) {
                 nx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
+                if (dy_bf16) {      // two bf16 partial matrices of the data-gradient GEMM (gemm_nn split2_bf16): bf16 -> fp32 is exact, the sum and the residual add are fp32
+                    const bf16* dyh = reinterpret_cast<const bf16*>(dy);
+                    const bf16x4 p0 = *reinterpret_cast<const bf16x4*>(dyh + yr * H + c), p1 = *reinterpret_cast<const bf16x4*>(dyh + dy_stride + yr * H + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nd[i][j] = (float)p0[j] + (float)p1[j];
+                } else {
                 nd[i] = *reinterpret_cast<const f32x4*>(dy + yr * H + c);
                 for (int k0 = 1; k0 < dy_parts; k0 += 8) {      // eight partial matrices' loads in flight at a time, added in split order
                     f32x4 t[8];
@@ -324,6 +330,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
                             for (int j = 0; j < 4; ++j) nd[i][j] += t[kk][j];
                         }
+                }
                 }
                 if (dy_resid) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(dy_resid + yr * H + c);
@@ -483,6 +490,7 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
     const LnBwdExtra e0 = {};
     const LnBwdExtra& ex = ext ? *ext : e0;
     if (ex.dy_parts > 1 && (grp != R || !g)) return CPT_ERR_SHAPE;
+    if (ex.dy_parts_bf16 && ex.dy_parts != 2) return CPT_ERR_SHAPE;
     if (ex.defer_reduce && !(g && part && (size_t)ln_bwd_part_rows(R) * nsum * H * 4 <= part_bytes)) return CPT_ERR_WORKSPACE;
     // rows per block: with atomics fewer blocks = fewer dgamma/dbeta atomics (2*H per block); with a partial-sum buffer (two-stage
     // column sums) one row per wave keeps 4x the rows in flight: the kernel is latency-bound otherwise (22 -> ~10 us at 3840 rows)
@@ -494,8 +502,8 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
     dim3 grid(nb + col_jobs_blocks(&jobs)), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
     const int dyp = ex.dy_parts > 1 ? ex.dy_parts : 1;
-#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr); \
-                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr); } while (0)
+#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, (ex.dy_parts_bf16 && dyp == 2) ? 1 : 0, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr); \
+                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, (ex.dy_parts_bf16 && dyp == 2) ? 1 : 0, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr); } while (0)
     if (lp16) { if (gelu_in) LNB(bf16, true); else LNB(bf16, false); }
     else      { if (gelu_in) LNB(float, true); else LNB(float, false); }
 #undef LNB

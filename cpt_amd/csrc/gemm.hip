@@ -1588,12 +1588,14 @@ int gemm_nt_partials(const void* A, int lda, const void* W, int ldw, const float
 
 // ---- NN form: out[M][N] = A[M][K] . W[K][N] (+ resid), W = an nn.Linear weight [out_features = K][in_features = N] as stored:
 // the data gradients dX = dY . W of the backward pass without a transposed weight copy --------------------------------------
+CPT_SWITCH(int g_nn_split2, 1);      // cpt_set_tuning(34, v): 1 (default) = the data-gradient GEMMs in front of a LayerNorm backward at 2048..6144 rows as two K-split bf16 partial matrices of 128 x 192 tiles
+void set_nn_split2(int v) { CPT_SWITCH_SET(g_nn_split2 = v); (void)v; }
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw) {
     return M > 0 && N > 0 && K > 0 && (N % 192 == 0 || N % 128 == 0) && K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0 && (size_t)K * ldw * 2 <= (size_t)0x7fffffff;
 }
 
 int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, int ldr, void* out, int out_dtype, int ldo, int M, int N, int K,
-            hipStream_t s, int w_rows, void* partials, size_t partial_bytes, const void* gelu_u, int ldu, float* gelu_colsum, int colsum_rows, int* S_out) {
+            hipStream_t s, int w_rows, void* partials, size_t partial_bytes, const void* gelu_u, int ldu, float* gelu_colsum, int colsum_rows, int* S_out, int split2_bf16) {
     if (S_out) *S_out = 1;
     if (!gemm_nn_eligible(M, N, K, lda, ldw)) return CPT_ERR_SHAPE;
     if (colsum_rows > 0 && (colsum_rows < (M + 31) / 32 || ldo % 4 || ldu % 8)) return CPT_ERR_SHAPE;      // partial-row bias sums: one row per 32-row wave block, vector epilogue
@@ -1609,6 +1611,17 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
     ex.w_rows = w_rows;
     ex.colsum = gelu_u ? gelu_colsum : nullptr;
     ex.colsum_rows = gelu_u && gelu_colsum ? colsum_rows : 0;
+    // round 6 (split2_bf16, with S_out): 2048..6144 rows, a long contraction and a consumer that adds partial matrices itself (the LayerNorm backward behind
+    // the data-gradient GEMMs): 128 x 192 tiles with K split over two workgroups instead of 64 x 192 tiles over the whole K.  The 64 x 192 tile is bound by
+    // its LDS-DMA operand stream (1.5 MFMAs per KiB of operands against 2.4); the two partial matrices leave as bf16 (the same bytes as one fp32 matrix; the
+    // fp32 residual is added by the consumer, not here) -- with fp32 partials the extra 35 MB per launch pair ate the gain (profiles/r06_ab_log.md)
+    if (S_out && split2_bf16 && g_nn_split2 && out_dtype == CPT_F32 && !gelu_u && partials && ldo == N && n192 && (!resid || ldr == N) && M >= 2048 && M <= 6144 &&
+        K >= 1536 && K % 128 == 0 && 2 * (size_t)M * N * 2 <= partial_bytes) {
+        int rc = launch_pipe<bf16, CPT_EPI_NONE, bf16, 128, 192, 4, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, nullptr, 0, (bf16*)partials, ldo, M, N, K, s, 2, &ex);
+        if (rc != CPT_OK) return rc;
+        *S_out = 2;
+        return CPT_OK;
+    }
     // few output tiles and a long contraction (the decoder's data gradient: 32 x 768 outputs over K = 30528 ran on 4 CUs for 220 us):
     // split K over up to 64 workgroups per tile, partial matrices added in split order
     if (out_dtype == CPT_F32 && (!resid || ldr == N) && partials && ldo == N && n192) {

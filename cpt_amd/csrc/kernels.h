@@ -79,6 +79,7 @@ __host__ __device__ inline size_t rowmap_row(const RowMap& m, int r) {
 struct LnBwdExtra {
     const float* stats;       // [R][2] (mean, rstd) of the forward (layernorm_rows_ex stat_out): the row statistics are not recomputed
     int dy_parts;             // > 1: dy holds that many split-K partial matrices dy_stride elements apart (compact rows only), added in split order
+    int dy_parts_bf16;        // the partial matrices are bf16 (gemm_nn split2_bf16), not fp32
     size_t dy_stride;
     const float* dy_resid;    // + this (the residual of the data-gradient GEMM whose partials dy holds)
     const ColJobs* jobs;      // column-sum jobs of earlier launches, run by extra workgroups of this one
@@ -153,7 +154,8 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
             hipStream_t s, int w_rows = 0, void* partials = nullptr, size_t partial_bytes = 0, const void* gelu_u = nullptr, int ldu = 0,
             float* gelu_colsum = nullptr,      // gelu_colsum [N] (with gelu_u): += column sums of out (fp32, before the bf16 rounding) = the gradient of the bias in front of the GELU
             int colsum_rows = 0,               // > 0 (round 6): gelu_colsum is [colsum_rows >= M / 32][N] partial rows (plain stores, one per 32-row wave block) for a later column-sum job
-            int* S_out = nullptr);             // non-NULL (round 6): where the launch splits K, leave the *S_out partial matrices in `partials` (no reduction launch, resid NOT added); *S_out = 1: out is complete
+            int* S_out = nullptr,              // non-NULL (round 6): where the launch splits K, leave the *S_out partial matrices in `partials` (no reduction launch, resid NOT added); *S_out = 1: out is complete
+            int split2_bf16 = 0);              // with S_out: the caller's consumer also takes TWO BF16 partial matrices (2048..6144 rows, long K: 128 x 192 tiles, K split in two); then *S_out = 2 means bf16 partials
 // gelu_u (bf16 out only): out = (A.W) * gelu'(u) with u bf16 [M][ldu] -- the GELU backward fused into the data-gradient GEMM
 // w_rows: rows of W that exist when K was rounded up to a multiple of 64 (A's extra columns must be zero); partials: split-K scratch
 // u = A.W^T + bias (bf16) and h = gelu(u) (bf16) from one bf16 GEMM (training forward of BertIntermediate)
@@ -236,6 +238,7 @@ void set_attn_qt_all(int v); // stand-alone attention, L > 128: the query tiles 
 int gemm_gelu_x3(const void* A3, int lda, const void* W3, int ldw, const float* bias, void* out_split, int M, int N, int K3, hipStream_t s);
 void set_fwd_split2(int v);  // training forward: FFN-down as two split-K partial matrices summed by the LayerNorm pass (1, default)
 void set_qkv_2pass(int v);   // stand-alone LayerNorm-consumer QKV projection through the GELU-less two-pass kernel (1, default)
+void set_nn_split2(int v);   // training backward: data gradients in front of a LayerNorm backward as two K-split bf16 partial matrices (1, default)
 void set_train_tail(int v);  // training step: the last encoder layer behind the attention on the head rows only (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
 void set_lnb_rpb(int v);     // LayerNorm backward: rows per workgroup of the two-stage column-sum form (experiments)

@@ -489,12 +489,12 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     // LayerNorm backward behind it, which adds them and the residual itself (*S_out = 1: `out` is complete)
     auto dgrad = [&](const void* dY, int ldy, int Nout_p, const void* Wt, int ldw, int Nout, int Kout, int rows,
                      const float* resid, void* out, int out_dt, const char* what, const void* gelu_u = nullptr, float* gelu_colsum = nullptr,
-                     int colsum_rows = 0, int* S_out = nullptr) -> int {
+                     int colsum_rows = 0, int* S_out = nullptr, int split2_bf16 = 0) -> int {
         if (S_out) *S_out = 1;
         // bf16, tile-aligned: the NN form reads the weight as stored (transpose reads in LDS)
         // (Nout < Nout_p: the K-tile padding columns of dY are zero and the weight rows beyond Nout read as zero)
         if (g_wgrad_tn && dt == CPT_BF16 && cpt::gemm_nn_eligible(rows, Kout, Nout_p, ldy, ldw)) {
-            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes, gelu_u, Kout, gelu_colsum, colsum_rows, S_out), what);
+            TRY(cpt::gemm_nn(dY, ldy, Wt, ldw, resid, Kout, out, out_dt, Kout, rows, Kout, Nout_p, s, Nout, tA, w.tA_bytes, gelu_u, Kout, gelu_colsum, colsum_rows, S_out, split2_bf16), what);
             return CPT_OK;
         }
         if (gelu_u) return NOT_FUSED;   // caller runs the unfused pair (dgrad, then gelu_bwd)
@@ -574,7 +574,8 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     const void* dpre_in = ph ? (dt == CPT_BF16 ? (const void*)dmask_lp : (const void*)dmask) : (dt == CPT_BF16 ? (const void*)dpre_lp : (const void*)dpre);
     const float* dpre_f = ph ? dmask : dpre;
     cpt::ColJobs pend = {};      // round 6: column-sum jobs waiting for a carrier launch (kernels.h)
-    int lnp_turn = 0, dxS = 1;   // dxS > 1: the gradient entering the layer lies in tA as that many K-split partial matrices (+ residual dpre)
+    int lnp_turn = 0, dxS = 1, dxB = 0;      // dxB: those partial matrices are bf16 (two of them, gemm_nn split2_bf16)
+      // dxS > 1: the gradient entering the layer lies in tA as that many K-split partial matrices (+ residual dpre)
     for (int l = d.layers - 1; l >= 0; --l) {
         const cpt_layer& y = m->layers[l];
         const cpt_layer_grads& gy = g->layers[l];
@@ -627,7 +628,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             const cpt::DropSpec sp2 = drop_spec(drop, 3 + 3 * l, false);
             cpt::LnBwdExtra e = {};
             e.stats = (const float*)LB(l, w.o_st2); e.jobs = &pend; e.defer_reduce = 1; e.keep_bits = (const unsigned short*)LB(l, w.o_kb2);
-            if (dxS > 1) { e.dy_parts = dxS; e.dy_stride = (size_t)M * H; e.dy_resid = dpre; }
+            if (dxS > 1) { e.dy_parts = dxS; e.dy_stride = (size_t)M * H; e.dy_resid = dpre; e.dy_parts_bf16 = dxB; }
             float* part = (float*)(ws + w.lnp[lnp_turn]);
             TRY(cpt::ln_bwd(dxS > 1 ? (const float*)tA : dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, ph ? dmask_lp : dpre_lp, dt, gy.ln2_g, gy.ln2_b,
                             M, H, M, 0, 0, 0, s, part, w.lnp_bytes, ph ? &sp2 : nullptr, gy.b_out, &e), "ln_bwd(ffn)+dropout+bias");
@@ -673,14 +674,15 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             if (rc) return rc;
         }
         int daS = 1;
-        rc = dgrad(dbig, I, I, y.w_in, H, I, H, M, dpre, da, CPT_F32, "dgrad(ffn up)+residual", nullptr, nullptr, 0, fuse_db ? &daS : nullptr);
+        rc = dgrad(dbig, I, I, y.w_in, H, I, H, M, dpre, da, CPT_F32, "dgrad(ffn up)+residual", nullptr, nullptr, 0, fuse_db ? &daS : nullptr, 1);
+        const int daB = (daS == 2 && M >= 2048) ? 1 : 0;      // (two partial matrices at 2048..6144 rows: the bf16 pair of gemm_nn's split2_bf16; at few rows K splits >= 4 ways in fp32)
         if (rc) return rc;
         // a = LN1(pre1); pre1 = ctx W_ao^T + b_ao + x_in
         if (fuse_db) {
             const cpt::DropSpec sp1 = drop_spec(drop, 2 + 3 * l, false);
             cpt::LnBwdExtra e = {};
             e.stats = (const float*)LB(l, w.o_st1); e.jobs = &pend; e.defer_reduce = 1; e.keep_bits = (const unsigned short*)LB(l, w.o_kb1);
-            if (daS > 1) { e.dy_parts = daS; e.dy_stride = (size_t)M * H; e.dy_resid = dpre; }
+            if (daS > 1) { e.dy_parts = daS; e.dy_stride = (size_t)M * H; e.dy_resid = dpre; e.dy_parts_bf16 = daB; }
             float* part = (float*)(ws + w.lnp[lnp_turn]);
             TRY(cpt::ln_bwd(daS > 1 ? (const float*)tA : da, (const float*)LB(l, w.o_pre1), y.ln1_g, d.ln_eps, dpre, triple ? (void*)(ws + w.dlp2) : (ph ? dmask_lp : dpre_lp), dt, gy.ln1_g, gy.ln1_b,
                             M, H, M, 0, 0, 0, s, part, w.lnp_bytes, ph ? &sp1 : nullptr, gy.b_ao, &e), "ln_bwd(attn)+dropout+bias");
@@ -722,7 +724,8 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         }
         // (layer 0's result feeds the embedding passes: complete; above that a K-split launch leaves its partial matrices to the next LayerNorm backward)
         dxS = 1;
-        rc = dgrad(dbig, 3 * H, 3 * H, y.w_qkv, H, 3 * H, H, M, dpre, dx, CPT_F32, "dgrad(qkv)+residual", nullptr, nullptr, 0, (fuse_db && l > 0) ? &dxS : nullptr);
+        rc = dgrad(dbig, 3 * H, 3 * H, y.w_qkv, H, 3 * H, H, M, dpre, dx, CPT_F32, "dgrad(qkv)+residual", nullptr, nullptr, 0, (fuse_db && l > 0) ? &dxS : nullptr, 1);
+        dxB = (dxS == 2 && M >= 2048) ? 1 : 0;
         if (rc) return rc;
         if (!fuse_db) ready(1 + l);
     }

@@ -102,6 +102,8 @@ int cpt_build_info(void);
  *          next row count it takes (at most 1.5x the real rows; the padded rows belong to no sequence), 0 = such batches run the row-major kernels; same bits
  *   key 33 training step, last encoder layer: 1 (default) = everything behind its attention (attention output, FFN, both LayerNorms; forward and backward) on
  *          the head's rows only -- one per sequence ([MASK], or [CLS] for the NSP head) -- when the batch carries no label grid; 0 = all rows
+ *   key 34 training backward, data-gradient GEMMs in front of a LayerNorm backward at 2048..6144 rows: 1 (default) = 128 x 192 tiles with K split over two
+ *          workgroups, two BF16 partial matrices added (with the fp32 residual) by the LayerNorm backward; 0 = 64 x 192 tiles over the whole K, fp32 out
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at

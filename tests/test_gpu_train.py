@@ -729,3 +729,37 @@ def test_hf_adamw_kernel_against_the_float64_vectors(dev, golden_dir):
             ref = torch.from_numpy(g[tag + key][-1])
             err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
             assert err < tol, (tag, key, err)
+
+
+@pytest.mark.ablation
+def test_bf16_partial_data_gradients_match_the_fp32_epilogue_form(dev):
+    """Round 6: at 2048..6144 rows the data-gradient GEMMs in front of a LayerNorm backward (FFN-up, Q|K|V) run 128 x 192 tiles with K split in two and hand the
+    LayerNorm backward two BF16 partial matrices (cpt_set_tuning key 34, default) instead of one fp32 matrix from 64 x 192 tiles with the residual in the
+    epilogue (34 = 0).  The GEMM part of that gradient is then rounded to bf16 twice before the fp32 residual is added: every gradient of the step against the
+    fp32-epilogue form, Oscar-base at 32 sequences, dropout on."""
+    from cpt_amd import _lib as L
+    from cpt_amd import train as T
+    cfg = cfgmod.oscar_base(num_hidden_layers=4)
+    m = _model(cfg, 27, dev, "bf16", dropout=0.1)
+    b = {k: v.to(dev) for k, v in synth.make_batch(32, cfg, seed=29).items()}
+    params = dict(m.named_parameters())
+
+    def grads(v):
+        L.check(L.lib().cpt_set_tuning(34, v), "cpt_set_tuning")
+        T.set_dropout_seed(m, 31)
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=b["colors"], mask_token_pos=b["mask_token_pos"])
+        loss.backward()
+        return {n: p.grad.double().clone() for n, p in params.items() if p.grad is not None}
+
+    ref = grads(0)
+    got = grads(1)
+    worst = ("", 0.0)
+    for n in ref:
+        if n.endswith("attention.self.key.bias"):
+            continue
+        rel = float((got[n] - ref[n]).norm()) / (float(ref[n].norm()) + 1e-30)
+        if rel > worst[1]:
+            worst = (n, rel)
+    assert worst[1] < 1e-2, worst          # 2^-9 per partial on the GEMM part of dx, averaged over the contraction of everything downstream
