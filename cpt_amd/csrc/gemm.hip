@@ -1075,8 +1075,9 @@ __device__ __forceinline__ void gemm_pipe_body(
                     }
                     if (GUARD && wcol0 + c >= N) continue;
                     if (ex.colsum_rows > 0) {      // this wave's 32 x WCOLS block owns row wrow0 / 32 of the partial table
-                        static_assert(!GG || MI == 1, "column-sum partial rows: one 32-row block per wave");
+                        static_assert(!GG || MI <= 2, "column-sum partial rows: one or two 32-row blocks per wave");
                         if ((wrow0 >> 5) < ex.colsum_rows) ex.colsum[(size_t)(wrow0 >> 5) * N + wcol0 + c] = t;
+                        if (MI == 2 && (wrow0 >> 5) + 1 < ex.colsum_rows) ex.colsum[(size_t)((wrow0 >> 5) + 1) * N + wcol0 + c] = 0.f;      // (the table has one row per 32 output rows: this wave's 64 rows own two, the sum sits in the first)
                     } else {
                         atomicAdd(ex.colsum + wcol0 + c, t);
                     }
@@ -1588,6 +1589,8 @@ int gemm_nt_partials(const void* A, int lda, const void* W, int ldw, const float
 
 // ---- NN form: out[M][N] = A[M][K] . W[K][N] (+ resid), W = an nn.Linear weight [out_features = K][in_features = N] as stored:
 // the data gradients dX = dY . W of the backward pass without a transposed weight copy --------------------------------------
+CPT_SWITCH(int g_nn_tile256, 1);     // cpt_set_tuning(35, v): 1 (default) = the GELU-gradient data-gradient GEMM on 256 x 192 tiles where 128-row tiles would make 1..2 rounds
+void set_nn_tile256(int v) { CPT_SWITCH_SET(g_nn_tile256 = v); (void)v; }
 CPT_SWITCH(int g_nn_split2, 1);      // cpt_set_tuning(34, v): 1 (default) = the data-gradient GEMMs in front of a LayerNorm backward at 2048..6144 rows as two K-split bf16 partial matrices of 128 x 192 tiles
 void set_nn_split2(int v) { CPT_SWITCH_SET(g_nn_split2 = v); (void)v; }
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw) {
@@ -1662,6 +1665,11 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
         if (gelu_u) {       // out = (A.W) * gelu'(u): the GELU backward rides in the epilogue (u bf16 [M][ldu])
             if (ldu % 8 || ((uintptr_t)gelu_u & 15)) return CPT_ERR_ALIGN;
             resid = (const float*)gelu_u; ldr = ldu;
+            // round 6: where 128-row tiles make between one and two rounds (M = 3840, N = 3072: 480 workgroups = 1.875 rounds on 256 CUs) and 256-row tiles make at
+            // most one, take 256 x 192 (8 waves of 64 x 96, 2-stage ring of 112 KB): 240 workgroups, 1.71 instead of 2.4... MFMAs per KiB of operands UP (2.7)
+            const long wg256 = (long)((M + 255) / 256) * (N / 192);
+            if (g_nn_tile256 && M >= 2048 && wg128 > 256 && wg128 < 512 && wg256 <= 256)
+                return launch_pipe<bf16, CPT_EPI_GELUGRAD, bf16, 256, 192, 4, 2, 2, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (bf16*)out, ldo, M, N, K, s, 1, &ex);
             return small ? CPT_NN(CPT_EPI_GELUGRAD, bf16, 64, 2) : CPT_NN(CPT_EPI_GELUGRAD, bf16, 128, 4);
         }
         return small ? CPT_NN(CPT_EPI_NONE, bf16, 64, 2) : CPT_NN(CPT_EPI_NONE, bf16, 128, 4);

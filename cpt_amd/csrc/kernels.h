@@ -238,6 +238,7 @@ void set_attn_qt_all(int v); // stand-alone attention, L > 128: the query tiles 
 int gemm_gelu_x3(const void* A3, int lda, const void* W3, int ldw, const float* bias, void* out_split, int M, int N, int K3, hipStream_t s);
 void set_fwd_split2(int v);  // training forward: FFN-down as two split-K partial matrices summed by the LayerNorm pass (1, default)
 void set_qkv_2pass(int v);   // stand-alone LayerNorm-consumer QKV projection through the GELU-less two-pass kernel (1, default)
+void set_nn_tile256(int v);
 void set_nn_split2(int v);   // training backward: data gradients in front of a LayerNorm backward as two K-split bf16 partial matrices (1, default)
 void set_train_tail(int v);  // training step: the last encoder layer behind the attention on the head rows only (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
