@@ -70,7 +70,7 @@ class Dropout(C.Structure):
 
 
 class Outputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("seq", "pooled", "logits", "loss", "rel")]
+    _fields_ = [(n, C.c_void_p) for n in ("seq", "pooled", "logits", "loss", "rel", "loss_mean")]
 
 
 _SIGS = {
@@ -191,8 +191,8 @@ def lib():
             fn = getattr(l, name)        # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if l.cpt_version() != 7:
-            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 7" % l.cpt_version())
+        if l.cpt_version() != 8:
+            raise RuntimeError("cpt_amd: libcpt_hip ABI version %d, expected 8" % l.cpt_version())
         _lib = l
     return _lib
 

@@ -19,12 +19,13 @@ int gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, con
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
              float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
-             int max_pos, int type_vocab, hipStream_t s, void* out_lo = nullptr, int out_panel = 0);   // out_lo: rows leave in the 3-byte residual form (hi -> out_lp); out_panel: at their panel positions
+             int max_pos, int type_vocab, hipStream_t s, void* out_lo = nullptr, int out_panel = 0, float* zero_f2 = nullptr, unsigned* zero_u1 = nullptr);   // zero_f2 / zero_u1 (round 6, training forward): two floats and one word cleared by the launch's first workgroup -- the loss accumulator and the finish ticket of the cross-entropy launch at the END of the same forward (no memset launch);   out_lo: rows leave in the 3-byte residual form (hi -> out_lp); out_panel: at their panel positions
 
 // bf16 inference: embed_ln (3-byte or bf16 output rows) and pad_cast(bf16) of the region features in ONE launch (they touch disjoint data)
 int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
                       const float* g, const float* bta, float eps, void* out_lp, void* out_lo, int B, int Lt, int L, int H, int vocab,
-                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s, int out_panel = 0);     // out_panel (round 5): out_lp / out_lo = the panel-layout residual stream
+                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s, int out_panel = 0,
+                      float* out_f32 = nullptr, float* zero_f2 = nullptr, unsigned* zero_u1 = nullptr);     // out_f32 / zero_*: the training forward's fp32 residual rows and cleared words (embed_ln above);   out_panel (round 5): out_lp / out_lo = the panel-layout residual stream
 
 int layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                    void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
@@ -51,7 +52,9 @@ int gather_rows(const void* src, int dtype, const int64_t* pos, void* out, int B
                 hipStream_t s, const int64_t* seq = nullptr, int n_seq = 0);      // seq: row b = position pos[b] of sequence seq[b] (of n_seq)
 
 int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V,
-            hipStream_t s);
+            hipStream_t s, unsigned* ticket = nullptr, float* mean_out = nullptr, float* loss_copy = nullptr);
+// ticket (round 6, a word holding 0, left at 0): the LAST workgroup to finish reads the totals back and writes mean_out[0] = sum / count and
+// loss_copy[0..1] = {sum, count} -- no divide kernel on the caller's side, no device-to-device copy of the totals
 
 int transpose_cast(const void* in, int in_dtype, int ldi, void* out, int out_dtype, int ldo, int R, int C, hipStream_t s);
 int colsum(const void* x, int dtype, int ld, float* out, int R, int C, hipStream_t s);

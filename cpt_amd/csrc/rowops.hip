@@ -256,6 +256,7 @@ struct EmbedArgs {
     signed char* out_lo;
     int B, Lt, L, H, vocab, max_pos, type_vocab;
     int out_panel;      // round 5: out_lp / out_lo are the panel-layout residual stream (3-byte form)
+    float* zero_f2; unsigned* zero_u1;      // round 6 (training forward): cleared by the first workgroup (kernels.h)
 };
 template <typename LP, int NA = MAXV>      // NA = 3: the H = 768 instantiation (a quarter fewer row registers, as layernorm768_kernel)
 __device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
@@ -267,6 +268,10 @@ __device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
     float* __restrict__ out_f32 = a.out_f32; LP* __restrict__ out_lp = (LP*)a.out_lp; signed char* __restrict__ out_lo = a.out_lo;
     const int B = a.B, Lt = a.Lt, L = a.L, H = a.H, vocab = a.vocab, max_pos = a.max_pos, type_vocab = a.type_vocab;
     const int lane = threadIdx.x & 63;
+    if (block == 0) {
+        if (a.zero_f2 && threadIdx.x < 2) a.zero_f2[threadIdx.x] = 0.f;
+        if (a.zero_u1 && threadIdx.x == 2) *a.zero_u1 = 0u;
+    }
     const int r = block * (ROW_THREADS / 64) + (threadIdx.x >> 6);
     if (r >= B * Lt) return;
     const int b = r / Lt, t = r % Lt;
@@ -304,14 +309,14 @@ __global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(EmbedArgs a) { em
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
              float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
-             int max_pos, int type_vocab, hipStream_t s, void* out_lo, int out_panel) {
+             int max_pos, int type_vocab, hipStream_t s, void* out_lo, int out_panel, float* zero_f2, unsigned* zero_u1) {
     if (B <= 0 || Lt <= 0 || L < Lt || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
     if (out_panel && (!out_lo || out_f32 || H % 16)) return CPT_ERR_SHAPE;
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
     if (!ids || !word || !posw || !typew || !g || !bta) return CPT_ERR_NULL;
     if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
     dim3 grid((B * Lt + 3) / 4), block(ROW_THREADS);
-    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0};
+    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0, zero_f2, zero_u1};
     if (out_lp && lp_dtype == CPT_BF16) { if (H == 768) embed_ln_kernel<bf16, 3><<<grid, block, 0, s>>>(a); else embed_ln_kernel<bf16><<<grid, block, 0, s>>>(a); }
     else { a.out_lo = nullptr; if (H == 768) embed_ln_kernel<float, 3><<<grid, block, 0, s>>>(a); else embed_ln_kernel<float><<<grid, block, 0, s>>>(a); }
     return CPT_OK;
@@ -382,15 +387,16 @@ __global__ __launch_bounds__(256) void embed_pad_kernel(EmbedArgs a, const float
 
 int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
                       const float* g, const float* bta, float eps, void* out_lp, void* out_lo, int B, int Lt, int L, int H, int vocab,
-                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s, int out_panel) {
-    if (out_panel && (!out_lo || H % 16)) return CPT_ERR_SHAPE;
+                      int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s, int out_panel,
+                      float* out_f32, float* zero_f2, unsigned* zero_u1) {
+    if (out_panel && (!out_lo || H % 16 || out_f32)) return CPT_ERR_SHAPE;
     if (B <= 0 || Lt <= 0 || L < Lt || H % 4 || H > 256 * MAXV || R <= 0 || K <= 0 || Kp < K || Kp % 8) return CPT_ERR_SHAPE;
     if (!ids || !word || !posw || !typew || !g || !bta || !out_lp || !x || !xo) return CPT_ERR_NULL;
     if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
     if (((uintptr_t)xo % 16) || ((uintptr_t)x % 8)) return CPT_ERR_ALIGN;
     const size_t n = (size_t)R * (Kp / 8);
     const int npad = (int)((n + 256 * PC_UNR - 1) / (256 * PC_UNR));
-    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, nullptr, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0};
+    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0, zero_f2, zero_u1};
     if (H == 768) embed_pad_kernel<3><<<dim3(npad + (B * Lt + 3) / 4), dim3(256), 0, s>>>(a, x, (bf16*)xo, R, K, Kp, npad);
     else embed_pad_kernel<MAXV><<<dim3(npad + (B * Lt + 3) / 4), dim3(256), 0, s>>>(a, x, (bf16*)xo, R, K, Kp, npad);
     return CPT_OK;
@@ -911,8 +917,22 @@ int gelu_parts(const float* partials, int S, void* out_bf16, size_t n, hipStream
 }
 
 // ---- cross entropy over rows (ignore_index = -1) ----------------------------------------------
+// the last workgroup to finish (ticket) turns the totals into the mean and a second copy of them: the training forward's loss needs no divide kernel
+// and no device-to-device copy behind this launch (round 6).  Every workgroup passes here, ignored rows too.
+__device__ __forceinline__ void ce_finish(float* __restrict__ loss, unsigned* __restrict__ ticket, float* __restrict__ mean_out, float* __restrict__ loss_copy) {
+    if (!ticket || threadIdx.x != 0) return;
+    __threadfence();
+    if (atomicAdd(ticket, 1u) != gridDim.x - 1) return;
+    __threadfence();
+    const float sum = atomicAdd(&loss[0], 0.f), cnt = atomicAdd(&loss[1], 0.f);      // (read at the device's coherence point)
+    if (mean_out) mean_out[0] = sum / cnt;       // 0 / 0 = NaN when every row is ignored, as torch's mean over no rows
+    if (loss_copy) { loss_copy[0] = sum; loss_copy[1] = cnt; }
+    *ticket = 0u;
+}
+
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                      float* __restrict__ loss, float* __restrict__ dlogits, int R, int V) {
+                                                      float* __restrict__ loss, float* __restrict__ dlogits, int R, int V,
+                                                      unsigned* __restrict__ ticket, float* __restrict__ mean_out, float* __restrict__ loss_copy) {
     __shared__ float red[8];
     const int r = blockIdx.x;
     const long lab = labels[r];
@@ -920,6 +940,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     float* d = dlogits ? dlogits + (size_t)r * V : nullptr;
     if (lab < 0 || lab >= V) {            // ignored row: no loss, zero gradient
         if (d) for (int c = threadIdx.x; c < V; c += 256) d[c] = 0.f;
+        ce_finish(loss, ticket, mean_out, loss_copy);
         return;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -940,6 +961,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
         atomicAdd(&loss[0], lse - x[lab]);
         atomicAdd(&loss[1], 1.0f);
     }
+    ce_finish(loss, ticket, mean_out, loss_copy);
     if (d) {
         const float inv = 1.0f / sum;
         for (int c = threadIdx.x; c < V; c += 256) d[c] = expf(x[c] - m) * inv - (c == lab ? 1.f : 0.f);
@@ -950,7 +972,8 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
 // maximum, the exponential sum and the gradient -- the 256-thread three-pass form above took 54 us for 32 rows of 30522
 constexpr int CE_NV = 32;
 __global__ __launch_bounds__(1024) void ce_rows_reg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                           float* __restrict__ loss, float* __restrict__ dlogits, int R, int V) {
+                                                           float* __restrict__ loss, float* __restrict__ dlogits, int R, int V,
+                                                           unsigned* __restrict__ ticket, float* __restrict__ mean_out, float* __restrict__ loss_copy) {
     __shared__ float red[32];
     const int r = blockIdx.x, tid = threadIdx.x;
     const long lab = labels[r];
@@ -958,6 +981,7 @@ __global__ __launch_bounds__(1024) void ce_rows_reg_kernel(const float* __restri
     float* d = dlogits ? dlogits + (size_t)r * V : nullptr;
     if (lab < 0 || lab >= V) {            // ignored row: no loss, zero gradient
         if (d) for (int c = tid; c < V; c += 1024) d[c] = 0.f;
+        ce_finish(loss, ticket, mean_out, loss_copy);
         return;
     }
     const int lane = tid & 63, w = tid >> 6;
@@ -988,6 +1012,7 @@ __global__ __launch_bounds__(1024) void ce_rows_reg_kernel(const float* __restri
         atomicAdd(&loss[0], m + logf(sum) - x[lab]);
         atomicAdd(&loss[1], 1.0f);
     }
+    ce_finish(loss, ticket, mean_out, loss_copy);
     if (d) {
         const float inv = 1.0f / sum;
 #pragma unroll
@@ -998,11 +1023,11 @@ __global__ __launch_bounds__(1024) void ce_rows_reg_kernel(const float* __restri
     }
 }
 
-int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V, hipStream_t s) {
+int ce_rows(const float* logits, const int64_t* labels, float* loss, float* dlogits, int R, int V, hipStream_t s, unsigned* ticket, float* mean_out, float* loss_copy) {
     if (R <= 0 || V <= 0) return CPT_ERR_SHAPE;
     if (!logits || !labels || !loss) return CPT_ERR_NULL;
-    if (V <= CE_NV * 1024) ce_rows_reg_kernel<<<dim3(R), dim3(1024), 0, s>>>(logits, labels, loss, dlogits, R, V);
-    else ce_rows_kernel<<<dim3(R), dim3(256), 0, s>>>(logits, labels, loss, dlogits, R, V);
+    if (V <= CE_NV * 1024) ce_rows_reg_kernel<<<dim3(R), dim3(1024), 0, s>>>(logits, labels, loss, dlogits, R, V, ticket, mean_out, loss_copy);
+    else ce_rows_kernel<<<dim3(R), dim3(256), 0, s>>>(logits, labels, loss, dlogits, R, V, ticket, mean_out, loss_copy);
     return CPT_OK;
 }
 

@@ -264,12 +264,22 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     auto need = [&](int bucket) { if (before_bucket) before_bucket(user, bucket); };
 
     need(0);
+    // (round 6: the embedding launch also clears the loss accumulator and the finish ticket of the cross-entropy launch at the end of this forward --
+    // no memset launch; with regions in bf16 it carries the region features' pad + cast as well, as the inference forward's first launch does)
+    float* loss_ws = (float*)(ws + w.loss);
+    unsigned* ce_ticket = (unsigned*)(ws + w.loss + 16);
+    const bool emb_pad = Li > 0 && dt == CPT_BF16 && d.img_dim_pad % 8 == 0 && !((uintptr_t)b->img_feats & 7);
+    if (emb_pad)
+        TRY(cpt::embed_ln_pad_cast(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, d.ln_eps,
+                                   LB(0, w.o_xin), nullptr, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, b->img_feats, ws + w.imgp, B * Li, d.img_dim, d.img_dim_pad, s, 0,
+                                   x_f32, o->loss, ce_ticket), "embed_ln + pad_cast(img_feats)");
+    else
     TRY(cpt::embed_ln(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g,
-                      m->emb_ln_b, d.ln_eps, x_f32, LB(0, w.o_xin), dt, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, s), "embed_ln");
+                      m->emb_ln_b, d.ln_eps, x_f32, LB(0, w.o_xin), dt, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, s, nullptr, 0, o->loss, ce_ticket), "embed_ln");
     if (Li > 0) {
         void* imgp = ws + w.imgp;
         float* imgpre = (float*)(ws + w.imgpre);
-        TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
+        if (!emb_pad) TRY(cpt::pad_cast(b->img_feats, imgp, dt, B * Li, d.img_dim, d.img_dim_pad, s), "pad_cast(img_feats)");
         TRY(gm(CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, imgpre, CPT_F32, H,
                       B * Li, H, d.img_dim_pad, s), "gemm(img_embedding)");
         const bool iln = d.use_img_ln && m->img_ln_g;       // use_img_layernorm = 0 (modeling_bert.py:263): the projection is used as is
@@ -397,11 +407,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
             pin = t2;
         }
         TRY(gm(CPT_EPI_NONE, pin, H, m->w_rel, H, m->b_rel, nullptr, 0, o->rel, CPT_F32, d.n_rel, B, d.n_rel, H, s), "gemm(seq_relationship)");
-        hipError_t e2 = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);
-        if (e2 != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e2, "zero loss: %s", hipGetErrorString(e2));
-        TRY(cpt::ce_rows(o->rel, b->labels, o->loss, (float*)(ws + w.dlogits), B, d.n_rel, s), "ce_rows(rel)");
-        e2 = hipMemcpyAsync(ws + w.loss, o->loss, 2 * sizeof(float), hipMemcpyDeviceToDevice, s);
-        if (e2 != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e2, "save loss: %s", hipGetErrorString(e2));
+        TRY(cpt::ce_rows(o->rel, b->labels, o->loss, (float*)(ws + w.dlogits), B, d.n_rel, s, ce_ticket, o->loss_mean, loss_ws), "ce_rows(rel)");
         return CPT_OK;
     }
     // Rh head rows: the [MASK] position of every sequence, or the n_rows labelled positions of a label grid (row_seq, mask_pos)
@@ -411,11 +417,8 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     TRY(cpt::layernorm_rows_ex(uh, m->tr_ln_g, m->tr_ln_b, d.ln_eps, dt == CPT_F32 ? (float*)t2 : nullptr,
                                dt == CPT_F32 ? nullptr : t2, dt, Rh, H, Rh, 0, 0, 1, s), "gelu+layernorm(head)");
     TRY(gm(CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, Rh, d.vocab, H, s), "gemm(decoder)");
-    hipError_t e = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);
-    if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "zero loss: %s", hipGetErrorString(e));
-    TRY(cpt::ce_rows(o->logits, b->labels, o->loss, (float*)(ws + w.dlogits), Rh, d.vocab, s), "ce_rows");
-    e = hipMemcpyAsync(ws + w.loss, o->loss, 2 * sizeof(float), hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return abi_fail(CPT_ERR_HIP - (int)e, "save loss: %s", hipGetErrorString(e));
+    // (the launch's last workgroup leaves {sum, count} in the workspace for the backward and the mean in o->loss_mean: no memset, copy or divide launch)
+    TRY(cpt::ce_rows(o->logits, b->labels, o->loss, (float*)(ws + w.dlogits), Rh, d.vocab, s, ce_ticket, o->loss_mean, loss_ws), "ce_rows");
     return CPT_OK;
 }
 

@@ -155,13 +155,13 @@ class _MLMLoss(torch.autograd.Function):
         Li = feats.size(1) if feats is not None else 0
         m, _ = eng.descriptor(train=True)
         dev = eng.flat.device
-        loss_acc = torch.empty(2, device=dev, dtype=torch.float32)
+        loss_acc = torch.empty(3, device=dev, dtype=torch.float32)      # {sum, count, mean}: the mean is written by the cross-entropy launch (cpt_outputs.loss_mean)
         if eng.head == "nsp":       # relation scores of the pooled [CLS] instead of vocabulary logits of the [MASK] row
             logits = torch.empty((B, m.dims.n_rel), device=dev, dtype=torch.float32)
-            o = L.Outputs(rel=logits.data_ptr(), loss=loss_acc.data_ptr())
+            o = L.Outputs(rel=logits.data_ptr(), loss=loss_acc.data_ptr(), loss_mean=loss_acc.data_ptr() + 8)
         else:
             logits = torch.empty((R if R else B, eng.cfg.vocab_size), device=dev, dtype=torch.float32)
-            o = L.Outputs(logits=logits.data_ptr(), loss=loss_acc.data_ptr())
+            o = L.Outputs(logits=logits.data_ptr(), loss=loss_acc.data_ptr(), loss_mean=loss_acc.data_ptr() + 8)
         bt = L.Batch(B=B, Lt=Lt, Li=Li, input_ids=ids.data_ptr(), token_type=L.ptr(seg), position_ids=L.ptr(pos),
                      attn_mask=L.ptr(mask), img_feats=L.ptr(feats), mask_pos=L.ptr(mpos), labels=labels.data_ptr(),
                      n_rows=R, row_seq=L.ptr(rseq), mask_3d=1 if (mask is not None and mask.dim() == 3) else 0)
@@ -190,7 +190,7 @@ class _MLMLoss(torch.autograd.Function):
         ctx.logits = logits
         ctx.mark_non_differentiable(logits)
         ctx.set_materialize_grads(False)      # (no zero-filled (R, V) gradient tensor for the scores on every backward)
-        return loss_acc[0] / loss_acc[1], logits
+        return loss_acc[2], logits
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_logits):

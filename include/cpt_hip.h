@@ -38,10 +38,11 @@
 extern "C" {
 #endif
 
-#define CPT_ABI_VERSION 7     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads, cpt_batch.n_rows / mask_3d / row_seq;
+#define CPT_ABI_VERSION 8     /* 2: CPT_ATTN_MASK_3D, cpt_gemm_ln_prod3 / cpt_resid3_*, cpt_gemm_tn / cpt_gemm_nn (round 2); 3: cpt_layer_fold.w_qkv_t, cpt_retile_k32; 4: cpt_panel_pack, cpt_gemm_ln_prod3_panel (round 3); 5: cpt_train_zero_grads, cpt_batch.n_rows / mask_3d / row_seq;
                                * 6: CPT_BF16X3 in cpt_train_* (fp32 master weights there, NOT the split copies cpt_model_fwd reads under the same tag: the training step's own tag is CPT_BF16X3_MASTERS),
                                *    cpt_set_tuning / cpt_prof_* / cpt_debug_gemm_trace declared in cpt_hip_debug.h, operator-level backward entry points, cpt_comm_*;
-                               * 7: cpt_adamw / cpt_adamw_ex take lr, betas, eps and weight decay as doubles (round 6) */
+                               * 7: cpt_adamw / cpt_adamw_ex take lr, betas, eps and weight decay as doubles (round 6);
+                               * 8: cpt_outputs.loss_mean (round 6) */
 
 enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2,
        CPT_BF16X3_MASTERS = 3 /* ABI 6, cpt_dims.dtype for cpt_train_* only: CPT_BF16X3 arithmetic on plain fp32 weight matrices (split per GEMM) */ };
@@ -176,6 +177,9 @@ typedef struct {
     float* logits;       /* CPT_OUT_MASK_LOGITS [B][V] or CPT_OUT_ALL_LOGITS [B][L][V] */
     float* loss;         /* CPT_OUT_LOSS: [2] = {sum of labelled-row losses, labelled-row count} */
     float* rel;          /* CPT_OUT_REL */
+    float* loss_mean;    /* ABI 8, cpt_train_fwd(_ex) only, optional (NULL: not written): [1] = loss[0] / loss[1], the value REC_MLM_CPT.forward /
+                          * NSPCPT.forward return (modeling_rec.py:147-150, modeling_vcr.py:126-128), written by the cross-entropy launch itself so that
+                          * the host needs no divide kernel behind the forward; cpt_model_fwd ignores the field */
 } cpt_outputs;
 
 /* Workspace the caller must supply for cpt_model_fwd with these flags (bytes). */
