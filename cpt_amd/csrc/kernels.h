@@ -132,7 +132,7 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
                       const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr,
                       int x_parts = 1, size_t x_stride = 0, int out_panel = 0, float* stat_out = nullptr, const RowMap* drop_rows = nullptr,
-                      unsigned short* keep_out = nullptr);     // keep_out (round 6, with drop): [R][64] keep bits of the row's dropout mask for ln_bwd (LnBwdExtra::keep_bits)     // stat_out (round 6): [R][2] (mean, rstd) of every row, for ln_bwd     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
+                      unsigned short* keep_out = nullptr, const float* resid_stat = nullptr, const float* resid_g = nullptr, const float* resid_b = nullptr);     // resid_stat / resid_g / resid_b (round 6): resid = the pre-LayerNorm rows of the LayerNorm in front, whose output is re-formed here from its [R][2] (mean, rstd), gain and shift (that launch then skips its fp32 output);   keep_out (round 6, with drop): [R][64] keep bits of the row's dropout mask for ln_bwd (LnBwdExtra::keep_bits)     // stat_out (round 6): [R][2] (mean, rstd) of every row, for ln_bwd     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
 // resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients
@@ -243,6 +243,7 @@ void set_fwd_split2(int v);  // training forward: FFN-down as two split-K partia
 void set_qkv_2pass(int v);   // stand-alone LayerNorm-consumer QKV projection through the GELU-less two-pass kernel (1, default)
 void set_nn_tile256(int v);
 void set_nn_split2(int v);   // training backward: data gradients in front of a LayerNorm backward as two K-split bf16 partial matrices (1, default)
+void set_ln_lean(int v);     // training forward: LayerNorm launches without fp32 output, residual re-formed by the next row pass (1, default)
 void set_train_tail(int v);  // training step: the last encoder layer behind the attention on the head rows only (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
 void set_lnb_rpb(int v);     // LayerNorm backward: rows per workgroup of the two-stage column-sum form (experiments)

@@ -95,7 +95,8 @@ template <typename LP, bool GELU_IN, int LN_RPW, int NA = 4>      // NA = 3: the
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
-    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride, int out_panel, float* __restrict__ stat_out, RowMap drows, unsigned short* __restrict__ keep_out) {      // stat_out (round 6): [R][2] (mean, rstd) per row for the backward pass; x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
+    const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride, int out_panel, float* __restrict__ stat_out, RowMap drows, unsigned short* __restrict__ keep_out,
+    const float* __restrict__ resid_stat, const float* __restrict__ resid_g, const float* __restrict__ resid_b) {      // resid_stat / resid_g / resid_b (round 6): `resid` holds the PRE-LayerNorm rows of the LayerNorm in front; the residual is re-formed from them with its (mean, rstd), gain and shift -- ln_write's expression -- so that launch need not write its fp32 output at all (11.8 MB per launch at 3840 rows);   stat_out (round 6): [R][2] (mean, rstd) per row for the backward pass; x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
     // x_parts / x_stride (round 3): x is x_parts split-K partial matrices of the dense layer in front, x_stride elements apart; the row that is
     // processed is their sum in split order (training forward: no reduction launch between the GEMM and this pass)
     // resid / dr / pre_out (training forward of LN(dropout(dense) + residual), modeling_bert.py:85-86,145 with the third-party
@@ -130,6 +131,19 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
                         }
                 }
                 if (resid) rr[u][i] = *reinterpret_cast<const f32x4*>(resid + (size_t)r * H + c);
+            }
+        }
+        if (resid && resid_stat) {
+            const float2 st = *reinterpret_cast<const float2*>(resid_stat + 2 * (size_t)r);
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = (lane + 64 * i) * 4;
+                if (i < nv && c < H) {
+                    const f32x4 gg = *reinterpret_cast<const f32x4*>(resid_g + c);
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(resid_b + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rr[u][i][j] = (rr[u][i][j] - st.x) * st.y * gg[j] + bb[j];
+                }
             }
         }
     }
@@ -205,8 +219,10 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm768_kernel(const float* 
 
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
-                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride, int out_panel, float* stat_out, const RowMap* drop_rows, unsigned short* keep_out) {
+                      int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride, int out_panel, float* stat_out, const RowMap* drop_rows, unsigned short* keep_out,
+                      const float* resid_stat, const float* resid_g, const float* resid_b) {
     if (x_parts < 1 || x_parts > 64) return CPT_ERR_SHAPE;
+    if (resid_stat && !(resid && resid_g && resid_b)) return CPT_ERR_NULL;
     if (out_panel && (!out_lo || out_f32 || H % 16)) return CPT_ERR_SHAPE;      // panel output: the 3-byte residual stream only (rows rounded up to 32 by the caller's buffer)
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
     if (R <= 0 || H <= 0 || H % 4 || H > 256 * MAXV || grp <= 0) return CPT_ERR_SHAPE;
@@ -230,9 +246,9 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
 #define LNK(LPT, GI)                                                                                                                              \
     do {                                                                                                                                          \
-        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out); \
-        else if (H == 768) layernorm_rows_kernel<LPT, GI, 1, 3><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out); \
-        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out);          \
+        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out, resid_stat, resid_g, resid_b); \
+        else if (H == 768) layernorm_rows_kernel<LPT, GI, 1, 3><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out, resid_stat, resid_g, resid_b); \
+        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out, resid_stat, resid_g, resid_b);          \
     } while (0)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
     else      { if (gelu_in) LNK(float, true); else LNK(float, false); }

@@ -28,6 +28,10 @@ using cpt::g_fwd_split2;
 // cpt_set_tuning(33, v): 1 (default) = the LAST encoder layer's attention output, FFN and both LayerNorms run on the head's rows only (one per
 // sequence: the [MASK] row, or [CLS] for the NSP head) in the training forward AND backward -- every other row of that layer's output is dead
 // (the loss reads B rows; modeling_rec.py:142-150) and so is its gradient; 0 = all rows
+// cpt_set_tuning(36, v): 1 (default) = with hidden dropout the LayerNorm launches of the training forward write no fp32 output; the row pass behind
+// re-forms the residual from the pre-LayerNorm rows kept for the backward, 0 = fp32 outputs written and read back
+namespace cpt { CPT_SWITCH(int g_ln_lean, 1); void set_ln_lean(int v) { CPT_SWITCH_SET(g_ln_lean = v); (void)v; } }
+using cpt::g_ln_lean;
 namespace cpt { CPT_SWITCH(int g_train_tail, 1); void set_train_tail(int v) { CPT_SWITCH_SET(g_train_tail = v); (void)v; } }
 using cpt::g_train_tail;
 namespace cpt { CPT_SWITCH(int g_bias_fuse, 3); void set_bias_fuse(int v) { CPT_SWITCH_SET(g_bias_fuse = v); (void)v; } }
@@ -297,10 +301,23 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         }
         return abi_check(gm(resid ? CPT_EPI_RESID : CPT_EPI_NONE, A, lda, W, K, bias, resid, N, out, CPT_F32, N, M, N, K, s), what);
     };
+    // round 6: with hidden dropout every residual add sits in a row pass, and that pass can re-form the LayerNorm output it adds from the
+    // pre-LayerNorm rows the backward keeps anyway (+ (mean, rstd), gain, shift): the LayerNorm launches then write no fp32 output
+    // (11.8 of 53-65 MB per launch at 3840 rows).  x_f32 is still written where the pruned last layer gathers its residual rows from it.
+    const bool lean = ph && g_ln_lean;
     for (int l = 0; l < d.layers; ++l) {
         const cpt_layer& y = m->layers[l];
         need(1 + l);
         void* xin = LB(l, w.o_xin);
+        const bool lean1 = lean && l > 0;       // (layer 0 adds the embedding rows: a real buffer)
+        const float* res1 = lean1 ? (const float*)LB(l - 1, w.o_pre2) : x_f32;
+        const float* res1_st = lean1 ? (const float*)LB(l - 1, w.o_st2) : nullptr;
+        const float* res1_g = lean1 ? m->layers[l - 1].ln2_g : nullptr; const float* res1_b = lean1 ? m->layers[l - 1].ln2_b : nullptr;
+        const float* res2 = lean ? (const float*)LB(l, w.o_pre1) : a_f32;
+        const float* res2_st = lean ? (const float*)LB(l, w.o_st1) : nullptr;
+        const float* res2_g = lean ? y.ln1_g : nullptr; const float* res2_b = lean ? y.ln1_b : nullptr;
+        float* a_out = lean ? nullptr : a_f32;
+        float* x_out = (lean && !(tail && l == d.layers - 2)) ? nullptr : x_f32;
         void* xnext = l + 1 < d.layers ? LB(l + 1, w.o_xin) : (void*)(ws + w.xout);
         TRY(gm(CPT_EPI_NONE, xin, H, y.w_qkv, H, y.b_qkv, nullptr, 0, LB(l, w.o_qkv), dt, 3 * H, M, 3 * H, H, s), "gemm(qkv)");
         const cpt::DropSpec da_spec = drop_spec(drop, 1 + 3 * l, true);
@@ -353,15 +370,17 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         if (int rp = dense_parts(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, "gemm(attn out, K split)"); rp != CPT_ERR_SHAPE) {
             if (rp) return rp;
             const cpt::DropSpec sp = drop_spec(drop, 2 + 3 * l, false);
-            TRY(cpt::layernorm_rows_ex(part, y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
-                                       x_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre1), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st1), nullptr, (unsigned short*)LB(l, w.o_kb1)), "partials+dropout(attn out)+residual+layernorm");
+            TRY(cpt::layernorm_rows_ex(part, y.ln1_g, y.ln1_b, d.ln_eps, a_out, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
+                                       res1, ph ? &sp : nullptr, (float*)LB(l, w.o_pre1), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st1), nullptr, (unsigned short*)LB(l, w.o_kb1),
+                                       res1_st, res1_g, res1_b), "partials+dropout(attn out)+residual+layernorm");
         } else
         if (ph) {   // LN(dropout(dense(ctx)) + x): the residual add moves from the GEMM epilogue into the dropout pass
             if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, nullptr, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
             // dropout + residual + LayerNorm in one row pass (pre1 = dropout(dense) + x is stored for the backward pass)
             const cpt::DropSpec sp = drop_spec(drop, 2 + 3 * l, false);
-            TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
-                                       x_f32, &sp, (float*)LB(l, w.o_pre1), nullptr, 1, 0, 0, (float*)LB(l, w.o_st1), nullptr, (unsigned short*)LB(l, w.o_kb1)), "dropout(attn out)+residual+layernorm");
+            TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_out, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
+                                       res1, &sp, (float*)LB(l, w.o_pre1), nullptr, 1, 0, 0, (float*)LB(l, w.o_st1), nullptr, (unsigned short*)LB(l, w.o_kb1),
+                                       res1_st, res1_g, res1_b), "dropout(attn out)+residual+layernorm");
         } else {
         if (int r_ = dense_f32(LB(l, w.o_ctx), H, y.w_ao, H, y.b_ao, x_f32, LB(l, w.o_pre1), H, "gemm(attn out)")) return r_;
         TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre1), y.ln1_g, y.ln1_b, d.ln_eps, a_f32, LB(l, w.o_a), dt, M, H, M, 0, 0, 0, s,
@@ -378,14 +397,16 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         if (int rp = dense_parts(LB(l, w.o_h), I, y.w_out, I, y.b_out, "gemm(ffn down, K split)"); rp != CPT_ERR_SHAPE) {
             if (rp) return rp;
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
-            TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
-                                       a_f32, ph ? &sp : nullptr, (float*)LB(l, w.o_pre2), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st2), nullptr, (unsigned short*)LB(l, w.o_kb2)), "partials+dropout(ffn down)+residual+layernorm");
+            TRY(cpt::layernorm_rows_ex(part, y.ln2_g, y.ln2_b, d.ln_eps, x_out, xnext, dt, M, H, M, 0, 0, 0, s,
+                                       res2, ph ? &sp : nullptr, (float*)LB(l, w.o_pre2), nullptr, Sp, (size_t)M * H, 0, (float*)LB(l, w.o_st2), nullptr, (unsigned short*)LB(l, w.o_kb2),
+                                       res2_st, res2_g, res2_b), "partials+dropout(ffn down)+residual+layernorm");
         } else
         if (ph) {
             if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, nullptr, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
             const cpt::DropSpec sp = drop_spec(drop, 3 + 3 * l, false);
-            TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,
-                                       a_f32, &sp, (float*)LB(l, w.o_pre2), nullptr, 1, 0, 0, (float*)LB(l, w.o_st2), nullptr, (unsigned short*)LB(l, w.o_kb2)), "dropout(ffn down)+residual+layernorm");
+            TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_out, xnext, dt, M, H, M, 0, 0, 0, s,
+                                       res2, &sp, (float*)LB(l, w.o_pre2), nullptr, 1, 0, 0, (float*)LB(l, w.o_st2), nullptr, (unsigned short*)LB(l, w.o_kb2),
+                                       res2_st, res2_g, res2_b), "dropout(ffn down)+residual+layernorm");
         } else {
         if (int r_ = dense_f32(LB(l, w.o_h), I, y.w_out, I, y.b_out, a_f32, LB(l, w.o_pre2), H, "gemm(ffn down)")) return r_;
         TRY(cpt::layernorm_rows_ex((const float*)LB(l, w.o_pre2), y.ln2_g, y.ln2_b, d.ln_eps, x_f32, xnext, dt, M, H, M, 0, 0, 0, s,

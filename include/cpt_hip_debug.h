@@ -106,6 +106,8 @@ int cpt_build_info(void);
  *          workgroups, two BF16 partial matrices added (with the fp32 residual) by the LayerNorm backward; 0 = 64 x 192 tiles over the whole K, fp32 out
  *   key 35 training backward, the GELU-gradient data-gradient GEMM (FFN-down): 1 (default) = 256 x 192 tiles where 128-row tiles would make between one and two
  *          rounds of workgroups and 256-row tiles at most one (M = 3840: 240 instead of 480 workgroups), 0 = 128 x 192 tiles
+ *   key 36 training forward with hidden dropout: 1 (default) = the LayerNorm launches write no fp32 output, the row pass behind re-forms the residual it adds
+ *          from the pre-LayerNorm rows kept for the backward (+ (mean, rstd), gain, shift); 0 = fp32 outputs written and read back
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at

