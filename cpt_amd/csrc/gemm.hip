@@ -1125,10 +1125,42 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group2_kernel(TnProb p0, TnPro
                                                                             nullptr, 0, ex, (int)blockIdx.x - (second ? wg0 : 0));
 }
 
+// out[i] = part[0][i] + part[1][i] + ... in split order (reduce_partials_kernel's arithmetic), by `nb` workgroups of NT threads; four elements' loads
+// (4 S of them) in flight per thread
+template <int NT>
+__device__ __forceinline__ void reduce_job_block(const ReduceJob& jb, int b, int nb) {
+    const f32x4* __restrict__ part = (const f32x4*)jb.part;
+    f32x4* __restrict__ out = (f32x4*)jb.out;
+    const size_t n4 = jb.n4, step = (size_t)nb * NT;
+    const int S = jb.S;
+    for (size_t i0 = (size_t)b * NT + threadIdx.x; i0 < n4; i0 += 4 * step) {
+        f32x4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const size_t i = i0 + u * step; if (i < n4) a[u] = part[i]; }
+        for (int k = 1; k < S; ++k) {
+            f32x4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const size_t i = i0 + u * step; if (i < n4) t[u] = part[(size_t)k * n4 + i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u][0] += t[u][0]; a[u][1] += t[u][1]; a[u][2] += t[u][2]; a[u][3] += t[u][3]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const size_t i = i0 + u * step; if (i < n4) out[i] = a[u]; }
+    }
+}
+__global__ __launch_bounds__(256) void reduce_job_kernel(ReduceJob jb) { reduce_job_block<256>(jb, (int)blockIdx.x, (int)gridDim.x); }
+int reduce_job_flush(const ReduceJob& job, hipStream_t s) {
+    if (job.S <= 1) return CPT_OK;
+    reduce_job_kernel<<<dim3((unsigned)std::min<size_t>((job.n4 + 1023) / 1024, 1024)), dim3(256), 0, s>>>(job);
+    return CPT_OK;
+}
+
 // ... and three: FFN down | FFN up | attention output (96 + 96 + 24 tiles at hidden 768: 216 CUs with the whole contraction each)
+// round 6: workgroups from nmain on (the CUs the tiles leave idle) add up the partial matrices of an EARLIER K-split launch (ReduceJob, kernels.h)
 template <int TBN>
-__global__ __launch_bounds__(512, 2) void gemm_tn_group3_kernel(TnProb p0, TnProb p1, TnProb p2, int K, int wg0, int wg1, EpiX ex) {
+__global__ __launch_bounds__(512, 2) void gemm_tn_group3_kernel(TnProb p0, TnProb p1, TnProb p2, int K, int wg0, int wg1, EpiX ex, ReduceJob job, int nmain) {
     const int bid = (int)blockIdx.x;
+    if (bid >= nmain) { reduce_job_block<512>(job, bid - nmain, (int)gridDim.x - nmain); return; }
     const int which = bid >= wg1 ? 2 : (bid >= wg0 ? 1 : 0);
     const TnProb& p = which == 2 ? p2 : (which == 1 ? p1 : p0);
     gemm_pipe_body<bf16, CPT_EPI_NONE, float, 128, TBN, 4, 2, 3, 1, 4, 1, 1>(p.A, p.lda, p.W, p.ldw, nullptr, nullptr, 0, p.out, p.ldo, p.M, p.N, K, 1,
@@ -1395,7 +1427,8 @@ int gemm_tn_eligible(int M, int N, int K, int lda, int ldw, int ldo) {
 }
 
 int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
-            hipStream_t s, int k_rows) {
+            hipStream_t s, int k_rows, ReduceJob* defer) {
+    if (defer) defer->S = 0;
     if (!gemm_tn_eligible(M, N, K, lda, ldw, ldo)) return CPT_ERR_SHAPE;
     if (k_rows < 0 || k_rows > K) return CPT_ERR_SHAPE;
     EpiX ex = {};
@@ -1421,6 +1454,7 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
     if (rc != CPT_OK) return rc;
     if (S > 1) {
         const size_t n4 = mat / 16;
+        if (defer) { *defer = ReduceJob{(const float*)partials, out, n4, S}; return CPT_OK; }      // (added up by a later launch's spare workgroups)
         const int blocks = (int)std::min<size_t>((n4 + 255) / 256, 2048);
         reduce_partials_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const f32x4*)partials, (f32x4*)out, n4, S);
     }
@@ -1502,7 +1536,7 @@ int gemm_tn_triple_eligible(int M0, int N0, int M1, int N1, int M2, int N2, int 
 }
 int gemm_tn_triple(const void* A0, int lda0, const void* W0, int ldw0, float* out0, int M0, int N0,
                    const void* A1, int lda1, const void* W1, int ldw1, float* out1, int M1, int N1,
-                   const void* A2, int lda2, const void* W2, int ldw2, float* out2, int M2, int N2, int K, int k_rows, hipStream_t s) {
+                   const void* A2, int lda2, const void* W2, int ldw2, float* out2, int M2, int N2, int K, int k_rows, hipStream_t s, const ReduceJob* carry) {
     if (!gemm_tn_triple_eligible(M0, N0, M1, N1, M2, N2, K)) return CPT_ERR_SHAPE;
     if (lda0 % 8 || ldw0 % 8 || lda1 % 8 || ldw1 % 8 || lda2 % 8 || ldw2 % 8 || k_rows < 0 || k_rows > K) return CPT_ERR_SHAPE;
     if (!A0 || !W0 || !out0 || !A1 || !W1 || !out1 || !A2 || !W2 || !out2) return CPT_ERR_NULL;
@@ -1525,7 +1559,18 @@ int gemm_tn_triple(const void* A0, int lda0, const void* W0, int ldw0, float* ou
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         attr_done = true;
     }
-    kern<<<dim3(t0 + t1 + t2), dim3(512), LDS, s>>>(p0, p1, p2, K, t0, t0 + t1, ex);
+    const int nmain = t0 + t1 + t2;
+    ReduceJob job = {};
+    int extra = 0;
+    if (carry && carry->S > 1) {
+        extra = 256 - nmain;                 // the CUs the tiles leave idle (one workgroup per CU: the ring takes 120 of 160 KB)
+        if (extra < 8) {                     // nothing idle: the job runs as its own launch in front
+            int rf = reduce_job_flush(*carry, s);
+            if (rf != CPT_OK) return rf;
+            extra = 0;
+        } else job = *carry;
+    }
+    kern<<<dim3(nmain + extra), dim3(512), LDS, s>>>(p0, p1, p2, K, t0, t0 + t1, ex, job, nmain);
     return CPT_OK;
 }
 

@@ -138,8 +138,12 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients
 // without operand transposes); needs gemm_tn_eligible; `partials` (optional) holds the split-K partial matrices
 int gemm_tn_eligible(int M, int N, int K, int lda, int ldw, int ldo);
+// ReduceJob (round 6): the addition of a K-split launch's S partial matrices (n4 float4 each, S > 1), in split order, LEFT for spare workgroups of a later
+// launch (gemm_tn_triple: 216 of 256 CUs busy at hidden 768) instead of a reduction launch of its own; S <= 1: no job
+struct ReduceJob { const float* part; float* out; size_t n4; int S; };
+int reduce_job_flush(const ReduceJob& job, hipStream_t s);     // a launch of its own (nothing left to carry it)
 int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K, void* partials, size_t partial_bytes,
-            hipStream_t s, int k_rows = 0);     // k_rows: rows of A / W that exist when K was rounded up to a multiple of 64
+            hipStream_t s, int k_rows = 0, ReduceJob* defer = nullptr);     // defer: a split launch fills *defer instead of launching the reduction;   k_rows: rows of A / W that exist when K was rounded up to a multiple of 64
 // two such products over the same K rows in one launch (the weight gradients of a layer's two FFN matrices, or of its attention
 // output and Q|K|V matrices); outputs dense (ldo = N).  CPT_ERR_SHAPE: not applicable, run two gemm_tn
 int gemm_tn_pair(const void* A0, int lda0, const void* W0, int ldw0, float* out0, int M0, int N0,
@@ -149,7 +153,7 @@ int gemm_tn_pair(const void* A0, int lda0, const void* W0, int ldw0, float* out0
 int gemm_tn_triple_eligible(int M0, int N0, int M1, int N1, int M2, int N2, int K);
 int gemm_tn_triple(const void* A0, int lda0, const void* W0, int ldw0, float* out0, int M0, int N0,
                    const void* A1, int lda1, const void* W1, int ldw1, float* out1, int M1, int N1,
-                   const void* A2, int lda2, const void* W2, int ldw2, float* out2, int M2, int N2, int K, int k_rows, hipStream_t s);
+                   const void* A2, int lda2, const void* W2, int ldw2, float* out2, int M2, int N2, int K, int k_rows, hipStream_t s, const ReduceJob* carry = nullptr);     // carry: run by the workgroups behind the tiles (CPT_ERR_SHAPE untouched: the caller flushes it)
 // out[M][N] = A[M][K] . W[K][N] (+ resid): W stored with the contraction index as its slow dimension (data gradients against an
 // nn.Linear weight as stored); bf16 operands, out fp32 (optionally + fp32 resid) or bf16
 int gemm_nn_eligible(int M, int N, int K, int lda, int ldw);
@@ -244,6 +248,7 @@ void set_qkv_2pass(int v);   // stand-alone LayerNorm-consumer QKV projection th
 void set_nn_tile256(int v);
 void set_nn_split2(int v);   // training backward: data gradients in front of a LayerNorm backward as two K-split bf16 partial matrices (1, default)
 void set_ln_lean(int v);     // training forward: LayerNorm launches without fp32 output, residual re-formed by the next row pass (1, default)
+void set_qkv_defer(int v);   // training backward: Q|K|V weight-gradient partial sums inside the next layer's three-problem weight-gradient launch (1, default)
 void set_train_tail(int v);  // training step: the last encoder layer behind the attention on the head rows only (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
 void set_lnb_rpb(int v);     // LayerNorm backward: rows per workgroup of the two-stage column-sum form (experiments)

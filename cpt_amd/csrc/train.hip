@@ -32,6 +32,10 @@ using cpt::g_fwd_split2;
 // re-forms the residual from the pre-LayerNorm rows kept for the backward, 0 = fp32 outputs written and read back
 namespace cpt { CPT_SWITCH(int g_ln_lean, 1); void set_ln_lean(int v) { CPT_SWITCH_SET(g_ln_lean = v); (void)v; } }
 using cpt::g_ln_lean;
+// cpt_set_tuning(37, v): 1 (default) = the K-split partial matrices of a layer's Q|K|V weight gradient are added up by the spare workgroups of the NEXT layer's
+// three-problem weight-gradient launch (no reduction launch), 0 = reduction launch behind the split launch
+namespace cpt { CPT_SWITCH(int g_qkv_defer, 1); void set_qkv_defer(int v) { CPT_SWITCH_SET(g_qkv_defer = v); (void)v; } }
+using cpt::g_qkv_defer;
 namespace cpt { CPT_SWITCH(int g_train_tail, 1); void set_train_tail(int v) { CPT_SWITCH_SET(g_train_tail = v); (void)v; } }
 using cpt::g_train_tail;
 namespace cpt { CPT_SWITCH(int g_bias_fuse, 3); void set_bias_fuse(int v) { CPT_SWITCH_SET(g_bias_fuse = v); (void)v; } }
@@ -48,6 +52,7 @@ struct TrainLayout {
     size_t xout, imgp, imgpre, rows, uh, t2, dlogits, loss;
     size_t dx, dpre, da, dpre_lp, dlp2, dctx, dbig, tA, tB, wT, gimg, dl_lp, dt2, duh, duh_lp, drows, dimg, dimg_lp, dmask, dmask_lp;
     size_t t_ctx, t_xres, t_pre1, t_a, t_af, t_u, t_h, t_pre2, t_st1, t_st2, t_kb1, t_kb2, t_dpre, t_dlpF, t_dlpA, t_dbig, t_da, t_dctx;      // round 6: the pruned last layer's compact [B][.] activations and gradients
+    size_t qkvp, qkvp_bytes;      // round 6: partial matrices of the Q|K|V weight gradient's K-split launch, added up by spare workgroups of the NEXT layer's three-problem weight-gradient launch
     size_t lnp[2], lnp_bytes, csp; int csp_rows;      // round 6: partial column sums left for a later launch's column-sum job -- two alternating LayerNorm-backward tables, the FFN-up bias rows of the GELU-gradient GEMM
     size_t sA, sW, sA_bytes, sW_bytes;      // bf16x3: split copies of a GEMM's two fp32 operands ([rows][hi | hi | lo] and [rows][hi | lo | hi])
     size_t total, tA_bytes, tB_bytes;
@@ -112,6 +117,13 @@ TrainLayout train_layout(const cpt_dims& d, int B, int Lt, int Li, int Rh) {
     w.lnp[0] = take(w.lnp_bytes); w.lnp[1] = take(w.lnp_bytes);
     w.csp_rows = (int)((M + 31) / 32);
     w.csp = take((size_t)w.csp_rows * I * 4);
+    {
+        // (gemm_tn splits K at most 256 / tiles ways, at most eight)
+        const size_t tiles = (3 * H / 128) * (H % 192 == 0 ? H / 192 : std::max<size_t>(H / 128, 1));
+        const size_t smax = (d.dtype == CPT_BF16 && tiles > 0) ? std::min<size_t>(8, 256 / std::max<size_t>(tiles, 1)) : 0;
+        w.qkvp_bytes = smax > 1 ? smax * 3 * H * H * 4 : 0;
+        w.qkvp = take(w.qkvp_bytes);
+    }
     {
         const size_t Bq = (size_t)B;
         w.t_ctx = take(Bq * H * es); w.t_xres = take(Bq * H * 4); w.t_pre1 = take(Bq * H * 4); w.t_a = take(Bq * H * es); w.t_af = take(Bq * H * 4);
@@ -475,11 +487,14 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     void* wT = ws + w.wT;
     // out[Nout][Kout] (fp32 gradient of a Linear weight) = dY^T . X over the M rows
     auto wgrad = [&](const void* dY, int dY_dt, int ldy, int Nout, const void* X, int ldx, int Kout, int rows, int rows_p,
-                     float* out, int ldo, const char* what) -> int {
+                     float* out, int ldo, const char* what, cpt::ReduceJob* defer = nullptr) -> int {
         // bf16, tile-aligned shapes: the TN form of the GEMM reads dY and X as they are (transpose reads in LDS); tA serves as
         // its split-K partial buffer.  Everything else (fp32 mode, head-sized problems) goes through explicit transposes.
         // (rows_p = rows rounded up to a K-tile: the missing rows read as zero through the buffer bounds)
         if (g_wgrad_tn && dt == CPT_BF16 && dY_dt == CPT_BF16 && cpt::gemm_tn_eligible(Nout, Kout, rows_p, ldy, ldx, ldo)) {
+            // (defer: the partial matrices go to their own buffer -- tA is reused right away -- and are added up by a later launch's spare workgroups)
+            if (defer && w.qkvp_bytes) TRY(cpt::gemm_tn(dY, ldy, X, ldx, out, ldo, Nout, Kout, rows_p, ws + w.qkvp, w.qkvp_bytes, s, rows, defer), what);
+            else
             TRY(cpt::gemm_tn(dY, ldy, X, ldx, out, ldo, Nout, Kout, rows_p, tA, w.tA_bytes, s, rows), what);
             return CPT_OK;
         }
@@ -598,6 +613,11 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     const void* dpre_in = ph ? (dt == CPT_BF16 ? (const void*)dmask_lp : (const void*)dmask) : (dt == CPT_BF16 ? (const void*)dpre_lp : (const void*)dpre);
     const float* dpre_f = ph ? dmask : dpre;
     cpt::ColJobs pend = {};      // round 6: column-sum jobs waiting for a carrier launch (kernels.h)
+    // round 6: the Q|K|V weight gradient's K-split partial matrices of layer l + 1 wait for the three-problem weight-gradient launch of layer l, whose tiles
+    // leave 40 of 256 CUs idle at hidden 768 (cpt_set_tuning key 37); the bucket of layer l + 1 is announced behind that launch
+    cpt::ReduceJob qjob = {};
+    int ready_after_triple = -1;
+    const bool qkv_defer = g_qkv_defer && g_wgrad_tn && g_wgrad_pair >= 2 && dt == CPT_BF16 && cpt::gemm_tn_triple_eligible(H, I, I, H, H, H, Mp);
     int lnp_turn = 0, dxS = 1, dxB = 0;      // dxB: those partial matrices are bf16 (two of them, gemm_nn split2_bf16)
       // dxS > 1: the gradient entering the layer lies in tA as that many K-split partial matrices (+ residual dpre)
     for (int l = d.layers - 1; l >= 0; --l) {
@@ -659,7 +679,10 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
             pend = cpt::ColJobs{};
             cpt::col_jobs_add(pend, part, cpt::ln_bwd_part_rows(M), 3 * H, 3 * H, H, gy.ln2_g, gy.ln2_b, gy.b_out);
             lnp_turn ^= 1;
-            if (l + 1 < d.layers) ready(1 + l + 1);      // the layer above is complete now: this launch added its attention-side LayerNorm's sums
+            if (l + 1 < d.layers) {      // the layer above is complete now: this launch added its attention-side LayerNorm's sums
+                if (qjob.S > 1) ready_after_triple = 1 + l + 1;      // (... but for its Q|K|V weight gradient, still in partial matrices)
+                else ready(1 + l + 1);
+            }
         } else {
         TRY(cpt::ln_bwd(dx, (const float*)LB(l, w.o_pre2), y.ln2_g, d.ln_eps, dpre, dt == CPT_BF16 ? dpre_lp : nullptr, dt, gy.ln2_g, gy.ln2_b,
                         M, H, M, 0, 0, 0, s, (float*)tB, w.tB_bytes), "ln_bwd(ffn)");
@@ -720,9 +743,15 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         TRY(cpt::colsum(dpre_f, CPT_F32, H, gy.b_ao, M, H, s), "colsum(b_ao)");
         }
         const void* dao_in = triple ? (const void*)(ws + w.dlp2) : dpre_in;      // gradient entering the attention output's dense layer
-        if (triple)
+        if (triple) {
             TRY(cpt::gemm_tn_triple(dpre_in, H, LB(l, w.o_h), I, gy.w_out, H, I, dbig, I, LB(l, w.o_a), H, gy.w_in, I, H,
-                                    dao_in, H, LB(l, w.o_ctx), H, gy.w_ao, H, H, Mp, M, s), "wgrad(ffn down | ffn up | attn out)");
+                                    dao_in, H, LB(l, w.o_ctx), H, gy.w_ao, H, H, Mp, M, s, &qjob), "wgrad(ffn down | ffn up | attn out) + partial sums of the layer above's wgrad(qkv)");
+            qjob = cpt::ReduceJob{};
+        } else if (qjob.S > 1) {
+            TRY(cpt::reduce_job_flush(qjob, s), "partial sums of wgrad(qkv)");
+            qjob = cpt::ReduceJob{};
+        }
+        if (ready_after_triple >= 0) { ready(ready_after_triple); ready_after_triple = -1; }
         rc = dgrad(dao_in, H, H, y.w_ao, H, H, H, M, nullptr, dctx, dt, "dgrad(attn out)");
         if (rc) return rc;
         }
@@ -735,7 +764,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
                                (dt == CPT_BF16 && !(b->mask_3d && b->attn_mask)) ? LB(l, w.o_ctx) : nullptr, (dt == CPT_BF16 && !(b->mask_3d && b->attn_mask)) ? (const float*)LB(l, w.o_ast) : nullptr), "attention_bwd+bias");
         if (!(g_bias_fuse & 2)) TRY(cpt::colsum(dbig, dt, 3 * H, gy.b_qkv, M, 3 * H, s), "colsum(b_qkv)");
         if (triple) {
-            rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)");
+            rc = wgrad(dbig, dt, 3 * H, 3 * H, LB(l, w.o_xin), H, H, M, Mp, gy.w_qkv, H, "wgrad(qkv)", (qkv_defer && fuse_db) ? &qjob : nullptr);
             if (rc) return rc;
         } else
         if (wgrad_pair(dpre_in, H, H, LB(l, w.o_ctx), H, H, gy.w_ao, dbig, 3 * H, 3 * H, LB(l, w.o_xin), H, H, gy.w_qkv, rc, "wgrad(attn out | qkv)")) {
@@ -754,6 +783,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         if (!fuse_db) ready(1 + l);
     }
     if (dt == CPT_BF16) {      // the last attention-side LayerNorm's sums (and whatever else still waits for a carrier launch)
+        if (qjob.S > 1) { TRY(cpt::reduce_job_flush(qjob, s), "partial sums of wgrad(qkv), first layer"); qjob = cpt::ReduceJob{}; }
         TRY(cpt::col_jobs_flush(pend, s), "column-sum jobs");
         pend = cpt::ColJobs{};
         ready(1);

@@ -108,6 +108,8 @@ int cpt_build_info(void);
  *          rounds of workgroups and 256-row tiles at most one (M = 3840: 240 instead of 480 workgroups), 0 = 128 x 192 tiles
  *   key 36 training forward with hidden dropout: 1 (default) = the LayerNorm launches write no fp32 output, the row pass behind re-forms the residual it adds
  *          from the pre-LayerNorm rows kept for the backward (+ (mean, rstd), gain, shift); 0 = fp32 outputs written and read back
+ *   key 37 training backward: 1 (default) = the K-split partial matrices of a layer's Q|K|V weight gradient are added up by the workgroups the NEXT layer's
+ *          three-problem weight-gradient launch leaves idle (216 of 256 CUs busy at hidden 768); 0 = a reduction launch of their own
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
