@@ -70,7 +70,7 @@ class Dropout(C.Structure):
 
 
 class Outputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("seq", "pooled", "logits", "loss", "rel", "loss_mean")]
+    _fields_ = [(n, C.c_void_p) for n in ("seq", "pooled", "logits", "loss", "rel", "loss_mean", "logit_cols")] + [("n_logit_cols", C.c_int64)]
 
 
 _SIGS = {

@@ -483,6 +483,10 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         return fail(CPT_ERR_SHAPE, "cpt_model_fwd: CPT_OUT_LOSS needs a logits output");
     if ((flags & CPT_OUT_LOSS) && (!b->labels || !o->loss)) return fail(CPT_ERR_NULL, "cpt_model_fwd: labels/loss required for CPT_OUT_LOSS");
     if ((flags & CPT_OUT_REL) && (!m->w_rel || d.n_rel <= 0)) return fail(CPT_ERR_NULL, "cpt_model_fwd: model has no seq_relationship head");
+    const bool cols = o->logit_cols != nullptr && o->n_logit_cols > 0;      // decoder on a list of vocabulary columns (cpt_outputs.logit_cols)
+    if (cols && (!(flags & CPT_OUT_MASK_LOGITS) || (flags & CPT_OUT_LOSS)))
+        return fail(CPT_ERR_SHAPE, "cpt_model_fwd: logit_cols goes with CPT_OUT_MASK_LOGITS and without CPT_OUT_LOSS");
+    if (cols && o->n_logit_cols > d.vocab) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: n_logit_cols %lld > vocabulary %d", (long long)o->n_logit_cols, d.vocab);
     const FwdLayout w = fwd_layout(d, B, Lt, Li, flags);
     if (workspace_bytes < w.total) return fail(CPT_ERR_WORKSPACE, "cpt_model_fwd: workspace %zu < required %zu bytes", workspace_bytes, w.total);
     if ((uintptr_t)workspace & 255) return fail(CPT_ERR_ALIGN, "cpt_model_fwd: workspace must be 256-byte aligned");
@@ -596,7 +600,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
     // ... and for the fp32 mode: the same launches as its all-row form (cpt_gemm + layernorm_rows), on the B gathered rows
     const bool tail_f32 = g_tail && d.dtype == CPT_F32 && d.layers >= 2 && !(flags & (CPT_OUT_SEQ | CPT_OUT_ALL_LOGITS)) && want_mask != want_cls;
     const size_t dec_bytes_t = (size_t)d.vocab * H * 2;
-    const size_t dec_pf0_t = (want_mask && m->w_dec && g_prefetch) ? ((dec_bytes_t / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023) : 0;
+    const size_t dec_pf0_t = (want_mask && m->w_dec && g_prefetch && !cols) ? ((dec_bytes_t / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023) : 0;
     if (Me != M && !rpanel) return fail(CPT_ERR_SHAPE, "cpt_model_fwd: internal: padded rows outside the panel residual mode");
     if (fold) {
         const int M = Me;       // (every launch of this block is row-wise or per sequence: the padded rows are computed and never read)
@@ -800,7 +804,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         // the decoder's weight table (47 MB at Oscar-base) is pulled into the Infinity Cache by spare workgroups of the head's two row launches:
         // g_dec_pf_pct percent by the first (gather + LayerNorm), the rest by the reduce + GELU + LayerNorm launch (cpt_set_tuning key 26)
         const size_t dec_bytes = (size_t)d.vocab * H * 2;
-        const size_t dec_pf0 = (dec_bytes / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023;
+        const size_t dec_pf0 = cols ? dec_bytes : ((dec_bytes / 100 * (size_t)g_dec_pf_pct) & ~(size_t)1023);      // (column list: no table prefetch -- dec_pf0 = all: nothing left for the second launch either)
         if (!all) {
             void* g = ws + w.rows;
             if (tail || tail_x3 || tail_f32) {
@@ -810,7 +814,7 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
                 const cpt_layer& yl = m->layers[d.layers - 1];
                 float* rf = (float*)(ws + w.rows_f32);
                 if (r3) TRY(cpt::head_rows_ln3(x_lp, x_lo, b->mask_pos, yl.ln2_g, yl.ln2_b, d.ln_eps, g, B, L, H, s,
-                                               g_prefetch ? m->w_dec : nullptr, dec_pf0, rpanel), "gather + merge + layernorm([MASK] rows)");
+                                               (g_prefetch && !cols) ? m->w_dec : nullptr, cols ? 0 : dec_pf0, rpanel), "gather + merge + layernorm([MASK] rows)");
                 else {
                 TRY(cpt::gather_rows(x_f32, CPT_F32, b->mask_pos, rf, B, L, H, s), "gather([MASK] pre-LN)");
                 TRY(cpt::layernorm_rows(rf, yl.ln2_g, yl.ln2_b, d.ln_eps, nullptr, g, dt, B, H, B, 0, 0, s), "layernorm([MASK] rows)");
@@ -834,6 +838,9 @@ int cpt_model_fwd(const cpt_model* m, const cpt_batch* b, const cpt_outputs* o, 
         TRY(gm(CPT_EPI_GELU, rows, H, m->w_tr, H, m->b_tr, nullptr, 0, t1, CPT_F32, H, R, H), "gemm(head transform)");
         TRY(cpt::layernorm_rows(t1, m->tr_ln_g, m->tr_ln_b, d.ln_eps, lp ? nullptr : (float*)t2, lp ? t2 : nullptr, dt, R, H, R, 0, 0, s), "layernorm(head)");
         }
+        if (cols)
+            TRY(cpt::decoder_cols(t2, x3 ? 2 : (lp ? 0 : 1), m->w_dec, m->b_dec, o->logit_cols, (int)o->n_logit_cols, o->logits, R, H, d.vocab, s), "decoder(column list)");
+        else
         TRY(gm(CPT_EPI_NONE, t2, H, m->w_dec, H, m->b_dec, nullptr, 0, o->logits, CPT_F32, d.vocab, R, d.vocab), "gemm(decoder)");
         if (flags & CPT_OUT_LOSS) {
             hipError_t e = hipMemsetAsync(o->loss, 0, 2 * sizeof(float), s);

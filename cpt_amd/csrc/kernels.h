@@ -180,6 +180,8 @@ int gemm_img_proj(const void* A, int lda, const void* W, int ldw, const float* b
 // workgroups (partials[S][M][N], S = head_transform_splits(K)); reduction + GELU + LayerNorm in one launch
 int head_rows_ln3(const void* hi, const void* lo, const int64_t* pos, const float* g, const float* bta, float eps, void* out_bf16, int R, int L, int H, hipStream_t s,
                   const void* pf = nullptr, size_t pf_bytes = 0, int src_panel = 0);     // src_panel (round 5): hi / lo in the panel layout; pf: region (the decoder's weight table) that leading blocks of the launch read into the Infinity Cache
+// decoder scores of a list of vocabulary columns only: out[R][n] = t[R][H] . W[cols[j]][:] + bias[cols[j]]   (mode 0 bf16 x bf16, 1 fp32 x fp32, 2 fp32 x the bf16x3 split table)
+int decoder_cols(const void* t, int mode, const void* W, const float* bias, const int64_t* cols, int n, float* out, int R, int H, int V, hipStream_t s);
 int head_transform_splits(int K);
 int gemm_head_transform(const void* A, int lda, const void* W, int ldw, const float* bias, float* partials, int M, int N, int K, hipStream_t s);
 int head_finish(const float* partials, int S, const float* g, const float* bta, float eps, void* out_bf16, int R, int H, hipStream_t s,

@@ -932,6 +932,56 @@ int gelu_parts(const float* partials, int S, void* out_bf16, size_t n, hipStream
     return CPT_OK;
 }
 
+// ---- decoder on a LIST of vocabulary columns (round 6; SURVEY a11 "or just colour columns") --------------------------------------
+// The zero- and few-shot drivers read a handful of colour-token columns of the [B][30522] prediction scores (zeroshot/refcoco_cpt.py:219,
+// fewshot/refcoco_cpt.py:272-291, gqa_cpt.py:598-600): out[r][j] = t[r] . W[cols[j]] + b[cols[j]] reads n rows of the decoder table instead of
+// streaming all 47 MB of it and writes B x n scores instead of B x V.  One workgroup per row, one column per wave at a time, fp32 accumulation.
+// MODE 0: bf16 rows x bf16 table [V][H];  1: fp32 x fp32;  2 (bf16x3): fp32 rows x the split table [V][hi | lo | hi] -- the weight is re-formed as hi + lo.
+template <int MODE>
+__global__ __launch_bounds__(256) void decoder_cols_kernel(const void* __restrict__ t_, const void* __restrict__ W_, const float* __restrict__ bias,
+                                                           const int64_t* __restrict__ cols, int n, float* __restrict__ out, int H, int V) {
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < n; j += 4) {
+        long c = cols[j];
+        c = c < 0 ? 0 : (c >= V ? V - 1 : c);       // (the host checks the list; never fault)
+        float acc = 0.f;
+        if constexpr (MODE == 0) {
+            const bf16* t = (const bf16*)t_ + (size_t)r * H; const bf16* w = (const bf16*)W_ + (size_t)c * H;
+            for (int k = lane * 4; k < H; k += 256) {
+                const bf16x4 a = *reinterpret_cast<const bf16x4*>(t + k), b = *reinterpret_cast<const bf16x4*>(w + k);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += (float)a[q] * (float)b[q];
+            }
+        } else if constexpr (MODE == 1) {
+            const float* t = (const float*)t_ + (size_t)r * H; const float* w = (const float*)W_ + (size_t)c * H;
+            for (int k = lane * 4; k < H; k += 256) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(t + k), b = *reinterpret_cast<const f32x4*>(w + k);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += a[q] * b[q];
+            }
+        } else {
+            const float* t = (const float*)t_ + (size_t)r * H; const bf16* w = (const bf16*)W_ + (size_t)c * 3 * H;
+            for (int k = lane * 4; k < H; k += 256) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(t + k);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(w + k), lo = *reinterpret_cast<const bf16x4*>(w + H + k);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += a[q] * ((float)hi[q] + (float)lo[q]);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[(size_t)r * n + j] = acc + (bias ? bias[c] : 0.f);
+    }
+}
+int decoder_cols(const void* t, int mode, const void* W, const float* bias, const int64_t* cols, int n, float* out, int R, int H, int V, hipStream_t s) {
+    if (R <= 0 || n <= 0 || H <= 0 || H % 4 || V <= 0) return CPT_ERR_SHAPE;
+    if (!t || !W || !cols || !out) return CPT_ERR_NULL;
+    if (mode == 0) decoder_cols_kernel<0><<<dim3(R), dim3(256), 0, s>>>(t, W, bias, cols, n, out, H, V);
+    else if (mode == 1) decoder_cols_kernel<1><<<dim3(R), dim3(256), 0, s>>>(t, W, bias, cols, n, out, H, V);
+    else if (mode == 2) decoder_cols_kernel<2><<<dim3(R), dim3(256), 0, s>>>(t, W, bias, cols, n, out, H, V);
+    else return CPT_ERR_DTYPE;
+    return CPT_OK;
+}
+
 // ---- cross entropy over rows (ignore_index = -1) ----------------------------------------------
 // the last workgroup to finish (ticket) turns the totals into the mean and a second copy of them: the training forward's loss needs no divide kernel
 // and no device-to-device copy behind this launch (round 6).  Every workgroup passes here, ignored rows too.

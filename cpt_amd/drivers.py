@@ -20,28 +20,41 @@ from .train import get_lr_sched
 logger = logging.getLogger(__name__)
 
 
-def val_queries(model, queries, none_id, device, few_shot=False, batch_queries=4):
+def val_queries(model, queries, none_id, device, few_shot=False, batch_queries=4, colour_columns_only=True):
     """queries: list of dicts with tensors ``img_feats (P,Li,D)``, ``input_ids (P,Lt)``,
     ``segment_ids``, ``attention_mask (P,Lt+Li)``, ``mask_token_pos (P,)`` and python lists
     ``colors`` (per proposal sequence: colour-token ids) and ``rects`` (per sequence: rectangles).
-    Returns {global query index: (max_idx, rect)} on every rank."""
+    Returns {global query index: (max_idx, rect)} on every rank.
+    colour_columns_only (default): the decoder scores only the vocabulary columns the selection reads -- every colour id of the queries + ``none_id``
+    (zeroshot/refcoco_cpt.py:219 gathers exactly those out of the (P, V) scores) -- instead of all V; same chosen indices."""
     model.eval()
     rank, world = cdist.rank_world()
     lo, hi = cdist.shard_range(len(queries), rank, world)
     chosen = torch.full((hi - lo,), -1, dtype=torch.int64, device=device)
+    col_ids, col_of, cols_dev = None, None, None
+    if colour_columns_only:
+        col_ids = sorted({int(c) for q in queries for s in q["colors"] for c in s} | {int(none_id)})
+        col_of = {c: i for i, c in enumerate(col_ids)}
+        cols_dev = torch.tensor(col_ids, dtype=torch.int64, device=device)
     for start in range(lo, hi, batch_queries):
         chunk = queries[start:min(start + batch_queries, hi)]
         cat = {k: torch.cat([q[k] for q in chunk], 0).to(device, non_blocking=True)
                for k in ("img_feats", "input_ids", "segment_ids", "attention_mask", "mask_token_pos")}
         with torch.no_grad():
-            scores = model(cat["input_ids"], cat["segment_ids"], cat["attention_mask"], img_feats=cat["img_feats"],
-                           mask_token_pos=cat["mask_token_pos"])[0]
+            if cols_dev is not None:
+                scores = model(cat["input_ids"], cat["segment_ids"], cat["attention_mask"], img_feats=cat["img_feats"],
+                               mask_token_pos=cat["mask_token_pos"], vocab_columns=cols_dev)[0]
+            else:
+                scores = model(cat["input_ids"], cat["segment_ids"], cat["attention_mask"], img_feats=cat["img_feats"],
+                               mask_token_pos=cat["mask_token_pos"])[0]
         # colour gather + per-query argmax run on the device (cpt_select_regions): only indices leave the GPU
         sets = [list(s) for q in chunk for s in q["colors"]]
+        if col_of is not None:      # (ids -> positions in the column list the scores were computed for)
+            sets = [[col_of[int(c)] for c in s] for s in sets]
         first = [0]
         for q in chunk:
             first.append(first[-1] + q["input_ids"].size(0))
-        idx = scoring.select_regions_device(scores, sets, first, none_id, few_shot=few_shot)
+        idx = scoring.select_regions_device(scores, sets, first, none_id if col_of is None else col_of[int(none_id)], few_shot=few_shot)
         chosen[start - lo:start - lo + len(chunk)] = idx
     allc = cdist.gather_fixed(chosen, len(queries), fill=-1).cpu().tolist()
     out = {}

@@ -439,8 +439,10 @@ class PackedModel(object):
         return ws
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, img_feats=None,
-                mask_pos=None, labels=None, flags=0):
-        """Returns dict with the outputs selected by `flags` (see _lib.OUT_*)."""
+                mask_pos=None, labels=None, flags=0, logit_cols=None):
+        """Returns dict with the outputs selected by `flags` (see _lib.OUT_*).
+        logit_cols (1-D int64 tensor of vocabulary ids, with OUT_MASK_LOGITS and no loss): ``logits`` holds those columns only, (B, len(logit_cols)),
+        in list order -- the decoder then reads len(logit_cols) rows of its table instead of streaming it (cpt_outputs.logit_cols)."""
         self.ensure_packed()
         self.refresh_shadow()
         if self.dtype == "bf16" and self.fold_ln:
@@ -486,9 +488,18 @@ class PackedModel(object):
         if flags & L.OUT_POOLED:
             out["pooled"] = torch.empty((B, H), device=dev, dtype=torch.float32)
             o.pooled = out["pooled"].data_ptr()
+        if logit_cols is not None:
+            if not (flags & L.OUT_MASK_LOGITS) or (flags & L.OUT_LOSS):
+                raise RuntimeError("cpt_amd: logit_cols goes with the [MASK]-row scores and without a loss")
+            logit_cols = prep(logit_cols.reshape(-1), torch.int64, "logit_cols")
+            if logit_cols.numel() == 0:
+                raise RuntimeError("cpt_amd: logit_cols is empty")
         if flags & L.OUT_MASK_LOGITS:
-            out["logits"] = torch.empty((B, V), device=dev, dtype=torch.float32)
+            out["logits"] = torch.empty((B, V if logit_cols is None else logit_cols.numel()), device=dev, dtype=torch.float32)
             o.logits = out["logits"].data_ptr()
+            if logit_cols is not None:
+                o.logit_cols = logit_cols.data_ptr()
+                o.n_logit_cols = logit_cols.numel()
         if flags & L.OUT_ALL_LOGITS:
             out["logits"] = torch.empty((B, Lseq, V), device=dev, dtype=torch.float32)
             o.logits = out["logits"].data_ptr()

@@ -42,7 +42,9 @@ class REC_MLM_CPT(_EngineMixin, BertPreTrainedModel):
         self._tie_or_clone_weights(self.cls.decoder, self.bert.embeddings.word_embeddings)
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, masked_lm_labels=None,
-                position_ids=None, head_mask=None, img_feats=None, mask_token_pos=None):
+                position_ids=None, head_mask=None, img_feats=None, mask_token_pos=None, vocab_columns=None):
+        # vocab_columns (extension, inference with mask_token_pos only): 1-D tensor of vocabulary ids -- the returned scores are (B, len(vocab_columns)),
+        # those columns of the (B, V) prediction scores in list order (the drivers read colour-token columns only: zeroshot/refcoco_cpt.py:219)
         _check_unsupported(self.config, head_mask, None)
         rows = mask_token_pos is not None
         flags = L.OUT_MASK_LOGITS if rows else L.OUT_ALL_LOGITS
@@ -52,6 +54,8 @@ class REC_MLM_CPT(_EngineMixin, BertPreTrainedModel):
             labels = masked_lm_labels
             if rows and labels.dim() == 2:       # (B, L) label grid of fewshot/refcoco_cpt.py:231-233
                 labels = labels[torch.arange(labels.size(0), device=labels.device), mask_token_pos]
+        if vocab_columns is not None and (not rows or masked_lm_labels is not None):
+            raise NotImplementedError("cpt_amd: vocab_columns goes with mask_token_pos and without masked_lm_labels")
         if torch.is_grad_enabled() and masked_lm_labels is not None and self.bert.img_embedding.weight.requires_grad:
             from .train import mlm_loss_with_grad
             if mask_token_pos is None:
@@ -72,7 +76,7 @@ class REC_MLM_CPT(_EngineMixin, BertPreTrainedModel):
             return mlm_loss_with_grad(self, input_ids, token_type_ids, attention_mask, labels, position_ids,
                                       img_feats, mask_token_pos)
         out = self._engine().forward(input_ids, token_type_ids, attention_mask, position_ids, img_feats,
-                                     mask_pos=mask_token_pos, labels=labels, flags=flags)
+                                     mask_pos=mask_token_pos, labels=labels, flags=flags, logit_cols=vocab_columns)
         outputs = (out["logits"],)
         if masked_lm_labels is not None:
             outputs = (out["loss"],) + outputs

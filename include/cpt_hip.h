@@ -42,7 +42,7 @@ extern "C" {
                                * 6: CPT_BF16X3 in cpt_train_* (fp32 master weights there, NOT the split copies cpt_model_fwd reads under the same tag: the training step's own tag is CPT_BF16X3_MASTERS),
                                *    cpt_set_tuning / cpt_prof_* / cpt_debug_gemm_trace declared in cpt_hip_debug.h, operator-level backward entry points, cpt_comm_*;
                                * 7: cpt_adamw / cpt_adamw_ex take lr, betas, eps and weight decay as doubles (round 6);
-                               * 8: cpt_outputs.loss_mean (round 6) */
+                               * 8: cpt_outputs.loss_mean, cpt_outputs.logit_cols / n_logit_cols (round 6) */
 
 enum { CPT_F32 = 0, CPT_BF16 = 1, CPT_BF16X3 = 2,
        CPT_BF16X3_MASTERS = 3 /* ABI 6, cpt_dims.dtype for cpt_train_* only: CPT_BF16X3 arithmetic on plain fp32 weight matrices (split per GEMM) */ };
@@ -180,6 +180,12 @@ typedef struct {
     float* loss_mean;    /* ABI 8, cpt_train_fwd(_ex) only, optional (NULL: not written): [1] = loss[0] / loss[1], the value REC_MLM_CPT.forward /
                           * NSPCPT.forward return (modeling_rec.py:147-150, modeling_vcr.py:126-128), written by the cross-entropy launch itself so that
                           * the host needs no divide kernel behind the forward; cpt_model_fwd ignores the field */
+    const int64_t* logit_cols;   /* ABI 8, cpt_model_fwd with CPT_OUT_MASK_LOGITS only, optional (NULL: every column): DEVICE list of n_logit_cols vocabulary ids;
+                                  * `logits` is then [B][n_logit_cols] -- the scores of those columns only, in list order.  What the zero- / few-shot
+                                  * drivers read of the [B][V] scores is a handful of colour-token columns (zeroshot/refcoco_cpt.py:219,
+                                  * fewshot/refcoco_cpt.py:272-291, gqa_cpt.py:598-600): the 47 MB decoder table is not streamed and B x V floats are not written.
+                                  * Not with CPT_OUT_LOSS / CPT_OUT_ALL_LOGITS (CPT_ERR_SHAPE).  Ids outside [0, V) are the caller's bug (clamped, never a fault) */
+    int64_t n_logit_cols;
 } cpt_outputs;
 
 /* Workspace the caller must supply for cpt_model_fwd with these flags (bytes). */

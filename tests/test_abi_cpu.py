@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(L.Dims) == 12 * 4 + 2 * 4
     assert ctypes.sizeof(L.Layer) == 12 * 8
     assert ctypes.sizeof(L.Batch) == 3 * 4 + 4 + 7 * 8 + 4 + 4 + 8     # 3 ints, padding, 7 pointers, n_rows, padding, row_seq (ABI 5)
-    assert ctypes.sizeof(L.Outputs) == 6 * 8
+    assert ctypes.sizeof(L.Outputs) == 8 * 8
     assert L.Model.layers.offset == ctypes.sizeof(L.Dims) + 9 * 8
 
 

@@ -119,6 +119,34 @@ def test_val_driver_matches_oracle_selection(dev):
             assert got[gi][0] == idx or margin < 1e-3, (gi, got[gi][0], idx, margin)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16x3"])
+def test_decoder_on_a_column_list_equals_those_columns_of_the_full_scores(dev, mode):
+    """Round 6 (SURVEY a11 "or just colour columns"; zeroshot/refcoco_cpt.py:219, gqa_cpt.py:598-600): cpt_outputs.logit_cols -- the decoder scores a list of
+    vocabulary columns only.  Against the same columns of the full (B, V) scores of the same mode (a dot product in fp32 instead of the MFMA tile's order),
+    duplicates and unsorted ids included; and the drivers' selections are the same with and without the column list."""
+    from cpt_amd import drivers
+    cfg = cfgmod.oscar_base(num_hidden_layers=2)
+    m, _, _ = _pair(cfg, 23, dev)
+    m.set_compute_dtype(mode)
+    b = {k: v.to(dev) for k, v in synth.make_batch(9, cfg, seed=5, vary_regions=True).items()}
+    ids = list(synth.COLOR_IDS) + [synth.NONE_ID, 0, cfg.vocab_size - 1, synth.COLOR_IDS[0]]
+    cols = torch.tensor(ids, dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        full = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"])[0]
+        part = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], mask_token_pos=b["mask_token_pos"], vocab_columns=cols)[0]
+    assert tuple(part.shape) == (9, len(ids))
+    err = float((part - full[:, cols]).abs().max())
+    print("column decoder %s: max |d| %.3e" % (mode, err))
+    assert err < {"fp32": 2e-5, "bf16": 2e-5, "bf16x3": 2e-4}[mode]      # (bf16: the same bf16 operands, fp32 sums in another order; bf16x3: hi + lo weights against the three-term product)
+    with pytest.raises(Exception):
+        m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], vocab_columns=cols)        # all-row scores: no column list
+    qs = _queries(cfg, 7, 3)
+    for few_shot in (False, True):
+        a = drivers.val_queries(m, qs, synth.NONE_ID, dev, few_shot=few_shot, batch_queries=3, colour_columns_only=True)
+        c = drivers.val_queries(m, qs, synth.NONE_ID, dev, few_shot=few_shot, batch_queries=3, colour_columns_only=False)
+        assert {k: v[0] for k, v in a.items()} == {k: v[0] for k, v in c.items()}
+
+
 def test_train_batch_driver_runs_and_learns(dev):
     from cpt_amd import drivers
     from cpt_amd.modeling_rec import REC_MLM_CPT
