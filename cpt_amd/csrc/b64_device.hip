@@ -52,15 +52,28 @@ __global__ __launch_bounds__(256) void b64_regions_kernel(const unsigned* __rest
     // unaligned-access mode -- instead of four and three 4-byte ones)
     typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     typedef unsigned u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
-    for (int c = threadIdx.x; c < chunks; c += 256) {
-        const u32x4_a4 w = *reinterpret_cast<const u32x4_a4*>(t + 4 * c);
-        const unsigned t0 = group(w[0], 16 * c), t1 = group(w[1], 16 * c + 4), t2 = group(w[2], 16 * c + 8), t3 = group(w[3], 16 * c + 12);
-        // bytes in memory order: t0[23:16] t0[15:8] t0[7:0] t1[23:16] ...
-        u32x3_a4 ov;
-        ov[0] = ((t0 >> 16) & 255u) | (((t0 >> 8) & 255u) << 8) | ((t0 & 255u) << 16) | (((t1 >> 16) & 255u) << 24);
-        ov[1] = ((t1 >> 8) & 255u) | ((t1 & 255u) << 8) | (((t2 >> 16) & 255u) << 16) | (((t2 >> 8) & 255u) << 24);
-        ov[2] = (t2 & 255u) | (((t3 >> 16) & 255u) << 8) | (((t3 >> 8) & 255u) << 16) | ((t3 & 255u) << 24);
-        *reinterpret_cast<u32x3_a4*>(o + 3 * c) = ov;
+    // (round 6: a thread's chunks three at a time with all three 16-byte loads in flight before the first table lookup -- float32[2054] is 684 chunks,
+    // 2.7 per thread: the one-at-a-time loop ran each thread's load -> lookup -> store chain three times in sequence)
+    for (int c0 = threadIdx.x; c0 < chunks; c0 += 3 * 256) {
+        u32x4_a4 wv[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = c0 + u * 256;
+            if (c < chunks) wv[u] = *reinterpret_cast<const u32x4_a4*>(t + 4 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = c0 + u * 256;
+            if (c >= chunks) continue;
+            const u32x4_a4 w = wv[u];
+            const unsigned t0 = group(w[0], 16 * c), t1 = group(w[1], 16 * c + 4), t2 = group(w[2], 16 * c + 8), t3 = group(w[3], 16 * c + 12);
+            // bytes in memory order: t0[23:16] t0[15:8] t0[7:0] t1[23:16] ...
+            u32x3_a4 ov;
+            ov[0] = ((t0 >> 16) & 255u) | (((t0 >> 8) & 255u) << 8) | ((t0 & 255u) << 16) | (((t1 >> 16) & 255u) << 24);
+            ov[1] = ((t1 >> 8) & 255u) | ((t1 & 255u) << 8) | (((t2 >> 16) & 255u) << 16) | (((t2 >> 8) & 255u) << 24);
+            ov[2] = (t2 & 255u) | (((t3 >> 16) & 255u) << 8) | (((t3 >> 8) & 255u) << 16) | ((t3 & 255u) << 24);
+            *reinterpret_cast<u32x3_a4*>(o + 3 * c) = ov;
+        }
     }
     if (threadIdx.x == 0) {
         // the groups behind the last whole chunk: up to three full ones, then the padded one (rem = 1: "xx==", rem = 2: "xxx=")

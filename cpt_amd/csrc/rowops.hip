@@ -274,7 +274,12 @@ struct EmbedArgs {
     int out_panel;      // round 5: out_lp / out_lo are the panel-layout residual stream (3-byte form)
     float* zero_f2; unsigned* zero_u1;      // round 6 (training forward): cleared by the first workgroup (kernels.h)
 };
-template <typename LP, int NA = MAXV>      // NA = 3: the H = 768 instantiation (a quarter fewer row registers, as layernorm768_kernel)
+// ERW rows per wave (round 6: 2 -- every gather of both rows in flight before the first row is reduced; with one row per wave the launch ran at the
+// latency of its ids -> table rows -> reduce -> store chain, 0.47 of 8 TB/s on the unique-bytes model at 4480 rows).  Per-row arithmetic unchanged: same bits.
+// Chosen per launch like the LayerNorm's rows per wave: measured 10.6 vs 8.9 us at 4480 rows (one resident round of waves either way: half the waves
+// only lengthen each wave's chain) and 49.7 vs 53.3 us at 35840 rows -- two rows per wave from 16384 rows on.
+constexpr int EMB_RPW2_ROWS = 16384;
+template <typename LP, int NA = MAXV, int ERW = 1>      // NA = 3: the H = 768 instantiation (a quarter fewer row registers, as layernorm768_kernel)
 __device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
     constexpr int MAXV = NA;
     const int64_t* __restrict__ ids = a.ids; const int64_t* __restrict__ tt = a.tt; const int64_t* __restrict__ pos = a.pos;
@@ -288,39 +293,52 @@ __device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
         if (a.zero_f2 && threadIdx.x < 2) a.zero_f2[threadIdx.x] = 0.f;
         if (a.zero_u1 && threadIdx.x == 2) *a.zero_u1 = 0u;
     }
-    const int r = block * (ROW_THREADS / 64) + (threadIdx.x >> 6);
-    if (r >= B * Lt) return;
-    const int b = r / Lt, t = r % Lt;
-    long wid = ids[r];
-    long pid = pos ? pos[r] : t;
-    long tid = tt ? tt[r] : 0;
-    // out-of-range ids would be a host bug; clamp so the kernel never faults
-    wid = wid < 0 ? 0 : (wid >= vocab ? vocab - 1 : wid);
-    pid = pid < 0 ? 0 : (pid >= max_pos ? max_pos - 1 : pid);
-    tid = tid < 0 ? 0 : (tid >= type_vocab ? type_vocab - 1 : tid);
+    const int r0 = (block * (ROW_THREADS / 64) + (threadIdx.x >> 6)) * ERW;
+    if (r0 >= B * Lt) return;
     const int nv = (H + 255) / 256;
-    f32x4 v[MAXV];
+    long wid[ERW], pid[ERW], tid[ERW];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (i < nv && c < H) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(word + (size_t)wid * H + c);
-            const f32x4 p = *reinterpret_cast<const f32x4*>(posw + (size_t)pid * H + c);
-            const f32x4 q = *reinterpret_cast<const f32x4*>(typew + (size_t)tid * H + c);
+    for (int u = 0; u < ERW; ++u) {
+        const int r = min(r0 + u, B * Lt - 1);
+        wid[u] = ids[r];
+        pid[u] = pos ? pos[r] : r % Lt;
+        tid[u] = tt ? tt[r] : 0;
+    }
+    f32x4 v[ERW][MAXV];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = a[j] + p[j] + q[j];
+    for (int u = 0; u < ERW; ++u) {
+        // out-of-range ids would be a host bug; clamp so the kernel never faults
+        wid[u] = wid[u] < 0 ? 0 : (wid[u] >= vocab ? vocab - 1 : wid[u]);
+        pid[u] = pid[u] < 0 ? 0 : (pid[u] >= max_pos ? max_pos - 1 : pid[u]);
+        tid[u] = tid[u] < 0 ? 0 : (tid[u] >= type_vocab ? type_vocab - 1 : tid[u]);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (i < nv && c < H) {
+                const f32x4 aw = *reinterpret_cast<const f32x4*>(word + (size_t)wid[u] * H + c);
+                const f32x4 p = *reinterpret_cast<const f32x4*>(posw + (size_t)pid[u] * H + c);
+                const f32x4 q = *reinterpret_cast<const f32x4*>(typew + (size_t)tid[u] * H + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[u][i][j] = aw[j] + p[j] + q[j];
+            }
         }
     }
-    float mean, rstd;
-    ln_stats<NA>(v, nv, lane, H, mean, rstd, eps);
-    const size_t orow = (size_t)b * L + t;
-    if (a.out_panel) ln_write<LP, NA>(v, nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
-    else
-    ln_write<LP, NA>(v, nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
-                     out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
+#pragma unroll
+    for (int u = 0; u < ERW; ++u) {
+        const int r = r0 + u;
+        if (r >= B * Lt) continue;
+        const int b = r / Lt, t = r % Lt;
+        float mean, rstd;
+        ln_stats<NA>(v[u], nv, lane, H, mean, rstd, eps);
+        const size_t orow = (size_t)b * L + t;
+        if (a.out_panel) ln_write<LP, NA>(v[u], nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
+        else
+        ln_write<LP, NA>(v[u], nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
+                         out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
+    }
 }
-template <typename LP, int NA = MAXV>
-__global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(EmbedArgs a) { embed_ln_block<LP, NA>(a, blockIdx.x); }
+template <typename LP, int NA = MAXV, int ERW = 1>
+__global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(EmbedArgs a) { embed_ln_block<LP, NA, ERW>(a, blockIdx.x); }
 
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
@@ -331,9 +349,10 @@ int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const fl
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
     if (!ids || !word || !posw || !typew || !g || !bta) return CPT_ERR_NULL;
     if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
-    dim3 grid((B * Lt + 3) / 4), block(ROW_THREADS);
+    const int erw = (B * Lt >= EMB_RPW2_ROWS && H == 768) ? 2 : 1;
+    dim3 grid((B * Lt + 4 * erw - 1) / (4 * erw)), block(ROW_THREADS);
     EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0, zero_f2, zero_u1};
-    if (out_lp && lp_dtype == CPT_BF16) { if (H == 768) embed_ln_kernel<bf16, 3><<<grid, block, 0, s>>>(a); else embed_ln_kernel<bf16><<<grid, block, 0, s>>>(a); }
+    if (out_lp && lp_dtype == CPT_BF16) { if (H == 768 && erw == 2) embed_ln_kernel<bf16, 3, 2><<<grid, block, 0, s>>>(a); else if (H == 768) embed_ln_kernel<bf16, 3><<<grid, block, 0, s>>>(a); else embed_ln_kernel<bf16><<<grid, block, 0, s>>>(a); }
     else { a.out_lo = nullptr; if (H == 768) embed_ln_kernel<float, 3><<<grid, block, 0, s>>>(a); else embed_ln_kernel<float><<<grid, block, 0, s>>>(a); }
     return CPT_OK;
 }
