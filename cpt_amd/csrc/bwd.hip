@@ -975,7 +975,10 @@ __device__ __forceinline__ int kq_off_tr(int row, int chunk) {
 template <int NKB, bool TR = false, bool HAVE = false>      // HAVE (TR only): ctx + stats given
 __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const int64_t* __restrict__ attn_mask,
                                                             const bf16* __restrict__ dctx, bf16* __restrict__ dqkv, int B, int L, int heads,
-                                                            DropSpec dr, float* __restrict__ dbias, const bf16* __restrict__ ctx, const float* __restrict__ stats) {
+                                                            DropSpec dr, float* __restrict__ dbias, const bf16* __restrict__ ctx, const float* __restrict__ stats, int split) {
+    // split (round 6, HAVE only): TWO workgroups per (sequence, head) -- with the forward's statistics the two phases below share nothing but the tiles, so
+    // workgroup 2 p runs phase A (dQ) and 2 p + 1 phase B (dK, dV) of pair p side by side.  For launches that leave most of the chip idle (4 sequences:
+    // 48 pairs on 256 CUs), where the launch lasts as long as ONE workgroup's load -> phase A -> phase B -> write-back chain.
     // ctx + stats (round 6, TR variants): the forward's context rows O and per-query softmax statistics (row max in base 2, 1 / row sum; attn_core.h
     // stat_row).  Phase A then needs neither the row reductions nor a second evaluation of the dP blocks: D = rowsum(dP . P) = rowsum(dO . O) (also
     // under dropout: O = P~ V) comes from the tile loads, and every key block is finished in one go (scores, dP, dS, dQ) instead of held.
@@ -1001,7 +1004,9 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
     uint32_t* sBits = reinterpret_cast<uint32_t*>(sD + LP);   // [NKB][LP] keep bits of the attention dropout: bit (key & 31) of word [key >> 5][query]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int pair = (TR && HAVE && split) ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int phase = (TR && HAVE && split) ? (int)(blockIdx.x & 1) : 2;      // 0: phase A only, 1: phase B only, 2: both
+    const int b = pair / heads, h = pair % heads;
     const int H = heads * 64;
     const size_t ldq = (size_t)3 * H;
     const bf16* base = qkv + (size_t)b * L * ldq + h * 64;
@@ -1068,7 +1073,7 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
         for (int u = tid; u < (LP / 2) * NKB; u += 256) {
             const int rp = u / NKB, kb = u % NKB;
             uint32_t w0 = 0, w1 = 0;
-            if (2 * rp < L && kb * 32 < L) drop_attn_bits2x32(dr, (uint32_t)blockIdx.x, (uint32_t)rp, (uint32_t)kb, w0, w1);
+            if (2 * rp < L && kb * 32 < L) drop_attn_bits2x32(dr, (uint32_t)pair, (uint32_t)rp, (uint32_t)kb, w0, w1);
             *reinterpret_cast<uint2*>(&sBits[kb * LP + 2 * rp]) = make_uint2(w0, w1);
         }
     }
@@ -1087,7 +1092,7 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
         if (key < LP) {
             sMask[key] = mreg[i];           // additive mask times log2(e): the softmax runs in base 2 (one v_exp_f32 per score), as in the forward kernel
             if constexpr (have) {                     // (rows beyond L: 1 / sum = 0 -> their probabilities are 0)
-                const float2 sv = key < L ? *reinterpret_cast<const float2*>(stats + 2 * ((size_t)blockIdx.x * L + key)) : float2{0.f, 0.f};
+                const float2 sv = key < L ? *reinterpret_cast<const float2*>(stats + 2 * ((size_t)pair * L + key)) : float2{0.f, 0.f};
                 sM[key] = sv.x; sLi[key] = sv.y;
             }
         }
@@ -1131,6 +1136,7 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
 
     // ================= phase A: query blocks (lane = query) =================
     if constexpr (have) {
+    if (phase != 1)
     for (int qb = wave; qb < NKB; qb += 4) {
         const float mq = sM[qb * 32 + fr], lq = sLi[qb * 32 + fr], dq = sD[qb * 32 + fr];
         bf16x8 fo[4], fqv[4];
@@ -1352,6 +1358,7 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
     __syncthreads();
 
     // ================= phase B: key blocks (lane = key) =================
+    if (phase != 0)
     for (int kb = wave; kb < NKB; kb += 4) {
         f32x16 aK[2], aV[2];
 #pragma unroll
@@ -1423,6 +1430,8 @@ __global__ __launch_bounds__(256, (TR && NKB <= 4) ? 2 : 1) void attn_bwd_mfma_k
     }
 }
 
+CPT_SWITCH(int g_attn_bwd_split, 1);       // cpt_set_tuning(38, v): two workgroups (one per phase) per (sequence, head) in small launches
+void set_attn_bwd_split(int v) { CPT_SWITCH_SET(g_attn_bwd_split = v); (void)v; }
 template <int NKB, bool TR = false>
 static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int heads, const DropSpec& dr,
                                 hipStream_t s, float* dbias, const void* ctx = nullptr, const float* stats = nullptr) {
@@ -1437,7 +1446,9 @@ static int attn_bwd_mfma_launch(const void* qkv, const int64_t* mask, const void
         if (e != hipSuccess) return CPT_ERR_HIP - (int)e;
         done[have ? 1 : 0][dev] = true;
     }
-    k<<<dim3(B * heads), dim3(256), lds, s>>>((const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, heads, dr, dbias, (const bf16*)ctx, stats);
+    // two workgroups per (sequence, head), one per phase, where even those leave CUs idle (the phases run side by side instead of one after the other)
+    const int split = (have && NKB <= 4 && g_attn_bwd_split && 2 * B * heads <= 256) ? 1 : 0;
+    k<<<dim3(B * heads * (1 + split)), dim3(256), lds, s>>>((const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, heads, dr, dbias, (const bf16*)ctx, stats, split);
     return CPT_OK;
 }
 

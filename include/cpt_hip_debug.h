@@ -110,6 +110,8 @@ int cpt_build_info(void);
  *          from the pre-LayerNorm rows kept for the backward (+ (mean, rstd), gain, shift); 0 = fp32 outputs written and read back
  *   key 37 training backward: 1 (default) = the K-split partial matrices of a layer's Q|K|V weight gradient are added up by the workgroups the NEXT layer's
  *          three-problem weight-gradient launch leaves idle (216 of 256 CUs busy at hidden 768); 0 = a reduction launch of their own
+ *   key 38 attention backward with the forward's statistics (bf16 training step, L <= 128): 1 (default) = where two workgroups per (sequence, head) still fit
+ *          one per CU (2 B heads <= 256: 4 sequences per GPU) the two phases (dQ | dK, dV) run in a workgroup each, side by side; 0 = one workgroup runs both
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
