@@ -784,9 +784,11 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     }
     if (dt == CPT_BF16) {      // the last attention-side LayerNorm's sums (and whatever else still waits for a carrier launch)
         if (qjob.S > 1) { TRY(cpt::reduce_job_flush(qjob, s), "partial sums of wgrad(qkv), first layer"); qjob = cpt::ReduceJob{}; }
+        if (Li <= 0) {      // (with regions the jobs ride on the region LayerNorm's backward below: no launch of their own)
         TRY(cpt::col_jobs_flush(pend, s), "column-sum jobs");
         pend = cpt::ColJobs{};
         ready(1);
+        }
     }
 
     // ---- region projection and text embeddings ----------------------------------------------------
@@ -796,8 +798,11 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         float* dimg = (float*)(ws + w.dimg);
         void* dimg_lp = ws + w.dimg_lp;
         const bool iln = d.use_img_ln && m->img_ln_g;
+        cpt::LnBwdExtra ei = {};
+        if (dt == CPT_BF16) ei.jobs = &pend;      // the first layer's attention-side column sums (and whatever else still waits): spare workgroups of this launch
         TRY(cpt::ln_bwd(dx, (const float*)(ws + w.imgpre), iln ? m->img_ln_g : nullptr, d.img_ln_eps, dimg, dt == CPT_BF16 ? dimg_lp : nullptr, dt,
-                        iln ? g->img_ln_g : nullptr, iln ? g->img_ln_b : nullptr, R, H, Li, L, Lt, 0, s), "ln_bwd(img)");
+                        iln ? g->img_ln_g : nullptr, iln ? g->img_ln_b : nullptr, R, H, Li, L, Lt, 0, s, nullptr, 0, nullptr, nullptr, &ei), "ln_bwd(img) + column-sum jobs");
+        if (dt == CPT_BF16) { pend = cpt::ColJobs{}; ready(1); }
         TRY(cpt::colsum(dimg, CPT_F32, H, g->b_img, R, H, s), "colsum(b_img)");
         float* gimg = (float*)(ws + w.gimg);      // (written whole by the weight-gradient GEMM: nothing to clear)
         rc = wgrad(dt == CPT_BF16 ? dimg_lp : (const void*)dimg, dt, H, H, ws + w.imgp, Dp, Dp, R, Rp, gimg, Dp, "wgrad(img_embedding)");

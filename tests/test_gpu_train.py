@@ -810,3 +810,38 @@ def test_deferred_partial_sums_and_lean_layernorm_leave_the_gradients_unchanged(
             worst = (n, rel)
     assert worst[1] < 2e-3, worst          # (a last-bit change of an fp32 residual moves bf16 roundings downstream)
     L.check(L.lib().cpt_set_tuning(-1, 0), "cpt_set_tuning")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_training_loss_is_the_mean_over_labelled_rows_written_by_the_cross_entropy_launch(dev, mode):
+    """Round 6 (ABI 8, cpt_outputs.loss_mean): the training forward's loss comes out of the cross-entropy launch itself (its last workgroup divides the totals and
+    leaves {sum, count} in the workspace for the backward; the embedding launch clears the accumulators) -- no memset, copy or divide launch.  Against
+    torch's CrossEntropyLoss(ignore_index=-1) on the returned scores (modeling_rec.py:147-150): some rows ignored; the same call twice (the finish ticket
+    resets itself); every row ignored -> NaN, as the reference's mean over no rows; and the gradient scale 1 / count reaches the backward."""
+    cfg = cfgmod.tiny()
+    m = _model(cfg, 5, dev, mode)
+    b = {k: v.to(dev) for k, v in synth.make_batch(6, cfg, seed=9, max_seq_len=20, img_seq_len=6).items()}
+    labels = b["colors"].clone()
+    labels[1] = -1
+    labels[4] = -1
+
+    def run(lab):
+        for p in m.parameters():
+            p.grad = None
+        loss, scores = m(b["input_ids"], b["segment_ids"], b["attention_mask"], img_feats=b["img_feats"], masked_lm_labels=lab, mask_token_pos=b["mask_token_pos"])
+        return loss, scores
+
+    for _ in range(2):
+        loss, scores = run(labels)
+        ref = torch.nn.functional.cross_entropy(scores.float(), labels, ignore_index=-1)
+        assert abs(float(loss.detach()) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    loss.backward()
+    g4 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    loss6, _ = run(b["colors"])
+    loss6.backward()
+    g6 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    n = "cls.transform.dense.weight" if "cls.transform.dense.weight" in g4 else next(k for k in g4 if k.endswith("transform.dense.weight"))
+    assert float((g4[n] - g6[n]).abs().max()) > 0      # (a different row set and 1 / 4 instead of 1 / 6)
+    none = torch.full_like(labels, -1)
+    loss0, _ = run(none)
+    assert torch.isnan(loss0.detach()).item()
