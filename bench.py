@@ -763,8 +763,8 @@ def main():
                 "traffic_source": "profiles/%s: rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled, see MI355X_MICROARCH.md), committed "
                                   "with the round's artefacts -- NOT measured inside this run" % os.path.basename(PMC_FILE),
                 "_want_live_pmc": bool(B == 64 and args.dtype == "bf16" and args.workload == "refcoco" and n_gpus == 1 and not args.no_live_pmc and not args.tune),
-                "peak_note": "2.5 PF/s is the 2.4 GHz spec figure; on this workload the package power limiter (PPT) is active for 43-47 % of the step's time and the "
-                             "shader clock averages 1.95 GHz (DESIGN.md 5j, profiles/r04_throttle_step_vs_chain.txt, r04_power_step_vs_chain.txt)",
+                "peak_note": "2.5 PF/s is the 2.4 GHz spec figure; on this workload the package power limiter (PPT) is active for 25-47 % of the step's time and the "
+                             "shader clock averages 1.95-2.02 GHz at 1.27-1.32 kW (profiles/r06_throttle_step_vs_chain.txt, r06_power_step.txt; rounds 4 and 6, three boxes)",
                 "avg_launch_ms": round(avg_ms, 5),
                 "flop_per_launch": gemm_flops(dom, M, H, I),
                 # every encoder GEMM against the same peak (gemm_qkv: projection flops only; its launches also run the attention)
