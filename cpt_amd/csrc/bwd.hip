@@ -483,7 +483,7 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
            float* dg, float* db, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
            float* part, size_t part_bytes, const DropSpec* drop, float* dbias, const LnBwdExtra* ext) {
     const DropSpec dr = drop ? *drop : DropSpec{};
-    if ((dr.thresh != 0 || dbias) && (!g || grp != R)) return CPT_ERR_SHAPE;      // mask / bias sums: compact rows only
+    if ((dr.thresh != 0 && (!g || grp != R)) || (dbias && !g)) return CPT_ERR_SHAPE;      // mask: compact rows only (its element index is the compact row's); bias sums: any row placement, but not the plain row gather
     const int nsum = dbias ? 3 : 2;
     if (R <= 0 || H % 4 || H > 256 * LNB_MAXV || grp <= 0) return CPT_ERR_SHAPE;
     if (!dy || (g && (!x || !dg || !db))) return CPT_ERR_NULL;      // g == NULL: identity (row gather only)
@@ -755,12 +755,43 @@ __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict
     const float k = scale * (dscale ? dscale[0] : 1.f) / fmaxf(loss_acc ? loss_acc[1] : 1.f, 1.f);
     out[idx] = from_f32<TO>(c < C ? x[(size_t)r * C + c] * k : 0.f);
 }
+// ... with the column sums of the ROUNDED output added into colsum[c] (round 6: the decoder / relation bias gradient -- one launch instead of scale_cast +
+// colsum): one thread per column, the R <= 64 head rows in a loop, eight loads in flight
+template <typename TO>
+__global__ __launch_bounds__(256) void scale_cast_colsum_kernel(const float* __restrict__ x, const float* __restrict__ loss_acc, float scale,
+                                                                const float* __restrict__ dscale, TO* __restrict__ out, int R, int C, int ldo,
+                                                                float* __restrict__ colsum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ldo) return;
+    const float k = scale * (dscale ? dscale[0] : 1.f) / fmaxf(loss_acc ? loss_acc[1] : 1.f, 1.f);
+    float acc = 0.f;
+    for (int r0 = 0; r0 < R; r0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (c < C && r0 + u < R) ? x[(size_t)(r0 + u) * C + c] * k : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r0 + u < R) {
+                const TO o = from_f32<TO>(v[u]);
+                out[(size_t)(r0 + u) * ldo + c] = o;
+                acc += (float)o;
+            }
+    }
+    if (c < C) atomicAdd(&colsum[c], acc);
+}
 int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
-               hipStream_t s) {
+               hipStream_t s, float* colsum_out) {
+    if (colsum_out && R <= 64) {
+        dim3 grid((unsigned)((ldo + 255) / 256)), block(256);
+        if (out_dtype == CPT_BF16) scale_cast_colsum_kernel<bf16><<<grid, block, 0, s>>>(x, loss_acc, scale, dscale, (bf16*)out, R, C, ldo, colsum_out);
+        else scale_cast_colsum_kernel<float><<<grid, block, 0, s>>>(x, loss_acc, scale, dscale, (float*)out, R, C, ldo, colsum_out);
+        return CPT_OK;
+    }
     const size_t n = (size_t)R * ldo;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (out_dtype == CPT_BF16) scale_cast_kernel<bf16><<<grid, block, 0, s>>>(x, loss_acc, scale, dscale, (bf16*)out, R, C, ldo);
     else scale_cast_kernel<float><<<grid, block, 0, s>>>(x, loss_acc, scale, dscale, (float*)out, R, C, ldo);
+    if (colsum_out) return colsum(out, out_dtype, ldo, colsum_out, R, C, s);      // (many rows: the tiled column-sum launch)
     return CPT_OK;
 }
 

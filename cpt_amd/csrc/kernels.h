@@ -112,7 +112,7 @@ constexpr int ZS_MAX = 224;
 struct ZeroSegs { float* p[ZS_MAX]; unsigned n[ZS_MAX]; int count; };     // 2.7 KB of kernel arguments
 int zero_segments(const ZeroSegs& z, hipStream_t s);
 int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
-               hipStream_t s);
+               hipStream_t s, float* colsum_out = nullptr);     // colsum_out (round 6): [C] += column sums of the rounded output (the bias gradient behind it), same launch at R <= 64
 int attention_bwd(int dtype, const void* qkv, const int64_t* attn_mask, const void* dctx, void* dqkv, int B, int L, int heads, hipStream_t s,
                   const DropSpec* drop = nullptr, float* dbias = nullptr, int mask_3d = 0,
                   const void* ctx = nullptr, const float* stats = nullptr);     // ctx + stats (round 6): the forward's context rows and softmax statistics -- the L <= 128 bf16 kernel then skips its statistics pass;     dbias [3H]: += column sums of dqkv (the stacked Q|K|V bias gradient); mask_3d: attn_mask is [B][L][L]

@@ -316,7 +316,7 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     // round 6: with hidden dropout every residual add sits in a row pass, and that pass can re-form the LayerNorm output it adds from the
     // pre-LayerNorm rows the backward keeps anyway (+ (mean, rstd), gain, shift): the LayerNorm launches then write no fp32 output
     // (11.8 of 53-65 MB per launch at 3840 rows).  x_f32 is still written where the pruned last layer gathers its residual rows from it.
-    const bool lean = ph && g_ln_lean;
+    const bool lean = ph && g_ln_lean && M >= 2048;      // (at few rows the row passes are pure latency chains: the extra (mean, rstd), gain and shift loads cost what the 1.5 MB buy)
     for (int l = 0; l < d.layers; ++l) {
         const cpt_layer& y = m->layers[l];
         need(1 + l);
@@ -566,8 +566,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         const int NR = d.n_rel, NRp = 64;
         const float* pooled = (const float*)(ws + w.uh);
         const void* pin = dt == CPT_BF16 ? (const void*)(ws + w.t2) : (const void*)pooled;
-        TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, loss_scale_dev, dl_lp, dt, B, NR, NRp, s), "scale(drel)");
-        TRY(cpt::colsum(dl_lp, dt, NRp, g->b_rel, B, NR, s), "colsum(cls.bias)");
+        TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, loss_scale_dev, dl_lp, dt, B, NR, NRp, s, g->b_rel), "scale(drel) + colsum(cls.bias)");
         rc = dgrad(dl_lp, NRp, NRp, m->w_rel, H, NR, H, B, nullptr, dt2, CPT_F32, "dgrad(seq_relationship)");
         if (rc) return rc;
         rc = wgrad(dl_lp, dt, NRp, NR, pin, H, H, B, Bp, g->w_rel, H, "wgrad(seq_relationship)");
@@ -580,16 +579,14 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         rc = dgrad(dpo, H, H, m->w_pool, H, H, H, B, nullptr, drows, CPT_F32, "dgrad(pooler)");
         if (rc) return rc;
     } else {
-    TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, loss_scale_dev, dl_lp, dt, Rh, V, Vp, s), "scale(dlogits)");
-    TRY(cpt::colsum(dl_lp, dt, Vp, g->b_dec, Rh, V, s), "colsum(cls.bias)");
+    TRY(cpt::scale_cast((const float*)(ws + w.dlogits), (const float*)(ws + w.loss), loss_scale, loss_scale_dev, dl_lp, dt, Rh, V, Vp, s, g->b_dec), "scale(dlogits) + colsum(cls.bias)");
     rc = dgrad(dl_lp, Vp, Vp, m->w_dec, H, V, H, Rh, nullptr, dt2, CPT_F32, "dgrad(decoder)");
     if (rc) return rc;
     rc = wgrad(dl_lp, dt, Vp, V, ws + w.t2, H, H, Rh, Bp, g->word_emb, H, "wgrad(decoder)");
     if (rc) return rc;
     TRY(cpt::ln_bwd(dt2, (const float*)(ws + w.uh), m->tr_ln_g, d.ln_eps, duh, dt == CPT_BF16 ? duh_lp : nullptr, dt, g->tr_ln_g,
-                    g->tr_ln_b, Rh, H, Rh, 0, 0, 1, s), "ln_bwd(head)");
+                    g->tr_ln_b, Rh, H, Rh, 0, 0, 1, s, nullptr, 0, nullptr, g->b_tr), "ln_bwd(head) + transform bias sums");      // (round 6: the bias gradient = column sums of this launch's output, summed inside it)
     const void* duh_in = dt == CPT_BF16 ? duh_lp : (const void*)duh;
-    TRY(cpt::colsum(duh, CPT_F32, H, g->b_tr, Rh, H, s), "colsum(transform bias)");
     rc = wgrad(duh_in, dt, H, H, ws + w.rows, H, H, Rh, Bp, g->w_tr, H, "wgrad(head transform)");
     if (rc) return rc;
     rc = dgrad(duh_in, H, H, m->w_tr, H, H, H, Rh, nullptr, drows, CPT_F32, "dgrad(head transform)");
@@ -801,9 +798,9 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
         cpt::LnBwdExtra ei = {};
         if (dt == CPT_BF16) ei.jobs = &pend;      // the first layer's attention-side column sums (and whatever else still waits): spare workgroups of this launch
         TRY(cpt::ln_bwd(dx, (const float*)(ws + w.imgpre), iln ? m->img_ln_g : nullptr, d.img_ln_eps, dimg, dt == CPT_BF16 ? dimg_lp : nullptr, dt,
-                        iln ? g->img_ln_g : nullptr, iln ? g->img_ln_b : nullptr, R, H, Li, L, Lt, 0, s, nullptr, 0, nullptr, nullptr, &ei), "ln_bwd(img) + column-sum jobs");
+                        iln ? g->img_ln_g : nullptr, iln ? g->img_ln_b : nullptr, R, H, Li, L, Lt, 0, s, nullptr, 0, nullptr, iln ? g->b_img : nullptr, &ei), "ln_bwd(img) + b_img sums + column-sum jobs");
         if (dt == CPT_BF16) { pend = cpt::ColJobs{}; ready(1); }
-        TRY(cpt::colsum(dimg, CPT_F32, H, g->b_img, R, H, s), "colsum(b_img)");
+        if (!iln) TRY(cpt::colsum(dimg, CPT_F32, H, g->b_img, R, H, s), "colsum(b_img)");      // (no region LayerNorm: the launch above is a plain row gather)
         float* gimg = (float*)(ws + w.gimg);      // (written whole by the weight-gradient GEMM: nothing to clear)
         rc = wgrad(dt == CPT_BF16 ? dimg_lp : (const void*)dimg, dt, H, H, ws + w.imgp, Dp, Dp, R, Rp, gimg, Dp, "wgrad(img_embedding)");
         if (rc) return rc;
