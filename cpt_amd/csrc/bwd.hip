@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      int R, int H, int grp, int grp_stride, int grp_off, int rows_per_block,
                                                      float* __restrict__ part, DropSpec dr, float* __restrict__ dbias,
                                                      const float* __restrict__ stats, int dy_parts, size_t dy_stride, const float* dy_resid, int dy_bf16,
-                                                     int nb_main, ColJobs jobs, RowMap drows, const unsigned short* __restrict__ keep_bits) {
+                                                     int nb_main, ColJobs jobs, RowMap drows, const unsigned short* __restrict__ keep_bits, DropSpec idr) {      // idr (round 6): dropout on the incoming gradient rows (LnBwdExtra::in_drop)
     // dr / dbias (training backward of LN(dropout(dense) + residual), round 2): dx_lp receives the gradient that enters the dense
     // layer -- dx through the dropout mask of the forward (regenerated, dropout.h; thresh 0: identity) -- and dbias its column
     // sums = the gradient of the dense bias; dx itself stays unmasked (it feeds the residual path).  Replaces a dropout_rows and
@@ -281,7 +281,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             for (int i = 0; i < LNB_MAXV; ++i) {
                 const int c = (lane + 64 * i) * 4;
                 if (i < nv && c < H) {
-                    const f32x4 o = *reinterpret_cast<const f32x4*>(dy + yrow * H + c);
+                    f32x4 o = *reinterpret_cast<const f32x4*>(dy + yrow * H + c);
+                    if (idr.thresh != 0) {
+                        bool keep[4];
+                        drop_hidden4(idr, ((uint64_t)yrow * H + c) >> 2, keep);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = keep[j] ? o[j] * idr.scale : 0.f;
+                    }
                     if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)r * H + c) = o;
                     if (dx_lp) {
                         if constexpr (sizeof(LP) == 2) {
@@ -336,6 +342,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     const f32x4 t = *reinterpret_cast<const f32x4*>(dy_resid + yr * H + c);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) nd[i][j] += t[j];
+                }
+                if (idr.thresh != 0) {
+                    bool keep[4];
+                    drop_hidden4(idr, ((uint64_t)yr * H + c) >> 2, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nd[i][j] = keep[j] ? nd[i][j] * idr.scale : 0.f;
                 }
             }
         }
@@ -502,8 +514,8 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
     dim3 grid(nb + col_jobs_blocks(&jobs)), block(256);
     const bool lp16 = dx_lp && lp_dtype == CPT_BF16;
     const int dyp = ex.dy_parts > 1 ? ex.dy_parts : 1;
-#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, (ex.dy_parts_bf16 && dyp == 2) ? 1 : 0, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr); \
-                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, (ex.dy_parts_bf16 && dyp == 2) ? 1 : 0, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr); } while (0)
+#define LNB(LPT, GI) do { if (H == 768) ln_bwd_kernel<LPT, GI, 3><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, (ex.dy_parts_bf16 && dyp == 2) ? 1 : 0, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr, ex.in_drop); \
+                          else ln_bwd_kernel<LPT, GI, 4><<<grid, block, 0, s>>>(dy, x, g, eps, dx, (LPT*)dx_lp, dg, db, R, H, grp, grp_stride, grp_off, rpb, part, dr, dbias, ex.stats, dyp, ex.dy_stride, ex.dy_resid, (ex.dy_parts_bf16 && dyp == 2) ? 1 : 0, nb, jobs, ex.drop_rows, (dr.thresh != 0 && H <= 1024) ? ex.keep_bits : nullptr, ex.in_drop); } while (0)
     if (lp16) { if (gelu_in) LNB(bf16, true); else LNB(bf16, false); }
     else      { if (gelu_in) LNB(float, true); else LNB(float, false); }
 #undef LNB
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const float* __restrict__ dy, const int64_t* __restrict__ ids, const int64_t* __restrict__ tt, const int64_t* __restrict__ pos,
     const float* __restrict__ word, const float* __restrict__ posw, const float* __restrict__ typew, const float* __restrict__ g,
     float eps, float* __restrict__ dword, float* __restrict__ dposw, float* __restrict__ dtypew, float* __restrict__ dg,
-    float* __restrict__ db, int B, int Lt, int L, int H, int vocab, int max_pos, int type_vocab, int rows_per_block) {
+    float* __restrict__ db, int B, int Lt, int L, int H, int vocab, int max_pos, int type_vocab, int rows_per_block, DropSpec idr) {
     __shared__ float red[2][4][256 * LNB_MAXV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = (H + 255) / 256;
@@ -575,6 +587,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xv[i][j] = a[j] + p[j] + q[j];
                 dv[i] = *reinterpret_cast<const f32x4*>(dy + ((size_t)b * L + t) * H + c);
+                if (idr.thresh != 0) {      // BertEmbeddings' dropout, backward: the mask of the forward at the same element index
+                    bool keep[4];
+                    drop_hidden4(idr, (((uint64_t)b * L + t) * H + c) >> 2, keep);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dv[i][j] = keep[j] ? dv[i][j] * idr.scale : 0.f;
+                }
                 s += xv[i][0] + xv[i][1] + xv[i][2] + xv[i][3];
             }
         }
@@ -674,12 +692,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
 int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
               const float* posw, const float* typew, const float* g, float eps, float* dword, float* dposw,
               float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,
-              int type_vocab, hipStream_t s) {
+              int type_vocab, hipStream_t s, const DropSpec* in_drop) {
     if (B <= 0 || Lt <= 0 || H % 4 || H > 256 * LNB_MAXV) return CPT_ERR_SHAPE;
     const int rpb = 16;
     dim3 grid((B * Lt + rpb - 1) / rpb), block(256);
     embed_bwd_kernel<<<grid, block, 0, s>>>(dy, ids, tt, pos, word, posw, typew, g, eps, dword, dposw, dtypew, dg, db,
-                                           B, Lt, L, H, vocab, max_pos, type_vocab, rpb);
+                                           B, Lt, L, H, vocab, max_pos, type_vocab, rpb, in_drop ? *in_drop : DropSpec{});
     return CPT_OK;
 }
 

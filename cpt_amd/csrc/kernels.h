@@ -19,13 +19,13 @@ int gemm(int dtype, int epi, const void* A, int lda, const void* W, int ldw, con
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
              float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
-             int max_pos, int type_vocab, hipStream_t s, void* out_lo = nullptr, int out_panel = 0, float* zero_f2 = nullptr, unsigned* zero_u1 = nullptr);   // zero_f2 / zero_u1 (round 6, training forward): two floats and one word cleared by the launch's first workgroup -- the loss accumulator and the finish ticket of the cross-entropy launch at the END of the same forward (no memset launch);   out_lo: rows leave in the 3-byte residual form (hi -> out_lp); out_panel: at their panel positions
+             int max_pos, int type_vocab, hipStream_t s, void* out_lo = nullptr, int out_panel = 0, float* zero_f2 = nullptr, unsigned* zero_u1 = nullptr, const struct DropSpec* out_drop = nullptr);   // out_drop (round 6): hidden dropout on the output rows (site mask at element index row * H + col, as dropout_rows)   // zero_f2 / zero_u1 (round 6, training forward): two floats and one word cleared by the launch's first workgroup -- the loss accumulator and the finish ticket of the cross-entropy launch at the END of the same forward (no memset launch);   out_lo: rows leave in the 3-byte residual form (hi -> out_lp); out_panel: at their panel positions
 
 // bf16 inference: embed_ln (3-byte or bf16 output rows) and pad_cast(bf16) of the region features in ONE launch (they touch disjoint data)
 int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
                       const float* g, const float* bta, float eps, void* out_lp, void* out_lo, int B, int Lt, int L, int H, int vocab,
                       int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s, int out_panel = 0,
-                      float* out_f32 = nullptr, float* zero_f2 = nullptr, unsigned* zero_u1 = nullptr);     // out_f32 / zero_*: the training forward's fp32 residual rows and cleared words (embed_ln above);   out_panel (round 5): out_lp / out_lo = the panel-layout residual stream
+                      float* out_f32 = nullptr, float* zero_f2 = nullptr, unsigned* zero_u1 = nullptr, const struct DropSpec* out_drop = nullptr);     // out_f32 / zero_*: the training forward's fp32 residual rows and cleared words (embed_ln above);   out_panel (round 5): out_lp / out_lo = the panel-layout residual stream
 
 int layernorm_rows(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                    void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
@@ -88,6 +88,8 @@ struct LnBwdExtra {
     const ColJobs* jobs;      // column-sum jobs of earlier launches, run by extra workgroups of this one
     int defer_reduce;         // 1: leave this launch's partial rows [ln_bwd_part_rows(R)][2 or 3][H] in `part` for a later job instead of launching the reduction
     RowMap drop_rows;         // dropout masks taken at these rows of the full tensor (compact head rows)
+    DropSpec in_drop;         // round 6: hidden dropout applied to the INCOMING gradient rows as they are read (element index (placed row) * H + col of that site's mask:
+                              // the embedding dropout's backward on the region rows, instead of a dropout pass over all rows in front); thresh 0: none
     const unsigned short* keep_bits;   // [R][64] the forward pass's keep bits (layernorm_rows_ex keep_out): bit 4 i + j of word [row][lane] = element (lane + 64 i) * 4 + j;
                               // the mask is then read, not regenerated (the Philox rounds were ~1/3 of the launch's VALU time); H <= 1024
 };
@@ -100,7 +102,7 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
 int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
               const float* posw, const float* typew, const float* g, float eps, float* dword, float* dposw,
               float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,
-              int type_vocab, hipStream_t s);
+              int type_vocab, hipStream_t s, const DropSpec* in_drop = nullptr);     // in_drop (round 6): BertEmbeddings' dropout applied to dy as it is read (element index (b L + t) H + col)
 // pruned last layer (round 6): out_a[b] = a[b][pos[b]] (bf16 rows), out_b[b] = bb[b][pos[b]] (fp32 rows) in one launch; and its inverse for the
 // backward: za [B][L][H] bf16 and zb [B][L][H] fp32 zero except row (b, pos[b]) = a_r[b] / b_r[b] (one launch: fill + rows)
 int tail_gather2(const void* a, const float* bb, const int64_t* pos, void* out_a, float* out_b, int B, int L, int H, hipStream_t s);
@@ -132,7 +134,7 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
                       int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off, int gelu_in, hipStream_t s,
                       const float* resid = nullptr, const DropSpec* drop = nullptr, float* pre_out = nullptr, void* out_lo = nullptr,
                       int x_parts = 1, size_t x_stride = 0, int out_panel = 0, float* stat_out = nullptr, const RowMap* drop_rows = nullptr,
-                      unsigned short* keep_out = nullptr, const float* resid_stat = nullptr, const float* resid_g = nullptr, const float* resid_b = nullptr);     // resid_stat / resid_g / resid_b (round 6): resid = the pre-LayerNorm rows of the LayerNorm in front, whose output is re-formed here from its [R][2] (mean, rstd), gain and shift (that launch then skips its fp32 output);   keep_out (round 6, with drop): [R][64] keep bits of the row's dropout mask for ln_bwd (LnBwdExtra::keep_bits)     // stat_out (round 6): [R][2] (mean, rstd) of every row, for ln_bwd     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
+                      unsigned short* keep_out = nullptr, const float* resid_stat = nullptr, const float* resid_g = nullptr, const float* resid_b = nullptr, const DropSpec* out_drop = nullptr);     // out_drop (round 6): hidden dropout on the OUTPUT rows, element index (output row) * H + col;     // resid_stat / resid_g / resid_b (round 6): resid = the pre-LayerNorm rows of the LayerNorm in front, whose output is re-formed here from its [R][2] (mean, rstd), gain and shift (that launch then skips its fp32 output);   keep_out (round 6, with drop): [R][64] keep bits of the row's dropout mask for ln_bwd (LnBwdExtra::keep_bits)     // stat_out (round 6): [R][2] (mean, rstd) of every row, for ln_bwd     // out_panel (round 5, with out_lo): out_lp / out_lo are the bases of the panel-layout residual stream; x_parts > 1: x holds that many split-K partial matrices, x_stride elements apart; the row processed is their sum in split order
 // resid / drop / pre_out: normalise dropout(x) + resid (element index row * H + col of the hidden-site mask) and store that sum
 
 // out[M][N] fp32 = sum_k A[k][m] W[k][n]: bf16 operands with the contraction index as the slow dimension (weight gradients

@@ -39,7 +39,10 @@ __device__ __forceinline__ size_t panel_quad(size_t row, int c, int H) {
 
 template <typename LP, int NA = MAXV>
 __device__ __forceinline__ void ln_write(const f32x4 (&v)[NA], int nv, int lane, int H, float mean, float rstd,
-                                         const float* g, const float* b, float* of, LP* ol, signed char* olo = nullptr, long long panel_row = -1) {
+                                         const float* g, const float* b, float* of, LP* ol, signed char* olo = nullptr, long long panel_row = -1,
+                                         const DropSpec* odrop = nullptr, size_t drop_row = 0) {
+    // odrop (round 6, training forward): hidden dropout on the OUTPUT row (BertEmbeddings' dropout / modeling_bert.py:266 on the region rows), element index
+    // drop_row * H + c of that site's mask -- the embedding launches apply it themselves instead of a dropout pass over all rows behind them
     constexpr int MAXV = NA;
     // olo != NULL (bf16 LP only): the row leaves in the 3-byte residual form (common.h r3_encode): hi -> ol, lo -> olo
     // panel_row >= 0 (round 5, with olo): ol / olo are the BASES of the panel-layout residual stream and the row lands at its quads there
@@ -55,6 +58,12 @@ __device__ __forceinline__ void ln_write(const f32x4 (&v)[NA], int nv, int lane,
                 for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
             } else {
                 y = v[i];
+            }
+            if (odrop && odrop->thresh != 0) {
+                bool keep[4];
+                drop_hidden4(*odrop, ((uint64_t)drop_row * H + c) >> 2, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = keep[j] ? y[j] * odrop->scale : 0.f;
             }
             if (of) *reinterpret_cast<f32x4*>(of + c) = y;
             if constexpr (sizeof(LP) == 2) {
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
     const float* x, const float* __restrict__ g, const float* __restrict__ bta, float eps,
     float* out_f32, LP* __restrict__ out_lp, int R, int H, int grp, int grp_stride, int grp_off,
     const float* resid, DropSpec dr, float* pre_out, signed char* __restrict__ out_lo, int x_parts, size_t x_stride, int out_panel, float* __restrict__ stat_out, RowMap drows, unsigned short* __restrict__ keep_out,
-    const float* __restrict__ resid_stat, const float* __restrict__ resid_g, const float* __restrict__ resid_b) {      // resid_stat / resid_g / resid_b (round 6): `resid` holds the PRE-LayerNorm rows of the LayerNorm in front; the residual is re-formed from them with its (mean, rstd), gain and shift -- ln_write's expression -- so that launch need not write its fp32 output at all (11.8 MB per launch at 3840 rows);   stat_out (round 6): [R][2] (mean, rstd) per row for the backward pass; x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
+    const float* __restrict__ resid_stat, const float* __restrict__ resid_g, const float* __restrict__ resid_b, DropSpec odr) {      // odr (round 6): dropout on the OUTPUT rows (ln_write odrop; index = output row);   resid_stat / resid_g / resid_b (round 6): `resid` holds the PRE-LayerNorm rows of the LayerNorm in front; the residual is re-formed from them with its (mean, rstd), gain and shift -- ln_write's expression -- so that launch need not write its fp32 output at all (11.8 MB per launch at 3840 rows);   stat_out (round 6): [R][2] (mean, rstd) per row for the backward pass; x / out_f32 / resid / pre_out may alias (in-place calls of the training step): no __restrict__ on them
     // x_parts / x_stride (round 3): x is x_parts split-K partial matrices of the dense layer in front, x_stride elements apart; the row that is
     // processed is their sum in split order (training forward: no reduction launch between the GEMM and this pass)
     // resid / dr / pre_out (training forward of LN(dropout(dense) + residual), modeling_bert.py:85-86,145 with the third-party
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_rows_kernel(
         if (out_panel) ln_write<LP, NA>(v[u], nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
         else
         ln_write<LP, NA>(v[u], nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
-                     out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
+                     out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr, -1, &odr, orow);
     }
 }
 
@@ -220,8 +229,10 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm768_kernel(const float* 
 int layernorm_rows_ex(const float* x, const float* g, const float* bta, float eps, float* out_f32,
                       void* out_lp, int lp_dtype, int R, int H, int grp, int grp_stride, int grp_off,
                       int gelu_in, hipStream_t s, const float* resid, const DropSpec* drop, float* pre_out, void* out_lo, int x_parts, size_t x_stride, int out_panel, float* stat_out, const RowMap* drop_rows, unsigned short* keep_out,
-                      const float* resid_stat, const float* resid_g, const float* resid_b) {
+                      const float* resid_stat, const float* resid_g, const float* resid_b, const DropSpec* out_drop) {
     if (x_parts < 1 || x_parts > 64) return CPT_ERR_SHAPE;
+    const DropSpec odr = out_drop ? *out_drop : DropSpec{};
+    if (odr.thresh != 0 && out_panel) return CPT_ERR_SHAPE;
     if (resid_stat && !(resid && resid_g && resid_b)) return CPT_ERR_NULL;
     if (out_panel && (!out_lo || out_f32 || H % 16)) return CPT_ERR_SHAPE;      // panel output: the 3-byte residual stream only (rows rounded up to 32 by the caller's buffer)
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
@@ -233,7 +244,7 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     // H = 768 rows without residual / dropout / GELU / split-K partials: the lean kernel, one row per wave (measured against two and four rows per wave:
     // profiles/r05_ab_log.md -- 0.59 / 0.72 of 8 TB/s at 7680 / 61440 rows for the bf16 output against 0.58 / 0.71 and 0.49 / 0.67; the general kernel: 0.56 / 0.55)
     if (keep_out && dr.thresh == 0) keep_out = nullptr;
-    if (H == 768 && !gelu_in && !resid && dr.thresh == 0 && !pre_out && x_parts == 1 && !stat_out) {
+    if (H == 768 && !gelu_in && !resid && dr.thresh == 0 && !pre_out && x_parts == 1 && !stat_out && odr.thresh == 0) {
         dim3 g768((R + 3) / 4), b768(ROW_THREADS);
         if (out_lp && lp_dtype == CPT_BF16)
             layernorm768_kernel<bf16, 1><<<g768, b768, 0, s>>>(x, g, bta, eps, out_f32, (bf16*)out_lp, R, grp, grp_stride, grp_off, (signed char*)out_lo, out_panel);
@@ -246,9 +257,9 @@ int layernorm_rows_ex(const float* x, const float* g, const float* bta, float ep
     const bool lp16 = out_lp && lp_dtype == CPT_BF16;
 #define LNK(LPT, GI)                                                                                                                              \
     do {                                                                                                                                          \
-        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out, resid_stat, resid_g, resid_b); \
-        else if (H == 768) layernorm_rows_kernel<LPT, GI, 1, 3><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out, resid_stat, resid_g, resid_b); \
-        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out, resid_stat, resid_g, resid_b);          \
+        if (rpw == 2) layernorm_rows_kernel<LPT, GI, 2><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out, resid_stat, resid_g, resid_b, odr); \
+        else if (H == 768) layernorm_rows_kernel<LPT, GI, 1, 3><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out, resid_stat, resid_g, resid_b, odr); \
+        else layernorm_rows_kernel<LPT, GI, 1><<<grid, block, 0, s>>>(x, g, bta, eps, out_f32, (LPT*)out_lp, R, H, grp, grp_stride, grp_off, resid, dr, pre_out, (signed char*)out_lo, x_parts, x_stride, out_panel, stat_out, drows, keep_out, resid_stat, resid_g, resid_b, odr);          \
     } while (0)
     if (lp16) { if (gelu_in) LNK(bf16, true); else LNK(bf16, false); }
     else      { if (gelu_in) LNK(float, true); else LNK(float, false); }
@@ -273,6 +284,7 @@ struct EmbedArgs {
     int B, Lt, L, H, vocab, max_pos, type_vocab;
     int out_panel;      // round 5: out_lp / out_lo are the panel-layout residual stream (3-byte form)
     float* zero_f2; unsigned* zero_u1;      // round 6 (training forward): cleared by the first workgroup (kernels.h)
+    DropSpec odrop;                         // round 6 (training forward): BertEmbeddings' dropout on the output rows (thresh 0: none)
 };
 // ERW rows per wave (round 6: 2 -- every gather of both rows in flight before the first row is reduced; with one row per wave the launch ran at the
 // latency of its ids -> table rows -> reduce -> store chain, 0.47 of 8 TB/s on the unique-bytes model at 4480 rows).  Per-row arithmetic unchanged: same bits.
@@ -334,7 +346,7 @@ __device__ __forceinline__ void embed_ln_block(const EmbedArgs& a, int block) {
         if (a.out_panel) ln_write<LP, NA>(v[u], nv, lane, H, mean, rstd, g, bta, nullptr, out_lp, out_lo, (long long)orow);
         else
         ln_write<LP, NA>(v[u], nv, lane, H, mean, rstd, g, bta, out_f32 ? out_f32 + orow * H : nullptr,
-                         out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr);
+                         out_lp ? out_lp + orow * H : nullptr, out_lo ? out_lo + orow * H : nullptr, -1, &a.odrop, orow);
     }
 }
 template <typename LP, int NA = MAXV, int ERW = 1>
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(ROW_THREADS) void embed_ln_kernel(EmbedArgs a) { em
 int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word,
              const float* posw, const float* typew, const float* g, const float* bta, float eps,
              float* out_f32, void* out_lp, int lp_dtype, int B, int Lt, int L, int H, int vocab,
-             int max_pos, int type_vocab, hipStream_t s, void* out_lo, int out_panel, float* zero_f2, unsigned* zero_u1) {
+             int max_pos, int type_vocab, hipStream_t s, void* out_lo, int out_panel, float* zero_f2, unsigned* zero_u1, const DropSpec* out_drop) {
     if (B <= 0 || Lt <= 0 || L < Lt || H % 4 || H > 256 * MAXV) return CPT_ERR_SHAPE;
     if (out_panel && (!out_lo || out_f32 || H % 16)) return CPT_ERR_SHAPE;
     if (out_lo && !(out_lp && lp_dtype == CPT_BF16)) return CPT_ERR_DTYPE;
@@ -351,7 +363,7 @@ int embed_ln(const int64_t* ids, const int64_t* tt, const int64_t* pos, const fl
     if (!pos && Lt > max_pos) return CPT_ERR_SHAPE;
     const int erw = (B * Lt >= EMB_RPW2_ROWS && H == 768) ? 2 : 1;
     dim3 grid((B * Lt + 4 * erw - 1) / (4 * erw)), block(ROW_THREADS);
-    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0, zero_f2, zero_u1};
+    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0, zero_f2, zero_u1, (out_drop && !out_panel) ? *out_drop : DropSpec{}};
     if (out_lp && lp_dtype == CPT_BF16) { if (H == 768 && erw == 2) embed_ln_kernel<bf16, 3, 2><<<grid, block, 0, s>>>(a); else if (H == 768) embed_ln_kernel<bf16, 3><<<grid, block, 0, s>>>(a); else embed_ln_kernel<bf16><<<grid, block, 0, s>>>(a); }
     else { a.out_lo = nullptr; if (H == 768) embed_ln_kernel<float, 3><<<grid, block, 0, s>>>(a); else embed_ln_kernel<float><<<grid, block, 0, s>>>(a); }
     return CPT_OK;
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(256) void embed_pad_kernel(EmbedArgs a, const float
 int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos, const float* word, const float* posw, const float* typew,
                       const float* g, const float* bta, float eps, void* out_lp, void* out_lo, int B, int Lt, int L, int H, int vocab,
                       int max_pos, int type_vocab, const float* x, void* xo, int R, int K, int Kp, hipStream_t s, int out_panel,
-                      float* out_f32, float* zero_f2, unsigned* zero_u1) {
+                      float* out_f32, float* zero_f2, unsigned* zero_u1, const DropSpec* out_drop) {
     if (out_panel && (!out_lo || H % 16 || out_f32)) return CPT_ERR_SHAPE;
     if (B <= 0 || Lt <= 0 || L < Lt || H % 4 || H > 256 * MAXV || R <= 0 || K <= 0 || Kp < K || Kp % 8) return CPT_ERR_SHAPE;
     if (!ids || !word || !posw || !typew || !g || !bta || !out_lp || !x || !xo) return CPT_ERR_NULL;
@@ -431,7 +443,7 @@ int embed_ln_pad_cast(const int64_t* ids, const int64_t* tt, const int64_t* pos,
     if (((uintptr_t)xo % 16) || ((uintptr_t)x % 8)) return CPT_ERR_ALIGN;
     const size_t n = (size_t)R * (Kp / 8);
     const int npad = (int)((n + 256 * PC_UNR - 1) / (256 * PC_UNR));
-    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0, zero_f2, zero_u1};
+    EmbedArgs a{ids, tt, pos, word, posw, typew, g, bta, eps, out_f32, out_lp, (signed char*)out_lo, B, Lt, L, H, vocab, max_pos, type_vocab, out_panel ? 1 : 0, zero_f2, zero_u1, (out_drop && !out_panel) ? *out_drop : DropSpec{}};
     if (H == 768) embed_pad_kernel<3><<<dim3(npad + (B * Lt + 3) / 4), dim3(256), 0, s>>>(a, x, (bf16*)xo, R, K, Kp, npad);
     else embed_pad_kernel<MAXV><<<dim3(npad + (B * Lt + 3) / 4), dim3(256), 0, s>>>(a, x, (bf16*)xo, R, K, Kp, npad);
     return CPT_OK;

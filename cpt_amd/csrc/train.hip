@@ -285,13 +285,16 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
     float* loss_ws = (float*)(ws + w.loss);
     unsigned* ce_ticket = (unsigned*)(ws + w.loss + 16);
     const bool emb_pad = Li > 0 && dt == CPT_BF16 && d.img_dim_pad % 8 == 0 && !((uintptr_t)b->img_feats & 7);
+    // (round 6: BertEmbeddings' dropout on the text rows and modeling_bert.py:266 on the region rows are applied by the launches that write those rows --
+    // the same site mask at the same element indices as the dropout pass over all rows they replace)
+    const cpt::DropSpec edrop = drop_spec(drop, 0, false);
     if (emb_pad)
         TRY(cpt::embed_ln_pad_cast(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, d.ln_eps,
                                    LB(0, w.o_xin), nullptr, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, b->img_feats, ws + w.imgp, B * Li, d.img_dim, d.img_dim_pad, s, 0,
-                                   x_f32, o->loss, ce_ticket), "embed_ln + pad_cast(img_feats)");
+                                   x_f32, o->loss, ce_ticket, ph ? &edrop : nullptr), "embed_ln + dropout + pad_cast(img_feats)");
     else
     TRY(cpt::embed_ln(b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g,
-                      m->emb_ln_b, d.ln_eps, x_f32, LB(0, w.o_xin), dt, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, s, nullptr, 0, o->loss, ce_ticket), "embed_ln");
+                      m->emb_ln_b, d.ln_eps, x_f32, LB(0, w.o_xin), dt, B, Lt, L, H, d.vocab, d.max_pos, d.type_vocab, s, nullptr, 0, o->loss, ce_ticket, ph ? &edrop : nullptr), "embed_ln + dropout");
     if (Li > 0) {
         void* imgp = ws + w.imgp;
         float* imgpre = (float*)(ws + w.imgpre);
@@ -299,11 +302,10 @@ int cpt_train_fwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_outputs* 
         TRY(gm(CPT_EPI_NONE, imgp, d.img_dim_pad, m->w_img, d.img_dim_pad, m->b_img, nullptr, 0, imgpre, CPT_F32, H,
                       B * Li, H, d.img_dim_pad, s), "gemm(img_embedding)");
         const bool iln = d.use_img_ln && m->img_ln_g;       // use_img_layernorm = 0 (modeling_bert.py:263): the projection is used as is
-        TRY(cpt::layernorm_rows(imgpre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, x_f32, LB(0, w.o_xin), dt, B * Li, H, Li, L, Lt, s),
-            "layernorm(img)");
+        TRY(cpt::layernorm_rows_ex(imgpre, iln ? m->img_ln_g : nullptr, iln ? m->img_ln_b : nullptr, d.img_ln_eps, x_f32, LB(0, w.o_xin), dt, B * Li, H, Li, L, Lt, 0, s,
+                                   nullptr, nullptr, nullptr, nullptr, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ph ? &edrop : nullptr),
+            "layernorm(img) + dropout");
     }
-    if (ph)   // BertEmbeddings' dropout on the text rows and modeling_bert.py:266 on the region rows: one pass over all rows
-        TRY(cpt::dropout_rows(x_f32, nullptr, x_f32, LB(0, w.o_xin), dt, M, H, drop_spec(drop, 0, false), s), "dropout(embeddings)");
     // dense layers with fp32 output (attn-out, FFN-down): at small row counts K is split over workgroups (gemm_nt_split)
     auto dense_f32 = [&](const void* A, int lda, const void* W, int K, const float* bias, const float* resid, void* out, int N, const char* what) -> int {
         if (dt == CPT_BF16 && g_wgrad_tn) {
@@ -789,13 +791,16 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     }
 
     // ---- region projection and text embeddings ----------------------------------------------------
-    if (ph) TRY(cpt::dropout_rows(dx, nullptr, dx, nullptr, dt, M, H, drop_spec(drop, 0, false), s), "dropout_bwd(embeddings)");
+    // (round 6: the embedding dropout's backward is applied by the two launches that read dx -- the region LayerNorm's backward and the embedding backward -- as
+    // they load their rows: no dropout pass over all rows in front of them)
+    const cpt::DropSpec edrop = drop_spec(drop, 0, false);
     if (Li > 0) {
         const int R = B * Li;
         float* dimg = (float*)(ws + w.dimg);
         void* dimg_lp = ws + w.dimg_lp;
         const bool iln = d.use_img_ln && m->img_ln_g;
         cpt::LnBwdExtra ei = {};
+        if (ph) ei.in_drop = edrop;
         if (dt == CPT_BF16) ei.jobs = &pend;      // the first layer's attention-side column sums (and whatever else still waits): spare workgroups of this launch
         TRY(cpt::ln_bwd(dx, (const float*)(ws + w.imgpre), iln ? m->img_ln_g : nullptr, d.img_ln_eps, dimg, dt == CPT_BF16 ? dimg_lp : nullptr, dt,
                         iln ? g->img_ln_g : nullptr, iln ? g->img_ln_b : nullptr, R, H, Li, L, Lt, 0, s, nullptr, 0, nullptr, iln ? g->b_img : nullptr, &ei), "ln_bwd(img) + b_img sums + column-sum jobs");
@@ -808,7 +813,7 @@ int cpt_train_bwd_ex(const cpt_model* m, const cpt_batch* b, const cpt_model_gra
     }
     TRY(cpt::embed_bwd(dx, b->input_ids, b->token_type, b->position_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g,
                        d.ln_eps, g->word_emb, g->pos_emb, g->type_emb, g->emb_ln_g, g->emb_ln_b, B, Lt, L, H, d.vocab, d.max_pos,
-                       d.type_vocab, s), "embed_bwd");
+                       d.type_vocab, s, ph ? &edrop : nullptr), "embed_bwd + dropout_bwd(embeddings)");
     ready(0);
     return CPT_OK;
 }
