@@ -694,7 +694,9 @@ int embed_bwd(const float* dy, const int64_t* ids, const int64_t* tt, const int6
               float* dtypew, float* dg, float* db, int B, int Lt, int L, int H, int vocab, int max_pos,
               int type_vocab, hipStream_t s, const DropSpec* in_drop) {
     if (B <= 0 || Lt <= 0 || H % 4 || H > 256 * LNB_MAXV) return CPT_ERR_SHAPE;
-    const int rpb = 16;
+    // rows per workgroup (round 6): 16 rows leave 18 workgroups at 4 sequences, each wave walking four rows' load -> reduce -> atomics chains in sequence
+    // (27.2 us; one row per wave: 11.7 us).  From 1024 rows on 16 stay (2240 rows: 35.0 us against 39.4 us at 8 -- twice the position-table and gain / shift atomics).
+    const int rpb = B * Lt >= 1024 ? 16 : 4;
     dim3 grid((B * Lt + rpb - 1) / rpb), block(256);
     embed_bwd_kernel<<<grid, block, 0, s>>>(dy, ids, tt, pos, word, posw, typew, g, eps, dword, dposw, dtypew, dg, db,
                                            B, Lt, L, H, vocab, max_pos, type_vocab, rpb, in_drop ? *in_drop : DropSpec{});

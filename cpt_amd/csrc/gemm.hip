@@ -1416,7 +1416,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const f32x4* __res
                                                               const f32x4* __restrict__ resid = nullptr) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         f32x4 a = part[i];
-        for (int k = 1; k < S; ++k) { const f32x4 b = part[(size_t)k * n4 + i]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+        // (round 6: eight partial matrices' loads in flight at a time, added in split order -- the one-by-one loop made a 16-way split of the head's 64 x 768
+        // data gradient a 20 us launch: sixteen memory round trips in sequence per thread)
+        for (int k0 = 1; k0 < S; k0 += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (k0 + kk < S) t[kk] = part[(size_t)(k0 + kk) * n4 + i];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (k0 + kk < S) { a[0] += t[kk][0]; a[1] += t[kk][1]; a[2] += t[kk][2]; a[3] += t[kk][3]; }
+        }
         if (resid) { const f32x4 r = resid[i]; a[0] += r[0]; a[1] += r[1]; a[2] += r[2]; a[3] += r[3]; }     // same order as the epilogue: sum, then + residual
         out[i] = a;
     }
