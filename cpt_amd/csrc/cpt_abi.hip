@@ -188,7 +188,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == -1) {       // every key back to its default (tests restore the library with this after every test)
         g_lp_resid = 0; g_fold_ln = 1; g_fuse_attn = 3; g_resid3 = 1; g_embed_pad = 1; g_dec_pf_pct = 40; g_x3_attn = 1; g_panel_ffn_multi = 1; cpt::set_lncons4(1); g_qkv_tiled = 1; g_panel = 1; g_prefetch = 1; g_rpanel = 1; g_tail = 1; g_row_pad = 1;
         cpt::set_gemm_variant(3); cpt::set_gemm_abl(0); cpt::set_q3_abl(0); cpt::set_attn_bwd_variant(1); cpt::set_splitk_target(384);
-        cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_ffn_2pass_min_tiles(192); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0); cpt::set_lnb_rpb(0); cpt::set_bias_fuse(3); cpt::set_train_tail(1); cpt::set_nn_split2(1); cpt::set_nn_tile256(1); cpt::set_ln_lean(1); cpt::set_qkv_defer(1); cpt::set_attn_bwd_split(1); cpt::set_wgrad_pair(2); cpt::set_qkv_2pass(1); cpt::set_fwd_split2(1); g_x3_fuse = 1; cpt::set_attn_qt_all(1); cpt::set_prod_waves(0);
+        cpt::set_gemm_skew(0); cpt::set_wgrad_tn(1); cpt::set_ffn_dma_late(1); cpt::set_ffn_2pass_min_tiles(192); cpt::set_prod_abl(0); cpt::set_gemm_trace_filter(255, 0); cpt::set_lnb_rpb(0); cpt::set_bias_fuse(3); cpt::set_train_tail(1); cpt::set_nn_split2(1); cpt::set_nn_tile256(1); cpt::set_ln_lean(1); cpt::set_qkv_defer(1); cpt::set_narrow_tiles(1); cpt::set_attn_bwd_split(1); cpt::set_wgrad_pair(2); cpt::set_qkv_2pass(1); cpt::set_fwd_split2(1); g_x3_fuse = 1; cpt::set_attn_qt_all(1); cpt::set_prod_waves(0);
         return CPT_OK;
     }
     if (key == 4) { g_lp_resid = value; return CPT_OK; }
@@ -227,6 +227,7 @@ int cpt_set_tuning(int key, int value) {
     if (key == 36) { cpt::set_ln_lean(value); return CPT_OK; }
     if (key == 37) { cpt::set_qkv_defer(value); return CPT_OK; }
     if (key == 38) { cpt::set_attn_bwd_split(value); return CPT_OK; }
+    if (key == 39) { cpt::set_narrow_tiles(value); return CPT_OK; }
     if (key == 29) { cpt::set_lncons4(value); return CPT_OK; }
     if (key == 26) { g_dec_pf_pct = value < 0 ? 0 : (value > 100 ? 100 : value); return CPT_OK; }
     if (key == 8) { cpt::set_gemm_trace_filter(value & 255, value >> 8); return CPT_OK; }   // diagnostic builds: trace filter (epilogue id | K << 8); 255: all

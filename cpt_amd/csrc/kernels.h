@@ -253,6 +253,7 @@ void set_nn_tile256(int v);
 void set_nn_split2(int v);   // training backward: data gradients in front of a LayerNorm backward as two K-split bf16 partial matrices (1, default)
 void set_ln_lean(int v);     // training forward: LayerNorm launches without fp32 output, residual re-formed by the next row pass (1, default)
 void set_attn_bwd_split(int v);   // attention backward: one workgroup per PHASE of a (sequence, head) pair where the launch fills less than half the chip (1, default)
+void set_narrow_tiles(int v);   // FFN-up forward / GELU-gradient GEMMs at few rows on 64 x 96 / 64 x 128 tiles (1, default)
 void set_qkv_defer(int v);   // training backward: Q|K|V weight-gradient partial sums inside the next layer's three-problem weight-gradient launch (1, default)
 void set_train_tail(int v);  // training step: the last encoder layer behind the attention on the head rows only (1, default)
 void set_bias_fuse(int v);   // training backward: bias-gradient column sums inside their producers (bit 0 b_in, bit 1 b_qkv)
