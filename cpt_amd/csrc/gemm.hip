@@ -1211,7 +1211,9 @@ CPT_SWITCH(int g_gemm_variant_sw, 3);
 #define CPT_CFG_64x192 64, 192, 2, 2, 3                   // 4 waves of 32x96: twice the workgroups when M is small
 #define CPT_CFG_384x256 384, 256, 4, 2, 2, 1, 1, 1        // 8 waves of 96x128 (192 accumulator registers), the whole LDS as a 2-stage ring
 
-CPT_SWITCH(int g_narrow_tiles, 1);      // cpt_set_tuning(39, v): 64 x 96 / 64 x 128 tiles for the FFN-up forward / GELU-gradient GEMMs where 64 x 192 tiles fill at most half the chip
+CPT_SWITCH(int g_narrow_tiles, 1);      // (values > 1, development build: the workgroup-count threshold itself instead of 128)
+#define NARROW_MAX (g_narrow_tiles > 1 ? (long)g_narrow_tiles : 128L)
+CPT_SWITCH(int g_narrow_dummy_, 0);      // cpt_set_tuning(39, v): 64 x 96 / 64 x 128 tiles for the FFN-up forward / GELU-gradient GEMMs where 64 x 192 tiles fill at most half the chip
 void set_narrow_tiles(int v) { CPT_SWITCH_SET(g_narrow_tiles = v); (void)v; }
 template <typename T, int EPI, typename OT>
 static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, const float* bias,
@@ -1232,7 +1234,7 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
     // round 6, few rows (the training forward's FFN-up at 4 sequences per GPU: M = 480, N = 3072 is 128 tiles of 64 x 192): 64 x 96 tiles (2 waves of 32 x 96,
     // the same wave tile) put 256 workgroups on the chip with 20 instead of 32 KB of operands per K-tile
     if constexpr (EPI == CPT_EPI_GELU2 || (EPI == CPT_EPI_NONE && sizeof(T) == 2)) {      // (... and the plain epilogue: the forward Q|K|V at few rows, 96 tiles of 64 x 192)
-        if (variant == 3 && g_narrow_tiles && N % 96 == 0 && (long)((M + 63) / 64) * ((N + 191) / 192) <= 128) {
+        if (variant == 3 && g_narrow_tiles && N % 96 == 0 && (long)((M + 63) / 64) * ((N + 191) / 192) <= NARROW_MAX) {
             launch_pipe<T, EPI, OT, 64, 96, 2, 1, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex);
             return;
         }
@@ -1471,7 +1473,7 @@ int gemm_tn(const void* A, int lda, const void* W, int ldw, float* out, int ldo,
     int rc;
     // (round 6: a short contraction that is not split and fills at most half the chip -- the Q|K|V weight gradient at 4 sequences per GPU, 72 tiles over
     // 8 K-tiles -- runs 64 x 192 tiles: 144 workgroups)
-    if (w192 && S == 1 && g_narrow_tiles && tiles <= 128)
+    if (w192 && S == 1 && g_narrow_tiles && tiles <= NARROW_MAX)
         rc = launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3, 1, 4, 1, 1>(a, lda, w, ldw, nullptr, nullptr, 0, dst, ldo, M, N, K, s, S, &ex);
     else
     if (w192) rc = launch_pipe<bf16, CPT_EPI_NONE, float, 128, 192, 4, 2, 3, 1, 4, 1, 1>(a, lda, w, ldw, nullptr, nullptr, 0, dst, ldo, M, N, K, s, S, &ex);
@@ -1655,7 +1657,7 @@ int gemm_nt_partials(const void* A, int lda, const void* W, int ldw, const float
     if (S < 3) return CPT_ERR_SHAPE;
     *S_out = S;
     // (round 6: where even the split leaves half the chip idle -- a short contraction, K = 768: 32 tiles x 4 splits -- 64 x 96 tiles, launch_fast's rule)
-    if (g_narrow_tiles && N % 96 == 0 && tiles * S <= 128)
+    if (g_narrow_tiles && N % 96 == 0 && tiles * S <= NARROW_MAX)
         return launch_pipe<bf16, CPT_EPI_NONE, float, 64, 96, 2, 1, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, partials, N, M, N, K, s, S);
     return launch_pipe<bf16, CPT_EPI_NONE, float, 64, 192, 2, 2, 3>((const bf16*)A, lda, (const bf16*)W, ldw, bias, nullptr, 0, partials, N, M, N, K, s, S);
 }
@@ -1745,12 +1747,12 @@ int gemm_nn(const void* A, int lda, const void* W, int ldw, const float* resid, 
                 return launch_pipe<bf16, CPT_EPI_GELUGRAD, bf16, 256, 192, 4, 2, 2, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (bf16*)out, ldo, M, N, K, s, 1, &ex);
             // round 6, few rows (4 sequences per GPU: M = 480, N = 3072 is 128 tiles of 64 x 192 -- half the chip idle, and the launch lasts as long as one
             // workgroup's twelve K-tiles): 64 x 128 tiles (4 waves of 32 x 64) put 192 workgroups on the chip with 24 instead of 32 KB of operands per K-tile
-            if (small && g_narrow_tiles && N % 128 == 0 && (long)((M + 63) / 64) * (N / 192) <= 128)
+            if (small && g_narrow_tiles && N % 128 == 0 && (long)((M + 63) / 64) * (N / 192) <= NARROW_MAX)
                 return launch_pipe<bf16, CPT_EPI_GELUGRAD, bf16, 64, 128, 2, 2, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (bf16*)out, ldo, M, N, K, s, 1, &ex);
             return small ? CPT_NN(CPT_EPI_GELUGRAD, bf16, 64, 2) : CPT_NN(CPT_EPI_GELUGRAD, bf16, 128, 4);
         }
         // (round 6: the attention output's data gradient at few rows is 32 tiles of 64 x 192: 64 x 64 tiles -- 2 waves of 32 x 64 -- make it 96 workgroups)
-        if (small && g_narrow_tiles && N % 64 == 0 && (long)((M + 63) / 64) * (N / 192) <= 64)
+        if (small && g_narrow_tiles && N % 64 == 0 && (long)((M + 63) / 64) * (N / 192) <= NARROW_MAX / 2)
             return launch_pipe<bf16, CPT_EPI_NONE, bf16, 64, 64, 2, 1, 3, 1, 4, 1, 2>(a, lda, w, ldw, nullptr, resid, ldr, (bf16*)out, ldo, M, N, K, s, 1, &ex);
         return small ? CPT_NN(CPT_EPI_NONE, bf16, 64, 2) : CPT_NN(CPT_EPI_NONE, bf16, 128, 4);
     }

@@ -113,7 +113,9 @@ int cpt_build_info(void);
  *   key 38 attention backward with the forward's statistics (bf16 training step, L <= 128): 1 (default) = where two workgroups per (sequence, head) still fit
  *          one per CU (2 B heads <= 256: 4 sequences per GPU) the two phases (dQ | dK, dV) run in a workgroup each, side by side; 0 = one workgroup runs both
  *   key 39 training step at few rows (4 sequences per GPU): 1 (default) = the FFN-up forward (u and gelu(u) out) on 64 x 96 tiles and the GELU-gradient
- *          data-gradient GEMM on 64 x 128 tiles where 64 x 192 tiles fill at most half the chip; 0 = 64 x 192 tiles
+ *          data-gradient GEMM on 64 x 128 tiles where 64 x 192 tiles fill at most half the chip (also: forward Q|K|V and attention output on 64 x 96, the
+ *          attention output's data gradient on 64 x 64, the unsplit TN weight gradient on 64 x 192); 0 = 64 x 192 / 128 x 192 tiles; v > 1 = the
+ *          workgroup-count threshold itself instead of 128 (256 at 32 sequences: 5.315 / 5.307 vs 5.321 / 5.316 ms -- nothing, the default stays 128)
  *   key -1 restores the default of every key (value ignored) */
 int cpt_set_tuning(int key, int value);
 /* Debug: when buf != NULL the pipelined GEMM writes 8 int64 per workgroup (shader-clock stamps at
