@@ -1227,12 +1227,6 @@ static void launch_fast(int variant, const T* A, int lda, const T* W, int ldw, c
     // workgroups pull the table through 239 CUs instead of the 159 of 64 x 192 tiles; same K order, same bits.
     if constexpr (EPI == CPT_EPI_NONE && sizeof(T) == 2 && CPT_DECODER_64x128) {
         if (variant == 3 && M <= 64 && N >= 8192) {
-#ifdef CPT_ABLATION
-            if (g_narrow_tiles == 2) {      // (development build, key 39 = 2: 64 x 64 tiles, two workgroups per CU pulling the table)
-                launch_pipe<T, EPI, OT, 64, 64, 2, 1, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex);
-                return;
-            }
-#endif
             launch_pipe<T, EPI, OT, 64, 128, 2, 2, 3>(A, lda, W, ldw, bias, resid, ldr, out, ldo, M, N, K, s, 1, ex);
             return;
         }
