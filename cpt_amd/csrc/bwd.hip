@@ -506,7 +506,7 @@ int ln_bwd(const float* dy, const float* x, const float* g, float eps, float* dx
     if (ex.defer_reduce && !(g && part && (size_t)ln_bwd_part_rows(R) * nsum * H * 4 <= part_bytes)) return CPT_ERR_WORKSPACE;
     // rows per block: with atomics fewer blocks = fewer dgamma/dbeta atomics (2*H per block); with a partial-sum buffer (two-stage
     // column sums) one row per wave keeps 4x the rows in flight: the kernel is latency-bound otherwise (22 -> ~10 us at 3840 rows)
-    int rpb = R >= 2048 ? 16 : 8;
+    int rpb = R >= 2048 ? 16 : (R > 256 ? 8 : 4);      // (a few rows -- the head's 4 .. 64 -- one per wave: each wave's row chain once instead of twice in sequence)
     if (g && part && (R >= 1024 || ex.defer_reduce) && (size_t)ln_bwd_part_rows(R) * nsum * H * 4 <= part_bytes) rpb = ln_bwd_rpb_two_stage(R); else part = nullptr;      // 8: two rows per wave, half the partial rows (3840 rows: 5.83 vs 5.89 ms per step; 960 blocks of 4 rows are 1.25 rounds of the 3 blocks per CU the 48 KB staging array allows)
     const int nb = (R + rpb - 1) / rpb;
     const ColJobs j0 = {};
@@ -781,28 +781,36 @@ template <typename TO>
 __global__ __launch_bounds__(256) void scale_cast_colsum_kernel(const float* __restrict__ x, const float* __restrict__ loss_acc, float scale,
                                                                 const float* __restrict__ dscale, TO* __restrict__ out, int R, int C, int ldo,
                                                                 float* __restrict__ colsum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= ldo) return;
+    // 64 columns per workgroup; wave w takes rows w, w + 4, ... (R <= 64: at most 16 per thread, all loads in flight), the four partial sums meet in LDS.
+    // (One thread per column over all rows was 11.9 us at the 32 head rows of the 32-sequence step: four, then one long, batch of strided loads per thread.)
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     const float k = scale * (dscale ? dscale[0] : 1.f) / fmaxf(loss_acc ? loss_acc[1] : 1.f, 1.f);
-    float acc = 0.f;
-    for (int r0 = 0; r0 < R; r0 += 8) {
-        float v[8];
+    float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (c < C && r0 + u < R) ? x[(size_t)(r0 + u) * C + c] * k : 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (r0 + u < R) {
-                const TO o = from_f32<TO>(v[u]);
-                out[(size_t)(r0 + u) * ldo + c] = o;
-                acc += (float)o;
-            }
+    for (int u = 0; u < 16; ++u) {
+        const int r = rg + 4 * u;
+        v[u] = (c < C && r < R) ? x[(size_t)r * C + c] * k : 0.f;
     }
-    if (c < C) atomicAdd(&colsum[c], acc);
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int r = rg + 4 * u;
+        if (c < ldo && r < R) {
+            const TO o = from_f32<TO>(v[u]);
+            out[(size_t)r * ldo + c] = o;
+            acc += (float)o;
+        }
+    }
+    part[rg][cx] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) atomicAdd(&colsum[c], part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
 }
 int scale_cast(const float* x, const float* loss_acc, float scale, const float* dscale, void* out, int out_dtype, int R, int C, int ldo,
                hipStream_t s, float* colsum_out) {
     if (colsum_out && R <= 64) {
-        dim3 grid((unsigned)((ldo + 255) / 256)), block(256);
+        dim3 grid((unsigned)((ldo + 63) / 64)), block(256);
         if (out_dtype == CPT_BF16) scale_cast_colsum_kernel<bf16><<<grid, block, 0, s>>>(x, loss_acc, scale, dscale, (bf16*)out, R, C, ldo, colsum_out);
         else scale_cast_colsum_kernel<float><<<grid, block, 0, s>>>(x, loss_acc, scale, dscale, (float*)out, R, C, ldo, colsum_out);
         return CPT_OK;

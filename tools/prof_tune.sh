@@ -10,6 +10,6 @@ cd $R
 python - <<PY
 import csv
 rows = list(csv.DictReader(open("$O/${T}_kernel_stats.csv")))
-for r in [q for q in rows if any(t in q["Name"] for t in ("embed_bwd","reduce_partials","adamw","ce_rows","tail_scatter","embed_pad"))]:
+for r in [q for q in rows if any(t in q["Name"] for t in ("scale_cast","ln_bwd","adamw","ce_rows"))]:
     print("%-70s %6d %8.2f" % (r["Name"][:70], int(r["Calls"]), float(r["AverageNs"]) / 1e3))
 PY
